@@ -1,0 +1,161 @@
+/*
+ * signerf_hip.h -- C ABI of libsignerf_hip.so, the MI355X (gfx950) implementation of the
+ * SIGNeRF reference-sheet render path.
+ *
+ * The reference is pure Python: the path is reached through two nerfstudio calls in
+ *   /root/reference/signerf/datasetgenerator/datasetgenerator.py:691   camera.generate_rays(camera_indices=0, aabb_box=graph.render_aabb)
+ *   /root/reference/signerf/datasetgenerator/datasetgenerator.py:694   graph.get_outputs_for_camera_ray_bundle(camera_ray_bundle)
+ * followed by the in-tree slab test
+ *   /root/reference/signerf/datasetgenerator/datasetgenerator.py:763   intersect_with_aabb(rays_o, rays_d, self.aabb)
+ * A maintainer binds this library with ctypes from the Model / Cameras plugin objects
+ * (INTEGRATION.md shows the stub).  Every entry point below names the reference interface
+ * it stands in for.
+ *
+ * Conventions
+ *   - plain C: no C++ types, no exceptions cross the boundary, no torch types.
+ *   - every function returns an int status: 0 = ok, non-zero = error; the text is available
+ *     from sn_last_error() (mirrors the RuntimeError raised at datasetgenerator.py:697-698).
+ *   - all tensor arguments are raw DEVICE pointers (fp32 unless stated) owned by the caller
+ *     (PyTorch-ROCm); the library borrows them for the duration of the call.  Weights are copied
+ *     once into library-owned device buffers by sn_upload_weights().
+ *   - work is enqueued on the caller's HIP stream (`stream` = hipStream_t); no hidden sync.
+ *   - a handle is re-entrant: render calls keep no state in the handle; scratch memory is
+ *     caller-provided (SnRenderOpts.workspace), sized by sn_workspace_bytes().  Concurrent
+ *     render calls on one handle (GUI thread + viewer thread, interface.py:83-116,
+ *     viewer.py:334-336) are therefore safe as long as weights are not being re-uploaded.
+ */
+#ifndef SIGNERF_HIP_H
+#define SIGNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SN_MAX_LEVELS 16
+#define SN_MAX_PROPOSALS 2
+
+#define SN_OK 0
+#define SN_ERR_INVALID 1     /* bad argument / unsupported architecture */
+#define SN_ERR_HIP 2         /* a HIP runtime call failed */
+#define SN_ERR_STATE 3       /* weights missing / not finalized */
+#define SN_ERR_WORKSPACE 4   /* workspace too small */
+
+typedef struct SnContext* SnHandle;
+typedef void* SnStream; /* hipStream_t */
+
+/* One hash-grid + MLP stack (nerfstudio MLPWithHashEncoding). */
+typedef struct SnHashMlpDesc {
+    int32_t num_levels;         /* L */
+    int32_t features_per_level; /* F, must be 2 */
+    int32_t log2_hashmap_size;  /* table rows per level = 1 << this */
+    int32_t hidden_dim;         /* 64 for the main field, 16 for proposal nets */
+    int32_t num_layers;         /* must be 2 (one hidden layer) */
+    int32_t out_dim;            /* 16 (1 + geo_feat_dim) main, 1 proposal */
+    float scalings[SN_MAX_LEVELS]; /* floor(base_res * growth**l), computed by the host exactly as HashEncoding does */
+} SnHashMlpDesc;
+
+/* Architecture of the nerfacto field + proposal nets (A0). */
+typedef struct SnFieldDesc {
+    SnHashMlpDesc main_field;
+    int32_t geo_feat_dim;         /* 15 */
+    int32_t hidden_dim_color;     /* 64 */
+    int32_t appearance_embed_dim; /* 32 (folded into the colour bias at finalize) */
+    int32_t sh_levels;            /* 4 */
+    int32_t sh_remap;             /* 0: SH evaluated on (d+1)/2 (torch fallback); 1: on d (tcnn) */
+    int32_t num_proposals;        /* 0..SN_MAX_PROPOSALS */
+    SnHashMlpDesc proposals[SN_MAX_PROPOSALS];
+    float average_init_density;   /* signerf_config.py:35 -> 0.01 */
+    float histogram_padding;      /* PDFSampler: 0.01 */
+} SnFieldDesc;
+
+/* Per-call render options (NerfactoModelConfig values that shape one eval render). */
+typedef struct SnRenderOpts {
+    int32_t num_proposal_iterations;               /* 0 => initial sampler feeds the main field directly */
+    int32_t num_proposal_samples[SN_MAX_PROPOSALS]; /* 256, 96 */
+    int32_t num_nerf_samples;                      /* 48 (64 in the synthetic benchmark) */
+    float near_plane;                              /* collider value used when nears == NULL (eval: 0) */
+    float far_plane;                               /* collider value used when fars == NULL (1000) */
+    int32_t chunk_rays;                            /* eval_num_rays_per_chunk (signerf_config.py:32); only the
+                                                      expected-depth clip bounds depend on it (A17) */
+    int32_t precision;                             /* 0: exact fp32 MFMA; 1: split-fp16 (hi+lo) MFMA, fp32 accumulate */
+    void* workspace;                               /* device scratch, >= sn_workspace_bytes() */
+    size_t workspace_bytes;
+    /* Sampler grids, DEVICE pointers, computed by the host shim with the very torch ops nerfstudio uses so
+     * that they are bit-identical to the reference's (torch.linspace's vectorised CPU fill has no simple
+     * closed form).  NULL => the library falls back to i/N and (k+0.5)/(M+1). */
+    const float* initial_spacing_bins;             /* [n0+1] = torch.linspace(0, 1, n0+1), n0 = first level's count */
+    const float* pdf_u[SN_MAX_PROPOSALS];          /* pdf_u[k]: [m+1] eval-mode u grid of resampling step k (m = next level's count) */
+} SnRenderOpts;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+
+/* Creates a context on the current HIP device.  Stands in for constructing the nerfacto
+ * Model's field modules (signerf.py:27, NerfactoModel.populate_modules). */
+int sn_create(const SnFieldDesc* desc, SnHandle* out);
+int sn_destroy(SnHandle h);
+/* Last error text of this handle (or of the failed sn_create when h == NULL). */
+const char* sn_last_error(SnHandle h);
+
+/* Copies one parameter tensor (host or device pointer) into the library.  `name` is the
+ * nerfstudio state-dict key the pipeline filters on (signerf_pipeline.py:93-132):
+ *   field.mlp_base.encoder.hash_table                       [L*T, 2]
+ *   field.mlp_base.mlp.layers.{0,1}.{weight,bias}
+ *   field.mlp_head.layers.{0,1,2}.{weight,bias}
+ *   field.embedding_appearance.mean                         [appearance_embed_dim] (mean over rows, A14)
+ *   proposal_networks.{i}.mlp_base.encoder.hash_table       [L*T, 2]
+ *   proposal_networks.{i}.mlp_base.mlp.layers.{0,1}.{weight,bias}
+ * Stands in for Model.load_state_dict (signerf_pipeline.py:129-131). */
+int sn_upload_weights(SnHandle h, const char* name, const void* data, size_t bytes, SnStream stream);
+/* Builds the device-side weight images (MFMA operand order, folded appearance bias). */
+int sn_finalize_weights(SnHandle h, SnStream stream);
+
+/* ---- row a5: Cameras.generate_rays (datasetgenerator.py:691) ----------------------------- */
+/* c2w: 12 floats (3x4 row-major) on the HOST.  Outputs are device pointers; any may be NULL.
+ * origins/directions [H,W,3], pixel_area/directions_norm [H,W,1].  If aabb (6 host floats: min xyz,
+ * max xyz) is non-NULL, nears/fars [H,W,1] are set from nerfstudio's clamped slab test (A1). */
+int sn_generate_rays(const float* c2w, float fx, float fy, float cx, float cy, int32_t height, int32_t width,
+                     float* origins, float* directions, float* pixel_area, float* directions_norm,
+                     const float* aabb, float* nears, float* fars, SnStream stream);
+
+/* ---- row a4: intersect_with_aabb (signerf/utils/intersection.py:5-56) -------------------- */
+/* aabb: 6 host floats (min xyz, max xyz).  nears/fars: [n_rays]. */
+int sn_intersect_with_aabb(const float* origins, const float* directions, int64_t n_rays, const float* aabb,
+                           float* nears, float* fars, SnStream stream);
+
+/* ---- rows a6-a17: Model.get_outputs_for_camera_ray_bundle (datasetgenerator.py:694) ------ */
+size_t sn_workspace_bytes(SnHandle h, int32_t height, int32_t width, const SnRenderOpts* opts);
+/* origins/directions: [H,W,3]; nears/fars: [H,W,1] or NULL (collider).  Outputs (any may be NULL):
+ * rgb [H,W,3], depth [H,W,1] (median), accumulation [H,W,1], expected_depth [H,W,1],
+ * prop_depth_i [H,W,1].  Row-major ray order, identical to the reference's chunk loop. */
+int sn_render_rays(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars,
+                   int32_t height, int32_t width, const SnRenderOpts* opts,
+                   float* rgb, float* depth, float* accumulation, float* expected_depth,
+                   float* prop_depth_0, float* prop_depth_1, SnStream stream);
+
+/* ---- stage-level entry points (same device code as the fused kernels; used by parity tests) */
+/* which: -1 main field, i >= 0 proposal net i.  q: [n,3] normalised positions in [0,1).
+ * features: [n, L*F] level-major; indices (nullable): [n, L, 8] int32 table rows incl. level offset,
+ * corner order as nerfstudio's hashed_0..7 (row a13). */
+int sn_hash_encode(SnHandle h, int32_t which, const float* q, int64_t n, float* features, int32_t* indices, SnStream stream);
+/* World positions [n,3] (+ directions [n,3] for the main field) -> density [n] and, main field only,
+ * rgb [n,3] (rows a9, a14, a15).  rgb/directions may be NULL. */
+int sn_field_forward(SnHandle h, int32_t which, const float* positions, const float* directions, int64_t n,
+                     int32_t precision, float* density, float* rgb, SnStream stream);
+/* Rows a10 + a17 on explicit per-sample inputs: euclid_bins [R,S+1], density [R,S], rgb_samples [R,S,3] ->
+ * weights [R,S], rgb [R,3], depth [R], median_index [R] (int32), accumulation [R], expected_depth [R]
+ * (clipped to the global [min,max] of the sample mid-points, i.e. one chunk). Outputs may be NULL. */
+int sn_composite(const float* euclid_bins, const float* density, const float* rgb_samples, int64_t n_rays, int32_t n_samples,
+                 float* weights, float* rgb, float* depth, int32_t* median_index, float* accumulation,
+                 float* expected_depth, SnStream stream);
+/* Row a11: spacing_bins [R,N+1], weights [R,N] -> new spacing bins [R,M+1] and searchsorted indices [R,M+1] (int32).
+ * u: [M+1] device floats (the eval-mode grid). */
+int sn_pdf_sample(const float* spacing_bins, const float* weights, int64_t n_rays, int32_t n_in, int32_t n_out,
+                  const float* u, float histogram_padding, float* new_bins, int32_t* inds, SnStream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGNERF_HIP_H */

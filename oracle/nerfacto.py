@@ -1,0 +1,525 @@
+"""CPU restatement (pure PyTorch, fp32) of nerfstudio 1.0.2's eval-mode nerfacto render.
+
+TEST INFRASTRUCTURE -- see ``oracle/__init__.py``.  **PARITY UNPINNED**: the
+arithmetic restated here lives in ``nerfstudio==1.0.2``
+(/root/reference/pyproject.toml:6), which is not in /root/reference and cannot
+be installed in this container; the reference holds no tests or golden vectors
+for it.  Every function names the SURVEY.md Appendix-A stage / §8(a) row it
+follows and the in-tree call site that reaches it:
+
+    signerf/datasetgenerator/datasetgenerator.py:691   camera.generate_rays(...)
+    signerf/datasetgenerator/datasetgenerator.py:694   graph.get_outputs_for_camera_ray_bundle(...)
+    signerf/signerf_config.py:32-35                    chunk = 1<<15, predict_normals, average_init_density = 0.01
+
+This is the *torch fallback* ("implementation='torch'") semantics -- the only
+nerfstudio path that runs on a CPU -- NOT the tinycudann semantics.
+
+Decisions the builder had to take (confidence "L"):
+  * SH input range: the torch fallback evaluates the SH basis directly on the
+    value the field hands it, i.e. on d' = (d + 1) / 2 (``sh_remap="torch"``).
+    tinycudann maps d' back to [-1, 1] first (``sh_remap="tcnn"``).  Default
+    is "torch" because the parity target is the CPU path.
+  * Normals (a16) are not produced: ``render_camera`` reads only ``rgb`` and
+    ``depth`` (datasetgenerator.py:700-701).
+
+Tensor conventions: everything fp32 on CPU; a parameter set is a plain dict
+keyed by nerfstudio state-dict names (see ``signerf_amd.scene``).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+# ----------------------------------------------------------------------------
+# configuration (A0)
+# ----------------------------------------------------------------------------
+
+
+@dataclass
+class HashMLPConfig:
+    """One hash-grid + MLP stack (``MLPWithHashEncoding`` in nerfstudio terms)."""
+
+    num_levels: int
+    base_res: int
+    max_res: int
+    log2_hashmap_size: int
+    features_per_level: int = 2
+    hidden_dim: int = 64
+    num_layers: int = 2
+    out_dim: int = 16
+
+
+@dataclass
+class NerfactoConfig:
+    """A0 defaults, with SIGNeRF's overrides (signerf_config.py:32-35)."""
+
+    near_plane: float = 0.05
+    far_plane: float = 1000.0
+    num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96)
+    num_nerf_samples_per_ray: int = 48
+    num_proposal_iterations: int = 2
+    eval_num_rays_per_chunk: int = 1 << 15
+    average_init_density: float = 0.01
+    histogram_padding: float = 0.01
+    geo_feat_dim: int = 15
+    appearance_embed_dim: int = 32
+    hidden_dim_color: int = 64
+    sh_levels: int = 4
+    sh_remap: str = "torch"
+    main: HashMLPConfig = field(
+        default_factory=lambda: HashMLPConfig(16, 16, 2048, 19, 2, 64, 2, 16)
+    )
+    proposals: Tuple[HashMLPConfig, ...] = (
+        HashMLPConfig(5, 16, 128, 17, 2, 16, 2, 1),
+        HashMLPConfig(5, 16, 256, 17, 2, 16, 2, 1),
+    )
+
+
+# ----------------------------------------------------------------------------
+# A1 -- ray generation (row a5)
+# ----------------------------------------------------------------------------
+
+
+def generate_rays(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, height: int, width: int):
+    """Pin-hole full-image ray bundle (A1).
+
+    Returns origins [H,W,3], directions [H,W,3], pixel_area [H,W,1],
+    directions_norm [H,W,1], camera_indices [H,W,1] (int64, all 0) and the
+    integer pixel coordinates [H,W,2] as (y, x).
+    """
+    c2w = c2w.to(torch.float32)
+    ys, xs = torch.meshgrid(torch.arange(height), torch.arange(width), indexing="ij")
+    coords_int = torch.stack([ys, xs], dim=-1)
+    coords = coords_int.to(torch.float32) + 0.5  # pixel centres, (y, x)
+    y = coords[..., 0]
+    x = coords[..., 1]
+    fx_t, fy_t = torch.tensor(fx, dtype=torch.float32), torch.tensor(fy, dtype=torch.float32)
+    cx_t, cy_t = torch.tensor(cx, dtype=torch.float32), torch.tensor(cy, dtype=torch.float32)
+    coord = torch.stack([(x - cx_t) / fx_t, -(y - cy_t) / fy_t], -1)
+    coord_x = torch.stack([(x - cx_t + 1) / fx_t, -(y - cy_t) / fy_t], -1)
+    coord_y = torch.stack([(x - cx_t) / fx_t, -(y - cy_t + 1) / fy_t], -1)
+    coord_stack = torch.stack([coord, coord_x, coord_y], dim=0)  # [3,H,W,2]
+    dirs = torch.empty((3, height, width, 3), dtype=torch.float32)
+    dirs[..., 0] = coord_stack[..., 0]
+    dirs[..., 1] = coord_stack[..., 1]
+    dirs[..., 2] = -1.0
+    rotation = c2w[:3, :3]
+    dirs = torch.sum(dirs[..., None, :] * rotation, dim=-1)  # d_world = R . d_cam
+    norm = torch.maximum(
+        torch.linalg.vector_norm(dirs, dim=-1, keepdim=True), torch.tensor([1e-20], dtype=torch.float32)
+    )
+    dirs = dirs / norm
+    origins = c2w[:3, 3].expand(height, width, 3).contiguous()
+    directions = dirs[0]
+    dx = torch.sqrt(torch.sum((directions - dirs[1]) ** 2, dim=-1))
+    dy = torch.sqrt(torch.sum((directions - dirs[2]) ** 2, dim=-1))
+    pixel_area = (dx * dy)[..., None]
+    camera_indices = torch.zeros((height, width, 1), dtype=torch.int64)
+    return {
+        "origins": origins,
+        "directions": directions.contiguous(),
+        "pixel_area": pixel_area,
+        "directions_norm": norm[0],
+        "camera_indices": camera_indices,
+        "coords": coords_int,
+    }
+
+
+def intersect_aabb_ns(origins: Tensor, directions: Tensor, aabb: Tensor, max_bound: float = 1e10, invalid_value: float = 1e10):
+    """nerfstudio's ``intersect_aabb`` used when ``generate_rays(aabb_box=...)`` (A1, confidence M).
+
+    ``aabb`` is the flattened [6] box (min xyz, max xyz).  NOT the in-tree
+    ``intersect_with_aabb`` (that one is ``oracle.signerf_utils``).
+    """
+    tx_min = (aabb[:3] - origins) / directions
+    tx_max = (aabb[3:] - origins) / directions
+    t_min = torch.stack((tx_min, tx_max)).amin(dim=0)
+    t_max = torch.stack((tx_min, tx_max)).amax(dim=0)
+    t_min = t_min.amax(dim=-1)
+    t_max = t_max.amin(dim=-1)
+    t_min = torch.clamp(t_min, min=0, max=max_bound)
+    t_max = torch.clamp(t_max, min=0, max=max_bound)
+    cond = t_max <= t_min
+    t_min = torch.where(cond, torch.tensor(invalid_value, dtype=t_min.dtype), t_min)
+    t_max = torch.where(cond, torch.tensor(invalid_value, dtype=t_max.dtype), t_max)
+    return t_min, t_max
+
+
+# ----------------------------------------------------------------------------
+# A3 / A4 -- collider and the initial (uniform-in-s) sampler (rows a7, a8)
+# ----------------------------------------------------------------------------
+
+
+def collider_near_far(num_rays: int, cfg: NerfactoConfig, training: bool = False):
+    """NearFarCollider (A3): eval near = 0, far = far_plane."""
+    ones = torch.ones((num_rays, 1), dtype=torch.float32)
+    near = cfg.near_plane if training else 0
+    return ones * near, ones * cfg.far_plane
+
+
+def spacing_fn(x: Tensor) -> Tensor:
+    """s(x) of UniformLinDispPiecewiseSampler (A4)."""
+    return torch.where(x < 1, x / 2, 1 - 1 / (2 * x))
+
+
+def spacing_fn_inv(x: Tensor) -> Tensor:
+    """s^-1(y) (A4)."""
+    return torch.where(x < 0.5, 2 * x, 1 / (2 - 2 * x))
+
+
+def spacing_to_euclidean(bins: Tensor, nears: Tensor, fars: Tensor) -> Tensor:
+    s_near, s_far = spacing_fn(nears), spacing_fn(fars)
+    return spacing_fn_inv(bins * s_far + (1 - bins) * s_near)
+
+
+def initial_sampler(nears: Tensor, fars: Tensor, num_samples: int):
+    """SpacedSampler in eval mode (no jitter) -> (spacing_bins [1,N+1], euclid_bins [R,N+1])."""
+    bins = torch.linspace(0.0, 1.0, num_samples + 1)[None, ...]
+    return bins, spacing_to_euclidean(bins, nears, fars)
+
+
+# ----------------------------------------------------------------------------
+# A5 / A6 -- sample positions, scene contraction (rows a9, a14 front half)
+# ----------------------------------------------------------------------------
+
+
+def sample_positions(origins: Tensor, directions: Tensor, starts: Tensor, ends: Tensor) -> Tensor:
+    """Frustums.get_positions (A5): o + d * (start + end) / 2.  starts/ends [R,N,1]."""
+    return origins[:, None, :] + directions[:, None, :] * (starts + ends) / 2
+
+
+def contract_inf(x: Tensor) -> Tensor:
+    """SceneContraction(order=inf) (A6)."""
+    mag = torch.linalg.norm(x, ord=float("inf"), dim=-1)[..., None]
+    return torch.where(mag < 1, x, (2 - (1 / mag)) * (x / mag))
+
+
+def normalized_positions(positions: Tensor):
+    """Contraction, (p+2)/4, selector, masking (A6) -> (q, selector)."""
+    q = contract_inf(positions)
+    q = (q + 2.0) / 4.0
+    selector = ((q > 0.0) & (q < 1.0)).all(dim=-1)
+    q = q * selector[..., None]
+    return q, selector
+
+
+# ----------------------------------------------------------------------------
+# A7 -- hash encoding, torch path (row a13)
+# ----------------------------------------------------------------------------
+
+HASH_PRIMES = (1, 2654435761, 805459861)
+
+
+def hash_scalings(num_levels: int, base_res: int, max_res: int) -> Tensor:
+    """Per-level grid scale floor(base * g**l), evaluated the way HashEncoding.__init__ does
+    (numpy float64 growth factor raised to an int64 torch tensor -> fp32)."""
+    levels = torch.arange(num_levels)
+    growth = np.exp((np.log(max_res) - np.log(base_res)) / (num_levels - 1)) if num_levels > 1 else 1
+    return torch.floor(base_res * growth**levels).to(torch.float32)
+
+
+def hash_fn(coords: Tensor, table_size: int, level_offsets: Tensor) -> Tensor:
+    """coords [...,L,3] int32 -> table row [...,L] int64 (products in int64)."""
+    c = coords * torch.tensor(HASH_PRIMES, dtype=torch.int64)
+    x = torch.bitwise_xor(c[..., 0], c[..., 1])
+    x = torch.bitwise_xor(x, c[..., 2])
+    x = x % table_size
+    x = x + level_offsets
+    return x
+
+
+def hash_corner_indices(q: Tensor, scalings: Tensor, log2_hashmap_size: int):
+    """Integer part of A7: returns (floor coords [P,L,3] int32, ceil coords, indices [P,L,8] int64, offset [P,L,3]).
+
+    Corner order k = 0..7 follows nerfstudio's hashed_0..hashed_7:
+      0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf   (x y z; c = ceil, f = floor)
+    """
+    table_size = 2**log2_hashmap_size
+    num_levels = scalings.shape[0]
+    level_offsets = torch.arange(num_levels) * table_size
+    scaled = q[..., None, :] * scalings.view(-1, 1)
+    sc = torch.ceil(scaled).type(torch.int32)
+    sf = torch.floor(scaled).type(torch.int32)
+    offset = scaled - sf
+
+    def pick(xs, ys, zs):
+        return torch.stack([xs[..., 0], ys[..., 1], zs[..., 2]], dim=-1)
+
+    corners = [
+        pick(sc, sc, sc),
+        pick(sc, sf, sc),
+        pick(sf, sf, sc),
+        pick(sf, sc, sc),
+        pick(sc, sc, sf),
+        pick(sc, sf, sf),
+        pick(sf, sf, sf),
+        pick(sf, sc, sf),
+    ]
+    idx = torch.stack([hash_fn(c, table_size, level_offsets) for c in corners], dim=-1)
+    return sf, sc, idx, offset
+
+
+def hash_encode(q: Tensor, table: Tensor, scalings: Tensor, log2_hashmap_size: int) -> Tensor:
+    """q [P,3] in [0,1) -> [P, L*F] level-major (A7)."""
+    _, _, idx, offset = hash_corner_indices(q, scalings, log2_hashmap_size)
+    f = [table[idx[..., k]] for k in range(8)]  # each [P,L,F]
+    ox, oy, oz = offset[..., 0:1], offset[..., 1:2], offset[..., 2:3]
+    f_03 = f[0] * ox + f[3] * (1 - ox)
+    f_12 = f[1] * ox + f[2] * (1 - ox)
+    f_56 = f[5] * ox + f[6] * (1 - ox)
+    f_47 = f[4] * ox + f[7] * (1 - ox)
+    f0312 = f_03 * oy + f_12 * (1 - oy)
+    f4756 = f_47 * oy + f_56 * (1 - oy)
+    enc = f0312 * oz + f4756 * (1 - oz)
+    return torch.flatten(enc, start_dim=-2, end_dim=-1)
+
+
+# ----------------------------------------------------------------------------
+# A8 / A9 -- MLPs and density (rows a9, a14)
+# ----------------------------------------------------------------------------
+
+
+def mlp_forward(x: Tensor, params: Dict[str, Tensor], prefix: str, num_layers: int, out_activation: Optional[str] = None) -> Tensor:
+    """nn.Linear stack with bias, ReLU between layers (A8)."""
+    for i in range(num_layers):
+        w = params[f"{prefix}.layers.{i}.weight"]
+        b = params[f"{prefix}.layers.{i}.bias"]
+        x = torch.nn.functional.linear(x, w, b)
+        if i < num_layers - 1:
+            x = torch.relu(x)
+    if out_activation == "sigmoid":
+        x = torch.sigmoid(x)
+    return x
+
+
+def density_field(params: Dict[str, Tensor], prefix: str, hcfg: HashMLPConfig, positions: Tensor, average_init_density: float):
+    """positions [R,N,3] (world) -> density [R,N,1], mlp_out [R,N,out_dim], q, selector  (A6-A9)."""
+    q, selector = normalized_positions(positions)
+    scalings = hash_scalings(hcfg.num_levels, hcfg.base_res, hcfg.max_res)
+    enc = hash_encode(q.view(-1, 3), params[f"{prefix}.encoder.hash_table"], scalings, hcfg.log2_hashmap_size)
+    h = mlp_forward(enc, params, f"{prefix}.mlp", hcfg.num_layers).view(*positions.shape[:-1], -1)
+    density = average_init_density * torch.exp(h[..., 0:1])
+    density = density * selector[..., None]
+    return density, h, q, selector
+
+
+# ----------------------------------------------------------------------------
+# A10 -- weights (row a10)
+# ----------------------------------------------------------------------------
+
+
+def get_weights(deltas: Tensor, densities: Tensor) -> Tensor:
+    """RaySamples.get_weights: [R,N,1] x [R,N,1] -> [R,N,1]."""
+    delta_density = deltas * densities
+    alphas = 1 - torch.exp(-delta_density)
+    transmittance = torch.cumsum(delta_density[..., :-1, :], dim=-2)
+    transmittance = torch.cat([torch.zeros((*transmittance.shape[:1], 1, 1)), transmittance], dim=-2)
+    transmittance = torch.exp(-transmittance)
+    weights = alphas * transmittance
+    return torch.nan_to_num(weights)
+
+
+# ----------------------------------------------------------------------------
+# A11 -- PDF resampling (row a11)
+# ----------------------------------------------------------------------------
+
+
+def pdf_u(num_samples: int) -> Tensor:
+    """Eval-mode u grid: num_samples+1 centred points."""
+    num_bins = num_samples + 1
+    u = torch.linspace(0.0, 1.0 - (1.0 / num_bins), steps=num_bins)
+    return u + 1.0 / (2 * num_bins)
+
+
+def pdf_sample(existing_bins: Tensor, weights: Tensor, num_samples: int, histogram_padding: float = 0.01, eps: float = 1e-5):
+    """existing_bins [R,N+1] (spacing domain), weights [R,N] -> new bins [R,num_samples+1], searchsorted inds [R,num_samples+1]."""
+    weights = weights + histogram_padding
+    weights_sum = torch.sum(weights, dim=-1, keepdim=True)
+    padding = torch.relu(eps - weights_sum)
+    weights = weights + padding / weights.shape[-1]
+    weights_sum = weights_sum + padding
+    pdf = weights / weights_sum
+    cdf = torch.min(torch.ones_like(pdf), torch.cumsum(pdf, dim=-1))
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], dim=-1)
+    u = pdf_u(num_samples).expand(*cdf.shape[:-1], num_samples + 1).contiguous()
+    inds = torch.searchsorted(cdf, u, side="right")
+    below = torch.clamp(inds - 1, 0, existing_bins.shape[-1] - 1)
+    above = torch.clamp(inds, 0, existing_bins.shape[-1] - 1)
+    cdf_g0 = torch.gather(cdf, -1, below)
+    bins_g0 = torch.gather(existing_bins, -1, below)
+    cdf_g1 = torch.gather(cdf, -1, above)
+    bins_g1 = torch.gather(existing_bins, -1, above)
+    t = torch.clip(torch.nan_to_num((u - cdf_g0) / (cdf_g1 - cdf_g0), 0), 0, 1)
+    bins = bins_g0 + t * (bins_g1 - bins_g0)
+    return bins, inds, cdf
+
+
+# ----------------------------------------------------------------------------
+# A13-A15 -- direction encoding, appearance, colour (row a15)
+# ----------------------------------------------------------------------------
+
+
+def sh_components(directions: Tensor, levels: int = 4) -> Tensor:
+    """Real SH basis up to ``levels`` (A13), evaluated on whatever it is handed."""
+    n = levels**2
+    comp = torch.zeros((*directions.shape[:-1], n), dtype=directions.dtype)
+    x, y, z = directions[..., 0], directions[..., 1], directions[..., 2]
+    xx, yy, zz = x**2, y**2, z**2
+    comp[..., 0] = 0.28209479177387814
+    if levels > 1:
+        comp[..., 1] = 0.4886025119029199 * y
+        comp[..., 2] = 0.4886025119029199 * z
+        comp[..., 3] = 0.4886025119029199 * x
+    if levels > 2:
+        comp[..., 4] = 1.0925484305920792 * x * y
+        comp[..., 5] = 1.0925484305920792 * y * z
+        comp[..., 6] = 0.9461746957575601 * zz - 0.31539156525251999
+        comp[..., 7] = 1.0925484305920792 * x * z
+        comp[..., 8] = 0.5462742152960396 * (xx - yy)
+    if levels > 3:
+        comp[..., 9] = 0.5900435899266435 * y * (3 * xx - yy)
+        comp[..., 10] = 2.890611442640554 * x * y * z
+        comp[..., 11] = 0.4570457994644658 * y * (5 * zz - 1)
+        comp[..., 12] = 0.3731763325901154 * z * (5 * zz - 3)
+        comp[..., 13] = 0.4570457994644658 * x * (5 * zz - 1)
+        comp[..., 14] = 1.445305721320277 * z * (xx - yy)
+        comp[..., 15] = 0.5900435899266435 * x * (xx - 3 * yy)
+    return comp
+
+
+def direction_encoding(directions: Tensor, cfg: NerfactoConfig) -> Tensor:
+    d = (directions + 1.0) / 2.0  # get_normalized_directions
+    if cfg.sh_remap == "tcnn":
+        d = d * 2.0 - 1.0
+    return sh_components(d, cfg.sh_levels)
+
+
+def field_rgb(params: Dict[str, Tensor], cfg: NerfactoConfig, directions: Tensor, mlp_out: Tensor) -> Tensor:
+    """directions [R,3], mlp_out [R,N,1+geo] -> rgb [R,N,3]  (A13-A15, eval mode, average appearance)."""
+    R, N = mlp_out.shape[:2]
+    d = direction_encoding(directions, cfg)[:, None, :].expand(R, N, -1)
+    geo = mlp_out[..., 1 : 1 + cfg.geo_feat_dim]
+    app = params["field.embedding_appearance.embedding.weight"].mean(dim=0)
+    app = torch.ones((R, N, cfg.appearance_embed_dim)) * app
+    h = torch.cat([d, geo, app], dim=-1).reshape(R * N, -1)
+    rgb = mlp_forward(h, params, "field.mlp_head", 3, out_activation="sigmoid")
+    return rgb.view(R, N, 3)
+
+
+# ----------------------------------------------------------------------------
+# A17 -- renderers (row a17)
+# ----------------------------------------------------------------------------
+
+
+def render_rgb(rgb: Tensor, weights: Tensor) -> Tensor:
+    """RGBRenderer, background 'last_sample', eval mode."""
+    rgb = torch.nan_to_num(rgb)
+    background = rgb[..., -1, :]
+    comp = torch.sum(weights * rgb, dim=-2)
+    acc = torch.sum(weights, dim=-2)
+    comp = comp + background * (1.0 - acc)
+    return torch.clamp(comp, min=0.0, max=1.0)
+
+
+def render_accumulation(weights: Tensor) -> Tensor:
+    return torch.sum(weights, dim=-2)
+
+
+def render_depth_median(weights: Tensor, starts: Tensor, ends: Tensor):
+    """DepthRenderer('median') -> (depth [R,1], median index [R,1] int64)."""
+    steps = (starts + ends) / 2
+    cumulative = torch.cumsum(weights[..., 0], dim=-1)
+    split = torch.ones((*weights.shape[:-2], 1)) * 0.5
+    idx = torch.searchsorted(cumulative, split, side="left")
+    idx = torch.clamp(idx, 0, steps.shape[-2] - 1)
+    return torch.gather(steps[..., 0], dim=-1, index=idx), idx
+
+
+def render_depth_expected(weights: Tensor, starts: Tensor, ends: Tensor) -> Tensor:
+    """DepthRenderer('expected'); the clip bounds are chunk-global (A17 quirk)."""
+    steps = (starts + ends) / 2
+    depth = torch.sum(weights * steps, dim=-2) / (torch.sum(weights, -2) + 1e-10)
+    return torch.clip(depth, steps.min(), steps.max())
+
+
+# ----------------------------------------------------------------------------
+# A12 + NerfactoModel.get_outputs -- one chunk (rows a12, a14-a17)
+# ----------------------------------------------------------------------------
+
+
+def get_outputs(params: Dict[str, Tensor], cfg: NerfactoConfig, origins: Tensor, directions: Tensor,
+                nears: Optional[Tensor] = None, fars: Optional[Tensor] = None, return_debug: bool = False):
+    """One chunk of rays [R,3] -> dict of [R,C] outputs (eval mode)."""
+    R = origins.shape[0]
+    if nears is None or fars is None:
+        nears, fars = collider_near_far(R, cfg)
+    dbg = {}
+    n_prop = cfg.num_proposal_iterations
+    weights = None
+    sbins = None
+    ebins = None
+    prop_depths: List[Tensor] = []
+    for level in range(n_prop + 1):
+        is_prop = level < n_prop
+        n = cfg.num_proposal_samples_per_ray[level] if is_prop else cfg.num_nerf_samples_per_ray
+        if level == 0:
+            sbins, ebins = initial_sampler(nears, fars, n)
+            sbins = sbins.expand(R, -1)
+        else:
+            annealed = torch.pow(weights, 1.0)
+            sbins, inds, _ = pdf_sample(sbins, annealed[..., 0], n, cfg.histogram_padding)
+            ebins = spacing_to_euclidean(sbins, nears, fars)
+            if return_debug:
+                dbg[f"pdf_inds_{level}"] = inds
+        starts, ends = ebins[:, :-1, None], ebins[:, 1:, None]
+        if is_prop:
+            pos = sample_positions(origins, directions, starts, ends)
+            density, _, _, _ = density_field(params, f"proposal_networks.{level}.mlp_base", cfg.proposals[level], pos, cfg.average_init_density)
+            weights = get_weights(ends - starts, density)
+            d, _ = render_depth_median(weights, starts, ends)
+            prop_depths.append(d)
+    pos = sample_positions(origins, directions, starts, ends)
+    density, h, q, selector = density_field(params, "field.mlp_base", cfg.main, pos, cfg.average_init_density)
+    rgb_s = field_rgb(params, cfg, directions, h)
+    weights = get_weights(ends - starts, density)
+    rgb = render_rgb(rgb_s, weights)
+    depth, med_idx = render_depth_median(weights, starts, ends)
+    out = {
+        "rgb": rgb,
+        "accumulation": render_accumulation(weights),
+        "depth": depth,
+        "expected_depth": render_depth_expected(weights, starts, ends),
+    }
+    for i, d in enumerate(prop_depths):
+        out[f"prop_depth_{i}"] = d
+    if return_debug:
+        dbg.update({"median_index": med_idx, "weights": weights, "density": density, "rgb_samples": rgb_s,
+                    "euclid_bins": ebins, "spacing_bins": sbins, "q": q, "selector": selector, "mlp_out": h})
+        out["_debug"] = dbg
+    return out
+
+
+def get_outputs_for_camera_ray_bundle(params: Dict[str, Tensor], cfg: NerfactoConfig, origins: Tensor, directions: Tensor,
+                                      nears: Optional[Tensor] = None, fars: Optional[Tensor] = None,
+                                      chunk: Optional[int] = None) -> Dict[str, Tensor]:
+    """Model.get_outputs_for_camera_ray_bundle (A2): row-major chunk loop over an [H,W] bundle."""
+    with torch.no_grad():
+        H, W = origins.shape[:2]
+        chunk = chunk or cfg.eval_num_rays_per_chunk
+        o = origins.reshape(-1, 3)
+        d = directions.reshape(-1, 3)
+        n = None if nears is None else nears.reshape(-1, 1)
+        f = None if fars is None else fars.reshape(-1, 1)
+        lists: Dict[str, List[Tensor]] = {}
+        for i in range(0, H * W, chunk):
+            out = get_outputs(params, cfg, o[i : i + chunk], d[i : i + chunk],
+                              None if n is None else n[i : i + chunk], None if f is None else f[i : i + chunk])
+            for k, v in out.items():
+                lists.setdefault(k, []).append(v)
+        return {k: torch.cat(v).view(H, W, -1) for k, v in lists.items()}

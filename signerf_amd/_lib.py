@@ -1,0 +1,136 @@
+"""ctypes binding of libsignerf_hip.so (the C ABI declared in include/signerf_hip.h).
+
+There is NO CPU fallback: if the library is missing or a call fails this module raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+SN_MAX_LEVELS = 16
+SN_MAX_PROPOSALS = 2
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libsignerf_hip.so")
+
+
+class SnHashMlpDesc(C.Structure):
+    _fields_ = [
+        ("num_levels", C.c_int32),
+        ("features_per_level", C.c_int32),
+        ("log2_hashmap_size", C.c_int32),
+        ("hidden_dim", C.c_int32),
+        ("num_layers", C.c_int32),
+        ("out_dim", C.c_int32),
+        ("scalings", C.c_float * SN_MAX_LEVELS),
+    ]
+
+
+class SnFieldDesc(C.Structure):
+    _fields_ = [
+        ("main_field", SnHashMlpDesc),
+        ("geo_feat_dim", C.c_int32),
+        ("hidden_dim_color", C.c_int32),
+        ("appearance_embed_dim", C.c_int32),
+        ("sh_levels", C.c_int32),
+        ("sh_remap", C.c_int32),
+        ("num_proposals", C.c_int32),
+        ("proposals", SnHashMlpDesc * SN_MAX_PROPOSALS),
+        ("average_init_density", C.c_float),
+        ("histogram_padding", C.c_float),
+    ]
+
+
+class SnRenderOpts(C.Structure):
+    _fields_ = [
+        ("num_proposal_iterations", C.c_int32),
+        ("num_proposal_samples", C.c_int32 * SN_MAX_PROPOSALS),
+        ("num_nerf_samples", C.c_int32),
+        ("near_plane", C.c_float),
+        ("far_plane", C.c_float),
+        ("chunk_rays", C.c_int32),
+        ("precision", C.c_int32),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_size_t),
+        ("initial_spacing_bins", C.c_void_p),
+        ("pdf_u", C.c_void_p * SN_MAX_PROPOSALS),
+    ]
+
+
+# name -> (restype, argtypes).  Must list every symbol include/signerf_hip.h declares
+# (tests/test_cabi.py checks the two against each other).
+_FP = C.c_void_p  # device pointer
+SIGNATURES = {
+    "sn_create": (C.c_int, [C.POINTER(SnFieldDesc), C.POINTER(C.c_void_p)]),
+    "sn_destroy": (C.c_int, [C.c_void_p]),
+    "sn_last_error": (C.c_char_p, [C.c_void_p]),
+    "sn_upload_weights": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sn_finalize_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sn_generate_rays": (C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32,
+                                   _FP, _FP, _FP, _FP, C.POINTER(C.c_float), _FP, _FP, C.c_void_p]),
+    "sn_intersect_with_aabb": (C.c_int, [_FP, _FP, C.c_int64, C.POINTER(C.c_float), _FP, _FP, C.c_void_p]),
+    "sn_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SnRenderOpts)]),
+    "sn_render_rays": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.POINTER(SnRenderOpts),
+                                 _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
+    "sn_hash_encode": (C.c_int, [C.c_void_p, C.c_int32, _FP, C.c_int64, _FP, _FP, C.c_void_p]),
+    "sn_field_forward": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, C.c_void_p]),
+    "sn_composite": (C.c_int, [_FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
+    "sn_pdf_sample": (C.c_int, [_FP, _FP, C.c_int64, C.c_int32, C.c_int32, _FP, C.c_float, _FP, _FP, C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+_lock = threading.Lock()
+
+
+class SignerfHipError(RuntimeError):
+    """Raised when the HIP library is missing or one of its entry points reports an error."""
+
+
+def load() -> C.CDLL:
+    """Loads libsignerf_hip.so (once).  Imports torch first so the process shares ONE HIP runtime."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        import torch  # noqa: F401  (loads torch/lib/libamdhip64.so before our library resolves it)
+
+        if not os.path.exists(LIB_PATH):
+            raise SignerfHipError(
+                f"{LIB_PATH} not found: build it with `python -m signerf_amd.build` (there is no CPU fallback)")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise SignerfHipError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(status: int, handle=None, what: str = "") -> None:
+    if status != 0:
+        lib = load()
+        msg = lib.sn_last_error(handle)
+        raise SignerfHipError(f"{what} failed (status {status}): {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> Optional[int]:
+    """Raw device pointer of a CUDA(HIP) fp32/int32 torch tensor (None passes NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SignerfHipError("tensor must live on the GPU (there is no CPU path)")
+    if not t.is_contiguous():
+        raise SignerfHipError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,91 @@
+"""Model configuration, field-for-field the subset of nerfstudio 1.0.2's ``NerfactoModelConfig`` that shapes an
+eval-mode render, plus the SIGNeRF overrides.
+
+Reference:
+  /root/reference/signerf/signerf.py:15-25          SIGNeRFModelConfig(NerfactoModelConfig)
+  /root/reference/signerf/signerf_config.py:31-36   eval_num_rays_per_chunk=1<<15, predict_normals=True, average_init_density=0.01
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Tuple, Type
+
+
+@dataclass
+class InstantiateConfig:
+    """nerfstudio's config idiom: ``config.setup(**kwargs)`` instantiates ``config._target(config, **kwargs)``."""
+
+    _target: Type = field(default=None, repr=False)
+
+    def setup(self, **kwargs) -> Any:
+        return self._target(self, **kwargs)
+
+
+def _default_proposal_args() -> List[Dict]:
+    return [
+        {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 128, "use_linear": False},
+        {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 256, "use_linear": False},
+    ]
+
+
+@dataclass
+class NerfactoModelConfig(InstantiateConfig):
+    """nerfacto defaults (A0)."""
+
+    _target: Type = field(default_factory=lambda: _nerfacto_model(), repr=False)
+    near_plane: float = 0.05
+    far_plane: float = 1000.0
+    background_color: str = "last_sample"
+    hidden_dim: int = 64
+    hidden_dim_color: int = 64
+    num_levels: int = 16
+    base_res: int = 16
+    max_res: int = 2048
+    log2_hashmap_size: int = 19
+    features_per_level: int = 2
+    num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96)
+    num_nerf_samples_per_ray: int = 48
+    num_proposal_iterations: int = 2
+    proposal_net_args_list: List[Dict] = field(default_factory=_default_proposal_args)
+    proposal_initial_sampler: str = "piecewise"
+    use_average_appearance_embedding: bool = True
+    appearance_embed_dim: int = 32
+    predict_normals: bool = False
+    disable_scene_contraction: bool = False
+    average_init_density: float = 1.0
+    eval_num_rays_per_chunk: int = 4096
+    implementation: str = "torch"
+    """Which nerfstudio semantics to reproduce: "torch" (the CPU-runnable fallback; the parity target).
+    Only affects the SH input convention (SURVEY.md A13)."""
+    num_train_data: int = 50
+    """Rows of the appearance embedding table (the new dataset's size; signerf_pipeline.py:110-111 drops the
+    trained table, so eval uses the mean of a freshly initialised one)."""
+    precision: str = "fp32"
+    """MFMA arithmetic of the tiny MLPs: "fp32" (exact) or "fp16x2" (hi+lo split, fp32 accumulate)."""
+
+
+@dataclass
+class SIGNeRFModelConfig(NerfactoModelConfig):
+    """signerf.py:15-25 + the values signerf_config.py:31-36 sets on it."""
+
+    _target: Type = field(default_factory=lambda: _signerf_model(), repr=False)
+    eval_num_rays_per_chunk: int = 1 << 15
+    predict_normals: bool = True
+    average_init_density: float = 0.01
+    use_lpips: bool = True
+    use_l1: bool = True
+    patch_size: int = 32
+    lpips_loss_mult: float = 1.0
+
+
+def _nerfacto_model():
+    from .nerfacto import NerfactoModel
+
+    return NerfactoModel
+
+
+def _signerf_model():
+    from .nerfacto import SIGNeRFModel
+
+    return SIGNeRFModel

@@ -1,0 +1,649 @@
+// sn_api.hip -- C ABI of libsignerf_hip.so (see include/signerf_hip.h for the contract and the
+// reference interfaces each entry point stands in for).  gfx950 only.
+#include "../../include/signerf_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "sn_device.h"
+#include "sn_main.h"
+#include "sn_proposal.h"
+#include "sn_stage.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+};
+
+}  // namespace
+
+struct SnContext {
+    SnFieldDesc desc;
+    int device = 0;
+    std::mutex mu;  // guards weights + error text only; render calls do not take it
+    std::string error;
+    std::map<std::string, std::vector<float>> host;  // small tensors (MLP layers, appearance mean)
+    DevBuf table_main;
+    DevBuf table_prop[SN_MAX_PROPOSALS];
+    DevBuf wimg_main;                   // SnMainImg
+    DevBuf wpack_prop[SN_MAX_PROPOSALS]; // SnPropPack
+    bool finalized = false;
+};
+
+namespace {
+
+int fail(SnHandle h, int code, const std::string& msg) {
+    if (h) {
+        std::lock_guard<std::mutex> g(h->mu);
+        h->error = msg;
+    } else {
+        g_create_error = msg;
+    }
+    return code;
+}
+
+#define SN_HIP(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) return fail(h, SN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+bool check_hashmlp(const SnHashMlpDesc& d, int levels, int hidden, int out, std::string& why) {
+    if (d.num_levels != levels) why = "num_levels must be " + std::to_string(levels);
+    else if (d.features_per_level != 2) why = "features_per_level must be 2";
+    else if (d.log2_hashmap_size < 4 || d.log2_hashmap_size > 24) why = "log2_hashmap_size out of range";
+    else if (d.hidden_dim != hidden) why = "hidden_dim must be " + std::to_string(hidden);
+    else if (d.num_layers != 2) why = "num_layers must be 2";
+    else if (d.out_dim != out) why = "out_dim must be " + std::to_string(out);
+    else return true;
+    return false;
+}
+
+inline int rho(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// Host-side construction of the LDS weight image consumed by sn_main_field_f32 (sn_main.h).
+// W1 [64,32], b1 [64]; W2 [16,64], b2 [16]; Wc1 [64,63], bc1 [64]; Wc2 [64,64], bc2; Wc3 [3,64], bc3 [3];
+// app [A] = mean appearance embedding (folded into the colour-layer-1 bias; A14).
+std::vector<float> build_main_image(const SnFieldDesc& d, const float* W1, const float* b1, const float* W2, const float* b2,
+                                    const float* Wc1, const float* bc1, const float* Wc2, const float* bc2, const float* Wc3,
+                                    const float* bc3, const float* app) {
+    std::vector<float> img(SnMainImg::TOTAL, 0.0f);
+    const int geo = d.geo_feat_dim;           // 15
+    const int sh = d.sh_levels * d.sh_levels;  // 16
+    const int cin = sh + geo + d.appearance_embed_dim;
+    auto put = [&](int base, int KS, int rt, int t, int lane, float v) {
+        img[base + ((rt * (KS / 4) + t / 4) * 64 + lane) * 4 + (t % 4)] = v;
+    };
+    // layer 1: slot (t,h) <-> feature 2t+h
+    for (int rt = 0; rt < 2; ++rt)
+        for (int t = 0; t < 16; ++t)
+            for (int lane = 0; lane < 64; ++lane) {
+                int row = rt * 32 + (lane & 31), h = lane >> 5;
+                put(SnMainImg::W1, 16, rt, t, lane, W1[row * 32 + 2 * t + h]);
+            }
+    // layer 2: 32 padded rows: 0 = h0, 1..15 = geo, 20 = h0 again (so that lanes 32-63 find their
+    // sample's density in their own half), rest zero.  slot (t = rt'*16 + r, h) <-> hidden rt'*32 + rho(r) + 4h
+    auto l2src = [&](int row) { return row < 16 ? row : (row == 20 ? 0 : -1); };
+    for (int t = 0; t < 32; ++t)
+        for (int lane = 0; lane < 64; ++lane) {
+            int row = lane & 31, h = lane >> 5, src = l2src(row);
+            int hid = (t / 16) * 32 + rho(t % 16) + 4 * h;
+            put(SnMainImg::W2, 32, 0, t, lane, src >= 0 ? W2[src * 64 + hid] : 0.0f);
+        }
+    // colour layer 1: k-steps 0..7 <- layer-2 rows rho(t)+4h (row 0 = h0 is not an input; rows 1..15 = geo 0..14
+    // = colour inputs sh+0 .. sh+14); k-steps 8..15 <- SH component 2(t-8)+h = colour input 2(t-8)+h
+    for (int rt = 0; rt < 2; ++rt)
+        for (int t = 0; t < 16; ++t)
+            for (int lane = 0; lane < 64; ++lane) {
+                int row = rt * 32 + (lane & 31), h = lane >> 5;
+                float v = 0.0f;
+                if (t < 8) {
+                    int l2row = rho(t) + 4 * h;
+                    if (l2row >= 1 && l2row <= geo) v = Wc1[row * cin + sh + (l2row - 1)];
+                } else {
+                    int s = 2 * (t - 8) + h;
+                    if (s < sh) v = Wc1[row * cin + s];
+                }
+                put(SnMainImg::WC1, 16, rt, t, lane, v);
+            }
+    // colour layer 2
+    for (int rt = 0; rt < 2; ++rt)
+        for (int t = 0; t < 32; ++t)
+            for (int lane = 0; lane < 64; ++lane) {
+                int row = rt * 32 + (lane & 31), h = lane >> 5;
+                int hid = (t / 16) * 32 + rho(t % 16) + 4 * h;
+                put(SnMainImg::WC2, 32, rt, t, lane, Wc2[row * 64 + hid]);
+            }
+    // bias images [rt][h][r] -> bias[rt*32 + rho(r) + 4h]
+    auto bias_img = [&](int base, int RT, auto&& f) {
+        for (int rt = 0; rt < RT; ++rt)
+            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 16; ++r) img[base + (rt * 2 + h) * 16 + r] = f(rt * 32 + rho(r) + 4 * h);
+    };
+    bias_img(SnMainImg::B1, 2, [&](int n) { return b1[n]; });
+    bias_img(SnMainImg::B2, 1, [&](int row) {
+        int src = l2src(row);
+        return src >= 0 ? b2[src] : 0.0f;
+    });
+    bias_img(SnMainImg::BC1, 2, [&](int n) {
+        float acc = bc1[n];
+        for (int a = 0; a < d.appearance_embed_dim; ++a) acc += Wc1[n * cin + sh + geo + a] * app[a];
+        return acc;
+    });
+    bias_img(SnMainImg::BC2, 2, [&](int n) { return bc2[n]; });
+    // colour layer 3 (VALU): [n][h][rt*16 + r] = Wc3[n][rt*32 + rho(r) + 4h]
+    for (int n = 0; n < 3; ++n)
+        for (int h = 0; h < 2; ++h)
+            for (int rt = 0; rt < 2; ++rt)
+                for (int r = 0; r < 16; ++r)
+                    img[SnMainImg::W3 + (n * 2 + h) * 32 + rt * 16 + r] = Wc3[n * 64 + rt * 32 + rho(r) + 4 * h];
+    for (int n = 0; n < 3; ++n) img[SnMainImg::B3 + n] = bc3[n];
+    return img;
+}
+
+const std::vector<float>* find(SnHandle h, const std::string& name, size_t count) {
+    auto it = h->host.find(name);
+    if (it == h->host.end() || it->second.size() != count) return nullptr;
+    return &it->second;
+}
+
+struct TileGeom {
+    int tw_log2, th_log2, tiles_x, tiles_y;
+};
+
+TileGeom tile_geometry(int height, int width) {
+    TileGeom g;
+    if (height >= 8) {
+        g.tw_log2 = 3;
+        g.th_log2 = 3;
+    } else {
+        g.tw_log2 = 6;
+        g.th_log2 = 0;
+    }
+    g.tiles_x = (width + (1 << g.tw_log2) - 1) >> g.tw_log2;
+    g.tiles_y = (height + (1 << g.th_log2) - 1) >> g.th_log2;
+    return g;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct WorkspacePlan {
+    size_t off_exp_raw, off_minmax, off_ebins, total;
+    int n_chunks;
+};
+
+WorkspacePlan plan_workspace(int height, int width, const SnRenderOpts& o) {
+    WorkspacePlan w;
+    const size_t n = (size_t)height * width;
+    const TileGeom g = tile_geometry(height, width);
+    size_t off = 0;
+    w.off_exp_raw = off;
+    off += align256(n * 4);
+    w.n_chunks = (int)((n + (size_t)o.chunk_rays - 1) / (size_t)o.chunk_rays);
+    w.off_minmax = off;
+    off += align256((size_t)w.n_chunks * 8);
+    w.off_ebins = off;
+    if (o.num_proposal_iterations > 0) off += align256((size_t)g.tiles_x * g.tiles_y * 64 * (o.num_nerf_samples + 1) * 4);
+    w.total = off;
+    return w;
+}
+
+bool valid_opts(const SnFieldDesc& d, const SnRenderOpts& o, std::string& why) {
+    if (o.num_proposal_iterations < 0 || o.num_proposal_iterations > d.num_proposals) why = "num_proposal_iterations exceeds the proposal nets of this handle";
+    else if (o.num_nerf_samples < 1 || o.num_nerf_samples > 1024) why = "num_nerf_samples out of range [1,1024]";
+    else if (o.chunk_rays < 1) why = "chunk_rays must be positive";
+    else if (o.precision != 0 && o.precision != 1) why = "precision must be 0 (fp32) or 1 (split fp16)";
+    else {
+        for (int i = 0; i < o.num_proposal_iterations; ++i)
+            if (o.num_proposal_samples[i] < 2 || o.num_proposal_samples[i] > SN_PROP_MAX_SAMPLES) {
+                why = "num_proposal_samples out of range [2," + std::to_string(SN_PROP_MAX_SAMPLES) + "]";
+                return false;
+            }
+        return true;
+    }
+    return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sn_create(const SnFieldDesc* desc, SnHandle* out) {
+    if (!desc || !out) return fail(nullptr, SN_ERR_INVALID, "sn_create: null argument");
+    std::string why;
+    if (!check_hashmlp(desc->main_field, 16, 64, 16, why)) return fail(nullptr, SN_ERR_INVALID, "main field: " + why);
+    if (desc->geo_feat_dim != 15 || desc->hidden_dim_color != 64 || desc->sh_levels != 4)
+        return fail(nullptr, SN_ERR_INVALID, "unsupported colour head: need geo_feat_dim 15, hidden_dim_color 64, sh_levels 4");
+    if (desc->appearance_embed_dim < 0 || desc->appearance_embed_dim > 256)
+        return fail(nullptr, SN_ERR_INVALID, "appearance_embed_dim out of range");
+    if (desc->num_proposals < 0 || desc->num_proposals > SN_MAX_PROPOSALS)
+        return fail(nullptr, SN_ERR_INVALID, "num_proposals out of range");
+    for (int i = 0; i < desc->num_proposals; ++i)
+        if (!check_hashmlp(desc->proposals[i], 5, 16, 1, why))
+            return fail(nullptr, SN_ERR_INVALID, "proposal net " + std::to_string(i) + ": " + why);
+    SnContext* c = new SnContext();
+    c->desc = *desc;
+    if (hipGetDevice(&c->device) != hipSuccess) {
+        delete c;
+        return fail(nullptr, SN_ERR_HIP, "hipGetDevice failed (no HIP device?)");
+    }
+    *out = c;
+    return SN_OK;
+}
+
+int sn_destroy(SnHandle h) {
+    if (!h) return SN_OK;
+    h->table_main.release();
+    h->wimg_main.release();
+    for (int i = 0; i < SN_MAX_PROPOSALS; ++i) {
+        h->table_prop[i].release();
+        h->wpack_prop[i].release();
+    }
+    delete h;
+    return SN_OK;
+}
+
+const char* sn_last_error(SnHandle h) {
+    if (!h) return g_create_error.c_str();
+    std::lock_guard<std::mutex> g(h->mu);
+    return h->error.c_str();
+}
+
+int sn_upload_weights(SnHandle h, const char* name, const void* data, size_t bytes, SnStream stream) {
+    if (!h || !name || !data) return fail(h, SN_ERR_INVALID, "sn_upload_weights: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const std::string n(name);
+    auto upload_table = [&](DevBuf& buf, const SnHashMlpDesc& d) -> int {
+        const size_t want = ((size_t)d.num_levels << d.log2_hashmap_size) * 2 * sizeof(float);
+        if (bytes != want) return fail(h, SN_ERR_INVALID, n + ": expected " + std::to_string(want) + " bytes, got " + std::to_string(bytes));
+        if (buf.bytes != want) {
+            buf.release();
+            SN_HIP(h, hipMalloc(&buf.ptr, want));
+            buf.bytes = want;
+        }
+        SN_HIP(h, hipMemcpyAsync(buf.ptr, data, want, hipMemcpyDefault, st));
+        SN_HIP(h, hipStreamSynchronize(st));
+        return SN_OK;
+    };
+    if (n == "field.mlp_base.encoder.hash_table") return upload_table(h->table_main, h->desc.main_field);
+    for (int i = 0; i < h->desc.num_proposals; ++i)
+        if (n == "proposal_networks." + std::to_string(i) + ".mlp_base.encoder.hash_table")
+            return upload_table(h->table_prop[i], h->desc.proposals[i]);
+    if (n.rfind("field.", 0) != 0 && n.rfind("proposal_networks.", 0) != 0)
+        return fail(h, SN_ERR_INVALID, "unknown parameter name: " + n);
+    if (bytes % sizeof(float) != 0 || bytes > (1u << 22)) return fail(h, SN_ERR_INVALID, n + ": bad size");
+    std::vector<float> v(bytes / sizeof(float));
+    SN_HIP(h, hipMemcpyAsync(v.data(), data, bytes, hipMemcpyDefault, st));
+    SN_HIP(h, hipStreamSynchronize(st));
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        h->host[n] = std::move(v);
+        h->finalized = false;
+    }
+    return SN_OK;
+}
+
+int sn_finalize_weights(SnHandle h, SnStream stream) {
+    if (!h) return SN_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const SnFieldDesc& d = h->desc;
+    if (!h->table_main.ptr) return fail(h, SN_ERR_STATE, "missing field.mlp_base.encoder.hash_table");
+    const int cin = d.sh_levels * d.sh_levels + d.geo_feat_dim + d.appearance_embed_dim;
+    struct Need {
+        const char* name;
+        size_t count;
+    };
+    const Need needs[] = {
+        {"field.mlp_base.mlp.layers.0.weight", 64 * 32}, {"field.mlp_base.mlp.layers.0.bias", 64},
+        {"field.mlp_base.mlp.layers.1.weight", 16 * 64}, {"field.mlp_base.mlp.layers.1.bias", 16},
+        {"field.mlp_head.layers.0.weight", (size_t)64 * cin}, {"field.mlp_head.layers.0.bias", 64},
+        {"field.mlp_head.layers.1.weight", 64 * 64}, {"field.mlp_head.layers.1.bias", 64},
+        {"field.mlp_head.layers.2.weight", 3 * 64}, {"field.mlp_head.layers.2.bias", 3},
+    };
+    const std::vector<float>* t[10];
+    for (int i = 0; i < 10; ++i) {
+        t[i] = find(h, needs[i].name, needs[i].count);
+        if (!t[i]) return fail(h, SN_ERR_STATE, std::string("missing or mis-sized parameter ") + needs[i].name);
+    }
+    std::vector<float> zero_app((size_t)d.appearance_embed_dim, 0.0f);
+    const std::vector<float>* app = &zero_app;
+    if (d.appearance_embed_dim > 0) {
+        app = find(h, "field.embedding_appearance.mean", (size_t)d.appearance_embed_dim);
+        if (!app) return fail(h, SN_ERR_STATE, "missing field.embedding_appearance.mean");
+    }
+    std::vector<float> img = build_main_image(d, t[0]->data(), t[1]->data(), t[2]->data(), t[3]->data(), t[4]->data(), t[5]->data(),
+                                              t[6]->data(), t[7]->data(), t[8]->data(), t[9]->data(), app->data());
+    if (!h->wimg_main.ptr) {
+        SN_HIP(h, hipMalloc(&h->wimg_main.ptr, img.size() * 4));
+        h->wimg_main.bytes = img.size() * 4;
+    }
+    SN_HIP(h, hipMemcpyAsync(h->wimg_main.ptr, img.data(), img.size() * 4, hipMemcpyHostToDevice, st));
+    for (int i = 0; i < d.num_proposals; ++i) {
+        const std::string pre = "proposal_networks." + std::to_string(i) + ".mlp_base.";
+        if (!h->table_prop[i].ptr) return fail(h, SN_ERR_STATE, "missing " + pre + "encoder.hash_table");
+        const std::vector<float>* w0 = find(h, pre + "mlp.layers.0.weight", 16 * 10);
+        const std::vector<float>* b0 = find(h, pre + "mlp.layers.0.bias", 16);
+        const std::vector<float>* w1 = find(h, pre + "mlp.layers.1.weight", 16);
+        const std::vector<float>* b1 = find(h, pre + "mlp.layers.1.bias", 1);
+        if (!w0 || !b0 || !w1 || !b1) return fail(h, SN_ERR_STATE, "missing or mis-sized MLP parameter under " + pre);
+        std::vector<float> pack(SN_PROP_PACK_FLOATS, 0.0f);
+        memcpy(pack.data() + SN_PROP_W0, w0->data(), 160 * 4);
+        memcpy(pack.data() + SN_PROP_B0, b0->data(), 16 * 4);
+        memcpy(pack.data() + SN_PROP_W1, w1->data(), 16 * 4);
+        pack[SN_PROP_B1] = (*b1)[0];
+        if (!h->wpack_prop[i].ptr) {
+            SN_HIP(h, hipMalloc(&h->wpack_prop[i].ptr, pack.size() * 4));
+            h->wpack_prop[i].bytes = pack.size() * 4;
+        }
+        SN_HIP(h, hipMemcpyAsync(h->wpack_prop[i].ptr, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, st));
+    }
+    SN_HIP(h, hipStreamSynchronize(st));
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        h->finalized = true;
+    }
+    return SN_OK;
+}
+
+int sn_generate_rays(const float* c2w, float fx, float fy, float cx, float cy, int32_t height, int32_t width, float* origins,
+                     float* directions, float* pixel_area, float* directions_norm, const float* aabb, float* nears, float* fars,
+                     SnStream stream) {
+    if (!c2w || height <= 0 || width <= 0) return fail(nullptr, SN_ERR_INVALID, "sn_generate_rays: bad argument");
+    SnRayGenParams p;
+    memcpy(p.c2w, c2w, sizeof(p.c2w));
+    p.fx = fx;
+    p.fy = fy;
+    p.cx = cx;
+    p.cy = cy;
+    p.height = height;
+    p.width = width;
+    p.origins = origins;
+    p.directions = directions;
+    p.pixel_area = pixel_area;
+    p.directions_norm = directions_norm;
+    p.has_aabb = aabb != nullptr;
+    if (aabb) memcpy(p.aabb, aabb, sizeof(p.aabb));
+    else memset(p.aabb, 0, sizeof(p.aabb));
+    p.nears = nears;
+    p.fars = fars;
+    const int64_t n = (int64_t)height * width;
+    hipLaunchKernelGGL(sn_generate_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_generate_rays launch: ") + hipGetErrorString(e));
+    return SN_OK;
+}
+
+int sn_intersect_with_aabb(const float* origins, const float* directions, int64_t n_rays, const float* aabb, float* nears,
+                           float* fars, SnStream stream) {
+    if (!origins || !directions || !aabb || !nears || !fars || n_rays < 0)
+        return fail(nullptr, SN_ERR_INVALID, "sn_intersect_with_aabb: bad argument");
+    if (n_rays == 0) return SN_OK;
+    SnAabb box;
+    memcpy(box.v, aabb, sizeof(box.v));
+    hipLaunchKernelGGL(sn_intersect_with_aabb_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       origins, directions, n_rays, box, nears, fars);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_intersect_with_aabb launch: ") + hipGetErrorString(e));
+    return SN_OK;
+}
+
+size_t sn_workspace_bytes(SnHandle h, int32_t height, int32_t width, const SnRenderOpts* opts) {
+    if (!h || !opts || height <= 0 || width <= 0 || opts->chunk_rays < 1) return 0;
+    return plan_workspace(height, width, *opts).total;
+}
+
+int sn_render_rays(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars, int32_t height,
+                   int32_t width, const SnRenderOpts* opts, float* rgb, float* depth, float* accumulation, float* expected_depth,
+                   float* prop_depth_0, float* prop_depth_1, SnStream stream) {
+    if (!h) return SN_ERR_INVALID;
+    if (!origins || !directions || !opts || height <= 0 || width <= 0) return fail(h, SN_ERR_INVALID, "sn_render_rays: bad argument");
+    if ((nears == nullptr) != (fars == nullptr)) return fail(h, SN_ERR_INVALID, "sn_render_rays: nears and fars must both be given or both be NULL");
+    if (!h->finalized) return fail(h, SN_ERR_STATE, "sn_render_rays: weights not finalized");
+    std::string why;
+    if (!valid_opts(h->desc, *opts, why)) return fail(h, SN_ERR_INVALID, "sn_render_rays: " + why);
+    if (opts->precision != 0) return fail(h, SN_ERR_INVALID, "sn_render_rays: precision 1 (split fp16) is not built yet");
+    const WorkspacePlan wp = plan_workspace(height, width, *opts);
+    if (!opts->workspace || opts->workspace_bytes < wp.total)
+        return fail(h, SN_ERR_WORKSPACE, "sn_render_rays: workspace too small, need " + std::to_string(wp.total) + " bytes");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)opts->workspace;
+    const SnFieldDesc& d = h->desc;
+    const TileGeom g = tile_geometry(height, width);
+    const int64_t n = (int64_t)height * width;
+    const int nprop = opts->num_proposal_iterations;
+
+    const float* d_sbins = opts->initial_spacing_bins;  // null => kernels fall back to i/N
+    uint32_t* d_minmax = nullptr;
+    float* d_exp_raw = nullptr;
+    if (expected_depth) {
+        d_minmax = (uint32_t*)(ws + wp.off_minmax);
+        d_exp_raw = (float*)(ws + wp.off_exp_raw);
+        SN_HIP(h, hipMemsetAsync(d_minmax, 0xff, (size_t)wp.n_chunks * 4, st));
+        SN_HIP(h, hipMemsetAsync(d_minmax + wp.n_chunks, 0x00, (size_t)wp.n_chunks * 4, st));
+    }
+
+    float* d_ebins = nullptr;
+    if (nprop > 0) {
+        d_ebins = (float*)(ws + wp.off_ebins);
+        SnPropParams pp;
+        memset(&pp, 0, sizeof(pp));
+        pp.origins = origins;
+        pp.directions = directions;
+        pp.nears = nears;
+        pp.fars = fars;
+        pp.sbins0 = d_sbins;
+        for (int i = 0; i < SN_MAX_PROPOSALS; ++i) pp.pdf_u[i] = opts->pdf_u[i];
+        pp.ebins_out = d_ebins;
+        pp.prop_depth[0] = prop_depth_0;
+        pp.prop_depth[1] = prop_depth_1;
+        pp.height = height;
+        pp.width = width;
+        pp.tile_w_log2 = g.tw_log2;
+        pp.tile_h_log2 = g.th_log2;
+        pp.tiles_x = g.tiles_x;
+        pp.tiles_y = g.tiles_y;
+        pp.n_levels = nprop;
+        for (int i = 0; i < nprop; ++i) {
+            pp.table[i] = (const float*)h->table_prop[i].ptr;
+            pp.wpack[i] = (const float*)h->wpack_prop[i].ptr;
+            pp.log2_t[i] = d.proposals[i].log2_hashmap_size;
+            for (int l = 0; l < 5; ++l) pp.scal[i][l] = d.proposals[i].scalings[l];
+            pp.n_samples[i] = opts->num_proposal_samples[i];
+        }
+        pp.n_final = opts->num_nerf_samples;
+        pp.near_plane = opts->near_plane;
+        pp.far_plane = opts->far_plane;
+        pp.avg_density = d.average_init_density;
+        pp.hist_pad = d.histogram_padding;
+        const int ntiles = g.tiles_x * g.tiles_y;
+        hipLaunchKernelGGL(sn_proposal_kernel, dim3((unsigned)((ntiles + SN_PROP_WAVES - 1) / SN_PROP_WAVES)), dim3(64 * SN_PROP_WAVES), 0, st, pp);
+        SN_HIP(h, hipGetLastError());
+    }
+
+    SnMainParams p;
+    memset(&p, 0, sizeof(p));
+    p.origins = origins;
+    p.directions = directions;
+    p.nears = nears;
+    p.fars = fars;
+    p.sbins = d_sbins;
+    p.ebins = d_ebins;
+    p.table = (const float*)h->table_main.ptr;
+    p.wimg = (const float*)h->wimg_main.ptr;
+    p.rgb = rgb;
+    p.depth = depth;
+    p.acc = accumulation;
+    p.exp_raw = d_exp_raw;
+    p.chunk_minmax = d_minmax;
+    p.n_chunks = wp.n_chunks;
+    for (int l = 0; l < 16; ++l) p.scal[l] = d.main_field.scalings[l];
+    p.height = height;
+    p.width = width;
+    p.n_samples = opts->num_nerf_samples;
+    p.tile_w_log2 = g.tw_log2;
+    p.tile_h_log2 = g.th_log2;
+    p.tiles_x = g.tiles_x;
+    p.tiles_y = g.tiles_y;
+    p.log2_t = d.main_field.log2_hashmap_size;
+    p.near_plane = opts->near_plane;
+    p.far_plane = opts->far_plane;
+    p.avg_density = d.average_init_density;
+    p.sh_remap = d.sh_remap;
+    p.chunk_rays = opts->chunk_rays;
+    const int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
+    const size_t lds_bytes = (size_t)SnMainImg::TOTAL * 4;
+    if (nprop > 0)
+        hipLaunchKernelGGL(sn_render_main_kernel<1>, dim3((unsigned)(gbx * gby)), dim3(256), lds_bytes, st, p);
+    else
+        hipLaunchKernelGGL(sn_render_main_kernel<0>, dim3((unsigned)(gbx * gby)), dim3(256), lds_bytes, st, p);
+    SN_HIP(h, hipGetLastError());
+    if (expected_depth) {
+        hipLaunchKernelGGL(sn_clip_expected_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_exp_raw, d_minmax, n,
+                           opts->chunk_rays, wp.n_chunks, expected_depth);
+        SN_HIP(h, hipGetLastError());
+    }
+    return SN_OK;
+}
+
+int sn_hash_encode(SnHandle h, int32_t which, const float* q, int64_t n, float* features, int32_t* indices, SnStream stream) {
+    if (!h) return SN_ERR_INVALID;
+    if (!q || !features || n < 0) return fail(h, SN_ERR_INVALID, "sn_hash_encode: bad argument");
+    if (which < -1 || which >= h->desc.num_proposals) return fail(h, SN_ERR_INVALID, "sn_hash_encode: bad field selector");
+    const SnHashMlpDesc& d = which < 0 ? h->desc.main_field : h->desc.proposals[which];
+    const DevBuf& tb = which < 0 ? h->table_main : h->table_prop[which];
+    if (!tb.ptr) return fail(h, SN_ERR_STATE, "sn_hash_encode: hash table not uploaded");
+    if (n == 0) return SN_OK;
+    SnHashStageParams p;
+    p.q = q;
+    p.n = n;
+    p.table = (const float*)tb.ptr;
+    for (int l = 0; l < 16; ++l) p.scal[l] = l < d.num_levels ? d.scalings[l] : 0.0f;
+    p.num_levels = d.num_levels;
+    p.log2_t = d.log2_hashmap_size;
+    p.features = features;
+    p.indices = indices;
+    hipLaunchKernelGGL(sn_hash_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    SN_HIP(h, hipGetLastError());
+    return SN_OK;
+}
+
+int sn_field_forward(SnHandle h, int32_t which, const float* positions, const float* directions, int64_t n, int32_t precision,
+                     float* density, float* rgb, SnStream stream) {
+    if (!h) return SN_ERR_INVALID;
+    if (!positions || !density || n < 0) return fail(h, SN_ERR_INVALID, "sn_field_forward: bad argument");
+    if (which < -1 || which >= h->desc.num_proposals) return fail(h, SN_ERR_INVALID, "sn_field_forward: bad field selector");
+    if (!h->finalized) return fail(h, SN_ERR_STATE, "sn_field_forward: weights not finalized");
+    if (precision != 0) return fail(h, SN_ERR_INVALID, "sn_field_forward: precision 1 (split fp16) is not built yet");
+    if (n == 0) return SN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (which < 0) {
+        SnFieldStageParams p;
+        p.positions = positions;
+        p.directions = directions;
+        p.n = n;
+        p.table = (const float*)h->table_main.ptr;
+        p.wimg = (const float*)h->wimg_main.ptr;
+        for (int l = 0; l < 16; ++l) p.scal[l] = h->desc.main_field.scalings[l];
+        p.log2_t = h->desc.main_field.log2_hashmap_size;
+        p.avg_density = h->desc.average_init_density;
+        p.sh_remap = h->desc.sh_remap;
+        p.density = density;
+        p.rgb = rgb;
+        hipLaunchKernelGGL(sn_main_field_stage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)SnMainImg::TOTAL * 4, st, p);
+    } else {
+        SnPropStageParams p;
+        p.positions = positions;
+        p.n = n;
+        p.table = (const float*)h->table_prop[which].ptr;
+        p.wpack = (const float*)h->wpack_prop[which].ptr;
+        for (int l = 0; l < 5; ++l) p.scal[l] = h->desc.proposals[which].scalings[l];
+        p.log2_t = h->desc.proposals[which].log2_hashmap_size;
+        p.avg_density = h->desc.average_init_density;
+        p.density = density;
+        hipLaunchKernelGGL(sn_prop_field_stage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    }
+    SN_HIP(h, hipGetLastError());
+    return SN_OK;
+}
+
+int sn_composite(const float* euclid_bins, const float* density, const float* rgb_samples, int64_t n_rays, int32_t n_samples,
+                 float* weights, float* rgb, float* depth, int32_t* median_index, float* accumulation, float* expected_depth,
+                 SnStream stream) {
+    if (!euclid_bins || !density || !rgb_samples || n_rays < 0 || n_samples < 1)
+        return fail(nullptr, SN_ERR_INVALID, "sn_composite: bad argument");
+    if (n_rays == 0) return SN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    SnCompositeStageParams p;
+    p.bins = euclid_bins;
+    p.density = density;
+    p.rgb_s = rgb_samples;
+    p.n_rays = n_rays;
+    p.n_samples = n_samples;
+    p.weights = weights;
+    p.rgb = rgb;
+    p.depth = depth;
+    p.median_index = median_index;
+    p.acc = accumulation;
+    p.exp_raw = nullptr;
+    p.minmax = nullptr;
+    uint32_t* mm = nullptr;
+    if (expected_depth) {
+        // expected_depth doubles as the raw buffer; min/max live in a small stream-ordered allocation
+        if (hipMallocAsync((void**)&mm, 8, st) != hipSuccess) return fail(nullptr, SN_ERR_HIP, "sn_composite: hipMallocAsync failed");
+        if (hipMemsetAsync(mm, 0xff, 4, st) != hipSuccess || hipMemsetAsync(mm + 1, 0x00, 4, st) != hipSuccess)
+            return fail(nullptr, SN_ERR_HIP, "sn_composite: memset failed");
+        p.exp_raw = expected_depth;
+        p.minmax = mm;
+    }
+    hipLaunchKernelGGL(sn_composite_kernel, dim3((unsigned)((n_rays + 127) / 128)), dim3(128), 0, st, p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && expected_depth) {
+        hipLaunchKernelGGL(sn_clip_expected_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, expected_depth, mm, n_rays,
+                           0x7fffffff, 1, expected_depth);
+        e = hipGetLastError();
+        (void)hipFreeAsync(mm, st);
+    }
+    if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_composite launch: ") + hipGetErrorString(e));
+    return SN_OK;
+}
+
+int sn_pdf_sample(const float* spacing_bins, const float* weights, int64_t n_rays, int32_t n_in, int32_t n_out, const float* u,
+                  float histogram_padding, float* new_bins, int32_t* inds, SnStream stream) {
+    if (!spacing_bins || !weights || !u || !new_bins || n_rays < 0 || n_in < 1 || n_in > SN_PROP_MAX_SAMPLES || n_out < 1 ||
+        n_out > SN_PROP_MAX_SAMPLES)
+        return fail(nullptr, SN_ERR_INVALID, "sn_pdf_sample: bad argument");
+    if (n_rays == 0) return SN_OK;
+    SnPdfStageParams p;
+    p.sbins = spacing_bins;
+    p.weights = weights;
+    p.n_rays = n_rays;
+    p.n_in = n_in;
+    p.n_out = n_out;
+    p.u = u;
+    p.hist_pad = histogram_padding;
+    p.new_bins = new_bins;
+    p.inds = inds;
+    hipLaunchKernelGGL(sn_pdf_stage_kernel, dim3((unsigned)((n_rays + SN_PROP_WAVES - 1) / SN_PROP_WAVES)), dim3(64 * SN_PROP_WAVES), 0,
+                       (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_pdf_sample launch: ") + hipGetErrorString(e));
+    return SN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+// sn_device.h -- device-side building blocks shared by the fused render kernels and the
+// stage-level kernels (gfx950 / CDNA4 only).
+//
+// Numerics contract (DESIGN.md "Numerics"):
+//   * everything that decides an INTEGER (hash-grid corner coordinates, table rows, searchsorted
+//     and median indices) is computed with un-fused IEEE fp32 ops in the operand order of the
+//     reference's torch-CPU path, so the integers are bit-identical given bit-identical inputs;
+//   * wherever torch-CPU uses cumsum (which accumulates fp32 data in fp64 and rounds each prefix
+//     to fp32) we accumulate in fp64 as well;
+//   * the remaining fp32 work (trilinear blend, MLPs, sums) is free to use FMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SN_DEV __device__ __forceinline__
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------
+// strict (no-FMA) helpers
+// ------------------------------------------------------------------------------------------
+
+// s(x) of UniformLinDispPiecewiseSampler
+SN_DEV float sn_spacing(float x) {
+#pragma clang fp contract(off)
+    return x < 1.0f ? x / 2.0f : 1.0f - 1.0f / (2.0f * x);
+}
+
+// s^-1(y)
+SN_DEV float sn_spacing_inv(float x) {
+#pragma clang fp contract(off)
+    return x < 0.5f ? 2.0f * x : 1.0f / (2.0f - 2.0f * x);
+}
+
+// spacing bin -> euclidean distance along the ray: s^-1(b * s_far + (1 - b) * s_near)
+SN_DEV float sn_euclid(float b, float s_near, float s_far) {
+#pragma clang fp contract(off)
+    float x = b * s_far + (1.0f - b) * s_near;
+    return sn_spacing_inv(x);
+}
+
+// Frustums.get_positions + SceneContraction(inf) + (p+2)/4 + selector (A5, A6).
+// Returns q (already multiplied by the selector) and the selector.
+SN_DEV bool sn_sample_q(const float o[3], const float d[3], float start, float end, float q[3]) {
+#pragma clang fp contract(off)
+    float t = start + end;
+    float p[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = o[c] + (d[c] * t) / 2.0f;
+    float mag = fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2]));
+    if (!(mag < 1.0f)) {
+        float k = 2.0f - (1.0f / mag);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[c] = k * (p[c] / mag);
+    }
+    bool sel = true;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        q[c] = (p[c] + 2.0f) / 4.0f;
+        sel = sel && (q[c] > 0.0f) && (q[c] < 1.0f);
+    }
+    float m = sel ? 1.0f : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[c] = q[c] * m;
+    return sel;
+}
+
+// Same, from a world position (stage-level field_forward).
+SN_DEV bool sn_position_q(const float pin[3], float q[3]) {
+#pragma clang fp contract(off)
+    float p[3] = {pin[0], pin[1], pin[2]};
+    float mag = fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2]));
+    if (!(mag < 1.0f)) {
+        float k = 2.0f - (1.0f / mag);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[c] = k * (p[c] / mag);
+    }
+    bool sel = true;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        q[c] = (p[c] + 2.0f) / 4.0f;
+        sel = sel && (q[c] > 0.0f) && (q[c] < 1.0f);
+    }
+    float m = sel ? 1.0f : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[c] = q[c] * m;
+    return sel;
+}
+
+// ------------------------------------------------------------------------------------------
+// hash grid (A7, torch path): every level hashed, corners ceil/floor, primes (1, 2654435761, 805459861)
+// ------------------------------------------------------------------------------------------
+
+struct SnHashLevel {
+    uint32_t row[8];  // table row within the level (before the level offset), nerfstudio corner order
+    float off[3];     // scaled - floor(scaled)
+};
+
+// Integer part.  uint32 wrap-around arithmetic equals the reference's int64 products followed by
+// `% 2**k` because only the low k <= 32 bits survive and coordinates are non-negative.
+SN_DEV void sn_hash_corners(const float q[3], float scale, uint32_t mask, SnHashLevel& hl) {
+#pragma clang fp contract(off)
+    uint32_t f[3], c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float x = q[a] * scale;
+        float fl = floorf(x);
+        hl.off[a] = x - fl;
+        f[a] = (uint32_t)(int)fl;
+        c[a] = (uint32_t)(int)ceilf(x);
+    }
+    const uint32_t P1 = 2654435761u, P2 = 805459861u;
+    uint32_t yf = f[1] * P1, yc = c[1] * P1, zf = f[2] * P2, zc = c[2] * P2;
+    // order: 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf
+    hl.row[0] = (c[0] ^ yc ^ zc) & mask;
+    hl.row[1] = (c[0] ^ yf ^ zc) & mask;
+    hl.row[2] = (f[0] ^ yf ^ zc) & mask;
+    hl.row[3] = (f[0] ^ yc ^ zc) & mask;
+    hl.row[4] = (c[0] ^ yc ^ zf) & mask;
+    hl.row[5] = (c[0] ^ yf ^ zf) & mask;
+    hl.row[6] = (f[0] ^ yf ^ zf) & mask;
+    hl.row[7] = (f[0] ^ yc ^ zf) & mask;
+}
+
+// Trilinear blend in the reference's association (x, then y, then z); FMA allowed.
+SN_DEV f32x2 sn_hash_blend(const f32x2 v[8], const float off[3]) {
+    float ox = off[0], oy = off[1], oz = off[2];
+    float nx = 1.0f - ox, ny = 1.0f - oy, nz = 1.0f - oz;
+    f32x2 f03 = v[0] * ox + v[3] * nx;
+    f32x2 f12 = v[1] * ox + v[2] * nx;
+    f32x2 f56 = v[5] * ox + v[6] * nx;
+    f32x2 f47 = v[4] * ox + v[7] * nx;
+    f32x2 f0312 = f03 * oy + f12 * ny;
+    f32x2 f4756 = f47 * oy + f56 * ny;
+    return f0312 * oz + f4756 * nz;
+}
+
+// Buffer resource over a hash table (base must be wave-uniform: a kernel argument).
+SN_DEV __amdgpu_buffer_rsrc_t sn_table_rsrc(const float* table, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, (int)bytes, 0x00020000);
+}
+
+SN_DEV f32x2 sn_table_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, uint32_t level_off_bytes) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)byte_off, (int)level_off_bytes, 0);
+    f32x2 o;
+    o.x = __uint_as_float(r.x);
+    o.y = __uint_as_float(r.y);
+    return o;
+}
+
+// Encode one point over L levels -> feat[2L], level-major.  `scal` must be wave-uniform.
+template <int L>
+SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], float* feat) {
+    const uint32_t mask = (1u << log2_t) - 1u;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        SnHashLevel hl;
+        sn_hash_corners(q, scal[l], mask, hl);
+        const uint32_t lvl = ((uint32_t)l << log2_t) * 8u;
+        f32x2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = sn_table_load(rsrc, hl.row[k] * 8u, lvl);
+        f32x2 e = sn_hash_blend(v, hl.off);
+        feat[2 * l] = e.x;
+        feat[2 * l + 1] = e.y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// SH basis, degree 4 (A13)
+// ------------------------------------------------------------------------------------------
+SN_DEV void sn_sh16(float x, float y, float z, float* c) {
+    float xx = x * x, yy = y * y, zz = z * z;
+    c[0] = 0.28209479177387814f;
+    c[1] = 0.4886025119029199f * y;
+    c[2] = 0.4886025119029199f * z;
+    c[3] = 0.4886025119029199f * x;
+    c[4] = 1.0925484305920792f * x * y;
+    c[5] = 1.0925484305920792f * y * z;
+    c[6] = 0.9461746957575601f * zz - 0.31539156525251999f;
+    c[7] = 1.0925484305920792f * x * z;
+    c[8] = 0.5462742152960396f * (xx - yy);
+    c[9] = 0.5900435899266435f * y * (3.0f * xx - yy);
+    c[10] = 2.890611442640554f * x * y * z;
+    c[11] = 0.4570457994644658f * y * (5.0f * zz - 1.0f);
+    c[12] = 0.3731763325901154f * z * (5.0f * zz - 3.0f);
+    c[13] = 0.4570457994644658f * x * (5.0f * zz - 1.0f);
+    c[14] = 1.445305721320277f * z * (xx - yy);
+    c[15] = 0.5900435899266435f * x * (xx - 3.0f * yy);
+}
+
+// direction -> the 16 SH inputs the colour MLP sees.  remap 0: basis evaluated on (d+1)/2 (torch
+// fallback); remap 1: on ((d+1)/2)*2-1 (tinycudann).
+SN_DEV void sn_direction_encoding(const float d[3], int remap, float* c) {
+    float e[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        e[a] = (d[a] + 1.0f) / 2.0f;
+        if (remap) e[a] = e[a] * 2.0f - 1.0f;
+    }
+    sn_sh16(e[0], e[1], e[2], c);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-ray compositing state (A10 + A17), one ray per lane, samples visited front to back
+// ------------------------------------------------------------------------------------------
+struct SnComposite {
+    double cum_tau;   // cumsum(delta*density) -- torch-CPU cumsum accumulates fp32 data in fp64
+    double cum_w;     // cumsum(weights) for the median search
+    float sum_w;      // accumulation
+    float sum_wd;     // sum(w * mid) for the expected depth
+    float c[3];       // sum(w * rgb)
+    float median;     // mid-point of the first sample with cum_w >= 0.5
+    int median_idx;
+    bool found;
+
+    SN_DEV void init() {
+        cum_tau = 0.0;
+        cum_w = 0.0;
+        sum_w = 0.f;
+        sum_wd = 0.f;
+        c[0] = c[1] = c[2] = 0.f;
+        median = 0.f;
+        median_idx = 0;
+        found = false;
+    }
+
+    // One sample.  Returns the weight.
+    SN_DEV float step(int i, float start, float end, float density, float r, float g, float b) {
+        float w, mid;
+        {
+#pragma clang fp contract(off)
+            float delta = end - start;
+            float tau = delta * density;
+            float alpha = 1.0f - expf(-tau);
+            float trans = expf(-(float)cum_tau);
+            w = alpha * trans;
+            if (w != w) w = 0.0f;  // nan_to_num
+            cum_tau += (double)tau;
+            mid = (start + end) / 2.0f;
+            cum_w += (double)w;
+        }
+        if (!found && (float)cum_w >= 0.5f) {
+            found = true;
+            median = mid;
+            median_idx = i;
+        }
+        sum_w += w;
+        sum_wd += w * mid;
+        c[0] += w * r;
+        c[1] += w * g;
+        c[2] += w * b;
+        return w;
+    }
+
+    // After the last sample (index n-1, mid-point last_mid, colour r,g,b = 'last_sample' background).
+    SN_DEV void finish(int n, float last_mid, float r, float g, float b, float out_rgb[3], float& depth, float& acc, float& exp_raw) {
+        if (!found) {
+            median = last_mid;
+            median_idx = n - 1;
+        }
+        float bgw = 1.0f - sum_w;
+        out_rgb[0] = fminf(fmaxf(c[0] + r * bgw, 0.0f), 1.0f);
+        out_rgb[1] = fminf(fmaxf(c[1] + g * bgw, 0.0f), 1.0f);
+        out_rgb[2] = fminf(fmaxf(c[2] + b * bgw, 0.0f), 1.0f);
+        depth = median;
+        acc = sum_w;
+        exp_raw = sum_wd / (sum_w + 1e-10f);
+    }
+};
+
+// order-preserving float <-> uint map for atomicMin/atomicMax on floats
+SN_DEV uint32_t sn_float_ordered(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+SN_DEV float sn_ordered_float(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// Exchange halves: afterwards a = [lanes 0-31: own a | lanes 32-63: lower partner's b],
+//                              b = [lanes 0-31: upper partner's a | lanes 32-63: own b].
+SN_DEV void sn_swap_halves(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}

@@ -1,0 +1,307 @@
+// sn_main.h -- the fused main-field render kernel (rows a13-a17 of SURVEY.md §8(a)).
+//
+// Mapping (DESIGN.md "Kernel K1"):
+//   lane  = one ray; wave = an 8x8 pixel tile (64 rays); workgroup = 2x2 tiles (256 threads).
+//   Every wave marches its 64 rays front to back, ONE sample per lane per step.  At each step
+//     1. each lane hash-encodes its own sample (16 levels x 8 gathers of 8 B; neighbouring
+//        pixels at equal depth share voxels, so the wave's 64 addresses per gather collapse to a
+//        few cache lines at fine levels and to 1-8 at coarse levels),
+//     2. the wave evaluates the density MLP (32->64->16) and the colour MLP (16 SH + 15 geo
+//        [+ folded appearance bias] ->64->64->3) on the matrix cores.  Weights are the MFMA A
+//        operand (read from an LDS image), activations the B operand (column = sample = lane&31),
+//        so the C/D layout of one layer IS the B layout of the next: layers chain in registers
+//        with no LDS round trip and no cross-lane traffic except one permlane32_swap per input
+//        register of the first layer,
+//     3. each lane composites its own ray (transmittance, rgb, accumulation, median / expected
+//        depth) -- no scan is needed because depth order is the loop order.
+//
+// MFMA layout facts used (cdna_hip_programming.md §3):
+//   v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31]
+//   A "k-slot" (t, h) of a layer = k-step t, lane half h.  rho(r) = (r&3)+8*(r>>2).
+#pragma once
+#include "sn_device.h"
+
+// LDS weight image of the main field, float offsets.  Built on the host by sn_api.hip
+// (build_main_image) -- keep the two in sync.
+struct SnMainImg {
+    static constexpr int W1 = 0;        // [rt=2][t4=4][lane=64][4]   32 -> 64
+    static constexpr int W2 = 2048;     // [rt=1][t4=8][64][4]        64 -> 32 rows (16 real + dup)
+    static constexpr int WC1 = 4096;    // [rt=2][t4=4][64][4]        (16 L2-rows + 16 SH) -> 64
+    static constexpr int WC2 = 6144;    // [rt=2][t4=8][64][4]        64 -> 64
+    static constexpr int B1 = 10240;    // [rt=2][h=2][16]
+    static constexpr int B2 = 10304;    // [1][2][16]
+    static constexpr int BC1 = 10336;   // [2][2][16]
+    static constexpr int BC2 = 10400;   // [2][2][16]
+    static constexpr int W3 = 10464;    // [n=3][h=2][32]
+    static constexpr int B3 = 10656;    // [4]
+    static constexpr int TOTAL = 10660; // floats (multiple of 4)
+};
+
+// acc[rt] (tile 0) / acc[rt] (tile 1) <- bias + W . op     (exact fp32 MFMA)
+template <int RT, int KS>
+SN_DEV void sn_mlp_layer_f32(const float* __restrict__ wimg, const float* __restrict__ bimg, const float* op0,
+                             const float* op1, f32x16* acc0, f32x16* acc1, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const f32x4* b = (const f32x4*)(bimg + (rt * 2 + h) * 16);
+        f32x4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+        f32x16 v = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+        acc0[rt] = v;
+        acc1[rt] = v;
+    }
+#pragma unroll
+    for (int t4 = 0; t4 < KS / 4; ++t4) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            f32x4 a = *(const f32x4*)(wimg + ((rt * (KS / 4) + t4) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], op0[4 * t4 + e], acc0[rt], 0, 0, 0);
+                acc1[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], op1[4 * t4 + e], acc1[rt], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// Per-ray direction operands: 8 k-steps x 2 tiles.
+struct SnShOps {
+    float t0[8], t1[8];
+    SN_DEV void build(const float d[3], int remap) {
+        float c[16];
+        sn_direction_encoding(d, remap, c);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float a = c[2 * u], b = c[2 * u + 1];
+            sn_swap_halves(a, b);
+            t0[u] = a;
+            t1[u] = b;
+        }
+    }
+};
+
+// Full main-field evaluation of the wave's 64 samples.  feat[32]: this lane's own hash features.
+// Returns this lane's own pre-activation density h0 and post-sigmoid rgb.
+SN_DEV void sn_main_field_f32(const float* __restrict__ lds, float* feat, const SnShOps& sh, int lane, float& h0, float rgb[3]) {
+    const bool upper = lane >= 32;
+    // ---- layer 1: 32 -> 64, ReLU ---------------------------------------------------------
+    float op0[32], op1[32];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        float a = feat[2 * t], b = feat[2 * t + 1];
+        sn_swap_halves(a, b);
+        op0[t] = a;
+        op1[t] = b;
+    }
+    f32x16 a0[2], a1[2];
+    sn_mlp_layer_f32<2, 16>(lds + SnMainImg::W1, lds + SnMainImg::B1, op0, op1, a0, a1, lane);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            op0[rt * 16 + r] = fmaxf(a0[rt][r], 0.0f);
+            op1[rt * 16 + r] = fmaxf(a1[rt][r], 0.0f);
+        }
+    // ---- layer 2: 64 -> 16 (rows 0..15 real; row 20 duplicates row 0 for the upper half) ----
+    f32x16 g0[1], g1[1];
+    sn_mlp_layer_f32<1, 32>(lds + SnMainImg::W2, lds + SnMainImg::B2, op0, op1, g0, g1, lane);
+    h0 = upper ? g1[0][8] : g0[0][0];
+    // ---- colour layer 1: (L2 rows 0..15 | SH16) -> 64, ReLU --------------------------------
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        op0[t] = g0[0][t];
+        op1[t] = g1[0][t];
+        op0[8 + t] = sh.t0[t];
+        op1[8 + t] = sh.t1[t];
+    }
+    sn_mlp_layer_f32<2, 16>(lds + SnMainImg::WC1, lds + SnMainImg::BC1, op0, op1, a0, a1, lane);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            op0[rt * 16 + r] = fmaxf(a0[rt][r], 0.0f);
+            op1[rt * 16 + r] = fmaxf(a1[rt][r], 0.0f);
+        }
+    // ---- colour layer 2: 64 -> 64, ReLU ----------------------------------------------------
+    sn_mlp_layer_f32<2, 32>(lds + SnMainImg::WC2, lds + SnMainImg::BC2, op0, op1, a0, a1, lane);
+    // ---- colour layer 3: 64 -> 3 on the VALU (a 32-row MFMA tile would be 90 % padding) -----
+    const int h = lane >> 5;
+    float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        const f32x4* w = (const f32x4*)(lds + SnMainImg::W3 + (n * 2 + h) * 32);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 wv = w[rt * 4 + r4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x0 = fmaxf(a0[rt][r4 * 4 + e], 0.0f);
+                    float x1 = fmaxf(a1[rt][r4 * 4 + e], 0.0f);
+                    p0[n] = fmaf(wv[e], x0, p0[n]);
+                    p1[n] = fmaf(wv[e], x1, p1[n]);
+                }
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        float a = p0[n], b = p1[n];
+        sn_swap_halves(a, b);  // lower: own tile-0 partial + upper's tile-0 partial; upper: tile 1
+        float x = a + b + lds[SnMainImg::B3 + n];
+        rgb[n] = 1.0f / (1.0f + expf(-x));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel
+// ------------------------------------------------------------------------------------------
+struct SnMainParams {
+    const float* origins;     // [H*W,3]
+    const float* directions;  // [H*W,3]
+    const float* nears;       // [H*W] or null
+    const float* fars;        // [H*W] or null
+    const float* sbins;       // [S+1] spacing bins (uniform mode), device
+    const float* ebins;       // bins mode: euclidean bins, [tile][S+1][64]
+    const float* table;       // main hash table [16 << log2_t, 2]
+    const float* wimg;        // SnMainImg (global copy)
+    float* rgb;
+    float* depth;
+    float* acc;
+    float* exp_raw;           // un-clipped expected depth (clipped by sn_clip_expected_kernel) or null
+    uint32_t* chunk_minmax;   // [2][n_chunks] ordered-uint mins then maxs of sample mid-points, or null
+    int n_chunks;
+    float scal[16];
+    int height, width, n_samples;
+    int tile_w_log2, tile_h_log2;  // tile = 2^a x 2^b pixels, a + b = 6
+    int tiles_x, tiles_y;          // tiles per row / column
+    int log2_t;
+    float near_plane, far_plane, avg_density;
+    int sh_remap;
+    int chunk_rays;
+};
+
+// XCD-aware, bijective block remap: the dispatcher places block b on XCD b % 8 (observed); give each
+// XCD a contiguous run of workgroups so neighbouring image tiles share an L2.  Speed only.
+SN_DEV int sn_xcd_remap(int b, int n) {
+    const int nx = 8;
+    int xcd = b % nx, k = b / nx;
+    int qn = n / nx, rn = n % nx;
+    int base = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
+    return base + k;
+}
+
+template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/>
+__global__ __launch_bounds__(256, 2) void sn_render_main_kernel(SnMainParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    for (int i = tid * 4; i < SnMainImg::TOTAL; i += 256 * 4) *(f32x4*)(lds + i) = *(const f32x4*)(p.wimg + i);
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup = 2x2 tiles
+    const int gbx = (p.tiles_x + 1) >> 1, gby = (p.tiles_y + 1) >> 1;
+    const int blk = sn_xcd_remap(blockIdx.x, gbx * gby);
+    const int tx = (blk % gbx) * 2 + (wave & 1);
+    const int ty = (blk / gbx) * 2 + (wave >> 1);
+    if (tx >= p.tiles_x || ty >= p.tiles_y) return;  // wave-uniform
+    const int tw = 1 << p.tile_w_log2;
+    const int px = (tx << p.tile_w_log2) + (lane & (tw - 1));
+    const int py = (ty << p.tile_h_log2) + (lane >> p.tile_w_log2);
+    const bool valid = px < p.width && py < p.height;
+    const int cx = min(px, p.width - 1), cy = min(py, p.height - 1);
+    const int64_t ray = (int64_t)cy * p.width + cx;
+
+    float o[3], d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = p.origins[ray * 3 + c];
+        d[c] = p.directions[ray * 3 + c];
+    }
+    const float near = p.nears ? p.nears[ray] : p.near_plane;
+    const float far = p.fars ? p.fars[ray] : p.far_plane;
+    const float s_near = sn_spacing(near), s_far = sn_spacing(far);
+    SnShOps sh;
+    sh.build(d, p.sh_remap);
+
+    const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table, (16u << p.log2_t) * 8u);
+    const int S = p.n_samples;
+    const float* eb = nullptr;
+    if (MODE == 1) eb = p.ebins + ((int64_t)(ty * p.tiles_x + tx) * (S + 1)) * 64 + lane;
+
+    SnComposite comp;
+    comp.init();
+    float t0 = MODE == 0 ? sn_euclid(p.sbins ? p.sbins[0] : 0.0f, s_near, s_far) : eb[0];
+    float first_mid = 0.f, last_mid = 0.f;
+    float r = 0.f, g = 0.f, b = 0.f;
+    for (int i = 0; i < S; ++i) {
+        const float t1 = MODE == 0 ? sn_euclid(p.sbins ? p.sbins[i + 1] : (float)(i + 1) / (float)S, s_near, s_far)
+                                   : eb[(int64_t)(i + 1) * 64];
+        float q[3];
+        const bool sel = sn_sample_q(o, d, t0, t1, q);
+        float feat[32];
+        sn_hash_encode<16>(rsrc, p.scal, p.log2_t, q, feat);
+        __builtin_amdgcn_sched_barrier(0);
+        float h0, rgb[3];
+        sn_main_field_f32(lds, feat, sh, lane, h0, rgb);
+        __builtin_amdgcn_sched_barrier(0);
+        const float density = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
+        r = rgb[0];
+        g = rgb[1];
+        b = rgb[2];
+        comp.step(i, t0, t1, density, r, g, b);
+        {
+#pragma clang fp contract(off)
+            last_mid = (t0 + t1) / 2.0f;
+        }
+        if (i == 0) first_mid = last_mid;
+        t0 = t1;
+    }
+    float out_rgb[3], depth, acc, exp_raw;
+    comp.finish(S, last_mid, r, g, b, out_rgb, depth, acc, exp_raw);
+    if (valid) {
+        const int64_t pix = (int64_t)py * p.width + px;
+        if (p.rgb) {
+            p.rgb[pix * 3 + 0] = out_rgb[0];
+            p.rgb[pix * 3 + 1] = out_rgb[1];
+            p.rgb[pix * 3 + 2] = out_rgb[2];
+        }
+        if (p.depth) p.depth[pix] = depth;
+        if (p.acc) p.acc[pix] = acc;
+        if (p.exp_raw) p.exp_raw[pix] = exp_raw;
+    }
+    // chunk-global [min, max] of the sample mid-points (A17 quirk): bins are monotone along a ray, so a
+    // ray contributes its first and last mid-point.  A tile straddles at most a few chunks.
+    if (p.chunk_minmax) {
+        const int my_chunk = valid ? (int)(((int64_t)py * p.width + px) / p.chunk_rays) : -1;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int c = __shfl(my_chunk, leader);
+            const bool mine = valid && my_chunk == c;
+            uint32_t lo = mine ? sn_float_ordered(first_mid) : 0xffffffffu;
+            uint32_t hi = mine ? sn_float_ordered(last_mid) : 0u;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) {
+                lo = min(lo, (uint32_t)__shfl_xor((int)lo, s));
+                hi = max(hi, (uint32_t)__shfl_xor((int)hi, s));
+            }
+            if (lane == leader) {
+                atomicMin(&p.chunk_minmax[c], lo);
+                atomicMax(&p.chunk_minmax[p.n_chunks + c], hi);
+            }
+            todo &= ~__ballot(mine);
+        }
+    }
+}
+
+// expected_depth = clip(raw, chunk min, chunk max)
+__global__ void sn_clip_expected_kernel(const float* raw, const uint32_t* chunk_minmax, int64_t n, int chunk_rays, int n_chunks,
+                                        float* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = (int)(i / chunk_rays);
+    float lo = sn_ordered_float(chunk_minmax[c]), hi = sn_ordered_float(chunk_minmax[n_chunks + c]);
+    out[i] = fminf(fmaxf(raw[i], lo), hi);
+}

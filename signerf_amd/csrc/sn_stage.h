@@ -1,0 +1,260 @@
+// sn_stage.h -- ray generation, slab tests and the stage-level kernels behind the parity entry
+// points of include/signerf_hip.h.  They call the SAME device functions as the fused kernels.
+#pragma once
+#include "sn_device.h"
+#include "sn_main.h"
+
+// ------------------------------------------------------------------------------------------
+// row a5: Cameras.generate_rays, pin-hole
+// ------------------------------------------------------------------------------------------
+struct SnRayGenParams {
+    float c2w[12];
+    float fx, fy, cx, cy;
+    int height, width;
+    float* origins;
+    float* directions;
+    float* pixel_area;
+    float* directions_norm;
+    int has_aabb;
+    float aabb[6];
+    float* nears;
+    float* fars;
+};
+
+SN_DEV void sn_cam_dir(const float* c2w, float u, float v, float out[3], float& norm) {
+#pragma clang fp contract(off)
+    // d_world[i] = sum_j d_cam[j] * R[i][j],  d_cam = (u, v, -1)
+    float w[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w[i] = (u * c2w[i * 4 + 0] + v * c2w[i * 4 + 1]) + (-1.0f) * c2w[i * 4 + 2];
+    float n = sqrtf((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]);
+    n = fmaxf(n, 1e-20f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = w[i] / n;
+    norm = n;
+}
+
+__global__ void sn_generate_rays_kernel(SnRayGenParams p) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)p.height * p.width;
+    if (i >= n) return;
+    const int iy = (int)(i / p.width), ix = (int)(i % p.width);
+    const float x = (float)ix + 0.5f, y = (float)iy + 0.5f;
+    const float u = (x - p.cx) / p.fx, v = -((y - p.cy) / p.fy);
+    const float ux = (x - p.cx + 1.0f) / p.fx;
+    const float vy = -((y - p.cy + 1.0f) / p.fy);
+    float d[3], dx[3], dy[3], nrm, n1, n2;
+    sn_cam_dir(p.c2w, u, v, d, nrm);
+    sn_cam_dir(p.c2w, ux, v, dx, n1);
+    sn_cam_dir(p.c2w, u, vy, dy, n2);
+    float o[3] = {p.c2w[3], p.c2w[7], p.c2w[11]};
+    if (p.origins) {
+        p.origins[i * 3 + 0] = o[0];
+        p.origins[i * 3 + 1] = o[1];
+        p.origins[i * 3 + 2] = o[2];
+    }
+    if (p.directions) {
+        p.directions[i * 3 + 0] = d[0];
+        p.directions[i * 3 + 1] = d[1];
+        p.directions[i * 3 + 2] = d[2];
+    }
+    if (p.pixel_area) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float e = d[c] - dx[c], f = d[c] - dy[c];
+            a = c == 0 ? e * e : a + e * e;
+            b = c == 0 ? f * f : b + f * f;
+        }
+        p.pixel_area[i] = sqrtf(a) * sqrtf(b);
+    }
+    if (p.directions_norm) p.directions_norm[i] = nrm;
+    if (p.has_aabb && p.nears && p.fars) {
+        // nerfstudio intersect_aabb: clamped slab test, invalid -> 1e10 (A1)
+        float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float a = (p.aabb[c] - o[c]) / d[c];
+            float b = (p.aabb[3 + c] - o[c]) / d[c];
+            tmin = fmaxf(tmin, fminf(a, b));
+            tmax = fminf(tmax, fmaxf(a, b));
+        }
+        tmin = fminf(fmaxf(tmin, 0.0f), 1e10f);
+        tmax = fminf(fmaxf(tmax, 0.0f), 1e10f);
+        if (tmax <= tmin) {
+            tmin = 1e10f;
+            tmax = 1e10f;
+        }
+        p.nears[i] = tmin;
+        p.fars[i] = tmax;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// row a4: intersect_with_aabb (signerf/utils/intersection.py:5-56): 1/(d + 1e-6), no clamping
+// ------------------------------------------------------------------------------------------
+struct SnAabb {
+    float v[6];
+};
+
+__global__ void sn_intersect_with_aabb_kernel(const float* origins, const float* directions, int64_t n, SnAabb box,
+                                              float* nears, float* fars) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float nr = -INFINITY, fr = INFINITY;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float o = origins[i * 3 + c];
+        float inv = 1.0f / (directions[i * 3 + c] + 1e-6f);
+        float a = (box.v[c] - o) * inv;
+        float b = (box.v[3 + c] - o) * inv;
+        nr = fmaxf(nr, fminf(a, b));
+        fr = fminf(fr, fmaxf(a, b));
+    }
+    nears[i] = nr;
+    fars[i] = fr;
+}
+
+// ------------------------------------------------------------------------------------------
+// row a13: hash encoding of explicit normalised positions
+// ------------------------------------------------------------------------------------------
+struct SnHashStageParams {
+    const float* q;
+    int64_t n;
+    const float* table;
+    float scal[16];
+    int num_levels, log2_t;
+    float* features;   // [n, 2L]
+    int32_t* indices;  // [n, L, 8] or null
+};
+
+__global__ void sn_hash_encode_kernel(SnHashStageParams p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    const float q[3] = {p.q[i * 3], p.q[i * 3 + 1], p.q[i * 3 + 2]};
+    const uint32_t mask = (1u << p.log2_t) - 1u;
+    const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table, ((uint32_t)p.num_levels << p.log2_t) * 8u);
+    for (int l = 0; l < p.num_levels; ++l) {
+        SnHashLevel hl;
+        sn_hash_corners(q, p.scal[l], mask, hl);
+        const uint32_t lvl = ((uint32_t)l << p.log2_t) * 8u;
+        f32x2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = sn_table_load(rsrc, hl.row[k] * 8u, lvl);
+            if (p.indices) p.indices[(i * p.num_levels + l) * 8 + k] = (int32_t)(hl.row[k] + ((uint32_t)l << p.log2_t));
+        }
+        f32x2 e = sn_hash_blend(v, hl.off);
+        p.features[i * 2 * p.num_levels + 2 * l] = e.x;
+        p.features[i * 2 * p.num_levels + 2 * l + 1] = e.y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// rows a14/a15: main field on explicit world positions (wave-level MFMA path, one point per lane)
+// ------------------------------------------------------------------------------------------
+struct SnFieldStageParams {
+    const float* positions;   // [n,3] world
+    const float* directions;  // [n,3] or null
+    int64_t n;
+    const float* table;
+    const float* wimg;
+    float scal[16];
+    int log2_t;
+    float avg_density;
+    int sh_remap;
+    float* density;  // [n]
+    float* rgb;      // [n,3] or null
+};
+
+__global__ __launch_bounds__(256, 2) void sn_main_field_stage_kernel(SnFieldStageParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    for (int i = tid * 4; i < SnMainImg::TOTAL; i += 256 * 4) *(f32x4*)(lds + i) = *(const f32x4*)(p.wimg + i);
+    __syncthreads();
+    const int lane = tid & 63;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + tid;
+    const int64_t j = i < p.n ? i : p.n - 1;
+    const float pos[3] = {p.positions[j * 3], p.positions[j * 3 + 1], p.positions[j * 3 + 2]};
+    float d[3] = {0.f, 0.f, 1.f};
+    if (p.directions) {
+        d[0] = p.directions[j * 3];
+        d[1] = p.directions[j * 3 + 1];
+        d[2] = p.directions[j * 3 + 2];
+    }
+    SnShOps sh;
+    sh.build(d, p.sh_remap);
+    float q[3];
+    const bool sel = sn_position_q(pos, q);
+    const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table, (16u << p.log2_t) * 8u);
+    float feat[32];
+    sn_hash_encode<16>(rsrc, p.scal, p.log2_t, q, feat);
+    float h0, rgb[3];
+    sn_main_field_f32(lds, feat, sh, lane, h0, rgb);
+    if (i < p.n) {
+        p.density[i] = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
+        if (p.rgb) {
+            p.rgb[i * 3] = rgb[0];
+            p.rgb[i * 3 + 1] = rgb[1];
+            p.rgb[i * 3 + 2] = rgb[2];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// rows a10 + a17 on explicit per-sample inputs (one ray per thread)
+// ------------------------------------------------------------------------------------------
+struct SnCompositeStageParams {
+    const float* bins;     // [R,S+1]
+    const float* density;  // [R,S]
+    const float* rgb_s;    // [R,S,3]
+    int64_t n_rays;
+    int n_samples;
+    float* weights;
+    float* rgb;
+    float* depth;
+    int32_t* median_index;
+    float* acc;
+    float* exp_raw;
+    uint32_t* minmax;  // [2]
+};
+
+__global__ void sn_composite_kernel(SnCompositeStageParams p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n_rays) return;
+    const int S = p.n_samples;
+    const float* b = p.bins + i * (S + 1);
+    SnComposite comp;
+    comp.init();
+    float r = 0.f, g = 0.f, bl = 0.f, first_mid = 0.f, last_mid = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float t0 = b[s], t1 = b[s + 1];
+        r = p.rgb_s[(i * S + s) * 3];
+        g = p.rgb_s[(i * S + s) * 3 + 1];
+        bl = p.rgb_s[(i * S + s) * 3 + 2];
+        const float w = comp.step(s, t0, t1, p.density[i * S + s], r, g, bl);
+        if (p.weights) p.weights[i * S + s] = w;
+        {
+#pragma clang fp contract(off)
+            last_mid = (t0 + t1) / 2.0f;
+        }
+        if (s == 0) first_mid = last_mid;
+    }
+    float out[3], depth, acc, er;
+    comp.finish(S, last_mid, r, g, bl, out, depth, acc, er);
+    if (p.rgb) {
+        p.rgb[i * 3] = out[0];
+        p.rgb[i * 3 + 1] = out[1];
+        p.rgb[i * 3 + 2] = out[2];
+    }
+    if (p.depth) p.depth[i] = depth;
+    if (p.median_index) p.median_index[i] = comp.median_idx;
+    if (p.acc) p.acc[i] = acc;
+    if (p.exp_raw) {
+        p.exp_raw[i] = er;
+        atomicMin(&p.minmax[0], sn_float_ordered(first_mid));
+        atomicMax(&p.minmax[1], sn_float_ordered(last_mid));
+    }
+}

@@ -1,0 +1,323 @@
+"""``NerfactoModel`` / ``SIGNeRFModel`` -- nerfstudio-``Model``-shaped objects whose eval render runs in the HIP library.
+
+The drop-in boundary.  What ``DatasetGenerator.render_camera`` touches
+(/root/reference/signerf/datasetgenerator/datasetgenerator.py:691-701):
+    graph.render_aabb, graph.eval(), graph.get_outputs_for_camera_ray_bundle(bundle) -> {"rgb","depth",...},
+    graph.train(), graph.device
+and what ``SIGNeRFPipeline`` touches (/root/reference/signerf/signerf_pipeline.py:93-132,151):
+    model.load_state_dict(state, strict=False) with keys under ``field.``, ``proposal_networks.`` (the appearance
+    embedding and camera-optimizer keys are deleted by the pipeline before the call), get_training_callbacks,
+    param groups "proposal_networks" / "fields" / "camera_opt" (signerf_config.py:47-60).
+
+The modules below hold the parameters under nerfstudio's torch-path state-dict names; their arithmetic lives in
+``csrc/`` and is reached through the C ABI -- there is no PyTorch forward and no CPU fallback.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+from .cameras import RayBundle, SceneBox
+from .config import NerfactoModelConfig, SIGNeRFModelConfig
+
+PRECISIONS = {"fp32": 0, "fp16x2": 1}
+
+
+# ------------------------------------------------------------------------------------------------------
+# parameter containers (state-dict layout of nerfstudio's "torch" implementation)
+# ------------------------------------------------------------------------------------------------------
+class HashEncoding(nn.Module):
+    """Parameters of nerfstudio's HashEncoding (torch path): ``hash_table`` [L*T, F]."""
+
+    def __init__(self, num_levels: int, min_res: int, max_res: int, log2_hashmap_size: int, features_per_level: int = 2,
+                 hash_init_scale: float = 0.001):
+        super().__init__()
+        self.num_levels, self.min_res, self.max_res = num_levels, min_res, max_res
+        self.log2_hashmap_size, self.features_per_level = log2_hashmap_size, features_per_level
+        table = torch.rand(size=((2**log2_hashmap_size) * num_levels, features_per_level)) * 2 - 1
+        self.hash_table = nn.Parameter(table * hash_init_scale)
+
+    def scalings(self) -> Tensor:
+        """floor(min_res * growth**level), evaluated exactly as HashEncoding.__init__ does (numpy float64 growth
+        factor raised to an int64 torch tensor -> fp32)."""
+        levels = torch.arange(self.num_levels)
+        growth = np.exp((np.log(self.max_res) - np.log(self.min_res)) / (self.num_levels - 1)) if self.num_levels > 1 else 1
+        return torch.floor(self.min_res * growth**levels).to(torch.float32)
+
+
+class MLP(nn.Module):
+    """Parameters of nerfstudio's torch MLP: ``layers`` = nn.Linear list (A8)."""
+
+    def __init__(self, in_dim: int, num_layers: int, layer_width: int, out_dim: int):
+        super().__init__()
+        dims = [in_dim] + [layer_width] * (num_layers - 1) + [out_dim]
+        self.layers = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(num_layers)])
+
+
+class MLPWithHashEncoding(nn.Module):
+    def __init__(self, num_levels, min_res, max_res, log2_hashmap_size, features_per_level, num_layers, layer_width, out_dim):
+        super().__init__()
+        self.encoder = HashEncoding(num_levels, min_res, max_res, log2_hashmap_size, features_per_level)
+        self.mlp = MLP(num_levels * features_per_level, num_layers, layer_width, out_dim)
+
+
+class Embedding(nn.Module):
+    def __init__(self, in_dim: int, out_dim: int):
+        super().__init__()
+        self.embedding = nn.Embedding(in_dim, out_dim)
+
+    def mean(self, dim=0):
+        return self.embedding.weight.mean(dim)
+
+
+class NerfactoField(nn.Module):
+    """Parameters of nerfstudio's NerfactoField (A6-A9, A13-A15)."""
+
+    def __init__(self, config: NerfactoModelConfig, num_images: int):
+        super().__init__()
+        self.geo_feat_dim = 15
+        self.mlp_base = MLPWithHashEncoding(config.num_levels, config.base_res, config.max_res, config.log2_hashmap_size,
+                                            config.features_per_level, 2, config.hidden_dim, 1 + self.geo_feat_dim)
+        self.embedding_appearance = Embedding(num_images, config.appearance_embed_dim)
+        self.mlp_head = MLP(16 + self.geo_feat_dim + config.appearance_embed_dim, 3, config.hidden_dim_color, 3)
+
+
+class HashMLPDensityField(nn.Module):
+    """Parameters of a proposal network (row a9)."""
+
+    def __init__(self, hidden_dim=16, log2_hashmap_size=17, num_levels=5, max_res=128, base_res=16, features_per_level=2,
+                 use_linear=False, **_):
+        super().__init__()
+        assert not use_linear, "use_linear proposal nets are not supported"
+        self.mlp_base = MLPWithHashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level, 2, hidden_dim, 1)
+
+
+# ------------------------------------------------------------------------------------------------------
+# the model
+# ------------------------------------------------------------------------------------------------------
+def _desc_of(enc: HashEncoding, hidden_dim: int, out_dim: int) -> _lib.SnHashMlpDesc:
+    d = _lib.SnHashMlpDesc()
+    d.num_levels = enc.num_levels
+    d.features_per_level = enc.features_per_level
+    d.log2_hashmap_size = enc.log2_hashmap_size
+    d.hidden_dim = hidden_dim
+    d.num_layers = 2
+    d.out_dim = out_dim
+    sc = enc.scalings().tolist()
+    for i in range(_lib.SN_MAX_LEVELS):
+        d.scalings[i] = sc[i] if i < len(sc) else 0.0
+    return d
+
+
+class NerfactoModel(nn.Module):
+    """Eval-mode nerfacto render on MI355X behind nerfstudio's ``Model`` surface."""
+
+    config: NerfactoModelConfig
+
+    def __init__(self, config: NerfactoModelConfig, scene_box: Optional[SceneBox] = None, num_train_data: Optional[int] = None,
+                 **kwargs):
+        super().__init__()
+        self.config = config
+        self.scene_box = scene_box
+        self.render_aabb: Optional[SceneBox] = None  # datasetgenerator.py:691 reads this
+        self.num_train_data = num_train_data if num_train_data is not None else config.num_train_data
+        self.kwargs = kwargs
+        self.device_indicator_param = nn.Parameter(torch.empty(0))
+        self._handle = C.c_void_p(None)
+        self._weights_dirty = True
+        self._weights_lock = threading.Lock()
+        self._grid_cache: Dict = {}
+        self.populate_modules()
+
+    # -- module set-up (names = nerfstudio's; signerf.py:32-39 overrides this and calls super) -------------
+    def populate_modules(self):
+        cfg = self.config
+        if cfg.disable_scene_contraction:
+            raise NotImplementedError("only the L-inf scene contraction path is built")
+        self.field = NerfactoField(cfg, self.num_train_data)
+        self.proposal_networks = nn.ModuleList()
+        for i in range(cfg.num_proposal_iterations):
+            args = cfg.proposal_net_args_list[min(i, len(cfg.proposal_net_args_list) - 1)]
+            self.proposal_networks.append(HashMLPDensityField(**args))
+
+    @property
+    def device(self):
+        return self.device_indicator_param.device
+
+    # -- plugin surface the pipeline / trainer expect ---------------------------------------------------------
+    def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
+        return {"proposal_networks": list(self.proposal_networks.parameters()), "fields": list(self.field.parameters())}
+
+    def get_training_callbacks(self, training_callback_attributes=None) -> List:
+        return []
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> dict:
+        raise NotImplementedError("training losses are outside the render path (SURVEY.md §2 row 8)")
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._weights_dirty = True
+        return out
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._weights_dirty = True
+        return out
+
+    def mark_weights_dirty(self):
+        """Call after mutating parameters in place (e.g. an optimizer step) so the next render re-uploads them."""
+        self._weights_dirty = True
+
+    # -- HIP engine ---------------------------------------------------------------------------------------------
+    def _field_desc(self) -> _lib.SnFieldDesc:
+        cfg = self.config
+        d = _lib.SnFieldDesc()
+        d.main_field = _desc_of(self.field.mlp_base.encoder, cfg.hidden_dim, 1 + self.field.geo_feat_dim)
+        d.geo_feat_dim = self.field.geo_feat_dim
+        d.hidden_dim_color = cfg.hidden_dim_color
+        d.appearance_embed_dim = cfg.appearance_embed_dim
+        d.sh_levels = 4
+        d.sh_remap = 0 if cfg.implementation == "torch" else 1
+        d.num_proposals = len(self.proposal_networks)
+        for i, net in enumerate(self.proposal_networks):
+            d.proposals[i] = _desc_of(net.mlp_base.encoder, net.mlp_base.mlp.layers[0].out_features, 1)
+        d.average_init_density = cfg.average_init_density
+        d.histogram_padding = 0.01
+        return d
+
+    def _ensure_engine(self):
+        lib = _lib.load()
+        if self.device.type != "cuda":
+            raise _lib.SignerfHipError("NerfactoModel renders on the GPU only: move it with .to('cuda') (no CPU fallback)")
+        with self._weights_lock:
+            if not self._handle:
+                desc = self._field_desc()
+                with torch.cuda.device(self.device):
+                    _lib.check(lib.sn_create(C.byref(desc), C.byref(self._handle)), None, "sn_create")
+            if self._weights_dirty:
+                self._upload(lib)
+                self._weights_dirty = False
+        return lib
+
+    def _upload(self, lib):
+        stream = _lib.current_stream()
+
+        def up(name: str, t: Tensor):
+            t = t.detach().to(torch.float32).contiguous()
+            buf = t if t.is_cuda else t.cpu()
+            _lib.check(lib.sn_upload_weights(self._handle, name.encode(), buf.data_ptr(), buf.numel() * 4, stream),
+                       self._handle, f"sn_upload_weights({name})")
+
+        with torch.cuda.device(self.device):
+            sd = self.state_dict()
+            for k, v in sd.items():
+                if k.endswith("hash_table") or ".mlp.layers." in k or k.startswith("field.mlp_head.layers."):
+                    up(k, v)
+            if self.config.appearance_embed_dim > 0:
+                if self.config.use_average_appearance_embedding:
+                    app = self.field.embedding_appearance.mean(0)
+                else:
+                    app = torch.zeros(self.config.appearance_embed_dim, device=self.device)
+                up("field.embedding_appearance.mean", app)
+            _lib.check(lib.sn_finalize_weights(self._handle, stream), self._handle, "sn_finalize_weights")
+
+    def __del__(self):
+        try:
+            if self._handle:
+                _lib.load().sn_destroy(self._handle)
+        except Exception:
+            pass
+
+    # sampler grids, computed with the same torch ops nerfstudio uses (bit-identical to the reference's)
+    def _grids(self, n_levels: int):
+        cfg = self.config
+        counts = list(cfg.num_proposal_samples_per_ray[:n_levels]) + [cfg.num_nerf_samples_per_ray]
+        key = (tuple(counts), str(self.device))
+        if key not in self._grid_cache:
+            bins0 = torch.linspace(0.0, 1.0, counts[0] + 1)
+            us = []
+            for m in counts[1:]:
+                nb = m + 1
+                u = torch.linspace(0.0, 1.0 - (1.0 / nb), steps=nb) + 1.0 / (2 * nb)
+                us.append(u.to(self.device))
+            self._grid_cache[key] = (bins0.to(self.device), us)
+        return self._grid_cache[key]
+
+    def _opts(self, H: int, W: int, lib):
+        cfg = self.config
+        n_levels = cfg.num_proposal_iterations
+        o = _lib.SnRenderOpts()
+        o.num_proposal_iterations = n_levels
+        for i in range(n_levels):
+            o.num_proposal_samples[i] = cfg.num_proposal_samples_per_ray[i]
+        o.num_nerf_samples = cfg.num_nerf_samples_per_ray
+        o.near_plane = cfg.near_plane if self.training else 0.0  # NearFarCollider: eval near = 0 (A3)
+        o.far_plane = cfg.far_plane
+        o.chunk_rays = cfg.eval_num_rays_per_chunk
+        o.precision = PRECISIONS[cfg.precision]
+        bins0, us = self._grids(n_levels)
+        o.initial_spacing_bins = bins0.data_ptr()
+        for i, u in enumerate(us):
+            o.pdf_u[i] = u.data_ptr()
+        need = lib.sn_workspace_bytes(self._handle, H, W, C.byref(o))
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+        o.workspace = ws.data_ptr()
+        o.workspace_bytes = ws.numel()
+        return o, (ws, bins0, us)
+
+    # -- rows a6-a17 ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """Whole-image render: dict of [H,W,C] fp32 tensors on the bundle's device ("rgb", "accumulation", "depth"
+        (median), "expected_depth", "prop_depth_i").  Rays are visited in the reference's row-major order; the
+        reference's 32 768-ray chunking only survives in the expected-depth clip bounds (A17)."""
+        H, W = camera_ray_bundle.origins.shape[:2]
+        out = self._render(camera_ray_bundle, H, W)
+        return {k: v.view(H, W, -1) for k, v in out.items()}
+
+    @torch.no_grad()
+    def get_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """Flat bundle [R,...] -> dict of [R,C]."""
+        R = len(ray_bundle)
+        out = self._render(ray_bundle.flatten(), 1, R)
+        return {k: v.view(R, -1) for k, v in out.items()}
+
+    def forward(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        return self.get_outputs(ray_bundle)
+
+    def _render(self, b: RayBundle, H: int, W: int) -> Dict[str, Tensor]:
+        lib = self._ensure_engine()
+        dev = self.device
+        f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+        origins, directions, nears, fars = f32(b.origins), f32(b.directions), f32(b.nears), f32(b.fars)
+        n = H * W
+        with torch.cuda.device(dev):
+            o, keep = self._opts(H, W, lib)
+            new = lambda c: torch.empty((n, c), dtype=torch.float32, device=dev)  # noqa: E731
+            rgb, depth, acc, exp = new(3), new(1), new(1), new(1)
+            props = [new(1) for _ in range(self.config.num_proposal_iterations)]
+            pp = [_lib.ptr(p) for p in props] + [None] * (2 - len(props))
+            st = lib.sn_render_rays(self._handle, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(nears), _lib.ptr(fars), H, W,
+                                    C.byref(o), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc), _lib.ptr(exp), pp[0], pp[1],
+                                    _lib.current_stream())
+            _lib.check(st, self._handle, "sn_render_rays")
+            # the workspace and grids are consumed by work already enqueued on this stream; the caching allocator
+            # is stream-ordered, so dropping `keep` here is safe.
+            del keep
+        out = {"rgb": rgb, "accumulation": acc, "depth": depth, "expected_depth": exp}
+        for i, p in enumerate(props):
+            out[f"prop_depth_{i}"] = p
+        return out
+
+
+class SIGNeRFModel(NerfactoModel):
+    """signerf.py:27-39: same render path; only training losses differ (out of scope here)."""
+
+    config: SIGNeRFModelConfig

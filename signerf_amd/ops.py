@@ -1,0 +1,86 @@
+"""Stage-level operators: thin Python wrappers over the stage entry points of the C ABI (same device code as the fused
+kernels).  Names follow the nerfstudio components they stand in for."""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+
+def _f32(t: Tensor) -> Tensor:
+    return t.to(torch.float32).contiguous()
+
+
+def hash_encode(model, q: Tensor, which: int = -1, return_indices: bool = False):
+    """HashEncoding forward (torch-path semantics, row a13).  q [n,3] in [0,1) -> features [n, L*F] (+ table rows [n,L,8])."""
+    lib = model._ensure_engine()
+    q = _f32(q)
+    n = q.shape[0]
+    enc = (model.field.mlp_base if which < 0 else model.proposal_networks[which].mlp_base).encoder
+    with torch.cuda.device(q.device):
+        feat = torch.empty((n, enc.num_levels * enc.features_per_level), dtype=torch.float32, device=q.device)
+        idx = torch.empty((n, enc.num_levels, 8), dtype=torch.int32, device=q.device) if return_indices else None
+        _lib.check(lib.sn_hash_encode(model._handle, which, _lib.ptr(q), n, _lib.ptr(feat), _lib.ptr(idx), _lib.current_stream()),
+                   model._handle, "sn_hash_encode")
+    return (feat, idx) if return_indices else feat
+
+
+def field_forward(model, positions: Tensor, directions: Optional[Tensor] = None, which: int = -1) -> Tuple[Tensor, Optional[Tensor]]:
+    """NerfactoField / HashMLPDensityField on explicit world positions (rows a9, a14, a15) -> density [n], rgb [n,3] | None."""
+    lib = model._ensure_engine()
+    pos = _f32(positions)
+    n = pos.shape[0]
+    d = None if directions is None else _f32(directions)
+    with torch.cuda.device(pos.device):
+        density = torch.empty((n,), dtype=torch.float32, device=pos.device)
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=pos.device) if (which < 0 and d is not None) else None
+        from .nerfacto import PRECISIONS
+
+        _lib.check(lib.sn_field_forward(model._handle, which, _lib.ptr(pos), _lib.ptr(d), n, PRECISIONS[model.config.precision],
+                                        _lib.ptr(density), _lib.ptr(rgb), _lib.current_stream()), model._handle, "sn_field_forward")
+    return density, rgb
+
+
+def composite(euclid_bins: Tensor, density: Tensor, rgb_samples: Tensor):
+    """RaySamples.get_weights + RGB / median-depth / accumulation / expected-depth renderers (rows a10, a17).
+
+    euclid_bins [R,S+1], density [R,S], rgb_samples [R,S,3] -> dict(weights [R,S], rgb [R,3], depth [R], median_index [R] int32,
+    accumulation [R], expected_depth [R])."""
+    lib = _lib.load()
+    b, dn, c = _f32(euclid_bins), _f32(density), _f32(rgb_samples)
+    R, S = dn.shape
+    dev = b.device
+    with torch.cuda.device(dev):
+        out = {
+            "weights": torch.empty((R, S), dtype=torch.float32, device=dev),
+            "rgb": torch.empty((R, 3), dtype=torch.float32, device=dev),
+            "depth": torch.empty((R,), dtype=torch.float32, device=dev),
+            "median_index": torch.empty((R,), dtype=torch.int32, device=dev),
+            "accumulation": torch.empty((R,), dtype=torch.float32, device=dev),
+            "expected_depth": torch.empty((R,), dtype=torch.float32, device=dev),
+        }
+        _lib.check(lib.sn_composite(_lib.ptr(b), _lib.ptr(dn), _lib.ptr(c), R, S, _lib.ptr(out["weights"]), _lib.ptr(out["rgb"]),
+                                    _lib.ptr(out["depth"]), _lib.ptr(out["median_index"]), _lib.ptr(out["accumulation"]),
+                                    _lib.ptr(out["expected_depth"]), _lib.current_stream()), None, "sn_composite")
+    return out
+
+
+def pdf_sample(spacing_bins: Tensor, weights: Tensor, num_samples: int, histogram_padding: float = 0.01):
+    """PDFSampler, eval mode (row a11): spacing_bins [R,N+1], weights [R,N] -> new bins [R,M+1], searchsorted indices [R,M+1]."""
+    lib = _lib.load()
+    sb, w = _f32(spacing_bins), _f32(weights)
+    R, N = w.shape
+    dev = sb.device
+    nb = num_samples + 1
+    u = (torch.linspace(0.0, 1.0 - (1.0 / nb), steps=nb) + 1.0 / (2 * nb)).to(dev)
+    with torch.cuda.device(dev):
+        bins = torch.empty((R, nb), dtype=torch.float32, device=dev)
+        inds = torch.empty((R, nb), dtype=torch.int32, device=dev)
+        _lib.check(lib.sn_pdf_sample(_lib.ptr(sb), _lib.ptr(w), R, N, num_samples, _lib.ptr(u), C.c_float(histogram_padding),
+                                     _lib.ptr(bins), _lib.ptr(inds), _lib.current_stream()), None, "sn_pdf_sample")
+    return bins, inds

@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """Builds (if stale) and returns the path of the C-ABI library.  hipcc cross-compiles without a GPU."""
+    from signerf_amd import build
+
+    return build.build(verbose=False)
+
+
+@pytest.fixture(scope="session")
+def gpu(built_lib):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    return torch.device("cuda", 0)

@@ -1,0 +1,100 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, exports every symbol that
+include/signerf_hip.h declares, and the ctypes mirrors of its structs have the C layout.  No compute calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from helpers import ROOT
+from signerf_amd import _lib
+
+HEADER = os.path.join(ROOT, "include", "signerf_hip.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sn_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_functions() == sorted(_lib.SIGNATURES.keys())
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", built_lib], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (sn_[a-z_0-9]+)", out))
+    assert set(_declared_functions()) <= exported
+    lib = _lib.load()
+    for name in _declared_functions():
+        assert getattr(lib, name) is not None
+
+
+def test_library_contains_gfx950_code_object(built_lib):
+    blob = open(built_lib, "rb").read()
+    assert b"gfx950" in blob and b"sn_render_main_kernel" in blob
+
+
+def test_ctypes_struct_layout_matches_c(tmp_path):
+    prog = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "signerf_hip.h"
+int main(void) {
+  printf("%zu %zu %zu\n", sizeof(SnHashMlpDesc), sizeof(SnFieldDesc), sizeof(SnRenderOpts));
+  printf("%zu %zu %zu %zu\n", offsetof(SnHashMlpDesc, scalings), offsetof(SnFieldDesc, proposals),
+         offsetof(SnFieldDesc, average_init_density), offsetof(SnFieldDesc, num_proposals));
+  printf("%zu %zu %zu %zu %zu\n", offsetof(SnRenderOpts, num_nerf_samples), offsetof(SnRenderOpts, chunk_rays),
+         offsetof(SnRenderOpts, workspace), offsetof(SnRenderOpts, initial_spacing_bins), offsetof(SnRenderOpts, pdf_u));
+  return 0;
+}
+"""
+    src = tmp_path / "layout.c"
+    src.write_text(prog)
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    want = [C.sizeof(_lib.SnHashMlpDesc), C.sizeof(_lib.SnFieldDesc), C.sizeof(_lib.SnRenderOpts),
+            _lib.SnHashMlpDesc.scalings.offset, _lib.SnFieldDesc.proposals.offset, _lib.SnFieldDesc.average_init_density.offset,
+            _lib.SnFieldDesc.num_proposals.offset,
+            _lib.SnRenderOpts.num_nerf_samples.offset, _lib.SnRenderOpts.chunk_rays.offset, _lib.SnRenderOpts.workspace.offset,
+            _lib.SnRenderOpts.initial_spacing_bins.offset, _lib.SnRenderOpts.pdf_u.offset]
+    assert got == want
+
+
+def test_error_path_without_gpu(built_lib):
+    """sn_create validates the architecture before touching the device, and reports through sn_last_error."""
+    lib = _lib.load()
+    d = _lib.SnFieldDesc()
+    d.main_field.num_levels = 7  # unsupported
+    h = C.c_void_p(None)
+    st = lib.sn_create(C.byref(d), C.byref(h))
+    assert st == 1 and not h
+    assert b"num_levels" in lib.sn_last_error(None)
+    with pytest.raises(_lib.SignerfHipError):
+        _lib.check(st, None, "sn_create")
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under signerf_amd/, bench.py's GPU leg or the C sources may use it."""
+    pkg = os.path.join(ROOT, "signerf_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "/root/reference" not in text or f.endswith(".py"), f  # docstring citations only
+
+
+def test_model_refuses_cpu_render():
+    import torch
+    from helpers import small_config
+    from signerf_amd.cameras import RayBundle
+
+    m = small_config(num_proposal_iterations=0).setup()
+    b = RayBundle(torch.zeros(2, 2, 3), torch.ones(2, 2, 3), torch.ones(2, 2, 1))
+    with pytest.raises(_lib.SignerfHipError):
+        m.get_outputs_for_camera_ray_bundle(b)

@@ -1,0 +1,147 @@
+"""End-to-end GPU parity: Cameras.generate_rays -> Model.get_outputs_for_camera_ray_bundle against the CPU oracle, on the
+BASELINE.json configurations at sizes the oracle finishes in seconds, plus size-independent properties at full size.
+Gate (north_star): per-pixel RMSE(rgb) <= 1e-3 and RMSE(depth) <= 1e-3."""
+import pytest
+import torch
+
+from helpers import make_model, oracle_config, rmse, small_config
+from oracle import nerfacto as onf
+from signerf_amd import Cameras, SceneBox, scene
+from signerf_amd.cameras import RayBundle
+
+pytestmark = pytest.mark.gpu
+RMSE_TOL = 1e-3
+
+
+def _render_pair(cfg, model, sd, gpu, H, W, cam=0, focal=None, aabb=None):
+    c2w = scene.benchmark_cameras(8)
+    focal = focal or float(W)
+    cams = Cameras(c2w[:, :3], focal, focal, W / 2, H / 2, W, H).to(gpu)
+    model.render_aabb = aabb
+    bundle = cams[cam].generate_rays(camera_indices=0, aabb_box=model.render_aabb)
+    model.eval()
+    out = model.get_outputs_for_camera_ray_bundle(bundle)
+    model.train()
+    # oracle on the SAME bundle (ray generation has its own test)
+    n = None if bundle.nears is None else bundle.nears.cpu()
+    f = None if bundle.fars is None else bundle.fars.cpu()
+    ref = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg), bundle.origins.cpu(), bundle.directions.cpu(), n, f)
+    model.render_aabb = None
+    return out, ref
+
+
+def _check(out, ref, keys=("rgb", "depth", "accumulation", "expected_depth")):
+    for k in keys:
+        assert out[k].shape == ref[k].shape, k
+        assert out[k].dtype == torch.float32 and out[k].is_cuda
+    e_rgb, e_depth = rmse(out["rgb"], ref["rgb"]), rmse(out["depth"], ref["depth"])
+    flips = int((out["depth"].cpu() != ref["depth"]).sum())
+    print(f"rmse rgb {e_rgb:.2e} depth {e_depth:.2e} acc {rmse(out['accumulation'], ref['accumulation']):.2e} "
+          f"median-depth mismatches {flips}/{ref['depth'].numel()}")
+    assert e_rgb <= RMSE_TOL and e_depth <= RMSE_TOL
+    assert rmse(out["accumulation"], ref["accumulation"]) <= RMSE_TOL
+    assert rmse(out["expected_depth"], ref["expected_depth"]) <= 5e-3
+    assert float(ref["rgb"].std()) > 0.05 and float(ref["depth"].std()) > 0.01   # non-vacuous
+
+
+def test_config1_plumbing_64x64x32(gpu):
+    """BASELINE.json configs[0]."""
+    cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=32)
+    model, sd = make_model(cfg, gpu)
+    out, ref = _render_pair(cfg, model, sd, gpu, 64, 64)
+    _check(out, ref)
+
+
+def test_config2_reduced_96x96x64_full_tables(gpu):
+    """BASELINE.json configs[1] at 96x96 (same field: L=16, T=2^19, 64 uniform samples)."""
+    cfg = scene.benchmark_config(64)
+    model, sd = make_model(cfg, gpu)
+    out, ref = _render_pair(cfg, model, sd, gpu, 96, 96, cam=1, focal=96.0)
+    _check(out, ref)
+    assert set(out.keys()) == {"rgb", "accumulation", "depth", "expected_depth"}
+
+
+def test_ragged_image_and_aabb_nears_fars(gpu):
+    """Image size not a multiple of the 8x8 tile + per-ray nears/fars from render_aabb (collider skipped)."""
+    cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=40)
+    model, sd = make_model(cfg, gpu)
+    box = SceneBox(aabb=torch.tensor([[-0.35, -0.35, -0.3], [0.35, 0.35, 0.3]]))
+    out, ref = _render_pair(cfg, model, sd, gpu, 45, 59, cam=2, focal=70.0, aabb=box)
+    hit = (ref["depth"] < 1e9)
+    assert 0.05 < float(hit.float().mean()) < 1.0
+    for k in ("rgb", "accumulation"):
+        assert rmse(out[k], ref[k]) <= RMSE_TOL, k
+    assert rmse(out["depth"][hit.to(out["depth"].device)], ref["depth"][hit]) <= RMSE_TOL
+    miss = ~hit
+    assert torch.equal(out["depth"].cpu()[miss], ref["depth"][miss])           # sentinel 1e10 mid-points survive exactly
+
+
+def test_config4_reduced_proposal_path(gpu):
+    """BASELINE.json configs[3] at 72x128: two proposal nets (256 + 96) + 48 main samples, full-size tables."""
+    cfg = scene.proposal_config()
+    model, sd = make_model(cfg, gpu)
+    out, ref = _render_pair(cfg, model, sd, gpu, 72, 128, cam=3, focal=150.0)
+    _check(out, ref)
+    for i in (0, 1):
+        assert rmse(out[f"prop_depth_{i}"], ref[f"prop_depth_{i}"]) <= 5e-3
+
+
+def test_flat_bundle_get_outputs(gpu):
+    """Model.get_outputs on a flat [R] bundle (the viewer's path) equals the image path ray for ray."""
+    cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=24)
+    model, sd = make_model(cfg, gpu)
+    c2w = scene.benchmark_cameras(8)
+    cams = Cameras(c2w[:, :3], 40.0, 40.0, 16.0, 16.0, 32, 32).to(gpu)
+    b = cams[4].generate_rays(0)
+    img = model.get_outputs_for_camera_ray_bundle(b)
+    flat = model.get_outputs(b.flatten())
+    assert flat["rgb"].shape == (1024, 3)
+    assert torch.equal(flat["rgb"].view(32, 32, 3), img["rgb"]) and torch.equal(flat["depth"].view(32, 32, 1), img["depth"])
+
+
+def test_full_size_properties_800x800x64(gpu):
+    """BASELINE.json configs[1] at FULL size: size-independent properties.
+    (1) determinism; (2) a 40x40 crop re-rendered as its own bundle is bit-identical (rays are independent, ray<->pixel map
+    exact); (3) that crop matches the oracle within the gate; (4) outputs are finite and in range."""
+    cfg = scene.benchmark_config(64)
+    model, sd = make_model(cfg, gpu)
+    c2w = scene.benchmark_cameras(8)
+    cams = Cameras(c2w[:, :3], 800.0, 800.0, 400.0, 400.0, 800, 800).to(gpu)
+    b = cams[0].generate_rays(0)
+    out = model.get_outputs_for_camera_ray_bundle(b)
+    out2 = model.get_outputs_for_camera_ray_bundle(b)
+    for k in ("rgb", "depth", "accumulation"):
+        assert torch.equal(out[k], out2[k]), k
+        assert torch.isfinite(out[k]).all()
+    assert float(out["rgb"].min()) >= 0 and float(out["rgb"].max()) <= 1
+    y0, x0 = 380, 417
+    crop = RayBundle(b.origins[y0:y0 + 40, x0:x0 + 40].contiguous(), b.directions[y0:y0 + 40, x0:x0 + 40].contiguous(),
+                     b.pixel_area[y0:y0 + 40, x0:x0 + 40].contiguous())
+    oc = model.get_outputs_for_camera_ray_bundle(crop)
+    assert torch.equal(oc["rgb"], out["rgb"][y0:y0 + 40, x0:x0 + 40])
+    assert torch.equal(oc["depth"], out["depth"][y0:y0 + 40, x0:x0 + 40])
+    ref = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg), crop.origins.cpu(), crop.directions.cpu())
+    assert rmse(oc["rgb"], ref["rgb"]) <= RMSE_TOL and rmse(oc["depth"], ref["depth"]) <= RMSE_TOL
+    assert float(out["rgb"].std()) > 0.05
+
+
+def test_state_dict_boundary(gpu):
+    """The pipeline's load path (signerf_pipeline.py:93-132): keys filtered, strict=False, appearance table dropped; and
+    re-loading different weights changes the render (weights are re-uploaded)."""
+    cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=16)
+    model, sd = make_model(cfg, gpu, seed=0)
+    c2w = scene.benchmark_cameras(8)
+    b = Cameras(c2w[:, :3], 20.0, 20.0, 8.0, 8.0, 16, 16).to(gpu)[0].generate_rays(0)
+    a = model.get_outputs_for_camera_ray_bundle(b)["rgb"].clone()
+    sd2 = scene.synthetic_state_dict(cfg, seed=5)
+    state = {"_model." + k: v for k, v in sd2.items()}
+    model_state = {k[len("_model."):]: v for k, v in state.items() if k.startswith("_model.")}
+    del model_state["field.embedding_appearance.embedding.weight"]
+    model_state["camera_optimizer.pose_adjustment"] = torch.zeros(3, 6)
+    del model_state["camera_optimizer.pose_adjustment"]
+    res = model.load_state_dict(model_state, strict=False)
+    assert "field.embedding_appearance.embedding.weight" in res.missing_keys and not res.unexpected_keys
+    c = model.get_outputs_for_camera_ray_bundle(b)["rgb"]
+    assert not torch.equal(a, c)
+    groups = model.get_param_groups()
+    assert set(groups) == {"proposal_networks", "fields"} and model.get_training_callbacks(None) == []

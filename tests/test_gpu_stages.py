@@ -1,0 +1,198 @@
+"""GPU parity of every stage of the path against the CPU oracle, through the C ABI.
+Integer results (ray<->pixel map, hash-grid table rows, searchsorted / median indices) must be BIT-EXACT; floating point
+within the tolerance written next to each assert (north_star: 1e-3 RMSE end to end)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, make_model, oracle_config, rmse, small_config
+from oracle import nerfacto as onf
+from oracle import signerf_utils as su
+from signerf_amd import Cameras, SceneBox, intersect_with_aabb, ops, scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model_small(gpu):
+    cfg = small_config()
+    model, sd = make_model(cfg, gpu)
+    return cfg, model, sd
+
+
+@pytest.fixture(scope="module")
+def model_full(gpu):
+    """Full-size tables (2^19 main, 2^17 proposal) -- BASELINE.json configs[3] architecture."""
+    cfg = scene.proposal_config()
+    model, sd = make_model(cfg, gpu)
+    return cfg, model, sd
+
+
+# ---- row a5 -----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,W,cam", [(64, 64, 0), (37, 53, 3), (8, 200, 5)])
+def test_generate_rays(gpu, H, W, cam):
+    c2w = scene.benchmark_cameras(8)
+    fx, fy, cx, cy = 1.2 * W, 1.1 * W, W / 2 + 0.25, H / 2 - 0.5
+    cams = Cameras(c2w[:, :3], fx, fy, cx, cy, W, H).to(gpu)
+    assert len(cams) == 8
+    b = cams[cam].generate_rays(camera_indices=0)
+    ref = onf.generate_rays(c2w[cam, :3], fx, fy, cx, cy, H, W)
+    assert b.origins.shape == (H, W, 3) and b.pixel_area.shape == (H, W, 1)
+    assert torch.equal(b.origins.cpu(), ref["origins"])                       # translation column, copied
+    assert int(b.camera_indices.max()) == cam and b.camera_indices.dtype == torch.int64
+    d = b.directions.cpu()
+    assert float((d - ref["directions"]).abs().max()) <= 2e-7               # fp32 ulp-level
+    assert float(((b.pixel_area.cpu() - ref["pixel_area"]).abs() / ref["pixel_area"]).max()) <= 1e-3
+    assert float((b.metadata["directions_norm"].cpu() - ref["directions_norm"]).abs().max()) <= 1e-6
+    # ray index <-> (y, x): pixel (y, x) must hold the direction through pixel centre (x+.5, y+.5) -- exact index map
+    y, x = H // 3, (2 * W) // 3
+    cam_dir = torch.tensor([(x + 0.5 - cx) / fx, -(y + 0.5 - cy) / fy, -1.0])
+    w = c2w[cam, :3, :3] @ cam_dir
+    assert torch.allclose(d[y, x], w / w.norm(), atol=1e-6)
+
+
+def test_generate_rays_with_aabb(gpu):
+    c2w = scene.benchmark_cameras(8)
+    cams = Cameras(c2w[:, :3], 60.0, 60.0, 24.0, 24.0, 48, 48).to(gpu)
+    box = SceneBox(aabb=torch.tensor([[-0.3, -0.3, -0.2], [0.3, 0.25, 0.2]]))
+    b = cams[2].generate_rays(camera_indices=0, aabb_box=box)
+    ref = onf.generate_rays(c2w[2, :3], 60.0, 60.0, 24.0, 24.0, 48, 48)
+    tmin, tmax = onf.intersect_aabb_ns(b.origins.cpu().reshape(-1, 3), b.directions.cpu().reshape(-1, 3), box.aabb.flatten())
+    assert torch.allclose(b.nears.cpu().reshape(-1), tmin, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(b.fars.cpu().reshape(-1), tmax, rtol=1e-6, atol=1e-6)
+    assert float((b.nears == 1e10).float().mean()) > 0.05  # some rays miss the box -> sentinel
+
+
+# ---- row a4 (golden, bit-exact) -----------------------------------------------------------------------------------
+def test_intersect_with_aabb_golden(gpu):
+    g = np.load(os.path.join(GOLDEN, "intersect_with_aabb.npz"))
+    o, d = torch.tensor(g["origins"]).to(gpu), torch.tensor(g["directions"]).to(gpu)
+    for box, n, f in (("aabb", "nears", "fars"), ("aabb2", "nears2", "fars2")):
+        nears, fars = intersect_with_aabb(o, d, torch.tensor(g[box]))
+        assert nears.shape == (o.shape[0], o.shape[1], 1)
+        assert np.array_equal(nears.cpu().numpy(), g[n])
+        assert np.array_equal(fars.cpu().numpy(), g[f])
+
+
+def test_intersect_with_aabb_large_matches_oracle(gpu):
+    g = torch.Generator().manual_seed(3)
+    o = (torch.rand(300, 400, 3, generator=g) - 0.5) * 2
+    d = torch.nn.functional.normalize(torch.randn(300, 400, 3, generator=g), dim=-1)
+    d[0, :10] = torch.tensor([0.0, 0.0, 1.0])
+    box = torch.tensor([[-0.1, -0.1, -0.1], [0.1, 0.1, 0.1]])
+    n, f = intersect_with_aabb(o.to(gpu), d.to(gpu), box)
+    rn, rf = su.intersect_with_aabb(o, d, box)
+    assert torch.equal(n.cpu(), rn) and torch.equal(f.cpu(), rf)
+
+
+# ---- row a13 --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("which", [-1, 0, 1])
+def test_hash_encode_indices_bit_exact(model_full, gpu, which):
+    cfg, model, sd = model_full
+    ocfg = oracle_config(cfg)
+    hc = ocfg.main if which < 0 else ocfg.proposals[which]
+    prefix = "field.mlp_base" if which < 0 else f"proposal_networks.{which}.mlp_base"
+    g = torch.Generator().manual_seed(11 + which)
+    q = torch.rand(20000, 3, generator=g)
+    q[:64] = torch.tensor([0.25, 0.5, 0.75])          # exactly on grid vertices at several levels
+    q[64:128] = 0.0
+    q[128:192] = torch.nextafter(torch.tensor(1.0), torch.tensor(0.0))
+    feat, idx = ops.hash_encode(model, q.to(gpu), which, return_indices=True)
+    sc = onf.hash_scalings(hc.num_levels, hc.base_res, hc.max_res)
+    _, _, ridx, _ = onf.hash_corner_indices(q, sc, hc.log2_hashmap_size)
+    assert torch.equal(idx.cpu().to(torch.int64), ridx)                       # BIT-EXACT table rows, all 8 corners, all levels
+    ref = onf.hash_encode(q, sd[f"{prefix}.encoder.hash_table"], sc, hc.log2_hashmap_size)
+    assert float((feat.cpu() - ref).abs().max()) <= 2e-6                      # table ~U(-1,1); blend differs by FMA rounding only
+
+
+# ---- rows a9, a14, a15 ------------------------------------------------------------------------------------------------
+def test_main_field_forward(model_full, gpu):
+    cfg, model, sd = model_full
+    ocfg = oracle_config(cfg)
+    g = torch.Generator().manual_seed(5)
+    n = 10000  # not a multiple of 64/256: exercises the ragged tail
+    pos = (torch.rand(n, 3, generator=g) - 0.5) * 3.0
+    pos[:100] *= 20.0                                   # far outside the unit box -> contraction branch
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    density, rgb = ops.field_forward(model, pos.to(gpu), dirs.to(gpu))
+    rd, rh, _, _ = onf.density_field(sd, "field.mlp_base", ocfg.main, pos[:, None, :], ocfg.average_init_density)
+    rrgb = onf.field_rgb(sd, ocfg, dirs, rh)[:, 0]
+    rel = ((density.cpu() - rd[:, 0, 0]).abs() / rd[:, 0, 0].clamp_min(1e-6)).max()
+    assert float(rel) <= 1e-4                                                # density relative error (exp of an fp32 MLP)
+    assert float((rgb.cpu() - rrgb).abs().max()) <= 2e-5                      # post-sigmoid colours
+    assert float(rrgb.std()) > 0.05                                           # not vacuous
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_proposal_field_forward(model_full, gpu, which):
+    cfg, model, sd = model_full
+    ocfg = oracle_config(cfg)
+    g = torch.Generator().manual_seed(6 + which)
+    pos = (torch.rand(5001, 3, generator=g) - 0.5) * 4.0
+    density, _ = ops.field_forward(model, pos.to(gpu), None, which)
+    rd, _, _, _ = onf.density_field(sd, f"proposal_networks.{which}.mlp_base", ocfg.proposals[which], pos[:, None, :], ocfg.average_init_density)
+    rel = ((density.cpu() - rd[:, 0, 0]).abs() / rd[:, 0, 0].clamp_min(1e-6)).max()
+    assert float(rel) <= 1e-4
+
+
+# ---- rows a10, a17 ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,S", [(1000, 48), (257, 64), (3, 1), (64, 256)])
+def test_composite(gpu, R, S):
+    g = torch.Generator().manual_seed(R + S)
+    bins = torch.cumsum(torch.rand(R, S + 1, generator=g) * 0.1, dim=-1)
+    density = torch.exp(torch.randn(R, S, generator=g) * 2.0)
+    density[: R // 4] = 0.0                                   # empty rays: acc 0, median clamps to S-1, rgb = last sample
+    if R > 10 and S > 5:
+        density[R // 4 : R // 4 + 5, 3] = 1e5                 # opaque slabs
+    rgb_s = torch.rand(R, S, 3, generator=g)
+    out = ops.composite(bins.to(gpu), density.to(gpu), rgb_s.to(gpu))
+    starts, ends = bins[:, :-1, None], bins[:, 1:, None]
+    w = onf.get_weights(ends - starts, density[..., None])
+    assert float((out["weights"].cpu() - w[..., 0]).abs().max()) <= 2e-6
+    d, idx = onf.render_depth_median(w, starts, ends)
+    # median index: bit-exact except where the GPU's expf differs from libm's by an ulp right at the 0.5 crossing
+    gi = out["median_index"].cpu().to(torch.int64)
+    flips = int((gi != idx[:, 0]).sum())
+    assert flips <= max(1, R // 500), f"{flips} median-index flips in {R} rays"
+    same = gi == idx[:, 0]
+    assert torch.equal(out["depth"].cpu()[same], d[same, 0])                   # same index -> identical mid-point (exact arithmetic)
+    assert float((out["rgb"].cpu() - onf.render_rgb(rgb_s, w)).abs().max()) <= 1e-5
+    assert float((out["accumulation"].cpu() - onf.render_accumulation(w)[:, 0]).abs().max()) <= 1e-5
+    assert float((out["expected_depth"].cpu() - onf.render_depth_expected(w, starts, ends)[:, 0]).abs().max()) <= 1e-4
+    empty = slice(0, R // 4)
+    if R // 4 > 0:
+        assert torch.all(gi[empty] == S - 1) and float(out["accumulation"][empty].abs().max()) == 0
+        assert torch.allclose(out["rgb"].cpu()[empty], rgb_s[empty, -1], atol=1e-7)
+
+
+def test_composite_median_bit_exact_given_identical_weights(gpu):
+    """With transmittance-free inputs (density 0 except one sample) exp() plays no role: index must match exactly."""
+    R, S = 500, 40
+    g = torch.Generator().manual_seed(1)
+    bins = torch.cumsum(torch.rand(R, S + 1, generator=g), dim=-1)
+    hit = torch.randint(0, S, (R,), generator=g)
+    density = torch.zeros(R, S)
+    density[torch.arange(R), hit] = 1e6
+    out = ops.composite(bins.to(gpu), density.to(gpu), torch.rand(R, S, 3, generator=g).to(gpu))
+    assert torch.equal(out["median_index"].cpu().to(torch.int64), hit)
+
+
+# ---- row a11 ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,N,M", [(300, 256, 96), (300, 96, 48), (5, 7, 3), (64, 64, 64)])
+def test_pdf_sample(gpu, R, N, M):
+    g = torch.Generator().manual_seed(N * M)
+    sb = torch.sort(torch.rand(R, N + 1, generator=g), dim=-1).values
+    sb[:, 0], sb[:, -1] = 0.0, 1.0
+    w = torch.rand(R, N, generator=g) ** 4
+    w[: R // 5] = 0.0                                          # zero-weight rays -> uniform pdf (padding branch)
+    if R > 10:
+        w[R // 5 : R // 5 + 3] = 0.0
+        w[R // 5 : R // 5 + 3, N // 2] = 1.0                   # one-hot
+    bins, inds = ops.pdf_sample(sb.to(gpu), w.to(gpu), M, 0.01)
+    rb, rinds, rcdf = onf.pdf_sample(sb, w, M, 0.01)
+    flips = int((inds.cpu().to(torch.int64) != rinds).sum())
+    assert flips <= max(1, (R * (M + 1)) // 2000), f"{flips} searchsorted flips"   # cdf differs by fp32 sum order only
+    assert float((bins.cpu() - rb).abs().max()) <= 2e-6
+    assert torch.all(bins[:, 1:] >= bins[:, :-1])
