@@ -248,6 +248,10 @@ struct SnComposite {
             median = mid;
             median_idx = i;
         }
+        // RGBRenderer (eval): torch.nan_to_num on the per-sample colours
+        if (r != r) r = 0.0f;
+        if (g != g) g = 0.0f;
+        if (b != b) b = 0.0f;
         sum_w += w;
         sum_wd += w * mid;
         c[0] += w * r;
@@ -258,6 +262,9 @@ struct SnComposite {
 
     // After the last sample (index n-1, mid-point last_mid, colour r,g,b = 'last_sample' background).
     SN_DEV void finish(int n, float last_mid, float r, float g, float b, float out_rgb[3], float& depth, float& acc, float& exp_raw) {
+        if (r != r) r = 0.0f;
+        if (g != g) g = 0.0f;
+        if (b != b) b = 0.0f;
         if (!found) {
             median = last_mid;
             median_idx = n - 1;

@@ -246,10 +246,16 @@ __global__ __launch_bounds__(256, 2) void sn_render_main_kernel(SnMainParams p) 
         float h0, rgb[3];
         sn_main_field_f32(lds, feat, sh, lane, h0, rgb);
         __builtin_amdgcn_sched_barrier(0);
-        const float density = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
+        float density = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
         r = rgb[0];
         g = rgb[1];
         b = rgb[2];
+        // A NaN position (e.g. the 1e10 sentinel of a ray that misses render_aabb overflows to inf/inf) is NaN all the
+        // way through the reference's field; v_max-based ReLU would launder it, so restore it here.
+        if ((q[0] != q[0]) | (q[1] != q[1]) | (q[2] != q[2])) {
+            density = __builtin_nanf("");
+            r = g = b = density;
+        }
         comp.step(i, t0, t1, density, r, g, b);
         {
 #pragma clang fp contract(off)

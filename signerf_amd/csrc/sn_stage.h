@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void sn_main_field_stage_kernel(SnFieldStag
     sn_hash_encode<16>(rsrc, p.scal, p.log2_t, q, feat);
     float h0, rgb[3];
     sn_main_field_f32(lds, feat, sh, lane, h0, rgb);
+    if ((q[0] != q[0]) | (q[1] != q[1]) | (q[2] != q[2])) h0 = rgb[0] = rgb[1] = rgb[2] = __builtin_nanf("");
     if (i < p.n) {
         p.density[i] = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
         if (p.rgb) {

@@ -65,15 +65,19 @@ def test_ragged_image_and_aabb_nears_fars(gpu):
     """Image size not a multiple of the 8x8 tile + per-ray nears/fars from render_aabb (collider skipped)."""
     cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=40)
     model, sd = make_model(cfg, gpu)
-    box = SceneBox(aabb=torch.tensor([[-0.35, -0.35, -0.3], [0.35, 0.35, 0.3]]))
+    box = SceneBox(aabb=torch.tensor([[-0.15, -0.12, -0.1], [0.12, 0.15, 0.1]]))
     out, ref = _render_pair(cfg, model, sd, gpu, 45, 59, cam=2, focal=70.0, aabb=box)
-    hit = (ref["depth"] < 1e9)
+    hit = (ref["depth"] < 1e6)
     assert 0.05 < float(hit.float().mean()) < 1.0
-    for k in ("rgb", "accumulation"):
-        assert rmse(out[k], ref[k]) <= RMSE_TOL, k
-    assert rmse(out["depth"][hit.to(out["depth"].device)], ref["depth"][hit]) <= RMSE_TOL
+    hg = hit.to(out["depth"].device)
+    for k, c in (("rgb", 3), ("accumulation", 1), ("depth", 1)):
+        assert rmse(out[k][hg.expand(-1, -1, c)], ref[k][hit.expand(-1, -1, c)]) <= RMSE_TOL, k
+    # rays that miss the box carry the 1e10 sentinel: their sample positions overflow (inf / NaN) in the reference too;
+    # what must survive is "nothing accumulated, colour = nan_to_num(background)", identically on both sides
     miss = ~hit
-    assert torch.equal(out["depth"].cpu()[miss], ref["depth"][miss])           # sentinel 1e10 mid-points survive exactly
+    assert float(out["accumulation"].cpu()[miss].abs().max()) == 0 and float(ref["accumulation"][miss].abs().max()) == 0
+    assert torch.equal(torch.nan_to_num(out["rgb"].cpu()[miss.expand(-1, -1, 3)]), torch.nan_to_num(ref["rgb"][miss.expand(-1, -1, 3)]))
+    assert torch.equal(torch.nan_to_num(out["depth"].cpu()[miss], nan=-1.0), torch.nan_to_num(ref["depth"][miss], nan=-1.0))
 
 
 def test_config4_reduced_proposal_path(gpu):

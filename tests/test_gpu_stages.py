@@ -41,7 +41,8 @@ def test_generate_rays(gpu, H, W, cam):
     ref = onf.generate_rays(c2w[cam, :3], fx, fy, cx, cy, H, W)
     assert b.origins.shape == (H, W, 3) and b.pixel_area.shape == (H, W, 1)
     assert torch.equal(b.origins.cpu(), ref["origins"])                       # translation column, copied
-    assert int(b.camera_indices.max()) == cam and b.camera_indices.dtype == torch.int64
+    # the SIGNeRF call site passes camera_indices=0 on a 0-dim camera (datasetgenerator.py:691): indices are all 0
+    assert int(b.camera_indices.max()) == 0 and int(b.camera_indices.min()) == 0 and b.camera_indices.dtype == torch.int64
     d = b.directions.cpu()
     assert float((d - ref["directions"]).abs().max()) <= 2e-7               # fp32 ulp-level
     assert float(((b.pixel_area.cpu() - ref["pixel_area"]).abs() / ref["pixel_area"]).max()) <= 1e-3
@@ -56,7 +57,7 @@ def test_generate_rays(gpu, H, W, cam):
 def test_generate_rays_with_aabb(gpu):
     c2w = scene.benchmark_cameras(8)
     cams = Cameras(c2w[:, :3], 60.0, 60.0, 24.0, 24.0, 48, 48).to(gpu)
-    box = SceneBox(aabb=torch.tensor([[-0.3, -0.3, -0.2], [0.3, 0.25, 0.2]]))
+    box = SceneBox(aabb=torch.tensor([[-0.12, -0.1, -0.08], [0.1, 0.12, 0.09]]))
     b = cams[2].generate_rays(camera_indices=0, aabb_box=box)
     ref = onf.generate_rays(c2w[2, :3], 60.0, 60.0, 24.0, 24.0, 48, 48)
     tmin, tmax = onf.intersect_aabb_ns(b.origins.cpu().reshape(-1, 3), b.directions.cpu().reshape(-1, 3), box.aabb.flatten())
@@ -192,7 +193,16 @@ def test_pdf_sample(gpu, R, N, M):
         w[R // 5 : R // 5 + 3, N // 2] = 1.0                   # one-hot
     bins, inds = ops.pdf_sample(sb.to(gpu), w.to(gpu), M, 0.01)
     rb, rinds, rcdf = onf.pdf_sample(sb, w, M, 0.01)
-    flips = int((inds.cpu().to(torch.int64) != rinds).sum())
-    assert flips <= max(1, (R * (M + 1)) // 2000), f"{flips} searchsorted flips"   # cdf differs by fp32 sum order only
-    assert float((bins.cpu() - rb).abs().max()) <= 2e-6
+    # searchsorted indices are integer work ON a cdf; the cdf itself is fp32 work whose last ulp depends on the order
+    # of an fp32 sum.  Indices must therefore agree everywhere except at provable near-ties |cdf_knot - u| <= 2 ulp
+    # (e.g. u = 0.5 against the knot 128/256 of a uniform pdf); count them, and require nothing else flips.
+    u = onf.pdf_u(M)
+    gap = (rcdf[:, None, :] - u[None, :, None]).abs().min(dim=-1).values      # [R, M+1] distance to the nearest knot
+    flipped = inds.cpu().to(torch.int64) != rinds
+    print(f"pdf_sample R={R} N={N} M={M}: {int(flipped.sum())} index flips, all at near-ties: "
+          f"{bool((gap[flipped] <= 2.4e-7).all())}; near-ties present: {int((gap <= 2.4e-7).sum())}")
+    assert bool((gap[flipped] <= 2.4e-7).all())
+    assert int(flipped.sum()) <= int((gap <= 2.4e-7).sum())
+    # a flipped tie still lands on (almost) the same bin value: the interpolant is continuous across a knot
+    assert float((bins.cpu() - rb).abs().max()) <= 1e-5
     assert torch.all(bins[:, 1:] >= bins[:, :-1])
