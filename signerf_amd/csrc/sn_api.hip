@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -508,10 +509,15 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
     p.chunk_rays = opts->chunk_rays;
     const int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
     const size_t lds_bytes = (size_t)SnMainImg::TOTAL * 4;
-    if (nprop > 0)
-        hipLaunchKernelGGL(sn_render_main_kernel<1>, dim3((unsigned)(gbx * gby)), dim3(256), lds_bytes, st, p);
-    else
-        hipLaunchKernelGGL(sn_render_main_kernel<0>, dim3((unsigned)(gbx * gby)), dim3(256), lds_bytes, st, p);
+    const dim3 grid((unsigned)(gbx * gby)), block(256);
+#define SN_LAUNCH_MAIN(MODE, ABL) hipLaunchKernelGGL((sn_render_main_kernel<MODE, ABL>), grid, block, lds_bytes, st, p)
+    const char* abl_env = getenv("SN_ABLATE");  // profiling only: non-zero gives WRONG images (see sn_main.h)
+    const int ablate = abl_env ? atoi(abl_env) : 0;
+    if (ablate == 2 && nprop == 0) SN_LAUNCH_MAIN(0, 2);
+    else if (ablate == 3 && nprop == 0) SN_LAUNCH_MAIN(0, 3);
+    else if (nprop > 0) SN_LAUNCH_MAIN(1, 0);
+    else SN_LAUNCH_MAIN(0, 0);
+#undef SN_LAUNCH_MAIN
     SN_HIP(h, hipGetLastError());
     if (expected_depth) {
         hipLaunchKernelGGL(sn_clip_expected_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_exp_raw, d_minmax, n,

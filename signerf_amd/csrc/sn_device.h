@@ -152,11 +152,14 @@ SN_DEV f32x2 sn_table_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, uint3
 }
 
 // Encode one point over L levels -> feat[2L], level-major.  `scal` must be wave-uniform.
-template <int L>
+// GROUP > 0 fences the instruction scheduler every GROUP levels: at most GROUP*8 gathers (GROUP*16 VGPRs) are in flight,
+// which keeps the fused kernels inside their register budget (the scheduler otherwise hoists all L*8 loads).
+template <int L, int GROUP = 0>
 SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], float* feat) {
     const uint32_t mask = (1u << log2_t) - 1u;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
+        if (GROUP > 0 && l > 0 && (l % GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
         SnHashLevel hl;
         sn_hash_corners(q, scal[l], mask, hl);
         const uint32_t lvl = ((uint32_t)l << log2_t) * 8u;

@@ -102,10 +102,13 @@ SN_DEV void sn_main_field_f32(const float* __restrict__ lds, float* feat, const 
             op0[rt * 16 + r] = fmaxf(a0[rt][r], 0.0f);
             op1[rt * 16 + r] = fmaxf(a1[rt][r], 0.0f);
         }
+    // (scheduler fences between layers: otherwise every LDS weight read of the whole MLP is hoisted to the top and spills)
+    __builtin_amdgcn_sched_barrier(0);
     // ---- layer 2: 64 -> 16 (rows 0..15 real; row 20 duplicates row 0 for the upper half) ----
     f32x16 g0[1], g1[1];
     sn_mlp_layer_f32<1, 32>(lds + SnMainImg::W2, lds + SnMainImg::B2, op0, op1, g0, g1, lane);
     h0 = upper ? g1[0][8] : g0[0][0];
+    __builtin_amdgcn_sched_barrier(0);
     // ---- colour layer 1: (L2 rows 0..15 | SH16) -> 64, ReLU --------------------------------
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -122,8 +125,10 @@ SN_DEV void sn_main_field_f32(const float* __restrict__ lds, float* feat, const 
             op0[rt * 16 + r] = fmaxf(a0[rt][r], 0.0f);
             op1[rt * 16 + r] = fmaxf(a1[rt][r], 0.0f);
         }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- colour layer 2: 64 -> 64, ReLU ----------------------------------------------------
     sn_mlp_layer_f32<2, 32>(lds + SnMainImg::WC2, lds + SnMainImg::BC2, op0, op1, a0, a1, lane);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- colour layer 3: 64 -> 3 on the VALU (a 32-row MFMA tile would be 90 % padding) -----
     const int h = lane >> 5;
     float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
@@ -156,6 +161,10 @@ SN_DEV void sn_main_field_f32(const float* __restrict__ lds, float* feat, const 
 // ------------------------------------------------------------------------------------------
 // kernel
 // ------------------------------------------------------------------------------------------
+#ifndef SN_MAIN_WAVES_PER_SIMD
+#define SN_MAIN_WAVES_PER_SIMD 3
+#endif
+
 struct SnMainParams {
     const float* origins;     // [H*W,3]
     const float* directions;  // [H*W,3]
@@ -191,8 +200,11 @@ SN_DEV int sn_xcd_remap(int b, int n) {
     return base + k;
 }
 
-template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/>
-__global__ __launch_bounds__(256, 2) void sn_render_main_kernel(SnMainParams p) {
+// ABLATE (profiling only, images are WRONG when non-zero; selected by the SN_ABLATE environment variable): 2 = hash phase
+// only (no MLP: density / colour faked from the features), 3 = VALU only (no table gathers either).  Measured r01:
+// full 7.7 ms, hash-only 2.8-3.0 ms (= the L1 tag-lookup floor), VALU-only 1.4 ms; the 204.8 M fp32 MFMAs alone are 5.6 ms.
+template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int ABLATE = 0>
+__global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_kernel(SnMainParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     for (int i = tid * 4; i < SnMainImg::TOTAL; i += 256 * 4) *(f32x4*)(lds + i) = *(const f32x4*)(p.wimg + i);
@@ -235,16 +247,50 @@ __global__ __launch_bounds__(256, 2) void sn_render_main_kernel(SnMainParams p) 
     float t0 = MODE == 0 ? sn_euclid(p.sbins ? p.sbins[0] : 0.0f, s_near, s_far) : eb[0];
     float first_mid = 0.f, last_mid = 0.f;
     float r = 0.f, g = 0.f, b = 0.f;
+#pragma unroll 1
     for (int i = 0; i < S; ++i) {
+        // The LDS weight reads are loop-invariant; LICM would hoist them all (368 VGPRs) and spill.  A compiler-only
+        // memory clobber per iteration keeps them inside the loop.
+        asm volatile("" ::: "memory");
         const float t1 = MODE == 0 ? sn_euclid(p.sbins ? p.sbins[i + 1] : (float)(i + 1) / (float)S, s_near, s_far)
                                    : eb[(int64_t)(i + 1) * 64];
         float q[3];
         const bool sel = sn_sample_q(o, d, t0, t1, q);
         float feat[32];
-        sn_hash_encode<16>(rsrc, p.scal, p.log2_t, q, feat);
+        if (ABLATE & 1) {
+#pragma unroll
+            for (int l = 0; l < 16; ++l) {
+                SnHashLevel hl;
+                sn_hash_corners(q, p.scal[l], (1u << p.log2_t) - 1u, hl);
+                f32x2 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[k].x = __uint_as_float((hl.row[k] & 0x7fffffu) | 0x3f800000u) - 1.5f;
+                    v[k].y = -v[k].x;
+                }
+                f32x2 e = sn_hash_blend(v, hl.off);
+                feat[2 * l] = e.x;
+                feat[2 * l + 1] = e.y;
+            }
+        } else {
+            sn_hash_encode<16, 4>(rsrc, p.scal, p.log2_t, q, feat);
+        }
         __builtin_amdgcn_sched_barrier(0);
         float h0, rgb[3];
-        sn_main_field_f32(lds, feat, sh, lane, h0, rgb);
+        if (ABLATE & 2) {
+            float a = 0.f, bsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                a += feat[k];
+                bsum = fmaf(feat[k], (float)(k & 3), bsum);
+            }
+            h0 = a * 0.1f + sh.t0[0];
+            rgb[0] = 0.5f + 0.1f * a;
+            rgb[1] = 0.5f + 0.1f * bsum;
+            rgb[2] = 0.5f - 0.1f * a;
+        } else {
+            sn_main_field_f32(lds, feat, sh, lane, h0, rgb);
+        }
         __builtin_amdgcn_sched_barrier(0);
         float density = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
         r = rgb[0];
