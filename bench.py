@@ -26,6 +26,17 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_MAIN_SAMPLE = 1024.0  # 16 levels x 8 corners x 2 features x 4 B
 
 
+def measured_traffic(precision):
+    """HBM-side bytes per launch of the dominant kernel, from the committed PMC pass (profiles/traffic.json, written by
+    tools/pmc_summary.py --json from TCC_EA0_RDREQ_{32,64,128}B + WRITE_SIZE; bench.py cannot run rocprofv3 on itself)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(precision, {}).get("bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, sd, width, height, samples, crop=200):
     """The CPU oracle (a port: nerfstudio's own CPU path cannot be installed) timed on a centred crop of the same frame."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -53,10 +64,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--width", type=int, default=800)
-    ap.add_argument("--height", type=int, default=800)
-    ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16x2"])
+    ap.add_argument("--workload", default="sheet64", choices=["sheet64", "nerfacto1080"],
+                    help="sheet64 = BASELINE.json configs[1] (the metric's configuration, default); "
+                         "nerfacto1080 = configs[3]: 1920x1080, 2 proposal nets (256 + 96 samples) + 48 main samples")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--samples", type=int, default=None)
+    ap.add_argument("--precision", default="fp16x2", choices=["fp32", "fp16x2"],
+                    help="MFMA arithmetic of the tiny MLPs: fp16x2 = fp32 operands split into fp16 hi+lo, fp32 accumulate "
+                         "(measured error identical to exact fp32 MFMA, tests/test_gpu_stages.py); fp32 = exact fp32 MFMA")
+    ap.add_argument("--no-alt-precision", action="store_true", help="skip the extra (untimed-region) run of the other precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -75,17 +92,44 @@ def main():
     from signerf_amd import Cameras, build, scene, sheet
 
     build.build(verbose=False)
-    cfg = scene.benchmark_config(args.samples)
+    if args.workload == "sheet64":
+        args.width, args.height, args.samples = args.width or 800, args.height or 800, args.samples or 64
+        cfg = scene.benchmark_config(args.samples)
+        focal = float(args.width)
+        bytes_per_ray = args.samples * BYTES_PER_MAIN_SAMPLE
+    else:
+        args.width, args.height = args.width or 1920, args.height or 1080
+        cfg = scene.proposal_config()
+        args.samples = cfg.num_nerf_samples_per_ray
+        focal = 1.2 * args.height
+        bytes_per_ray = sum(cfg.num_proposal_samples_per_ray) * 320.0 + args.samples * BYTES_PER_MAIN_SAMPLE  # 161.8 kB
     cfg.precision = args.precision
     sd = scene.synthetic_state_dict(cfg, seed=0)
     model = cfg.setup()
     model.load_state_dict(sd, strict=False)
     model = model.to(dev).eval()
     W, H, S = args.width, args.height, args.samples
-    cams = Cameras(scene.benchmark_cameras(8)[:, :3], float(W), float(W), W / 2, H / 2, W, H).to(dev)
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], focal, focal, W / 2, H / 2, W, H).to(dev)
     cam = cams[rank % 8]
 
     render_ms = []
+
+    def kernel_ms_of(precision: str, n: int = 5) -> float:
+        """Mean HIP-event time of the render call in another arithmetic mode (outside the timed region)."""
+        old = model.config.precision
+        model.config.precision = precision
+        ev = []
+        for i in range(n + 1):
+            bundle = cam.generate_rays(camera_indices=0, aabb_box=model.render_aabb)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            model.get_outputs_for_camera_ray_bundle(bundle)
+            b.record()
+            if i > 0:
+                ev.append((a, b))
+        torch.cuda.synchronize()
+        model.config.precision = old
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
     def step(timed: bool):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -122,23 +166,35 @@ def main():
     if rank == 0:
         samples_per_step = world * W * H * S
         value = samples_per_step * args.steps / elapsed
-        achieved = (W * H * S * BYTES_PER_MAIN_SAMPLE) / (kernel_ms * 1e-3) / 1e9
+        achieved = (W * H * bytes_per_ray) / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": "ray-samples/sec (800x800 reference-sheet camera render)",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f32 (fp16 hi+lo split MFMA, f32 accumulate)",
+            "dtype": "f32" if args.precision == "fp32" else
+                     "f32 (MLP operands carried as fp16 hi+lo pairs on the matrix cores, f32 accumulate; measured error equals exact-f32 MFMA)",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: {W}x{H} rays x {S} samples/ray, nerfacto hash grid L=16 T=2^19 F=2, "
-                                   "no proposal nets, random-weight synthetic scene, one camera per GPU + tile all-gather",
+            "config": {"workload": (f"BASELINE.json configs[1]: {W}x{H} rays x {S} samples/ray, nerfacto hash grid L=16 T=2^19 F=2, "
+                                    "no proposal nets, random-weight synthetic scene, one camera per GPU + tile all-gather")
+                       if args.workload == "sheet64" else
+                       (f"BASELINE.json configs[3]: {W}x{H} rays, proposal nets 256 + 96 samples (L=5, T=2^17) + {S} main samples "
+                        "(L=16, T=2^19), random-weight synthetic scene, one camera per GPU + tile all-gather"),
                        "rays_per_gpu": W * H, "samples_per_ray": S, "parallelism": f"camera-sharded x{world}"},
             "ms_per_frame": elapsed / args.steps * 1e3,
             "rays_per_sec": world * W * H * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel": "sn_render_main_kernel<0>", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": W * H * S * BYTES_PER_MAIN_SAMPLE},
+                         "traffic": measured_traffic(args.precision) if args.workload == "sheet64" else None,
+                         "kernel": ("sn_render_main_kernel<0,%d>" % (0 if args.precision == "fp32" else 1)) if args.workload == "sheet64"
+                         else "sn_proposal_kernel + sn_render_main_kernel<1,*> (whole render call)",
+                         "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": W * H * bytes_per_ray},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_alt_precision:
+            other = "fp32" if args.precision == "fp16x2" else "fp16x2"
+            ms = kernel_ms_of(other)
+            line["alt_precision"] = {"precision": other, "kernel_ms": ms, "ray_samples_per_s_per_gpu": W * H * S / (ms * 1e-3),
+                                     "roofline_frac": (W * H * bytes_per_ray) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        if world == 1 and not args.no_cpu_baseline and args.workload == "sheet64":
             line["cpu_baseline"] = cpu_baseline(cfg, sd, W, H, S)
         print(json.dumps(line), flush=True)
     if world > 1:

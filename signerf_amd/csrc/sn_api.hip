@@ -42,7 +42,8 @@ struct SnContext {
     std::map<std::string, std::vector<float>> host;  // small tensors (MLP layers, appearance mean)
     DevBuf table_main;
     DevBuf table_prop[SN_MAX_PROPOSALS];
-    DevBuf wimg_main;                   // SnMainImg
+    DevBuf wimg_main;                   // SnMainImg (fp32 MFMA operands)
+    DevBuf wimg_main_h;                 // SnMainImgH (fp16 hi+lo MFMA operands)
     DevBuf wpack_prop[SN_MAX_PROPOSALS]; // SnPropPack
     bool finalized = false;
 };
@@ -158,6 +159,84 @@ std::vector<float> build_main_image(const SnFieldDesc& d, const float* W1, const
     return img;
 }
 
+
+// ---- fp16 helpers (host) -------------------------------------------------------------------------------------
+uint16_t f32_to_f16_rne(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7bffu);  // saturate instead of inf (matches cvt_pkrtz on the device side)
+    if (x < 0x38800000u) {                                     // subnormal half (or zero)
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int shift = 126 - (int)(x >> 23);                // 14..24
+        uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+        uint32_t half = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1u), mid = 1u << (shift - 1);
+        if (rem > mid || (rem == mid && (half & 1u))) ++half;
+        return (uint16_t)(sign | half);
+    }
+    uint32_t half = ((x - 0x38000000u) >> 13);
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) ++half;
+    return (uint16_t)(sign | half);
+}
+
+float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else {
+            int sh = 0;
+            while (!(m & 0x400u)) { m <<= 1; ++sh; }
+            x = sign | ((uint32_t)(113 - sh) << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+// fp16x2 LDS image consumed by sn_main_field_h: same rows / folded bias as build_main_image, other k-slot order.
+std::vector<float> build_main_image_h(const SnFieldDesc& d, const float* W1, const float* W2, const float* Wc1, const float* Wc2,
+                                      const std::vector<float>& img32) {
+    std::vector<float> out(SnMainImg::TOTAL, 0.0f);
+    uint16_t* hw = (uint16_t*)out.data();
+    const int geo = d.geo_feat_dim, sh = d.sh_levels * d.sh_levels, cin = sh + geo + d.appearance_embed_dim;
+    auto put = [&](int base_bytes, int KS, int rt, int s, int lane, int e, float w) {
+        const uint16_t hi = f32_to_f16_rne(w);
+        const uint16_t lo = f32_to_f16_rne(w - f16_to_f32(hi));
+        const size_t off = (size_t)base_bytes / 2 + ((size_t)((rt * KS + s) * 2) * 64 + lane) * 8 + e;
+        hw[off] = hi;
+        hw[off + 512] = lo;  // the lo plane follows 64 lanes x 8 halves later
+    };
+    auto l2src = [&](int row) { return row < 16 ? row : (row == 20 ? 0 : -1); };
+    for (int lane = 0; lane < 64; ++lane) {
+        const int h = lane >> 5, i = lane & 31;
+        for (int e = 0; e < 8; ++e) {
+            for (int rt = 0; rt < 2; ++rt)
+                for (int s = 0; s < 2; ++s) put(SnMainImgH::W1, 2, rt, s, lane, e, W1[(rt * 32 + i) * 32 + 16 * s + 8 * h + e]);
+            for (int s = 0; s < 4; ++s) {  // hidden unit of slot (s = 2 rt' + s', h, e): rt'*32 + rho(8 s' + e) + 4h
+                const int hid = (s / 2) * 32 + rho(8 * (s % 2) + e) + 4 * h, src = l2src(i);
+                put(SnMainImgH::W2, 4, 0, s, lane, e, src >= 0 ? W2[src * 64 + hid] : 0.0f);
+                for (int rt = 0; rt < 2; ++rt) put(SnMainImgH::WC2, 4, rt, s, lane, e, Wc2[(rt * 32 + i) * 64 + hid]);
+            }
+            for (int rt = 0; rt < 2; ++rt) {
+                const int row = rt * 32 + i;
+                const int l2row = rho(e) + 4 * h;  // k-step 0: layer-2 rows
+                put(SnMainImgH::WC1, 2, rt, 0, lane, e, (l2row >= 1 && l2row <= geo) ? Wc1[row * cin + sh + (l2row - 1)] : 0.0f);
+                const int comp = 8 * h + e;        // k-step 1: SH components
+                put(SnMainImgH::WC1, 2, rt, 1, lane, e, comp < sh ? Wc1[row * cin + comp] : 0.0f);
+            }
+        }
+    }
+    memcpy((char*)out.data() + SnMainImgH::FP32, img32.data() + SnMainImg::B1, (size_t)SnMainImgH::TAIL_FLOATS * 4);
+    return out;
+}
+
 const std::vector<float>* find(SnHandle h, const std::string& name, size_t count) {
     auto it = h->host.find(name);
     if (it == h->host.end() || it->second.size() != count) return nullptr;
@@ -252,6 +331,7 @@ int sn_destroy(SnHandle h) {
     if (!h) return SN_OK;
     h->table_main.release();
     h->wimg_main.release();
+    h->wimg_main_h.release();
     for (int i = 0; i < SN_MAX_PROPOSALS; ++i) {
         h->table_prop[i].release();
         h->wpack_prop[i].release();
@@ -335,6 +415,12 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         h->wimg_main.bytes = img.size() * 4;
     }
     SN_HIP(h, hipMemcpyAsync(h->wimg_main.ptr, img.data(), img.size() * 4, hipMemcpyHostToDevice, st));
+    std::vector<float> imgh = build_main_image_h(d, t[0]->data(), t[2]->data(), t[4]->data(), t[6]->data(), img);
+    if (!h->wimg_main_h.ptr) {
+        SN_HIP(h, hipMalloc(&h->wimg_main_h.ptr, imgh.size() * 4));
+        h->wimg_main_h.bytes = imgh.size() * 4;
+    }
+    SN_HIP(h, hipMemcpyAsync(h->wimg_main_h.ptr, imgh.data(), imgh.size() * 4, hipMemcpyHostToDevice, st));
     for (int i = 0; i < d.num_proposals; ++i) {
         const std::string pre = "proposal_networks." + std::to_string(i) + ".mlp_base.";
         if (!h->table_prop[i].ptr) return fail(h, SN_ERR_STATE, "missing " + pre + "encoder.hash_table");
@@ -418,7 +504,6 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
     if (!h->finalized) return fail(h, SN_ERR_STATE, "sn_render_rays: weights not finalized");
     std::string why;
     if (!valid_opts(h->desc, *opts, why)) return fail(h, SN_ERR_INVALID, "sn_render_rays: " + why);
-    if (opts->precision != 0) return fail(h, SN_ERR_INVALID, "sn_render_rays: precision 1 (split fp16) is not built yet");
     const WorkspacePlan wp = plan_workspace(height, width, *opts);
     if (!opts->workspace || opts->workspace_bytes < wp.total)
         return fail(h, SN_ERR_WORKSPACE, "sn_render_rays: workspace too small, need " + std::to_string(wp.total) + " bytes");
@@ -486,7 +571,7 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
     p.sbins = d_sbins;
     p.ebins = d_ebins;
     p.table = (const float*)h->table_main.ptr;
-    p.wimg = (const float*)h->wimg_main.ptr;
+    p.wimg = (const float*)(opts->precision == 0 ? h->wimg_main.ptr : h->wimg_main_h.ptr);
     p.rgb = rgb;
     p.depth = depth;
     p.acc = accumulation;
@@ -510,13 +595,19 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
     const int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
     const size_t lds_bytes = (size_t)SnMainImg::TOTAL * 4;
     const dim3 grid((unsigned)(gbx * gby)), block(256);
-#define SN_LAUNCH_MAIN(MODE, ABL) hipLaunchKernelGGL((sn_render_main_kernel<MODE, ABL>), grid, block, lds_bytes, st, p)
+#define SN_LAUNCH_MAIN(MODE, PREC, ABL) hipLaunchKernelGGL((sn_render_main_kernel<MODE, PREC, ABL>), grid, block, lds_bytes, st, p)
     const char* abl_env = getenv("SN_ABLATE");  // profiling only: non-zero gives WRONG images (see sn_main.h)
     const int ablate = abl_env ? atoi(abl_env) : 0;
-    if (ablate == 2 && nprop == 0) SN_LAUNCH_MAIN(0, 2);
-    else if (ablate == 3 && nprop == 0) SN_LAUNCH_MAIN(0, 3);
-    else if (nprop > 0) SN_LAUNCH_MAIN(1, 0);
-    else SN_LAUNCH_MAIN(0, 0);
+    const bool split = opts->precision == 1;
+    if (ablate == 2 && nprop == 0) SN_LAUNCH_MAIN(0, 0, 2);
+    else if (ablate == 3 && nprop == 0) SN_LAUNCH_MAIN(0, 0, 3);
+    else if (nprop > 0) {
+        if (split) SN_LAUNCH_MAIN(1, 1, 0);
+        else SN_LAUNCH_MAIN(1, 0, 0);
+    } else {
+        if (split) SN_LAUNCH_MAIN(0, 1, 0);
+        else SN_LAUNCH_MAIN(0, 0, 0);
+    }
 #undef SN_LAUNCH_MAIN
     SN_HIP(h, hipGetLastError());
     if (expected_depth) {
@@ -555,7 +646,7 @@ int sn_field_forward(SnHandle h, int32_t which, const float* positions, const fl
     if (!positions || !density || n < 0) return fail(h, SN_ERR_INVALID, "sn_field_forward: bad argument");
     if (which < -1 || which >= h->desc.num_proposals) return fail(h, SN_ERR_INVALID, "sn_field_forward: bad field selector");
     if (!h->finalized) return fail(h, SN_ERR_STATE, "sn_field_forward: weights not finalized");
-    if (precision != 0) return fail(h, SN_ERR_INVALID, "sn_field_forward: precision 1 (split fp16) is not built yet");
+    if (precision != 0 && precision != 1) return fail(h, SN_ERR_INVALID, "sn_field_forward: precision must be 0 or 1");
     if (n == 0) return SN_OK;
     hipStream_t st = (hipStream_t)stream;
     if (which < 0) {
@@ -564,14 +655,17 @@ int sn_field_forward(SnHandle h, int32_t which, const float* positions, const fl
         p.directions = directions;
         p.n = n;
         p.table = (const float*)h->table_main.ptr;
-        p.wimg = (const float*)h->wimg_main.ptr;
+        p.wimg = (const float*)(precision == 0 ? h->wimg_main.ptr : h->wimg_main_h.ptr);
         for (int l = 0; l < 16; ++l) p.scal[l] = h->desc.main_field.scalings[l];
         p.log2_t = h->desc.main_field.log2_hashmap_size;
         p.avg_density = h->desc.average_init_density;
         p.sh_remap = h->desc.sh_remap;
         p.density = density;
         p.rgb = rgb;
-        hipLaunchKernelGGL(sn_main_field_stage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)SnMainImg::TOTAL * 4, st, p);
+        if (precision == 0)
+            hipLaunchKernelGGL(sn_main_field_stage_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)SnMainImg::TOTAL * 4, st, p);
+        else
+            hipLaunchKernelGGL(sn_main_field_stage_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)SnMainImg::TOTAL * 4, st, p);
     } else {
         SnPropStageParams p;
         p.positions = positions;

@@ -158,6 +158,215 @@ SN_DEV void sn_main_field_f32(const float* __restrict__ lds, float* feat, const 
     }
 }
 
+// ==========================================================================================
+// Split-precision variant ("fp16x2"): every fp32 operand x is split into fp16 hi + lo (x = hi + lo to ~2^-22), and
+// each product group is three v_mfma_f32_32x32x16_f16 (hi.hi + hi.lo + lo.hi; the lo.lo term, ~2^-22 relative, is
+// dropped) with fp32 accumulation.  3 x 1/16-cost MFMAs replace one fp32 MFMA: 120 MFMAs x 32 cycles per wave-step
+// instead of 320 x 64.  Layout facts: A[i=l&31][k=8(l>>5)+e], B[k=8(l>>5)+e][j=l&31], e = 0..7 (one f16x8 = 4 VGPRs);
+// C/D as for fp32.  A k-slot is (s = 16-wide k-step, h = lane half, e).
+// Range: |x| beyond 65504 saturates (cvt_pkrtz) -- trained nerfacto activations are O(1..100).
+// ==========================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// byte offsets of the fp16x2 LDS image; weights [rt][s][hi|lo][lane][8 halves]
+struct SnMainImgH {
+    static constexpr int W1 = 0;          // 2 rt x 2 s x 2 x 1 KiB
+    static constexpr int W2 = 8192;       // 1 x 4 x 2 KiB
+    static constexpr int WC1 = 16384;     // 2 x 2 x 2 KiB
+    static constexpr int WC2 = 24576;     // 2 x 4 x 2 KiB
+    static constexpr int FP32 = 40960;    // then the fp32 tail, same sub-layout as SnMainImg from B1 on
+    static constexpr int TAIL_FLOATS = SnMainImg::TOTAL - SnMainImg::B1;
+    static constexpr int TOTAL_BYTES = FP32 + TAIL_FLOATS * 4;  // 42640
+    static constexpr int B1 = 0, B2 = SnMainImg::B2 - SnMainImg::B1, BC1 = SnMainImg::BC1 - SnMainImg::B1,
+                         BC2 = SnMainImg::BC2 - SnMainImg::B1, W3 = SnMainImg::W3 - SnMainImg::B1, B3 = SnMainImg::B3 - SnMainImg::B1;
+};
+
+// two fp32 -> packed fp16 hi pair and lo pair
+SN_DEV void sn_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const float ah = __uint_as_float(__float_as_uint(a) & 0xffffe000u);
+    const float bh = __uint_as_float(__float_as_uint(b) & 0xffffe000u);
+    hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(ah, bh));
+    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a - ah, b - bh));
+}
+
+// gfx950 hazard found on hardware (r01): a VALU write (v_cvt_pkrtz_f16_f32 / v_sub / v_and ...) of a register that a
+// following v_mfma_f32_32x32x16_f16 reads as its 4-VGPR B operand must be separated from it by wait states that hipcc
+// (ROCm 7.2) does not insert: otherwise the MFMA occasionally sees the register's PREVIOUS contents in lanes 48-63 (the
+// last 16-lane pass of the write).  Symptom: ~5 of 10 000 tiles per frame with colour off by ~1e-3, different tiles every
+// run.  SN_OP_GUARD pins 8 wait states after every operand construction (22 x 8 cycles per wave-step: free).
+#ifndef SN_OP_GUARD
+#define SN_OP_GUARD 1
+#endif
+struct SnOpH {  // one B operand (8 k-slots of one 32-sample tile), hi and lo parts
+    u32x4 hi, lo;
+    SN_DEV void set(const float v[8]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint32_t h, l;
+            sn_split2(v[2 * e], v[2 * e + 1], h, l);
+            hi[e] = h;
+            lo[e] = l;
+        }
+#if SN_OP_GUARD
+        asm volatile("s_nop 7" : "+v"(hi), "+v"(lo));
+#endif
+    }
+};
+
+#define SN_MFMA_H(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, ACC, 0, 0, 0)
+
+template <int RT, int KS>
+SN_DEV void sn_mlp_layer_h(const char* __restrict__ wimg, const float* __restrict__ bimg, const SnOpH* op0, const SnOpH* op1,
+                           f32x16* acc0, f32x16* acc1, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const f32x4* b = (const f32x4*)(bimg + (rt * 2 + h) * 16);
+        f32x4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+        f32x16 v = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+        acc0[rt] = v;
+        acc1[rt] = v;
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        f16x8 ah[RT], al[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const char* base = wimg + (((rt * KS + s) * 2) * 64 + lane) * 16;
+            ah[rt] = __builtin_bit_cast(f16x8, *(const u32x4*)base);
+            al[rt] = __builtin_bit_cast(f16x8, *(const u32x4*)(base + 1024));
+        }
+        const f16x8 bh0 = __builtin_bit_cast(f16x8, op0[s].hi), bl0 = __builtin_bit_cast(f16x8, op0[s].lo);
+        const f16x8 bh1 = __builtin_bit_cast(f16x8, op1[s].hi), bl1 = __builtin_bit_cast(f16x8, op1[s].lo);
+        // small terms first, then hi.hi; independent accumulators interleaved
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            SN_MFMA_H(acc0[rt], al[rt], bh0);
+            SN_MFMA_H(acc1[rt], al[rt], bh1);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            SN_MFMA_H(acc0[rt], ah[rt], bl0);
+            SN_MFMA_H(acc1[rt], ah[rt], bl1);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            SN_MFMA_H(acc0[rt], ah[rt], bh0);
+            SN_MFMA_H(acc1[rt], ah[rt], bh1);
+        }
+    }
+}
+
+// per-ray direction operands, fp16x2 form: slot (h, e) <-> SH component 8h + e
+struct SnShOpsH {
+    SnOpH t0, t1;
+    SN_DEV void build(const float d[3], int remap) {
+        float c[16];
+        sn_direction_encoding(d, remap, c);
+        float v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = c[e], b = c[8 + e];
+            sn_swap_halves(a, b);
+            v0[e] = a;
+            v1[e] = b;
+        }
+        t0.set(v0);
+        t1.set(v1);
+    }
+};
+
+// ReLU + split of one 32-row accumulator tile into its two B operands (k-steps 2rt, 2rt+1)
+SN_DEV void sn_acc_to_ops(const f32x16& acc, bool relu, SnOpH& s0, SnOpH& s1) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = relu ? fmaxf(acc[r], 0.0f) : acc[r];
+    s0.set(v);
+    s1.set(v + 8);
+}
+
+SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const SnShOpsH& sh, int lane, float& h0, float rgb[3]) {
+    const bool upper = lane >= 32;
+    const float* tail = (const float*)(ldsb + SnMainImgH::FP32);
+    SnOpH op0[4], op1[4];
+    // ---- layer 1: slot (s, h, e) <-> feature 16 s + 8 h + e ----
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = feat[16 * s + e], b = feat[16 * s + 8 + e];
+            sn_swap_halves(a, b);
+            v0[e] = a;
+            v1[e] = b;
+        }
+        op0[s].set(v0);
+        op1[s].set(v1);
+    }
+    f32x16 a0[2], a1[2];
+    sn_mlp_layer_h<2, 2>(ldsb + SnMainImgH::W1, tail + SnMainImgH::B1, op0, op1, a0, a1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        sn_acc_to_ops(a0[rt], true, op0[2 * rt], op0[2 * rt + 1]);
+        sn_acc_to_ops(a1[rt], true, op1[2 * rt], op1[2 * rt + 1]);
+    }
+    // ---- layer 2 ----
+    f32x16 g0[1], g1[1];
+    sn_mlp_layer_h<1, 4>(ldsb + SnMainImgH::W2, tail + SnMainImgH::B2, op0, op1, g0, g1, lane);
+    h0 = upper ? g1[0][8] : g0[0][0];
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- colour layer 1: k-step 0 <- layer-2 regs 0..7 (rows rho(e)+4h), k-step 1 <- SH ----
+    {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v0[e] = g0[0][e];
+            v1[e] = g1[0][e];
+        }
+        op0[0].set(v0);
+        op1[0].set(v1);
+        op0[1] = sh.t0;
+        op1[1] = sh.t1;
+    }
+    sn_mlp_layer_h<2, 2>(ldsb + SnMainImgH::WC1, tail + SnMainImgH::BC1, op0, op1, a0, a1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        sn_acc_to_ops(a0[rt], true, op0[2 * rt], op0[2 * rt + 1]);
+        sn_acc_to_ops(a1[rt], true, op1[2 * rt], op1[2 * rt + 1]);
+    }
+    // ---- colour layer 2 ----
+    sn_mlp_layer_h<2, 4>(ldsb + SnMainImgH::WC2, tail + SnMainImgH::BC2, op0, op1, a0, a1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- colour layer 3 on the VALU (fp32, as in the fp32 variant) ----
+    const int h = lane >> 5;
+    float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        const f32x4* w = (const f32x4*)(tail + SnMainImgH::W3 + (n * 2 + h) * 32);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 wv = w[rt * 4 + r4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p0[n] = fmaf(wv[e], fmaxf(a0[rt][r4 * 4 + e], 0.0f), p0[n]);
+                    p1[n] = fmaf(wv[e], fmaxf(a1[rt][r4 * 4 + e], 0.0f), p1[n]);
+                }
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        float a = p0[n], b = p1[n];
+        sn_swap_halves(a, b);
+        float x = a + b + tail[SnMainImgH::B3 + n];
+        rgb[n] = 1.0f / (1.0f + expf(-x));
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // kernel
 // ------------------------------------------------------------------------------------------
@@ -203,10 +412,11 @@ SN_DEV int sn_xcd_remap(int b, int n) {
 // ABLATE (profiling only, images are WRONG when non-zero; selected by the SN_ABLATE environment variable): 2 = hash phase
 // only (no MLP: density / colour faked from the features), 3 = VALU only (no table gathers either).  Measured r01:
 // full 7.7 ms, hash-only 2.8-3.0 ms (= the L1 tag-lookup floor), VALU-only 1.4 ms; the 204.8 M fp32 MFMAs alone are 5.6 ms.
-template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int ABLATE = 0>
+template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int PREC /*0 fp32 MFMA, 1 fp16 hi+lo split MFMA*/, int ABLATE = 0>
 __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_kernel(SnMainParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
+    // both weight images are SnMainImg::TOTAL floats (42 640 B)
     for (int i = tid * 4; i < SnMainImg::TOTAL; i += 256 * 4) *(f32x4*)(lds + i) = *(const f32x4*)(p.wimg + i);
     __syncthreads();
 
@@ -235,7 +445,9 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
     const float far = p.fars ? p.fars[ray] : p.far_plane;
     const float s_near = sn_spacing(near), s_far = sn_spacing(far);
     SnShOps sh;
-    sh.build(d, p.sh_remap);
+    SnShOpsH shh;
+    if (PREC == 0) sh.build(d, p.sh_remap);
+    else shh.build(d, p.sh_remap);
 
     const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table, (16u << p.log2_t) * 8u);
     const int S = p.n_samples;
@@ -284,12 +496,14 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
                 a += feat[k];
                 bsum = fmaf(feat[k], (float)(k & 3), bsum);
             }
-            h0 = a * 0.1f + sh.t0[0];
+            h0 = a * 0.1f + d[0];
             rgb[0] = 0.5f + 0.1f * a;
             rgb[1] = 0.5f + 0.1f * bsum;
             rgb[2] = 0.5f - 0.1f * a;
-        } else {
+        } else if (PREC == 0) {
             sn_main_field_f32(lds, feat, sh, lane, h0, rgb);
+        } else {
+            sn_main_field_h((const char*)lds, feat, shh, lane, h0, rgb);
         }
         __builtin_amdgcn_sched_barrier(0);
         float density = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);

@@ -169,6 +169,7 @@ struct SnFieldStageParams {
     float* rgb;      // [n,3] or null
 };
 
+template <int PREC>
 __global__ __launch_bounds__(256, 2) void sn_main_field_stage_kernel(SnFieldStageParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -185,14 +186,17 @@ __global__ __launch_bounds__(256, 2) void sn_main_field_stage_kernel(SnFieldStag
         d[2] = p.directions[j * 3 + 2];
     }
     SnShOps sh;
-    sh.build(d, p.sh_remap);
+    SnShOpsH shh;
+    if (PREC == 0) sh.build(d, p.sh_remap);
+    else shh.build(d, p.sh_remap);
     float q[3];
     const bool sel = sn_position_q(pos, q);
     const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table, (16u << p.log2_t) * 8u);
     float feat[32];
     sn_hash_encode<16>(rsrc, p.scal, p.log2_t, q, feat);
     float h0, rgb[3];
-    sn_main_field_f32(lds, feat, sh, lane, h0, rgb);
+    if (PREC == 0) sn_main_field_f32(lds, feat, sh, lane, h0, rgb);
+    else sn_main_field_h((const char*)lds, feat, shh, lane, h0, rgb);
     if ((q[0] != q[0]) | (q[1] != q[1]) | (q[2] != q[2])) h0 = rgb[0] = rgb[1] = rgb[2] = __builtin_nanf("");
     if (i < p.n) {
         p.density[i] = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);

@@ -52,9 +52,11 @@ def test_config1_plumbing_64x64x32(gpu):
     _check(out, ref)
 
 
-def test_config2_reduced_96x96x64_full_tables(gpu):
-    """BASELINE.json configs[1] at 96x96 (same field: L=16, T=2^19, 64 uniform samples)."""
+@pytest.mark.parametrize("precision", ["fp32", "fp16x2"])
+def test_config2_reduced_96x96x64_full_tables(gpu, precision):
+    """BASELINE.json configs[1] at 96x96 (same field: L=16, T=2^19, 64 uniform samples), both MFMA arithmetic modes."""
     cfg = scene.benchmark_config(64)
+    cfg.precision = precision
     model, sd = make_model(cfg, gpu)
     out, ref = _render_pair(cfg, model, sd, gpu, 96, 96, cam=1, focal=96.0)
     _check(out, ref)
@@ -80,9 +82,11 @@ def test_ragged_image_and_aabb_nears_fars(gpu):
     assert torch.equal(torch.nan_to_num(out["depth"].cpu()[miss], nan=-1.0), torch.nan_to_num(ref["depth"][miss], nan=-1.0))
 
 
-def test_config4_reduced_proposal_path(gpu):
+@pytest.mark.parametrize("precision", ["fp32", "fp16x2"])
+def test_config4_reduced_proposal_path(gpu, precision):
     """BASELINE.json configs[3] at 72x128: two proposal nets (256 + 96) + 48 main samples, full-size tables."""
     cfg = scene.proposal_config()
+    cfg.precision = precision
     model, sd = make_model(cfg, gpu)
     out, ref = _render_pair(cfg, model, sd, gpu, 72, 128, cam=3, focal=150.0)
     _check(out, ref)
@@ -101,6 +105,22 @@ def test_flat_bundle_get_outputs(gpu):
     flat = model.get_outputs(b.flatten())
     assert flat["rgb"].shape == (1024, 3)
     assert torch.equal(flat["rgb"].view(32, 32, 3), img["rgb"]) and torch.equal(flat["depth"].view(32, 32, 1), img["depth"])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x2"])
+def test_render_is_deterministic(gpu, precision):
+    """Five full-size renders must be bit-identical.  (Catches instruction hazards: without SN_OP_GUARD the fp16x2 kernel
+    returns lanes 48-63 of ~5 tiles per frame from stale MFMA operands, different tiles every run.)"""
+    cfg = scene.benchmark_config(64)
+    cfg.precision = precision
+    model, sd = make_model(cfg, gpu)
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 800.0, 800.0, 400.0, 400.0, 800, 800).to(gpu)
+    b = cams[5].generate_rays(0)
+    first = model.get_outputs_for_camera_ray_bundle(b)
+    for _ in range(4):
+        again = model.get_outputs_for_camera_ray_bundle(b)
+        for k in ("rgb", "depth", "accumulation", "expected_depth"):
+            assert torch.equal(first[k], again[k]), k
 
 
 def test_full_size_properties_800x800x64(gpu):
