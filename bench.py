@@ -168,7 +168,7 @@ def main():
         value = samples_per_step * args.steps / elapsed
         achieved = (W * H * bytes_per_ray) / (kernel_ms * 1e-3) / 1e9
         line = {
-            "metric": "ray-samples/sec (800x800 reference-sheet camera render)",
+            "metric": "ray-samples/sec (%dx%d reference-sheet camera render)" % (W, H),
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -264,7 +265,8 @@ TileGeom tile_geometry(int height, int width) {
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WorkspacePlan {
-    size_t off_exp_raw, off_minmax, off_ebins, total;
+    size_t off_exp_raw, off_minmax, off_ebins, off_prop_scratch, total;
+    int prop_blocks;
     int n_chunks;
 };
 
@@ -279,7 +281,16 @@ WorkspacePlan plan_workspace(int height, int width, const SnRenderOpts& o) {
     w.off_minmax = off;
     off += align256((size_t)w.n_chunks * 8);
     w.off_ebins = off;
-    if (o.num_proposal_iterations > 0) off += align256((size_t)g.tiles_x * g.tiles_y * 64 * (o.num_nerf_samples + 1) * 4);
+    w.off_prop_scratch = off;
+    w.prop_blocks = 0;
+    if (o.num_proposal_iterations > 0) {
+        off += align256((size_t)g.tiles_x * g.tiles_y * 64 * (o.num_nerf_samples + 1) * 4);
+        // persistent proposal waves: what the chip holds (256 CUs x 4 workgroups of SN_PROP_WAVES waves), at most one per tile
+        const int ntiles = g.tiles_x * g.tiles_y;
+        w.prop_blocks = std::min((ntiles + SN_PROP_WAVES - 1) / SN_PROP_WAVES, 256 * 4);
+        w.off_prop_scratch = off;
+        off += align256((size_t)w.prop_blocks * SN_PROP_WAVES * SN_PROP_SCRATCH_FLOATS * 4);
+    }
     w.total = off;
     return w;
 }
@@ -536,6 +547,7 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
         pp.sbins0 = d_sbins;
         for (int i = 0; i < SN_MAX_PROPOSALS; ++i) pp.pdf_u[i] = opts->pdf_u[i];
         pp.ebins_out = d_ebins;
+        pp.scratch = (float*)(ws + wp.off_prop_scratch);
         pp.prop_depth[0] = prop_depth_0;
         pp.prop_depth[1] = prop_depth_1;
         pp.height = height;
@@ -557,8 +569,7 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
         pp.far_plane = opts->far_plane;
         pp.avg_density = d.average_init_density;
         pp.hist_pad = d.histogram_padding;
-        const int ntiles = g.tiles_x * g.tiles_y;
-        hipLaunchKernelGGL(sn_proposal_kernel, dim3((unsigned)((ntiles + SN_PROP_WAVES - 1) / SN_PROP_WAVES)), dim3(64 * SN_PROP_WAVES), 0, st, pp);
+        hipLaunchKernelGGL(sn_proposal_kernel, dim3((unsigned)wp.prop_blocks), dim3(64 * SN_PROP_WAVES), 0, st, pp);
         SN_HIP(h, hipGetLastError());
     }
 
@@ -739,8 +750,7 @@ int sn_pdf_sample(const float* spacing_bins, const float* weights, int64_t n_ray
     p.hist_pad = histogram_padding;
     p.new_bins = new_bins;
     p.inds = inds;
-    hipLaunchKernelGGL(sn_pdf_stage_kernel, dim3((unsigned)((n_rays + SN_PROP_WAVES - 1) / SN_PROP_WAVES)), dim3(64 * SN_PROP_WAVES), 0,
-                       (hipStream_t)stream, p);
+    hipLaunchKernelGGL(sn_pdf_stage_kernel, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_pdf_sample launch: ") + hipGetErrorString(e));
     return SN_OK;

@@ -1,15 +1,20 @@
 // sn_proposal.h -- the proposal-sampler kernel (rows a8-a12 of SURVEY.md §8(a)).
 //
-// Mapping (DESIGN.md "Kernel K2"): one wave owns one 8x8 pixel tile and walks its 64 rays ONE RAY AT A
-// TIME with the 64 lanes spread over that ray's samples (256 / 96 samples = 4 / 1.5 lane-rounds):
-//   * consecutive samples of a ray fall into the same or neighbouring coarse voxels (5 levels,
-//     res 16..256), so a wave's gather addresses coalesce;
-//   * transmittance and CDF are prefix sums ALONG the ray = wave scans (DPP/permute shuffles, fp64 to
-//     mirror torch-CPU's cumsum), the inverse-CDF lookup is a per-lane binary search in a 1 KB
-//     per-wave LDS array ("LDS staging of per-ray samples");
-//   * the tiny density MLP (10->16->1, 352 FLOP) runs on the VALU with wave-uniform weights in SGPRs.
-// The final sample bins are written in [tile][bin][lane=ray] order, which is exactly the coalesced
-// order in which sn_render_main_kernel<1> (lane = ray) consumes them.
+// Mapping (DESIGN.md "Kernel K2"): the SAME mapping as the main kernel -- lane = ray, wave = 8x8 pixel tile, every lane
+// marching its own ray front to back.
+//   * r01 measured the first design (one ray per wave, lanes spread ALONG the ray, wave scans + LDS binary search) to be
+//     L1-tag-lookup bound: 19 cache lines per gather instruction (one per voxel the ray crosses), 24.96 G TCP accesses =
+//     the kernel's cycle count.  With lanes ACROSS an 8x8 tile at equal depth a gather touches 1-2 lines at proposal
+//     resolutions (<= 256^3).
+//   * marching order = prefix order, so transmittance, CDF and median are running sums (fp64, mirroring torch-CPU cumsum):
+//     no scans, no shuffles;
+//   * per-ray weights are staged through an L2/HBM scratch in [sample][lane] order (coalesced 256-B rows; 2 KB per ray and
+//     level, read back once) -- a 64 KB-per-wave LDS copy would cap occupancy at 2 waves per CU;
+//   * inverse-CDF resampling is a per-lane merge of the sorted u grid with the running CDF (searchsorted(right) == "all u in
+//     [cdf_i, cdf_{i+1})");
+//   * the tiny density MLP (10->16->1, 352 FLOP) runs on the VALU with wave-uniform weights from the scalar cache.
+// Waves are persistent over tiles (grid = what the chip holds) so the scratch is per wave, not per tile.  The final
+// sample bins are written in [tile][bin][lane=ray] order, exactly the order in which sn_render_main_kernel<1> reads them.
 #pragma once
 #include "../../include/signerf_hip.h"
 #include "sn_device.h"
@@ -45,109 +50,62 @@ SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t rsrc, const SnScal5& scal, int lo
     return out;
 }
 
-// ---- wave-level primitives ---------------------------------------------------------------------
-SN_DEV double sn_shfl_up_f64(double v, int delta) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl_up(lo, delta);
-    hi = __shfl_up(hi, delta);
-    return __hiloint2double(hi, lo);
-}
-SN_DEV double sn_shfl_f64(double v, int src) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl(lo, src);
-    hi = __shfl(hi, src);
-    return __hiloint2double(hi, lo);
-}
-// inclusive prefix sum over the 64 lanes
-SN_DEV double sn_wave_scan_f64(double v, int lane) {
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        double n = sn_shfl_up_f64(v, s);
-        if (lane >= s) v += n;
-    }
-    return v;
-}
-SN_DEV double sn_wave_sum_f64(double v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        int lo = __double2loint(v), hi = __double2hiint(v);
-        lo = __shfl_xor(lo, s);
-        hi = __shfl_xor(hi, s);
-        v += __hiloint2double(hi, lo);
-    }
-    return v;
-}
-// Orders this wave's LDS traffic (a wave's DS ops complete in issue order; only the compiler must be fenced).
-SN_DEV void sn_wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// ---- PDFSampler, eval mode (A11), for ONE ray held in this wave's LDS arrays ---------------------
-// sb [N+1] spacing bins, wl [N] weights -> nb [M+1] new spacing bins; cdf [N+1] scratch.
-// u: global [M+1] or null (fallback (k+0.5)/(M+1)).  inds: optional global [M+1] int32.
-SN_DEV void sn_pdf_wave(const float* sb, const float* wl, float* cdf, float* nb, int N, int M, const float* __restrict__ u, float pad,
-                        int lane, int32_t* inds) {
-    // weights + padding, their sum
-    double part = 0.0;
-    for (int i = lane; i < N; i += 64) {
-#pragma clang fp contract(off)
-        part += (double)(wl[i] + pad);
-    }
-    float wsum = (float)sn_wave_sum_f64(part);
+// ---- PDFSampler, eval mode (A11), one ray per lane --------------------------------------------------------------------
+// Streams the N weights of this lane's ray from `w` (stride 64 floats: [sample][lane]) and emits the M+1 new spacing bins
+// through `emit(j, bin, idx)`.  sb(i) returns the existing spacing bin i (0..N).  u: [M+1] grid (LDS or global).
+// searchsorted(cdf, u, side="right") = number of knots <= u, so u_j belongs to interval i iff cdf_i <= u_j < cdf_{i+1}.
+struct SnPdfNorm {
     float padding, denom;
-    {
+    // weights_sum = sum(w + pad); padding = relu(1e-5 - sum); denom = sum + padding; per-sample padding / N
+    SN_DEV void set(double sum_wp, int N) {
 #pragma clang fp contract(off)
-        padding = fmaxf(1e-5f - wsum, 0.0f);
-        denom = wsum + padding;
-        padding = padding / (float)N;
+        const float wsum = (float)sum_wp;
+        const float pd = fmaxf(1e-5f - wsum, 0.0f);
+        denom = wsum + pd;
+        padding = pd / (float)N;
     }
-    // cdf = min(1, cumsum(pdf)), prepend 0
-    double carry = 0.0;
-    for (int c = 0; c < N; c += 64) {
-        const int i = c + lane;
-        float pdf = 0.0f;
-        if (i < N) {
-#pragma clang fp contract(off)
-            pdf = ((wl[i] + pad) + padding) / denom;
-        }
-        double incl = sn_wave_scan_f64((double)pdf, lane) + carry;
-        if (i < N) cdf[i + 1] = fminf(1.0f, (float)incl);
-        carry = sn_shfl_f64(incl, 63);
-    }
-    if (lane == 0) cdf[0] = 0.0f;
-    sn_wave_lds_fence();
-    // inverse CDF
-    for (int j = lane; j <= M; j += 64) {
-        float uj;
-        if (u) uj = u[j];
-        else {
-#pragma clang fp contract(off)
-            uj = ((float)j + 0.5f) / (float)(M + 1);
-        }
-        // searchsorted(cdf, u, side="right") = number of entries <= u
-        int lo = 0, hi = N + 1;
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if (cdf[mid] <= uj) lo = mid + 1;
-            else hi = mid;
-        }
-        const int idx = lo;
-        const int below = min(max(idx - 1, 0), N), above = min(max(idx, 0), N);
-        float t, v;
+};
+
+template <typename SB, typename EMIT>
+SN_DEV void sn_pdf_lane(const float* __restrict__ w, int wstride, int N, int M, const float* u, float pad, const SnPdfNorm& nm, SB sb,
+                        EMIT emit) {
+    int j = 0;
+    double cum = 0.0;
+    float c_prev = 0.0f, b_prev = sb(0);
+    float uj = u[0];
+    for (int i = 0; i < N; ++i) {
+        float c_next, b_next = sb(i + 1);
         {
 #pragma clang fp contract(off)
-            const float c0 = cdf[below], c1 = cdf[above], b0 = sb[below], b1 = sb[above];
-            t = (uj - c0) / (c1 - c0);
-            if (t != t) t = 0.0f;
-            t = fminf(fmaxf(t, 0.0f), 1.0f);
-            v = b0 + t * (b1 - b0);
+            const float pdf = ((w[(int64_t)i * wstride] + pad) + nm.padding) / nm.denom;
+            cum += (double)pdf;
+            c_next = fminf(1.0f, (float)cum);
         }
-        nb[j] = v;
-        if (inds) inds[j] = idx;
+        while (__any(j <= M && uj < c_next)) {
+            if (j <= M && uj < c_next) {
+                float t, v;
+                {
+#pragma clang fp contract(off)
+                    t = (uj - c_prev) / (c_next - c_prev);
+                    if (t != t) t = 0.0f;
+                    t = fminf(fmaxf(t, 0.0f), 1.0f);
+                    v = b_prev + t * (b_next - b_prev);
+                }
+                emit(j, v, i + 1);
+                ++j;
+                uj = u[min(j, M)];
+            }
+        }
+        c_prev = c_next;
+        b_prev = b_next;
     }
-    sn_wave_lds_fence();
+    // u_j >= cdf_N: idx = N + 1, below = above = N -> bins_g0 + t * 0 with t clipped to [0, 1]
+    while (__any(j <= M)) {
+        if (j <= M) {
+            emit(j, b_prev, N + 1);
+            ++j;
+        }
+    }
 }
 
 // ---- proposal kernel -----------------------------------------------------------------------------
@@ -156,10 +114,11 @@ struct SnPropParams {
     const float* directions;
     const float* nears;
     const float* fars;
-    const float* sbins0;                  // [n_samples[0]+1] initial spacing bins
-    const float* pdf_u[SN_MAX_PROPOSALS]; // u grid of resampling step k, or null
+    const float* sbins0;                  // [n_samples[0]+1] initial spacing bins, or null (i / n0)
+    const float* pdf_u[SN_MAX_PROPOSALS]; // u grid of resampling step k, or null ((j + 0.5) / (m + 1))
     float* ebins_out;                     // [tile][n_final+1][64]
     float* prop_depth[SN_MAX_PROPOSALS];  // [H*W] or null
+    float* scratch;                       // [n_waves][SN_PROP_SCRATCH_FLOATS]
     const float* table[SN_MAX_PROPOSALS];
     const float* wpack[SN_MAX_PROPOSALS];
     float scal[SN_MAX_PROPOSALS][5];
@@ -171,127 +130,133 @@ struct SnPropParams {
     float near_plane, far_plane, avg_density, hist_pad;
 };
 
+// per-wave scratch: weights [256][64] + two spacing-bin arrays [257][64]
+#define SN_PROP_SCRATCH_W 0
+#define SN_PROP_SCRATCH_B0 (SN_PROP_MAX_SAMPLES * 64)
+#define SN_PROP_SCRATCH_B1 (SN_PROP_SCRATCH_B0 + (SN_PROP_MAX_SAMPLES + 1) * 64)
+#define SN_PROP_SCRATCH_FLOATS (SN_PROP_SCRATCH_B1 + (SN_PROP_MAX_SAMPLES + 1) * 64)
+
+// shared per-workgroup LDS: the sampler grids
 struct SnPropLds {
-    float a[SN_PROP_MAX_SAMPLES + 4];  // spacing bins (ping)
-    float b[SN_PROP_MAX_SAMPLES + 4];  // spacing bins (pong)
-    float w[SN_PROP_MAX_SAMPLES + 4];
-    float cdf[SN_PROP_MAX_SAMPLES + 4];
+    float sb0[SN_PROP_MAX_SAMPLES + 4];
+    float u[SN_MAX_PROPOSALS][SN_PROP_MAX_SAMPLES + 4];
+    // MLP weight packs.  They are wave-uniform, but the per-iteration compiler memory clobber (needed against LICM) makes
+    // hipcc fetch global weights with VECTOR loads -- 49 extra TA instructions per sample, more than the 40 hash gathers
+    // (measured r01: SQ_INSTS_SMEM ~ 0, VMEM reads 2.2x the expected count).  From LDS they are broadcast ds_reads.
+    float wpack[SN_MAX_PROPOSALS][SN_PROP_PACK_FLOATS];
 };
 
-// One proposal level for one ray: evaluate density net LV at the N samples given by spacing bins sb,
-// write weights to wl, return the median depth of this level (prop_depth_LV).
-template <int LV>
-SN_DEV float sn_prop_level(const SnPropParams& p, const float* sb, float* wl, int N, const float o[3], const float d[3], float s_near,
-                           float s_far, int lane) {
+// One proposal level for this lane's ray: density net LV at the N samples whose spacing bins are sb(0..N); writes the
+// weights to w[i * 64] and returns sum(w + pad) (fp64) and the level's median depth.
+template <int LV, typename SB>
+SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* __restrict__ w, int N, const float o[3], const float d[3], float s_near,
+                          float s_far, double& sum_wp, float& median_out) {
     SnScal5 scal;
 #pragma unroll
     for (int l = 0; l < 5; ++l) scal.v[l] = p.scal[LV][l];
     const int log2_t = p.log2_t[LV];
     const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table[LV], (5u << log2_t) * 8u);
-    const float* __restrict__ wp = p.wpack[LV];
-    double carry_tau = 0.0, carry_w = 0.0;
+    double cum_tau = 0.0, cum_w = 0.0, swp = 0.0;
     bool found = false;
-    float median = 0.0f, last_mid = 0.0f;
-    for (int c = 0; c < N; c += 64) {
-        const int i = min(c + lane, N - 1);
-        const bool live = c + lane < N;
-        const float e0 = sn_euclid(sb[i], s_near, s_far), e1 = sn_euclid(sb[i + 1], s_near, s_far);
+    float median = 0.0f, mid = 0.0f;
+    float e0 = sn_euclid(sb(0), s_near, s_far);
+#pragma unroll 1
+    for (int i = 0; i < N; ++i) {
+        // keep the (loop-invariant) MLP weight loads inside the loop: hoisted, they cost ~200 registers (see sn_main.h)
+        asm volatile("" ::: "memory");
+        const float e1 = sn_euclid(sb(i + 1), s_near, s_far);
         float q[3];
         const bool sel = sn_sample_q(o, d, e0, e1, q);
         const float h0 = sn_prop_h0(rsrc, scal, log2_t, wp, q);
         const float density = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
-        float tau, mid;
+        float wt;
         {
 #pragma clang fp contract(off)
-            tau = live ? (e1 - e0) * density : 0.0f;
+            const float tau = (e1 - e0) * density;
+            wt = (1.0f - expf(-tau)) * expf(-(float)cum_tau);
+            if (wt != wt) wt = 0.0f;
+            cum_tau += (double)tau;
             mid = (e0 + e1) / 2.0f;
+            cum_w += (double)wt;
+            swp += (double)(wt + p.hist_pad);
         }
-        const double incl = sn_wave_scan_f64((double)tau, lane) + carry_tau;
-        float w;
-        {
-#pragma clang fp contract(off)
-            const float excl = (float)(incl - (double)tau);
-            w = (1.0f - expf(-tau)) * expf(-excl);
-            if (w != w) w = 0.0f;
-            if (!live) w = 0.0f;
-        }
-        // NOTE: (incl - tau) re-derives the exclusive prefix; fp64 sums of fp32 data are exact for any
-        // realistic dynamic range, so this equals torch's sequential cumsum of the preceding terms.
-        if (live) wl[i] = w;
-        carry_tau = sn_shfl_f64(incl, 63);
-        const double cw = sn_wave_scan_f64((double)w, lane) + carry_w;
-        carry_w = sn_shfl_f64(cw, 63);
-        const unsigned long long hit = __ballot(live && (float)cw >= 0.5f);
-        if (!found && hit) {
+        if (!found && (float)cum_w >= 0.5f) {
             found = true;
-            median = __shfl(mid, __ffsll((long long)hit) - 1);
+            median = mid;
         }
-        const int last_lane = min(N - 1 - c, 63);
-        last_mid = __shfl(mid, last_lane);
+        w[(int64_t)i * 64] = wt;
+        e0 = e1;
     }
-    sn_wave_lds_fence();
-    return found ? median : last_mid;
+    sum_wp = swp;
+    median_out = found ? median : mid;
 }
 
-__global__ __launch_bounds__(64 * SN_PROP_WAVES) void sn_proposal_kernel(SnPropParams p) {
-    __shared__ SnPropLds lds_all[SN_PROP_WAVES];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SnPropLds& L = lds_all[wave];
-    const int tile = blockIdx.x * SN_PROP_WAVES + wave;
-    if (tile >= p.tiles_x * p.tiles_y) return;
-    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-    const int tw = 1 << p.tile_w_log2;
-    // lane-resident copy of this tile's 64 rays
-    const int px = (tx << p.tile_w_log2) + (lane & (tw - 1));
-    const int py = (ty << p.tile_h_log2) + (lane >> p.tile_w_log2);
-    const bool valid = px < p.width && py < p.height;
-    const int64_t ray = (int64_t)min(py, p.height - 1) * p.width + min(px, p.width - 1);
-    float ro[3], rd[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        ro[c] = p.origins[ray * 3 + c];
-        rd[c] = p.directions[ray * 3 + c];
+__global__ __launch_bounds__(64 * SN_PROP_WAVES, 4) void sn_proposal_kernel(SnPropParams p) {
+    __shared__ SnPropLds L;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // sampler grids -> LDS (per-lane indexed later)
+    const int n0 = p.n_samples[0];
+    for (int i = tid; i <= n0; i += 64 * SN_PROP_WAVES) L.sb0[i] = p.sbins0 ? p.sbins0[i] : (float)i / (float)n0;
+    for (int k = 0; k < p.n_levels; ++k) {
+        const int m = k + 1 < p.n_levels ? p.n_samples[k + 1] : p.n_final;
+        for (int j = tid; j <= m; j += 64 * SN_PROP_WAVES) {
+#pragma clang fp contract(off)
+            L.u[k][j] = p.pdf_u[k] ? p.pdf_u[k][j] : ((float)j + 0.5f) / (float)(m + 1);
+        }
+        for (int j = tid; j < SN_PROP_PACK_FLOATS; j += 64 * SN_PROP_WAVES) L.wpack[k][j] = p.wpack[k][j];
     }
-    const float rnear = p.nears ? p.nears[ray] : p.near_plane;
-    const float rfar = p.fars ? p.fars[ray] : p.far_plane;
-    float my_depth0 = 0.0f, my_depth1 = 0.0f;
-    float* eb_tile = p.ebins_out + (int64_t)tile * (p.n_final + 1) * 64;
+    __syncthreads();
 
-    for (int r = 0; r < 64; ++r) {
+    const int n_tiles = p.tiles_x * p.tiles_y;
+    const int wave_global = blockIdx.x * SN_PROP_WAVES + wave;
+    const int n_waves = gridDim.x * SN_PROP_WAVES;
+    float* __restrict__ sc = p.scratch + (int64_t)wave_global * SN_PROP_SCRATCH_FLOATS + lane;
+    float* __restrict__ W = sc + SN_PROP_SCRATCH_W;
+    float* __restrict__ B0 = sc + SN_PROP_SCRATCH_B0;
+    float* __restrict__ B1 = sc + SN_PROP_SCRATCH_B1;
+    const int tw = 1 << p.tile_w_log2;
+
+#pragma unroll 1
+    for (int tile = wave_global; tile < n_tiles; tile += n_waves) {
+        const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+        const int px = (tx << p.tile_w_log2) + (lane & (tw - 1));
+        const int py = (ty << p.tile_h_log2) + (lane >> p.tile_w_log2);
+        const bool valid = px < p.width && py < p.height;
+        const int64_t ray = (int64_t)min(py, p.height - 1) * p.width + min(px, p.width - 1);
         float o[3], d[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            o[c] = __shfl(ro[c], r);
-            d[c] = __shfl(rd[c], r);
+            o[c] = p.origins[ray * 3 + c];
+            d[c] = p.directions[ray * 3 + c];
         }
-        const float s_near = sn_spacing(__shfl(rnear, r)), s_far = sn_spacing(__shfl(rfar, r));
-        // level 0: the initial (uniform in s) sampler
-        const int n0 = p.n_samples[0];
-        for (int i = lane; i <= n0; i += 64) L.a[i] = p.sbins0 ? p.sbins0[i] : (float)i / (float)n0;
-        sn_wave_lds_fence();
-        const float dep0 = sn_prop_level<0>(p, L.a, L.w, n0, o, d, s_near, s_far, lane);
-        if (lane == r) my_depth0 = dep0;
-        const float* cur = L.a;
-        int ncur = n0;
-        if (p.n_levels > 1) {
-            const int n1 = p.n_samples[1];
-            sn_pdf_wave(L.a, L.w, L.cdf, L.b, n0, n1, p.pdf_u[0], p.hist_pad, lane, nullptr);
-            const float dep1 = sn_prop_level<1>(p, L.b, L.w, n1, o, d, s_near, s_far, lane);
-            if (lane == r) my_depth1 = dep1;
-            cur = L.b;
-            ncur = n1;
-        }
-        // final resampling -> the main field's bins
-        float* nxt = cur == L.a ? L.b : L.a;
-        sn_pdf_wave(cur, L.w, L.cdf, nxt, ncur, p.n_final, p.pdf_u[p.n_levels - 1], p.hist_pad, lane, nullptr);
-        for (int j = lane; j <= p.n_final; j += 64) eb_tile[(int64_t)j * 64 + r] = sn_euclid(nxt[j], s_near, s_far);
-        sn_wave_lds_fence();
-    }
-    if (valid) {
+        const float s_near = sn_spacing(p.nears ? p.nears[ray] : p.near_plane);
+        const float s_far = sn_spacing(p.fars ? p.fars[ray] : p.far_plane);
+        float* eb_tile = p.ebins_out + (int64_t)tile * (p.n_final + 1) * 64 + lane;
         const int64_t pix = (int64_t)py * p.width + px;
-        if (p.prop_depth[0]) p.prop_depth[0][pix] = my_depth0;
-        if (p.n_levels > 1 && p.prop_depth[1]) p.prop_depth[1][pix] = my_depth1;
+
+        // level 0: the initial (uniform in s) sampler
+        double sum_wp;
+        float med;
+        sn_prop_level<0>(p, L.wpack[0], [&](int i) { return L.sb0[i]; }, W, n0, o, d, s_near, s_far, sum_wp, med);
+        if (valid && p.prop_depth[0]) p.prop_depth[0][pix] = med;
+        SnPdfNorm nm;
+        nm.set(sum_wp, n0);
+        if (p.n_levels == 1) {
+            sn_pdf_lane(W, 64, n0, p.n_final, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; },
+                        [&](int j, float v, int) { eb_tile[(int64_t)j * 64] = sn_euclid(v, s_near, s_far); });
+        } else {
+            const int n1 = p.n_samples[1];
+            sn_pdf_lane(W, 64, n0, n1, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; },
+                        [&](int j, float v, int) { B0[(int64_t)j * 64] = v; });
+            sn_prop_level<1>(p, L.wpack[1], [&](int i) { return B0[(int64_t)i * 64]; }, W, n1, o, d, s_near, s_far, sum_wp, med);
+            if (valid && p.prop_depth[1]) p.prop_depth[1][pix] = med;
+            nm.set(sum_wp, n1);
+            sn_pdf_lane(W, 64, n1, p.n_final, L.u[1], p.hist_pad, nm, [&](int i) { return B0[(int64_t)i * 64]; },
+                        [&](int j, float v, int) { eb_tile[(int64_t)j * 64] = sn_euclid(v, s_near, s_far); });
+        }
+        (void)B1;
     }
 }
 
@@ -332,17 +297,25 @@ struct SnPdfStageParams {
     int32_t* inds;    // [R,M+1] or null
 };
 
-__global__ __launch_bounds__(64 * SN_PROP_WAVES) void sn_pdf_stage_kernel(SnPdfStageParams p) {
-    __shared__ SnPropLds lds_all[SN_PROP_WAVES];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SnPropLds& L = lds_all[wave];
-    const int64_t r = (int64_t)blockIdx.x * SN_PROP_WAVES + wave;
-    if (r >= p.n_rays) return;
+// one ray per lane, row-major inputs (test sizes only; the fused kernel streams [sample][lane] rows)
+__global__ __launch_bounds__(64) void sn_pdf_stage_kernel(SnPdfStageParams p) {
+    const int64_t r0 = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t r = r0 < p.n_rays ? r0 : p.n_rays - 1;
+    const bool live = r0 < p.n_rays;
     const int N = p.n_in, M = p.n_out;
-    for (int i = lane; i <= N; i += 64) L.a[i] = p.sbins[r * (N + 1) + i];
-    for (int i = lane; i < N; i += 64) L.w[i] = p.weights[r * N + i];
-    sn_wave_lds_fence();
-    sn_pdf_wave(L.a, L.w, L.cdf, L.b, N, M, p.u, p.hist_pad, lane, p.inds ? p.inds + r * (M + 1) : nullptr);
-    for (int j = lane; j <= M; j += 64) p.new_bins[r * (M + 1) + j] = L.b[j];
+    const float* w = p.weights + r * N;
+    const float* sb = p.sbins + r * (N + 1);
+    double swp = 0.0;
+    for (int i = 0; i < N; ++i) {
+#pragma clang fp contract(off)
+        swp += (double)(w[i] + p.hist_pad);
+    }
+    SnPdfNorm nm;
+    nm.set(swp, N);
+    sn_pdf_lane(w, 1, N, M, p.u, p.hist_pad, nm, [&](int i) { return sb[i]; }, [&](int j, float v, int idx) {
+        if (live) {
+            p.new_bins[r * (M + 1) + j] = v;
+            if (p.inds) p.inds[r * (M + 1) + j] = idx;
+        }
+    });
 }
