@@ -155,6 +155,23 @@ int sn_composite(const float* euclid_bins, const float* density, const float* rg
 int sn_pdf_sample(const float* spacing_bins, const float* weights, int64_t n_rays, int32_t n_in, int32_t n_out,
                   const float* u, float histogram_padding, float* new_bins, int32_t* inds, SnStream stream);
 
+/* ---- the mask + condition step after the render, "aabb" masking mode ------------------
+ * (signerf/datasetgenerator/datasetgenerator.py:758-818).  Stays on the device: no cv2 round trip (:776-778), no host sync on
+ * `torch.sum(visible_mask) > 1e-6` (:770). */
+typedef struct SnMaskOpts {
+    int32_t inverse_mask;            /* DatasetGeneratorConfig.inverse_mask */
+    int32_t dilate_w, dilate_h;      /* mask_dialation, cv2.MORPH_ELLIPSE size; 0 = no dilation; each <= 64 */
+    int32_t has_manual_depth;        /* manual_depth is not None */
+    double manual_min, manual_max;   /* Python numbers in the reference: (max - min) is formed in double, then cast to fp32 */
+    float additional_depth_radius;   /* 0.1 */
+} SnMaskOpts;
+size_t sn_mask_workspace_bytes(int32_t height, int32_t width);
+/* origins/directions [H,W,3], depth [H,W,1] (device); aabb: 6 host floats (min xyz, max xyz).
+ * Outputs (device): mask [H,W,1] uint8 (0/1), condition [H,W,1] fp32 (may be NULL: with_condition=False). */
+int sn_aabb_mask_condition(const float* origins, const float* directions, const float* depth, int32_t height, int32_t width,
+                           const float* aabb, const SnMaskOpts* opts, uint8_t* mask, float* condition, void* workspace,
+                           size_t workspace_bytes, SnStream stream);
+
 #ifdef __cplusplus
 }
 #endif

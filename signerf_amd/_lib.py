@@ -60,6 +60,18 @@ class SnRenderOpts(C.Structure):
     ]
 
 
+class SnMaskOpts(C.Structure):
+    _fields_ = [
+        ("inverse_mask", C.c_int32),
+        ("dilate_w", C.c_int32),
+        ("dilate_h", C.c_int32),
+        ("has_manual_depth", C.c_int32),
+        ("manual_min", C.c_double),
+        ("manual_max", C.c_double),
+        ("additional_depth_radius", C.c_float),
+    ]
+
+
 # name -> (restype, argtypes).  Must list every symbol include/signerf_hip.h declares
 # (tests/test_cabi.py checks the two against each other).
 _FP = C.c_void_p  # device pointer
@@ -79,6 +91,9 @@ SIGNATURES = {
     "sn_field_forward": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, C.c_void_p]),
     "sn_composite": (C.c_int, [_FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
     "sn_pdf_sample": (C.c_int, [_FP, _FP, C.c_int64, C.c_int32, C.c_int32, _FP, C.c_float, _FP, _FP, C.c_void_p]),
+    "sn_mask_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "sn_aabb_mask_condition": (C.c_int, [_FP, _FP, _FP, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(SnMaskOpts), _FP, _FP,
+                                         C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -16,6 +16,7 @@
 
 #include "sn_device.h"
 #include "sn_main.h"
+#include "sn_mask.h"
 #include "sn_proposal.h"
 #include "sn_stage.h"
 
@@ -753,6 +754,82 @@ int sn_pdf_sample(const float* spacing_bins, const float* weights, int64_t n_ray
     hipLaunchKernelGGL(sn_pdf_stage_kernel, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_pdf_sample launch: ") + hipGetErrorString(e));
+    return SN_OK;
+}
+
+
+size_t sn_mask_workspace_bytes(int32_t height, int32_t width) {
+    if (height <= 0 || width <= 0) return 0;
+    const size_t n = (size_t)height * width;
+    return align256(n) + align256((size_t)height * (width + 1) * 4) + 256;
+}
+
+int sn_aabb_mask_condition(const float* origins, const float* directions, const float* depth, int32_t height, int32_t width,
+                           const float* aabb, const SnMaskOpts* opts, uint8_t* mask, float* condition, void* workspace,
+                           size_t workspace_bytes, SnStream stream) {
+    if (!origins || !directions || !depth || !aabb || !opts || !mask || height <= 0 || width <= 0)
+        return fail(nullptr, SN_ERR_INVALID, "sn_aabb_mask_condition: bad argument");
+    if (opts->dilate_w < 0 || opts->dilate_h < 0 || opts->dilate_w > SN_MASK_MAX_K || opts->dilate_h > SN_MASK_MAX_K ||
+        ((opts->dilate_w == 0) != (opts->dilate_h == 0)))
+        return fail(nullptr, SN_ERR_INVALID, "sn_aabb_mask_condition: dilation size must be 0 or within [1,64] in both dimensions");
+    if (!workspace || workspace_bytes < sn_mask_workspace_bytes(height, width))
+        return fail(nullptr, SN_ERR_WORKSPACE, "sn_aabb_mask_condition: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)height * width;
+    SnMaskParams p;
+    memset(&p, 0, sizeof(p));
+    p.origins = origins;
+    p.directions = directions;
+    p.depth = depth;
+    p.height = height;
+    p.width = width;
+    memcpy(p.aabb, aabb, sizeof(p.aabb));
+    p.inverse_mask = opts->inverse_mask;
+    p.dilate = opts->dilate_w > 0;
+    if (p.dilate) {
+        // cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (w, h)): row i covers [c - dx, c + dx + 1) with
+        // dx = round(c * sqrt((r*r - dy*dy) / (r*r))), r = h/2, c = w/2, dy = i - r (rows with |dy| > r are empty)
+        const int kw = opts->dilate_w, kh = opts->dilate_h;
+        const int r = kh / 2, c = kw / 2;
+        const double inv_r2 = r ? 1.0 / ((double)r * r) : 0.0;
+        p.el.kw = kw;
+        p.el.kh = kh;
+        p.el.ax = kw / 2;
+        p.el.ay = kh / 2;
+        for (int i = 0; i < kh; ++i) {
+            int j1 = 0, j2 = 0;
+            if (kw == 1 && kh == 1) j2 = 1;  // a 1x1 element is a rectangle
+            else {
+                const int dy = i - r;
+                if (std::abs(dy) <= r) {
+                    const int dx = (int)std::nearbyint(c * std::sqrt((r * r - dy * dy) * inv_r2));
+                    j1 = std::max(c - dx, 0);
+                    j2 = std::min(c + dx + 1, kw);
+                }
+            }
+            p.el.j1[i] = (short)j1;
+            p.el.j2[i] = (short)j2;
+        }
+    }
+    p.has_manual_depth = opts->has_manual_depth;
+    p.manual_min = (float)opts->manual_min;
+    p.manual_range = (float)(opts->manual_max - opts->manual_min);
+    p.depth_radius = opts->additional_depth_radius;
+    char* ws = (char*)workspace;
+    p.vis = (uint8_t*)ws;
+    p.prefix = (int32_t*)(ws + align256(n));
+    p.stats = (uint32_t*)(ws + align256(n) + align256((size_t)height * (width + 1) * 4));
+    p.mask = mask;
+    p.condition = condition;
+    hipError_t e = hipMemsetAsync(p.stats, 0, 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(p.stats + 1, 0xff, 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(p.stats + 2, 0, 4, st);
+    if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_aabb_mask_condition memset: ") + hipGetErrorString(e));
+    hipLaunchKernelGGL(sn_mask_visible_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    if (p.dilate) hipLaunchKernelGGL(sn_mask_prefix_kernel, dim3((unsigned)height), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(sn_mask_condition_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_aabb_mask_condition launch: ") + hipGetErrorString(e));
     return SN_OK;
 }
 

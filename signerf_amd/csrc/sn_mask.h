@@ -1,0 +1,139 @@
+// sn_mask.h -- SURVEY.md §8(f) row 1: the step right after the render on every camera, "aabb" masking mode
+// (/root/reference/signerf/datasetgenerator/datasetgenerator.py:758-818).  The reference round-trips the mask through the
+// CPU for cv2.dilate (:776-778) and syncs on `torch.sum(visible_mask) > 1e-6` (:770); here everything stays on the device:
+//   K-a  slab test (intersection.py:5-56) + visibility mask + count / masked-depth min,max (atomics)
+//   K-b  per-row prefix counts of the mask
+//   K-c  elliptical dilation as "any set pixel in a per-row run" (2 prefix lookups per structuring-element row) fused with
+//        the condition image 1 - clamp((depth - dmin) / (dmax - dmin)), and the "nothing visible -> zeros" branch.
+#pragma once
+#include "sn_device.h"
+
+#define SN_MASK_MAX_K 64
+
+struct SnEllipse {
+    int kw, kh, ax, ay;       // size and anchor (cv2 default anchor = ksize / 2)
+    short j1[SN_MASK_MAX_K];  // per row: columns [j1, j2) are set
+    short j2[SN_MASK_MAX_K];
+};
+
+struct SnMaskParams {
+    const float* origins;
+    const float* directions;
+    const float* depth;
+    int height, width;
+    float aabb[6];
+    int inverse_mask;
+    int dilate;  // 0: mask = visible mask
+    SnEllipse el;
+    int has_manual_depth;
+    float manual_min, manual_range, depth_radius;  // manual_range = (float)((double)max - (double)min), formed on the host
+    uint8_t* vis;      // [H*W] scratch
+    int32_t* prefix;   // [H][W+1] scratch
+    uint32_t* stats;   // [0] count, [1] ordered min depth, [2] ordered max depth
+    uint8_t* mask;     // [H*W] out
+    float* condition;  // [H*W] out
+};
+
+__global__ void sn_mask_visible_kernel(SnMaskParams p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)p.height * p.width;
+    bool vis = false, sel = false;
+    float dep = 0.0f;
+    if (i < n) {
+#pragma clang fp contract(off)
+        float nr = -INFINITY, fr = INFINITY;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float o = p.origins[i * 3 + c];
+            const float inv = 1.0f / (p.directions[i * 3 + c] + 1e-6f);
+            const float a = (p.aabb[c] - o) * inv, b = (p.aabb[3 + c] - o) * inv;
+            nr = fmaxf(nr, fminf(a, b));
+            fr = fminf(fr, fmaxf(a, b));
+        }
+        dep = p.depth[i];
+        const bool non_empty = (nr < fr) && (nr > 0.0f);  // FIXME in the reference: cameras inside the box are ignored
+        vis = (nr < dep) && (dep < fr) && non_empty;
+        if (p.inverse_mask) vis = !vis;
+        p.vis[i] = vis ? 1 : 0;
+        sel = vis && (dep * 1.0f > 0.0f);  // depth[(depth * visible_mask) > 0]
+    }
+    // wave-level reduction, one atomic per wave
+    const unsigned long long bv = __ballot(vis);
+    uint32_t lo = sel ? sn_float_ordered(dep) : 0xffffffffu, hi = sel ? sn_float_ordered(dep) : 0u;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, s));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, s));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bv) atomicAdd(&p.stats[0], (uint32_t)__popcll(bv));
+        if (lo != 0xffffffffu) {
+            atomicMin(&p.stats[1], lo);
+            atomicMax(&p.stats[2], hi);
+        }
+    }
+}
+
+// one wave per row: prefix[y][x] = number of set pixels in row y at columns < x
+__global__ __launch_bounds__(64) void sn_mask_prefix_kernel(SnMaskParams p) {
+    const int y = blockIdx.x, lane = threadIdx.x;
+    const uint8_t* row = p.vis + (int64_t)y * p.width;
+    int32_t* out = p.prefix + (int64_t)y * (p.width + 1);
+    int carry = 0;
+    if (lane == 0) out[0] = 0;
+    for (int c = 0; c < p.width; c += 64) {
+        const int x = c + lane;
+        int v = x < p.width ? row[x] : 0;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const int t = __shfl_up(v, s);
+            if (lane >= s) v += t;
+        }
+        if (x < p.width) out[x + 1] = carry + v;
+        carry += __shfl(v, 63);
+    }
+}
+
+__global__ void sn_mask_condition_kernel(SnMaskParams p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)p.height * p.width;
+    if (i >= n) return;
+    const uint32_t count = p.stats[0];
+    if (count == 0) {  // is_visible == False: zero mask, zero condition (datasetgenerator.py:812-818)
+        p.mask[i] = 0;
+        if (p.condition) p.condition[i] = 0.0f;
+        return;
+    }
+    const int y = (int)(i / p.width), x = (int)(i % p.width);
+    bool m = p.vis[i] != 0;
+    if (p.dilate) {
+        // cv2.dilate: dst(x,y) = max over set (i,j) of src(x + j - ax, y + i - ay); pixels outside the image do not contribute
+        m = false;
+        for (int r = 0; r < p.el.kh && !m; ++r) {
+            const int yy = y + r - p.el.ay;
+            if (yy < 0 || yy >= p.height) continue;
+            const int a = max(x + p.el.j1[r] - p.el.ax, 0), b = min(x + p.el.j2[r] - p.el.ax, p.width);
+            if (a >= b) continue;
+            const int32_t* pr = p.prefix + (int64_t)yy * (p.width + 1);
+            m = pr[b] - pr[a] > 0;
+        }
+    }
+    p.mask[i] = m ? 1 : 0;
+    if (p.condition) {
+#pragma clang fp contract(off)
+        float dmin, range;
+        if (p.has_manual_depth) {
+            dmin = p.manual_min;
+            range = p.manual_range;
+        } else {
+            // torch.min / torch.max of an empty selection raise in the reference; here an empty selection (all visible depths
+            // <= 0) leaves the sentinels, which map to -inf / +inf -> condition NaN-free but meaningless.  Not reachable with
+            // positive depths.
+            dmin = sn_ordered_float(p.stats[1]) - p.depth_radius;
+            const float dmax = sn_ordered_float(p.stats[2]) + p.depth_radius;
+            range = dmax - dmin;
+        }
+        const float dn = (p.depth[i] - dmin) / range;
+        p.condition[i] = 1.0f - fminf(fmaxf(dn, 0.0f), 1.0f);
+    }
+}

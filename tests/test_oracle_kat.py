@@ -158,3 +158,31 @@ def test_proposal_path_runs_and_is_monotone():
     assert eb.shape == (192, 49) and torch.all(eb[:, 1:] >= eb[:, :-1])
     for k in ("rgb", "depth", "accumulation", "expected_depth", "prop_depth_0", "prop_depth_1"):
         assert torch.isfinite(out[k]).all(), k
+
+
+def test_ellipse_element_matches_opencv_documented_shapes():
+    """cv2.getStructuringElement(cv2.MORPH_ELLIPSE, ...) as printed in OpenCV's morphology tutorial."""
+    from oracle import signerf_utils as su
+
+    assert su.ellipse_element(3, 3).tolist() == [[0, 1, 0], [1, 1, 1], [0, 1, 0]]
+    assert su.ellipse_element(5, 5).tolist() == [[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]]
+    e = su.ellipse_element(50, 50)
+    assert e.shape == (50, 50) and e[0].sum() == 1 and e[25].sum() == 50 and e[:, 25].sum() == 50
+    assert (e == e[:, ::-1][:, np.r_[49, 0:49]]).mean() > 0.9  # roughly symmetric about column 25
+
+
+def test_dilate_single_pixel_reproduces_the_flipped_element():
+    from oracle import signerf_utils as su
+
+    src = np.zeros((21, 23))
+    src[10, 11] = 1.0
+    elem = su.ellipse_element(5, 7)
+    out = su.dilate(src, elem)
+    # dst(y,x) = max src(y + i - ay, x + j - ax): a single source pixel paints the element reflected about its anchor
+    painted = out[10 - 3 : 10 + 4, 11 - 2 : 11 + 3] > 0
+    assert np.array_equal(painted, elem[::-1, ::-1].astype(bool))
+    assert (out > 0).sum() == elem.sum()
+    # border: a pixel in the corner only paints what falls inside
+    src2 = np.zeros((6, 6))
+    src2[0, 0] = 1
+    assert (su.dilate(src2, su.ellipse_element(3, 3)) > 0).sum() == 3
