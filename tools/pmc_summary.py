@@ -44,5 +44,21 @@ def main():
                 print("%s / SQ_WAVE_CYCLES = %.3f" % (k, a[k] / a["SQ_WAVE_CYCLES"]))
 
 
+    if "--json" in sys.argv:  # python tools/pmc_summary.py DIR PATTERN --json PRECISION  -> updates profiles/traffic.json
+        import json
+        prec = sys.argv[sys.argv.index("--json") + 1]
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+        try:
+            cur = json.load(open(path))
+        except (OSError, ValueError):
+            cur = {}
+        rd = 32 * a.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * a.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * a.get("TCC_EA0_RDREQ_128B_sum", 0)
+        wr = a.get("WRITE_SIZE", 0) * 1024
+        cur[prec] = {"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+                     "source": "tools/pmc_passes.sh: TCC_EA0_RDREQ_{32,64,128}B_sum x size + WRITE_SIZE KiB, kernel " + pat}
+        json.dump(cur, open(path, "w"), indent=1)
+        print("updated", path)
+
+
 if __name__ == "__main__":
     main()
