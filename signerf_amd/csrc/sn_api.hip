@@ -44,6 +44,8 @@ struct SnContext {
     std::map<std::string, std::vector<float>> host;  // small tensors (MLP layers, appearance mean)
     DevBuf table_main;
     DevBuf table_prop[SN_MAX_PROPOSALS];
+    DevBuf pairs_prop[SN_MAX_PROPOSALS];  // x-paired copies of the proposal tables (sn_device.h), rebuilt by sn_finalize_weights
+    SnPairInfo pinfo_prop[SN_MAX_PROPOSALS];
     DevBuf wimg_main;                   // SnMainImg (fp32 MFMA operands)
     DevBuf wimg_main_h;                 // SnMainImgH (fp16 hi+lo MFMA operands)
     DevBuf wpack_prop[SN_MAX_PROPOSALS]; // SnPropPack
@@ -245,6 +247,35 @@ const std::vector<float>* find(SnHandle h, const std::string& name, size_t count
     return &it->second;
 }
 
+// Builds the x-paired copy of one hash table (sn_device.h): per level l, (bitlen(scale_l) + 1) tables of T 16-byte entries.
+int build_pairs(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, DevBuf& pairs, SnPairInfo& info, hipStream_t st) {
+    const uint32_t T = 1u << d.log2_hashmap_size;
+    uint64_t entries = 0;
+    int n_t[SN_MAX_LEVELS];
+    for (int l = 0; l < d.num_levels; ++l) {
+        int bits = 0;
+        for (uint32_t s = (uint32_t)d.scalings[l]; s; s >>= 1) ++bits;
+        n_t[l] = bits + 1;
+        info.base[l] = (uint32_t)entries;
+        entries += (uint64_t)n_t[l] * T;
+    }
+    for (int l = d.num_levels; l < SN_MAX_LEVELS; ++l) info.base[l] = 0;
+    const uint64_t bytes = entries * 16;
+    if (bytes >= (1ull << 32)) return fail(h, SN_ERR_INVALID, "paired hash tables exceed the 4 GiB buffer-descriptor range");
+    if (pairs.bytes != bytes) {
+        pairs.release();
+        SN_HIP(h, hipMalloc(&pairs.ptr, bytes));
+        pairs.bytes = bytes;
+    }
+    for (int l = 0; l < d.num_levels; ++l) {
+        const uint64_t n = (uint64_t)n_t[l] * T;
+        hipLaunchKernelGGL(sn_build_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)table.ptr,
+                           (float*)pairs.ptr, l, d.log2_hashmap_size, info.base[l], n_t[l]);
+    }
+    SN_HIP(h, hipGetLastError());
+    return SN_OK;
+}
+
 struct TileGeom {
     int tw_log2, th_log2, tiles_x, tiles_y;
 };
@@ -346,6 +377,7 @@ int sn_destroy(SnHandle h) {
     h->wimg_main_h.release();
     for (int i = 0; i < SN_MAX_PROPOSALS; ++i) {
         h->table_prop[i].release();
+        h->pairs_prop[i].release();
         h->wpack_prop[i].release();
     }
     delete h;
@@ -372,6 +404,10 @@ int sn_upload_weights(SnHandle h, const char* name, const void* data, size_t byt
         }
         SN_HIP(h, hipMemcpyAsync(buf.ptr, data, want, hipMemcpyDefault, st));
         SN_HIP(h, hipStreamSynchronize(st));
+        {
+            std::lock_guard<std::mutex> g(h->mu);
+            h->finalized = false;  // the paired copies must be rebuilt
+        }
         return SN_OK;
     };
     if (n == "field.mlp_base.encoder.hash_table") return upload_table(h->table_main, h->desc.main_field);
@@ -452,6 +488,8 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         }
         SN_HIP(h, hipMemcpyAsync(h->wpack_prop[i].ptr, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, st));
     }
+    for (int i = 0; i < d.num_proposals; ++i)
+        if (int rc = build_pairs(h, d.proposals[i], h->table_prop[i], h->pairs_prop[i], h->pinfo_prop[i], st)) return rc;
     SN_HIP(h, hipStreamSynchronize(st));
     {
         std::lock_guard<std::mutex> g(h->mu);
@@ -559,7 +597,9 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
         pp.tiles_y = g.tiles_y;
         pp.n_levels = nprop;
         for (int i = 0; i < nprop; ++i) {
-            pp.table[i] = (const float*)h->table_prop[i].ptr;
+            pp.pairs[i] = (const float*)h->pairs_prop[i].ptr;
+            pp.pinfo[i] = h->pinfo_prop[i];
+            pp.pairs_bytes[i] = (uint32_t)h->pairs_prop[i].bytes;
             pp.wpack[i] = (const float*)h->wpack_prop[i].ptr;
             pp.log2_t[i] = d.proposals[i].log2_hashmap_size;
             for (int l = 0; l < 5; ++l) pp.scal[i][l] = d.proposals[i].scalings[l];
@@ -647,6 +687,14 @@ int sn_hash_encode(SnHandle h, int32_t which, const float* q, int64_t n, float* 
     p.log2_t = d.log2_hashmap_size;
     p.features = features;
     p.indices = indices;
+    // Proposal nets: when the weights are finalized the features come from the x-paired tables (the production layout of K2);
+    // SN_HASH_PLAIN=1 forces the plain table so that tests can check the two layouts against each other.
+    const char* plain = getenv("SN_HASH_PLAIN");
+    const bool use_pairs = which >= 0 && h->finalized && !(plain && atoi(plain));
+    p.pairs = use_pairs ? (const float*)h->pairs_prop[which].ptr : nullptr;
+    if (which >= 0) p.pinfo = h->pinfo_prop[which];
+    else memset(&p.pinfo, 0, sizeof(p.pinfo));
+    p.pairs_bytes = which >= 0 ? (uint32_t)h->pairs_prop[which].bytes : 0u;
     hipLaunchKernelGGL(sn_hash_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     SN_HIP(h, hipGetLastError());
     return SN_OK;
@@ -682,7 +730,9 @@ int sn_field_forward(SnHandle h, int32_t which, const float* positions, const fl
         SnPropStageParams p;
         p.positions = positions;
         p.n = n;
-        p.table = (const float*)h->table_prop[which].ptr;
+        p.pairs = (const float*)h->pairs_prop[which].ptr;
+        p.pinfo = h->pinfo_prop[which];
+        p.pairs_bytes = (uint32_t)h->pairs_prop[which].bytes;
         p.wpack = (const float*)h->wpack_prop[which].ptr;
         for (int l = 0; l < 5; ++l) p.scal[l] = h->desc.proposals[which].scalings[l];
         p.log2_t = h->desc.proposals[which].log2_hashmap_size;

@@ -485,6 +485,8 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
                 feat[2 * l + 1] = e.y;
             }
         } else {
+            // plain table: the x-paired layout (sn_device.h) measured no gain here (r01: 4.11 vs 4.18 ms) -- splitting a level
+            // into per-t tables loses the x-locality of the plain layout (16 consecutive x share a 128-B line)
             sn_hash_encode<16, 4>(rsrc, p.scal, p.log2_t, q, feat);
         }
         __builtin_amdgcn_sched_barrier(0);

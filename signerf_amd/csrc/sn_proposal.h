@@ -34,9 +34,10 @@ struct SnScal5 {
 };
 
 // pre-activation density of one proposal net at normalised position q
-SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t rsrc, const SnScal5& scal, int log2_t, const float* __restrict__ w, const float q[3]) {
+SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, const SnScal5& scal, int log2_t, const float* __restrict__ w,
+                        const float q[3]) {
     float feat[10];
-    sn_hash_encode<5>(rsrc, scal.v, log2_t, q, feat);
+    sn_hash_encode_pairs<5>(prsrc, pi, scal.v, log2_t, q, feat);
     float out = w[SN_PROP_B1];
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
@@ -119,7 +120,9 @@ struct SnPropParams {
     float* ebins_out;                     // [tile][n_final+1][64]
     float* prop_depth[SN_MAX_PROPOSALS];  // [H*W] or null
     float* scratch;                       // [n_waves][SN_PROP_SCRATCH_FLOATS]
-    const float* table[SN_MAX_PROPOSALS];
+    const float* pairs[SN_MAX_PROPOSALS];  // x-paired tables (sn_device.h)
+    SnPairInfo pinfo[SN_MAX_PROPOSALS];
+    uint32_t pairs_bytes[SN_MAX_PROPOSALS];
     const float* wpack[SN_MAX_PROPOSALS];
     float scal[SN_MAX_PROPOSALS][5];
     int log2_t[SN_MAX_PROPOSALS];
@@ -155,7 +158,10 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
 #pragma unroll
     for (int l = 0; l < 5; ++l) scal.v[l] = p.scal[LV][l];
     const int log2_t = p.log2_t[LV];
-    const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table[LV], (5u << log2_t) * 8u);
+    const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.pairs[LV], p.pairs_bytes[LV]);
+    SnPairInfo pi;
+#pragma unroll
+    for (int l = 0; l < 5; ++l) pi.base[l] = p.pinfo[LV].base[l];
     double cum_tau = 0.0, cum_w = 0.0, swp = 0.0;
     bool found = false;
     float median = 0.0f, mid = 0.0f;
@@ -167,7 +173,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
         const float e1 = sn_euclid(sb(i + 1), s_near, s_far);
         float q[3];
         const bool sel = sn_sample_q(o, d, e0, e1, q);
-        const float h0 = sn_prop_h0(rsrc, scal, log2_t, wp, q);
+        const float h0 = sn_prop_h0(rsrc, pi, scal, log2_t, wp, q);
         const float density = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
         float wt;
         {
@@ -264,7 +270,9 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, 4) void sn_proposal_kernel(SnPr
 struct SnPropStageParams {
     const float* positions;
     int64_t n;
-    const float* table;
+    const float* pairs;
+    SnPairInfo pinfo;
+    uint32_t pairs_bytes;
     const float* wpack;
     float scal[5];
     int log2_t;
@@ -281,8 +289,8 @@ __global__ void sn_prop_field_stage_kernel(SnPropStageParams p) {
     SnScal5 scal;
 #pragma unroll
     for (int l = 0; l < 5; ++l) scal.v[l] = p.scal[l];
-    const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table, (5u << p.log2_t) * 8u);
-    const float h0 = sn_prop_h0(rsrc, scal, p.log2_t, p.wpack, q);
+    const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.pairs, p.pairs_bytes);
+    const float h0 = sn_prop_h0(rsrc, p.pinfo, scal, p.log2_t, p.wpack, q);
     if (i < p.n) p.density[i] = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
 }
 

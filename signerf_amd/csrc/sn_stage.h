@@ -128,6 +128,9 @@ struct SnHashStageParams {
     int num_levels, log2_t;
     float* features;   // [n, 2L]
     int32_t* indices;  // [n, L, 8] or null
+    const float* pairs;  // x-paired tables: when non-null the features come from them (must equal the plain path bit for bit)
+    SnPairInfo pinfo;
+    uint32_t pairs_bytes;
 };
 
 __global__ void sn_hash_encode_kernel(SnHashStageParams p) {
@@ -147,8 +150,17 @@ __global__ void sn_hash_encode_kernel(SnHashStageParams p) {
             if (p.indices) p.indices[(i * p.num_levels + l) * 8 + k] = (int32_t)(hl.row[k] + ((uint32_t)l << p.log2_t));
         }
         f32x2 e = sn_hash_blend(v, hl.off);
-        p.features[i * 2 * p.num_levels + 2 * l] = e.x;
-        p.features[i * 2 * p.num_levels + 2 * l + 1] = e.y;
+        if (!p.pairs) {
+            p.features[i * 2 * p.num_levels + 2 * l] = e.x;
+            p.features[i * 2 * p.num_levels + 2 * l + 1] = e.y;
+        }
+    }
+    if (p.pairs) {
+        const __amdgpu_buffer_rsrc_t prsrc = sn_table_rsrc(p.pairs, p.pairs_bytes);
+        float feat[32];
+        if (p.num_levels == 16) sn_hash_encode_pairs<16>(prsrc, p.pinfo, p.scal, p.log2_t, q, feat);
+        else sn_hash_encode_pairs<5>(prsrc, p.pinfo, p.scal, p.log2_t, q, feat);
+        for (int k = 0; k < 2 * p.num_levels; ++k) p.features[i * 2 * p.num_levels + k] = feat[k];
     }
 }
 
