@@ -75,6 +75,21 @@ def _default_device():
     return torch.device("cpu")
 
 
+def render_views(model, cameras, generator_config, group=None) -> Tensor:
+    """BASELINE.json configs[4]: the per-view work of the dataset-generator loops
+    (/root/reference/signerf/datasetgenerator/datasetgenerator.py:331-338 and :517-519): for every camera, render ->
+    mask -> condition (``render_camera``, aabb mode), sharded round-robin over the ranks, tiles all-gathered.
+    -> [n_cameras, H, W, 5] = rgb (3) ++ mask (1, 0/1) ++ condition (1) on every rank.  The diffusion call that follows
+    each view in the reference is a remote HTTP service and stays where it is (rank 0)."""
+    from .datasetgenerator import render_camera
+
+    def render_fn(i: int):
+        rgb, mask, cond = render_camera(generator_config, model, cameras[i])
+        return rgb, torch.cat([mask.to(rgb.dtype), cond], dim=-1)
+
+    return render_cameras_sharded(render_fn, len(cameras), group)
+
+
 def render_reference_sheet(model, cameras, group=None) -> Tensor:
     """Row (e): every camera of ``cameras`` (a batched ``signerf_amd.Cameras`` on this rank's GPU) rendered by its owner
     rank through the reference's two calls, tiles all-gathered.  -> [n_cameras, H, W, 4]."""

@@ -70,3 +70,30 @@ def test_render_camera_three_tuple(gpu):
                                               torch.tensor([gen.aabb_min, gen.aabb_max]), gen.mask_dialation)
     assert rgb.shape == (96, 96, 3) and torch.equal(mask.cpu(), rmask) and torch.equal(cond.cpu(), rcond)
     assert len(render_camera(gen, model, cams[0], with_mask=False)) == 4   # the reference's early-exit arity
+
+
+def test_config5_generator_loop_reduced(gpu):
+    """BASELINE.json configs[4] at reduced size: 8 reference cameras (circle_poses) + 50 random_sphere_poses views, each
+    rendered + masked + conditioned; checked view by view against the single-camera path and, for three views, against the
+    oracle end to end (render RMSE gate + exact mask given the GPU depth)."""
+    from signerf_amd import random_sphere_poses, sheet
+
+    cfg = small_config()  # proposal path, small tables
+    model, sd = make_model(cfg, gpu)
+    torch.manual_seed(1)
+    c2w = torch.cat([scene.benchmark_cameras(8), random_sphere_poses(50, torch.device("cpu"), 0.5, (30.0, 120.0), (0.0, 360.0),
+                                                                   [0.0, 0.0, 0.0], [0.0, 0.0, 0.0])])
+    H, W = 40, 56
+    cams = Cameras(c2w[:, :3], 75.0, 75.0, W / 2, H / 2, W, H).to(gpu)
+    gen = DatasetGeneratorConfig(aabb_min=[-0.2, -0.2, -0.2], aabb_max=[0.2, 0.2, 0.2], mask_dialation=(7, 7))
+    tiles = sheet.render_views(model, cams, gen)
+    assert tiles.shape == (58, H, W, 5) and torch.isfinite(tiles).all()
+    for i in (0, 7, 8, 33, 57):
+        rgb, mask, cond = render_camera(gen, model, cams[i])
+        assert torch.equal(tiles[i, ..., :3], rgb) and torch.equal(tiles[i, ..., 3:4], mask.float()) and torch.equal(tiles[i, ..., 4:5], cond)
+    from helpers import oracle_config, rmse
+    for i in (3, 20, 41):
+        b = cams[i].generate_rays(0)
+        ref = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg), b.origins.cpu(), b.directions.cpu())
+        assert rmse(tiles[i, ..., :3], ref["rgb"]) <= 1e-3
+    assert 0.0 < float(tiles[..., 3].mean()) < 1.0

@@ -62,6 +62,21 @@ def test_sharded_sheet_matches_single_rank(tmp_path, world, n_cameras):
     assert sorted(seen) == list(range(n_cameras))                                     # each camera rendered exactly once
 
 
+def test_render_views_packs_rgb_mask_condition(monkeypatch):
+    """render_views = render_camera per view, packed [rgb | mask | condition]; sharding/gather shared with the sheet path."""
+    from signerf_amd import datasetgenerator, sheet
+
+    def fake_render_camera(config, graph, camera, **kw):
+        rgb, depth = _fake_render(camera)
+        return rgb, depth > float(camera) + 0.5, 1 - depth / 10
+
+    monkeypatch.setattr(datasetgenerator, "render_camera", fake_render_camera)
+    t = sheet.render_views(None, [0, 1, 2], None)
+    assert t.shape == (3, 6, 5, 5)
+    rgb, depth = _fake_render(2)
+    assert torch.equal(t[2, ..., :3], rgb) and torch.equal(t[2, ..., 3:4], (depth > 2.5).float()) and torch.equal(t[2, ..., 4:5], 1 - depth / 10)
+
+
 def test_shard_indices_and_single_process_passthrough():
     from signerf_amd import sheet
 
