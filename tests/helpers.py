@@ -48,9 +48,9 @@ def small_config(**kw):
     return SIGNeRFModelConfig(**base)
 
 
-def make_model(cfg, device, seed=0):
+def make_model(cfg, device, seed=0, **scene_kw):
     """HIP-backed model with the synthetic scene loaded; returns (model, cpu state dict)."""
-    sd = scene.synthetic_state_dict(cfg, seed=seed)
+    sd = scene.synthetic_state_dict(cfg, seed=seed, **scene_kw)
     model = cfg.setup()
     model.load_state_dict(sd, strict=False)
     model.field.embedding_appearance.embedding.weight.data.copy_(sd["field.embedding_appearance.embedding.weight"])

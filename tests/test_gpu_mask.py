@@ -79,7 +79,7 @@ def test_config5_generator_loop_reduced(gpu):
     from signerf_amd import random_sphere_poses, sheet
 
     cfg = small_config()  # proposal path, small tables
-    model, sd = make_model(cfg, gpu)
+    model, sd = make_model(cfg, gpu, density_bias=5.0)  # denser scene: median depth ~0.45, i.e. inside the box below
     torch.manual_seed(1)
     c2w = torch.cat([scene.benchmark_cameras(8), random_sphere_poses(50, torch.device("cpu"), 0.5, (30.0, 120.0), (0.0, 360.0),
                                                                    [0.0, 0.0, 0.0], [0.0, 0.0, 0.0])])
