@@ -172,6 +172,11 @@ int sn_aabb_mask_condition(const float* origins, const float* directions, const 
                            const float* aabb, const SnMaskOpts* opts, uint8_t* mask, float* condition, void* workspace,
                            size_t workspace_bytes, SnStream stream);
 
+/* ---- tensor_to_image's numeric part (signerf/utils/image_tensor_converter.py:7-33) -------
+ * out[i] = (uint8)(in[i] * 255): a TRUNCATING cast, no rounding, no clamp (numpy astype semantics on x86: float -> int32 ->
+ * low 8 bits; NaN -> 0).  in: [n] fp32 device, out: [n] uint8 device. */
+int sn_tensor_to_uint8(const float* in, int64_t n, uint8_t* out, SnStream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -883,4 +883,14 @@ int sn_aabb_mask_condition(const float* origins, const float* directions, const 
     return SN_OK;
 }
 
+
+int sn_tensor_to_uint8(const float* in, int64_t n, uint8_t* out, SnStream stream) {
+    if (!in || !out || n < 0) return fail(nullptr, SN_ERR_INVALID, "sn_tensor_to_uint8: bad argument");
+    if (n == 0) return SN_OK;
+    hipLaunchKernelGGL(sn_tensor_to_uint8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, n, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_tensor_to_uint8 launch: ") + hipGetErrorString(e));
+    return SN_OK;
+}
+
 }  // extern "C"

@@ -137,3 +137,16 @@ __global__ void sn_mask_condition_kernel(SnMaskParams p) {
         p.condition[i] = 1.0f - fminf(fmaxf(dn, 0.0f), 1.0f);
     }
 }
+
+// tensor_to_image (image_tensor_converter.py:21-23,28-30): x * 255 then numpy's astype(uint8) -- truncation toward zero,
+// no clamp; out-of-range values wrap like the x86 cvttss2si + byte-truncate sequence numpy compiles to.
+__global__ void sn_tensor_to_uint8_kernel(const float* __restrict__ in, int64_t n, uint8_t* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = in[i] * 255.0f;
+    int iv;
+    if (v != v || v >= 2147483648.0f || v < -2147483648.0f) iv = (int)0x80000000;  // cvttss2si "integer indefinite"
+    else iv = (int)v;
+    out[i] = (uint8_t)(iv & 0xff);
+}

@@ -1,0 +1,128 @@
+"""Output formats of the generated dataset -- SURVEY.md §8(f) row 3.
+
+Mirrors what the reference writes so that ``SIGNeRFDataParser`` (signerf/data/signerf_dataparser.py:99-170,210-228) reads it
+unchanged:
+  * ``tensor_to_image``  /root/reference/signerf/utils/image_tensor_converter.py:7-33 -- x*255 with a TRUNCATING uint8 cast
+    (254.9/255 -> 254), done by a kernel; only the finished bytes cross PCIe;
+  * directory layout    datasetgenerator.py:146-182 (images/ masks/ conditions/ rendered/ originals/ *_<f>/ references/);
+  * transforms.json     datasetgenerator.py:286-295 (header) and :447-466 (one frame per saved view);
+  * ``load_previous_experiment_cameras``  signerf/utils/load_previous_experiment_cameras.py:12-54 (the reader of the same file).
+PNG encoding itself is PIL on the host, as in the reference.
+"""
+
+from __future__ import annotations
+
+import json
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+
+def tensor_to_uint8(tensor: Tensor) -> Tensor:
+    """[H,W,C] fp32 on the GPU -> [H,W,C] uint8 on the GPU, (uint8)(x * 255) truncating."""
+    lib = _lib.load()
+    t = tensor.detach().to(torch.float32).contiguous()
+    with torch.cuda.device(t.device):
+        out = torch.empty(t.shape, dtype=torch.uint8, device=t.device)
+        _lib.check(lib.sn_tensor_to_uint8(_lib.ptr(t), t.numel(), _lib.ptr(out), _lib.current_stream()), None, "sn_tensor_to_uint8")
+    return out
+
+
+def tensor_to_image(tensor: Tensor):
+    """image_tensor_converter.py:7-33: [H,W,3] -> RGB image, [H,W,1] -> 'L' image."""
+    from PIL import Image
+
+    assert len(tensor.shape) == 3, "Tensor must be of shape (H, W, C)"
+    u8 = tensor_to_uint8(tensor).cpu().numpy()
+    if tensor.shape[2] == 1:
+        return Image.fromarray(u8.squeeze(), "L")
+    assert tensor.shape[2] == 3, "Tensor must be of shape (H, W, 3)"
+    return Image.fromarray(u8)
+
+
+def image_to_tensor(image) -> Tensor:
+    """image_tensor_converter.py:35-54."""
+    import numpy as np
+
+    if image.mode == "RGBA":
+        image = image.convert("RGB")
+    return torch.from_numpy(np.array(image, dtype="float32")) / 255.0
+
+
+def load_previous_experiment_cameras(transforms_path: Union[str, Path]) -> Tuple[Tensor, Optional[Tensor], bool]:
+    """load_previous_experiment_cameras.py:12-54: (reference c2w [R,3,4], synthetic c2w [S,3,4] | None, is_combined)."""
+    with open(transforms_path) as f:
+        transforms = json.load(f)
+    frames = transforms["frames"]
+
+    def stack(indices: List[int]) -> Tensor:
+        return torch.stack([torch.tensor(frames[i]["scene_transform_matrix"][:3], dtype=torch.float32) for i in indices], dim=0)
+
+    reference = stack(transforms["reference_indices"])
+    synthetic = stack(transforms["generated_indices"]) if transforms.get("is_synthetic") else None
+    return reference, synthetic, bool(transforms.get("is_combined", False))
+
+
+class GeneratedDataset:
+    """Directory + transforms.json writer with the reference's layout and keys."""
+
+    SUBDIRS = ("images", "masks", "conditions", "rendered", "originals")
+
+    def __init__(self, path: Union[str, Path], dataset_name: str, downscale_factor: int = 2):
+        self.dataset_path = Path(path) / dataset_name
+        self.downscale_factor = downscale_factor
+        self.dirs: Dict[str, Path] = {}
+
+    def init_directory(self) -> None:
+        """datasetgenerator.py:146-175 (config.yml is the reference's yaml pickle of its own config class; not written here)."""
+        self.dataset_path.mkdir(parents=True, exist_ok=True)
+        for name in self.SUBDIRS:
+            for key, d in ((name, self.dataset_path / name), (f"{name}_scaled", self.dataset_path / f"{name}_{self.downscale_factor}")):
+                d.mkdir(parents=True, exist_ok=True)
+                self.dirs[key] = d
+        self.dirs["references"] = self.dataset_path / "references"
+        self.dirs["references"].mkdir(parents=True, exist_ok=True)
+        self.transforms_path = self.dataset_path / "transforms.json"
+
+    @staticmethod
+    def new_transforms(original_transform_matrix: Tensor, original_scale_factor: float, is_synthetic: bool = False,
+                       is_combined: bool = False) -> Dict[str, Any]:
+        """datasetgenerator.py:286-295."""
+        return {"camera_model": "OPENCV", "orientation_override": "none", "method": "SIGNeRF", "is_synthetic": is_synthetic,
+                "is_combined": is_combined, "frames": [],
+                "original_transform_matrix": original_transform_matrix.cpu().numpy().tolist(),
+                "original_scale_factor": original_scale_factor}
+
+    def save_generated_images(self, idx: int, images: Dict[str, Tensor], camera, current_transforms: Dict[str, Any],
+                              is_original: bool = False) -> Dict[str, Any]:
+        """datasetgenerator.py:398-468: PNGs by key + one frame appended to the transforms."""
+        def save(key: str, directory: str, stem: str):
+            if key in images:
+                tensor_to_image(images[key]).save(self.dirs[directory] / f"{stem}_{idx}.png")
+
+        save("edited", "images", "image")
+        save("render", "originals" if is_original else "rendered", "image")
+        save("mask", "masks", "mask")
+        save("condition", "conditions", "condition")
+        save("edited_scaled", "images_scaled", "image")
+        save("render_scaled", "rendered_scaled", "image")  # the reference writes both cases to rendered_<f> (:436-440)
+        save("mask_scaled", "masks_scaled", "mask")
+        save("condition_scaled", "conditions_scaled", "condition")
+        c2w = torch.cat([camera.camera_to_worlds.cpu(), torch.tensor([[0.0, 0.0, 0.0, 1.0]])], dim=0).numpy().tolist()
+        current_transforms["frames"].append({
+            "fl_x": camera.fx.item(), "fl_y": camera.fy.item(), "cx": camera.cx.item(), "cy": camera.cy.item(),
+            "w": camera.width.item(), "h": camera.height.item(),
+            "file_path": f"./images/image_{idx}.png",
+            "_mask_path": f"./masks/mask_{idx}.png",
+            "transform_matrix": c2w,  # scene space, like the reference (FIXME at datasetgenerator.py:464)
+            "scene_transform_matrix": c2w,
+        })
+        return current_transforms
+
+    def write_transforms(self, transforms: Dict[str, Any]) -> None:
+        with open(self.transforms_path, "w", encoding="utf8") as f:
+            json.dump(transforms, f, indent=4)
