@@ -190,14 +190,6 @@ SN_DEV void sn_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
     lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a - ah, b - bh));
 }
 
-// gfx950 hazard found on hardware (r01): a VALU write (v_cvt_pkrtz_f16_f32 / v_sub / v_and ...) of a register that a
-// following v_mfma_f32_32x32x16_f16 reads as its 4-VGPR B operand must be separated from it by wait states that hipcc
-// (ROCm 7.2) does not insert: otherwise the MFMA occasionally sees the register's PREVIOUS contents in lanes 48-63 (the
-// last 16-lane pass of the write).  Symptom: ~5 of 10 000 tiles per frame with colour off by ~1e-3, different tiles every
-// run.  SN_OP_GUARD pins 8 wait states after every operand construction (22 x 8 cycles per wave-step: free).
-#ifndef SN_OP_GUARD
-#define SN_OP_GUARD 1
-#endif
 struct SnOpH {  // one B operand (8 k-slots of one 32-sample tile), hi and lo parts
     u32x4 hi, lo;
     SN_DEV void set(const float v[8]) {
@@ -208,13 +200,21 @@ struct SnOpH {  // one B operand (8 k-slots of one 32-sample tile), hi and lo pa
             hi[e] = h;
             lo[e] = l;
         }
-#if SN_OP_GUARD
-        asm volatile("s_nop 7" : "+v"(hi), "+v"(lo));
-#endif
     }
 };
 
-#define SN_MFMA_H(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, ACC, 0, 0, 0)
+// f16 MFMA with its operand wait states INSIDE the statement.
+// gfx950 hazard found on hardware (r01): a VALU write (v_cvt_pkrtz_f16_f32, v_sub, v_and, or a register-allocator v_mov) of a
+// VGPR that a following v_mfma_f32_32x32x16_f16 reads (4-VGPR A/B operand, or C) must be separated from it by wait states
+// that hipcc (ROCm 7.2) does not insert; otherwise the MFMA occasionally sees the register's PREVIOUS contents in lanes
+// 48-63 (the last 16-lane pass of the write): ~5 of 10 000 tiles per frame with colour off by ~1e-3, different tiles every
+// run.  Waiting after the operand construction in C++ is not enough -- the allocator may still put a copy right before the
+// MFMA -- so the nops sit in the same asm statement as the instruction.  Consequences of hiding the MFMA from the compiler:
+//   * results must not be read by the VALU before SN_MFMA_H_DRAIN2 (>= 12 wait states after an 8-pass XDL op), and must not
+//     be SPILLED in between (the kernels using this path are built spill-free, see sn_render_main_kernel);
+//   * dependent MFMAs on one accumulator are separated by at least one other MFMA (32 cycles) by construction below.
+#define SN_MFMA_H(ACC, A, B) asm volatile("s_nop 7\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+#define SN_MFMA_H_DRAIN2(X, Y) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(X), "+v"(Y))
 
 template <int RT, int KS>
 SN_DEV void sn_mlp_layer_h(const char* __restrict__ wimg, const float* __restrict__ bimg, const SnOpH* op0, const SnOpH* op1,
@@ -256,6 +256,9 @@ SN_DEV void sn_mlp_layer_h(const char* __restrict__ wimg, const float* __restric
             SN_MFMA_H(acc1[rt], ah[rt], bh1);
         }
     }
+    // the compiler does not know these asm statements are MFMAs: drain the matrix pipe before anything reads the results
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) SN_MFMA_H_DRAIN2(acc0[rt], acc1[rt]);
 }
 
 // per-ray direction operands, fp16x2 form: slot (h, e) <-> SH component 8h + e
@@ -413,7 +416,11 @@ SN_DEV int sn_xcd_remap(int b, int n) {
 // only (no MLP: density / colour faked from the features), 3 = VALU only (no table gathers either).  Measured r01:
 // full 7.7 ms, hash-only 2.8-3.0 ms (= the L1 tag-lookup floor), VALU-only 1.4 ms; the 204.8 M fp32 MFMAs alone are 5.6 ms.
 template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int PREC /*0 fp32 MFMA, 1 fp16 hi+lo split MFMA*/, int ABLATE = 0>
-__global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_kernel(SnMainParams p) {
+// fp16x2 kernels run at 2 waves per SIMD (256-VGPR budget): their MFMAs are inline asm (SN_MFMA_H), so the kernel MUST NOT
+// spill -- a compiler-placed scratch_store of an accumulator right after a hidden MFMA would read it before the matrix pipe
+// has written it (measured: the 168-VGPR build, which spills, flickers; this one does not).  signerf_amd/build.py enforces
+// "0 spills" for these kernels.  The fp32 kernels use the MFMA builtin (hazards handled by hipcc) and keep 3 waves.
+__global__ __launch_bounds__(256, PREC == 1 ? 2 : SN_MAIN_WAVES_PER_SIMD) void sn_render_main_kernel(SnMainParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     // both weight images are SnMainImg::TOTAL floats (42 640 B)

@@ -109,15 +109,15 @@ def test_flat_bundle_get_outputs(gpu):
 
 @pytest.mark.parametrize("precision", ["fp32", "fp16x2"])
 def test_render_is_deterministic(gpu, precision):
-    """Five full-size renders must be bit-identical.  (Catches instruction hazards: without SN_OP_GUARD the fp16x2 kernel
-    returns lanes 48-63 of ~5 tiles per frame from stale MFMA operands, different tiles every run.)"""
+    """Repeated full-size renders must be bit-identical.  (Catches instruction hazards: without the wait states in SN_MFMA_H the
+    fp16x2 kernel returns lanes 48-63 of ~5 tiles per frame from stale MFMA operands, different tiles every run.)"""
     cfg = scene.benchmark_config(64)
     cfg.precision = precision
     model, sd = make_model(cfg, gpu)
     cams = Cameras(scene.benchmark_cameras(8)[:, :3], 800.0, 800.0, 400.0, 400.0, 800, 800).to(gpu)
     b = cams[5].generate_rays(0)
     first = model.get_outputs_for_camera_ray_bundle(b)
-    for _ in range(4):
+    for _ in range(11):
         again = model.get_outputs_for_camera_ray_bundle(b)
         for k in ("rgb", "depth", "accumulation", "expected_depth"):
             assert torch.equal(first[k], again[k]), k
