@@ -73,7 +73,7 @@ int fail(SnHandle h, int code, const std::string& msg) {
 bool check_hashmlp(const SnHashMlpDesc& d, int levels, int hidden, int out, std::string& why) {
     if (d.num_levels != levels) why = "num_levels must be " + std::to_string(levels);
     else if (d.features_per_level != 2) why = "features_per_level must be 2";
-    else if (d.log2_hashmap_size < 4 || d.log2_hashmap_size > 24) why = "log2_hashmap_size out of range";
+    else if (d.log2_hashmap_size < 4 || d.log2_hashmap_size > 21) why = "log2_hashmap_size out of range [4,21]";
     else if (d.hidden_dim != hidden) why = "hidden_dim must be " + std::to_string(hidden);
     else if (d.num_layers != 2) why = "num_layers must be 2";
     else if (d.out_dim != out) why = "out_dim must be " + std::to_string(out);

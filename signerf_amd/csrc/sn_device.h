@@ -95,8 +95,8 @@ SN_DEV bool sn_position_q(const float pin[3], float q[3]) {
 // ------------------------------------------------------------------------------------------
 
 struct SnHashLevel {
-    uint32_t row[8];  // table row within the level (before the level offset), nerfstudio corner order
-    float off[3];     // scaled - floor(scaled)
+    uint32_t boff[8];  // BYTE offset (row * 8) within the level, nerfstudio corner order
+    float off[3];      // scaled - floor(scaled)
 };
 
 // Integer part.  uint32 wrap-around arithmetic equals the reference's int64 products followed by
@@ -112,17 +112,24 @@ SN_DEV void sn_hash_corners(const float q[3], float scale, uint32_t mask, SnHash
         f[a] = (uint32_t)(int)fl;
         c[a] = (uint32_t)(int)ceilf(x);
     }
-    const uint32_t P1 = 2654435761u, P2 = 805459861u;
-    uint32_t yf = f[1] * P1, yc = c[1] * P1, zf = f[2] * P2, zc = c[2] * P2;
+    // Only the low log2(T) bits of the products survive `& mask`, so the primes can be reduced mod T first (T <= 2^24 is
+    // enforced by sn_create); coordinates are < 2^24, and v_mul_u32_u24 returns the exact low 32 bits of a 24x24-bit product,
+    // so the FULL-RATE 24-bit multiply gives the same masked bits as the reference's int64 product (v_mul_lo_u32 is quarter
+    // rate).  Bit-exact: tests/test_gpu_stages.py compares every table row.
+    // The rows are wanted as byte offsets (x 8): shifting the three xor components instead of the eight results folds the
+    // shift of y and z into the (reduced) primes -- (P & mask) << 3 still fits 24 bits for T <= 2^21 -- and leaves two shifts.
+    const uint32_t P1 = (2654435761u & mask) << 3, P2 = (805459861u & mask) << 3, m8 = mask << 3;
+    const uint32_t yf = __umul24(f[1], P1), yc = __umul24(c[1], P1), zf = __umul24(f[2], P2), zc = __umul24(c[2], P2);
+    const uint32_t xf = f[0] << 3, xc = c[0] << 3;
     // order: 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf
-    hl.row[0] = (c[0] ^ yc ^ zc) & mask;
-    hl.row[1] = (c[0] ^ yf ^ zc) & mask;
-    hl.row[2] = (f[0] ^ yf ^ zc) & mask;
-    hl.row[3] = (f[0] ^ yc ^ zc) & mask;
-    hl.row[4] = (c[0] ^ yc ^ zf) & mask;
-    hl.row[5] = (c[0] ^ yf ^ zf) & mask;
-    hl.row[6] = (f[0] ^ yf ^ zf) & mask;
-    hl.row[7] = (f[0] ^ yc ^ zf) & mask;
+    hl.boff[0] = (xc ^ yc ^ zc) & m8;
+    hl.boff[1] = (xc ^ yf ^ zc) & m8;
+    hl.boff[2] = (xf ^ yf ^ zc) & m8;
+    hl.boff[3] = (xf ^ yc ^ zc) & m8;
+    hl.boff[4] = (xc ^ yc ^ zf) & m8;
+    hl.boff[5] = (xc ^ yf ^ zf) & m8;
+    hl.boff[6] = (xf ^ yf ^ zf) & m8;
+    hl.boff[7] = (xf ^ yc ^ zf) & m8;
 }
 
 // Trilinear blend in the reference's association (x, then y, then z); FMA allowed.
@@ -166,7 +173,7 @@ SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int l
         const uint32_t lvl = ((uint32_t)l << log2_t) * 8u;
         f32x2 v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = sn_table_load(rsrc, hl.row[k] * 8u, lvl);
+        for (int k = 0; k < 8; ++k) v[k] = sn_table_load(rsrc, hl.boff[k], lvl);
         f32x2 e = sn_hash_blend(v, hl.off);
         feat[2 * l] = e.x;
         feat[2 * l + 1] = e.y;
@@ -220,8 +227,8 @@ SN_DEV void sn_hash_encode_pairs(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo&
                 c[a] = (uint32_t)(int)ceilf(x);
             }
         }
-        const uint32_t P1 = 2654435761u, P2 = 805459861u;
-        const uint32_t yf = f[1] * P1, yc = c[1] * P1, zf = f[2] * P2, zc = c[2] * P2;
+        const uint32_t P1 = 2654435761u & mask, P2 = 805459861u & mask;  // see sn_hash_corners
+        const uint32_t yf = __umul24(f[1], P1), yc = __umul24(c[1], P1), zf = __umul24(f[2], P2), zc = __umul24(c[2], P2);
         const uint32_t t = (uint32_t)__builtin_ctz(~f[0]);  // trailing ones of xf (xf < 2^31, so ~xf != 0)
         const uint32_t base = pi.base[l] + (t << log2_t);
         // pair k: .xy = floor-x corner, .zw = ceil-x corner of (y?, z?)
@@ -376,6 +383,11 @@ SN_DEV uint32_t sn_float_ordered(float f) {
 SN_DEV float sn_ordered_float(uint32_t u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
+
+// ReLU as ONE integer max on the bit pattern (hipcc turns fmaxf(x, 0) on an MFMA result into TWO v_max_f32, a canonicalising
+// one first, and folds v_med3(x, 0, inf) back into the same pair): negative floats are negative ints, -0.0 is INT_MIN, positive
+// floats keep their bits.  NaN handling is restored separately where it matters (sn_main.h).
+SN_DEV float sn_relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
 // Exchange halves: afterwards a = [lanes 0-31: own a | lanes 32-63: lower partner's b],
 //                              b = [lanes 0-31: upper partner's a | lanes 32-63: own b].

@@ -99,8 +99,8 @@ SN_DEV void sn_main_field_f32(const float* __restrict__ lds, float* feat, const 
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            op0[rt * 16 + r] = fmaxf(a0[rt][r], 0.0f);
-            op1[rt * 16 + r] = fmaxf(a1[rt][r], 0.0f);
+            op0[rt * 16 + r] = sn_relu(a0[rt][r]);
+            op1[rt * 16 + r] = sn_relu(a1[rt][r]);
         }
     // (scheduler fences between layers: otherwise every LDS weight read of the whole MLP is hoisted to the top and spills)
     __builtin_amdgcn_sched_barrier(0);
@@ -122,8 +122,8 @@ SN_DEV void sn_main_field_f32(const float* __restrict__ lds, float* feat, const 
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            op0[rt * 16 + r] = fmaxf(a0[rt][r], 0.0f);
-            op1[rt * 16 + r] = fmaxf(a1[rt][r], 0.0f);
+            op0[rt * 16 + r] = sn_relu(a0[rt][r]);
+            op1[rt * 16 + r] = sn_relu(a1[rt][r]);
         }
     __builtin_amdgcn_sched_barrier(0);
     // ---- colour layer 2: 64 -> 64, ReLU ----------------------------------------------------
@@ -142,8 +142,8 @@ SN_DEV void sn_main_field_f32(const float* __restrict__ lds, float* feat, const 
                 f32x4 wv = w[rt * 4 + r4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float x0 = fmaxf(a0[rt][r4 * 4 + e], 0.0f);
-                    float x1 = fmaxf(a1[rt][r4 * 4 + e], 0.0f);
+                    float x0 = sn_relu(a0[rt][r4 * 4 + e]);
+                    float x1 = sn_relu(a1[rt][r4 * 4 + e]);
                     p0[n] = fmaf(wv[e], x0, p0[n]);
                     p1[n] = fmaf(wv[e], x1, p1[n]);
                 }
@@ -154,7 +154,7 @@ SN_DEV void sn_main_field_f32(const float* __restrict__ lds, float* feat, const 
         float a = p0[n], b = p1[n];
         sn_swap_halves(a, b);  // lower: own tile-0 partial + upper's tile-0 partial; upper: tile 1
         float x = a + b + lds[SnMainImg::B3 + n];
-        rgb[n] = 1.0f / (1.0f + expf(-x));
+        rgb[n] = __builtin_amdgcn_rcpf(1.0f + expf(-x));  // v_rcp_f32 (1 ulp) instead of an IEEE divide: colours are fp work
     }
 }
 
@@ -187,7 +187,8 @@ SN_DEV void sn_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
     const float ah = __uint_as_float(__float_as_uint(a) & 0xffffe000u);
     const float bh = __uint_as_float(__float_as_uint(b) & 0xffffe000u);
     hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(ah, bh));
-    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a - ah, b - bh));
+    const f32x2 d = f32x2{a, b} - f32x2{ah, bh};  // one v_pk_add_f32
+    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(d.x, d.y));
 }
 
 struct SnOpH {  // one B operand (8 k-slots of one 32-sample tile), hi and lo parts
@@ -284,7 +285,7 @@ struct SnShOpsH {
 SN_DEV void sn_acc_to_ops(const f32x16& acc, bool relu, SnOpH& s0, SnOpH& s1) {
     float v[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = relu ? fmaxf(acc[r], 0.0f) : acc[r];
+    for (int r = 0; r < 16; ++r) v[r] = relu ? sn_relu(acc[r]) : acc[r];
     s0.set(v);
     s1.set(v + 8);
 }
@@ -356,8 +357,8 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
                 f32x4 wv = w[rt * 4 + r4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    p0[n] = fmaf(wv[e], fmaxf(a0[rt][r4 * 4 + e], 0.0f), p0[n]);
-                    p1[n] = fmaf(wv[e], fmaxf(a1[rt][r4 * 4 + e], 0.0f), p1[n]);
+                    p0[n] = fmaf(wv[e], sn_relu(a0[rt][r4 * 4 + e]), p0[n]);
+                    p1[n] = fmaf(wv[e], sn_relu(a1[rt][r4 * 4 + e]), p1[n]);
                 }
             }
     }
@@ -366,13 +367,17 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
         float a = p0[n], b = p1[n];
         sn_swap_halves(a, b);
         float x = a + b + tail[SnMainImgH::B3 + n];
-        rgb[n] = 1.0f / (1.0f + expf(-x));
+        rgb[n] = __builtin_amdgcn_rcpf(1.0f + expf(-x));  // v_rcp_f32 (1 ulp) instead of an IEEE divide: colours are fp work
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // kernel
 // ------------------------------------------------------------------------------------------
+// levels whose gathers are in flight together in the fp16x2 kernels (256-VGPR budget); the fp32 kernels (168 VGPRs) use 4
+#ifndef SN_HASH_GROUP_H
+#define SN_HASH_GROUP_H 8
+#endif
 #ifndef SN_MAIN_WAVES_PER_SIMD
 #define SN_MAIN_WAVES_PER_SIMD 3
 #endif
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(256, PREC == 1 ? 2 : SN_MAIN_WAVES_PER_SIMD) void s
                 f32x2 v[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    v[k].x = __uint_as_float((hl.row[k] & 0x7fffffu) | 0x3f800000u) - 1.5f;
+                    v[k].x = __uint_as_float((hl.boff[k] & 0x7fffffu) | 0x3f800000u) - 1.5f;
                     v[k].y = -v[k].x;
                 }
                 f32x2 e = sn_hash_blend(v, hl.off);
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(256, PREC == 1 ? 2 : SN_MAIN_WAVES_PER_SIMD) void s
         } else {
             // plain table: the x-paired layout (sn_device.h) measured no gain here (r01: 4.11 vs 4.18 ms) -- splitting a level
             // into per-t tables loses the x-locality of the plain layout (16 consecutive x share a 128-B line)
-            sn_hash_encode<16, 4>(rsrc, p.scal, p.log2_t, q, feat);
+            sn_hash_encode<16, (PREC == 1 ? SN_HASH_GROUP_H : 4)>(rsrc, p.scal, p.log2_t, q, feat);
         }
         __builtin_amdgcn_sched_barrier(0);
         float h0, rgb[3];

@@ -44,7 +44,7 @@ SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, cons
         float a = w[SN_PROP_B0 + n];
 #pragma unroll
         for (int k = 0; k < 10; ++k) a = fmaf(w[SN_PROP_W0 + n * 10 + k], feat[k], a);
-        out = fmaf(w[SN_PROP_W1 + n], fmaxf(a, 0.0f), out);
+        out = fmaf(w[SN_PROP_W1 + n], sn_relu(a), out);
     }
     // v_max-based ReLU launders NaN; the reference's field is NaN all the way for a NaN position
     if ((q[0] != q[0]) | (q[1] != q[1]) | (q[2] != q[2])) out = __builtin_nanf("");

@@ -146,8 +146,8 @@ __global__ void sn_hash_encode_kernel(SnHashStageParams p) {
         f32x2 v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            v[k] = sn_table_load(rsrc, hl.row[k] * 8u, lvl);
-            if (p.indices) p.indices[(i * p.num_levels + l) * 8 + k] = (int32_t)(hl.row[k] + ((uint32_t)l << p.log2_t));
+            v[k] = sn_table_load(rsrc, hl.boff[k], lvl);
+            if (p.indices) p.indices[(i * p.num_levels + l) * 8 + k] = (int32_t)((hl.boff[k] >> 3) + ((uint32_t)l << p.log2_t));
         }
         f32x2 e = sn_hash_blend(v, hl.off);
         if (!p.pairs) {
