@@ -391,7 +391,15 @@ SN_DEV float sn_relu(float x) { return __int_as_float(max(__float_as_int(x), 0))
 
 // Exchange halves: afterwards a = [lanes 0-31: own a | lanes 32-63: lower partner's b],
 //                              b = [lanes 0-31: upper partner's a | lanes 32-63: own b].
+// gfx950 hazard found on hardware (r01, tools/determinism_probe.py): v_permlane32_swap must not read a VGPR in the wait states
+// right after a VALU instruction wrote it.  hipcc (ROCm 7.2) places the swap directly behind its producer; when the two issue
+// back to back the swap sees the register's PREVIOUS contents in lanes 48-63 (the last 16-lane pass of the write) -- observed
+// as ~5 of 10 000 tiles per frame with colour off by ~1e-3, different tiles every run, only in the operand built for the
+// upper half-wave.  One wait state removed every failure under an amplified test (idle issue slots forced with s_nop in the
+// other phases: ~300 bad tiles per frame without it, 0 with it); two are used.  The nop is tied to both operands so it sits
+// between their producers and the swap whatever the scheduler does.
 SN_DEV void sn_swap_halves(float& a, float& b) {
+    asm volatile("s_nop 1" : "+v"(a), "+v"(b));
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     a = __uint_as_float(r[0]);
     b = __uint_as_float(r[1]);

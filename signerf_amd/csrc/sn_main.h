@@ -204,18 +204,7 @@ struct SnOpH {  // one B operand (8 k-slots of one 32-sample tile), hi and lo pa
     }
 };
 
-// f16 MFMA with its operand wait states INSIDE the statement.
-// gfx950 hazard found on hardware (r01): a VALU write (v_cvt_pkrtz_f16_f32, v_sub, v_and, or a register-allocator v_mov) of a
-// VGPR that a following v_mfma_f32_32x32x16_f16 reads (4-VGPR A/B operand, or C) must be separated from it by wait states
-// that hipcc (ROCm 7.2) does not insert; otherwise the MFMA occasionally sees the register's PREVIOUS contents in lanes
-// 48-63 (the last 16-lane pass of the write): ~5 of 10 000 tiles per frame with colour off by ~1e-3, different tiles every
-// run.  Waiting after the operand construction in C++ is not enough -- the allocator may still put a copy right before the
-// MFMA -- so the nops sit in the same asm statement as the instruction.  Consequences of hiding the MFMA from the compiler:
-//   * results must not be read by the VALU before SN_MFMA_H_DRAIN2 (>= 12 wait states after an 8-pass XDL op), and must not
-//     be SPILLED in between (the kernels using this path are built spill-free, see sn_render_main_kernel);
-//   * dependent MFMAs on one accumulator are separated by at least one other MFMA (32 cycles) by construction below.
-#define SN_MFMA_H(ACC, A, B) asm volatile("s_nop 7\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
-#define SN_MFMA_H_DRAIN2(X, Y) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(X), "+v"(Y))
+#define SN_MFMA_H(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, ACC, 0, 0, 0)
 
 template <int RT, int KS>
 SN_DEV void sn_mlp_layer_h(const char* __restrict__ wimg, const float* __restrict__ bimg, const SnOpH* op0, const SnOpH* op1,
@@ -257,9 +246,6 @@ SN_DEV void sn_mlp_layer_h(const char* __restrict__ wimg, const float* __restric
             SN_MFMA_H(acc1[rt], ah[rt], bh1);
         }
     }
-    // the compiler does not know these asm statements are MFMAs: drain the matrix pipe before anything reads the results
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) SN_MFMA_H_DRAIN2(acc0[rt], acc1[rt]);
 }
 
 // per-ray direction operands, fp16x2 form: slot (h, e) <-> SH component 8h + e
@@ -341,26 +327,28 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
         sn_acc_to_ops(a0[rt], true, op0[2 * rt], op0[2 * rt + 1]);
         sn_acc_to_ops(a1[rt], true, op1[2 * rt], op1[2 * rt + 1]);
     }
-    // ---- colour layer 2 ----
-    sn_mlp_layer_h<2, 4>(ldsb + SnMainImgH::WC2, tail + SnMainImgH::BC2, op0, op1, a0, a1, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- colour layer 3 on the VALU (fp32, as in the fp32 variant) ----
+    // ---- colour layer 2 (two 32-row passes: halves the live accumulators, same MFMAs) + colour layer 3 on the VALU ----
     const int h = lane >> 5;
     float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int n = 0; n < 3; ++n) {
-        const f32x4* w = (const f32x4*)(tail + SnMainImgH::W3 + (n * 2 + h) * 32);
+    for (int rt = 0; rt < 2; ++rt) {
+        f32x16 c0[1], c1[1];
+        sn_mlp_layer_h<1, 4>(ldsb + SnMainImgH::WC2 + rt * 8192, tail + SnMainImgH::BC2 + rt * 32, op0, op1, c0, c1, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int n = 0; n < 3; ++n) {
+            const f32x4* w = (const f32x4*)(tail + SnMainImgH::W3 + (n * 2 + h) * 32);
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 f32x4 wv = w[rt * 4 + r4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    p0[n] = fmaf(wv[e], sn_relu(a0[rt][r4 * 4 + e]), p0[n]);
-                    p1[n] = fmaf(wv[e], sn_relu(a1[rt][r4 * 4 + e]), p1[n]);
+                    p0[n] = fmaf(wv[e], sn_relu(c0[0][r4 * 4 + e]), p0[n]);
+                    p1[n] = fmaf(wv[e], sn_relu(c1[0][r4 * 4 + e]), p1[n]);
                 }
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
@@ -374,9 +362,9 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
 // ------------------------------------------------------------------------------------------
 // kernel
 // ------------------------------------------------------------------------------------------
-// levels whose gathers are in flight together in the fp16x2 kernels (256-VGPR budget); the fp32 kernels (168 VGPRs) use 4
-#ifndef SN_HASH_GROUP_H
-#define SN_HASH_GROUP_H 8
+// levels whose gathers are in flight together (64 VGPRs of loads at 4) and the occupancy the kernels are compiled for (168 VGPRs)
+#ifndef SN_HASH_GROUP
+#define SN_HASH_GROUP 4
 #endif
 #ifndef SN_MAIN_WAVES_PER_SIMD
 #define SN_MAIN_WAVES_PER_SIMD 3
@@ -421,11 +409,7 @@ SN_DEV int sn_xcd_remap(int b, int n) {
 // only (no MLP: density / colour faked from the features), 3 = VALU only (no table gathers either).  Measured r01:
 // full 7.7 ms, hash-only 2.8-3.0 ms (= the L1 tag-lookup floor), VALU-only 1.4 ms; the 204.8 M fp32 MFMAs alone are 5.6 ms.
 template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int PREC /*0 fp32 MFMA, 1 fp16 hi+lo split MFMA*/, int ABLATE = 0>
-// fp16x2 kernels run at 2 waves per SIMD (256-VGPR budget): their MFMAs are inline asm (SN_MFMA_H), so the kernel MUST NOT
-// spill -- a compiler-placed scratch_store of an accumulator right after a hidden MFMA would read it before the matrix pipe
-// has written it (measured: the 168-VGPR build, which spills, flickers; this one does not).  signerf_amd/build.py enforces
-// "0 spills" for these kernels.  The fp32 kernels use the MFMA builtin (hazards handled by hipcc) and keep 3 waves.
-__global__ __launch_bounds__(256, PREC == 1 ? 2 : SN_MAIN_WAVES_PER_SIMD) void sn_render_main_kernel(SnMainParams p) {
+__global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_kernel(SnMainParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     // both weight images are SnMainImg::TOTAL floats (42 640 B)
@@ -499,7 +483,7 @@ __global__ __launch_bounds__(256, PREC == 1 ? 2 : SN_MAIN_WAVES_PER_SIMD) void s
         } else {
             // plain table: the x-paired layout (sn_device.h) measured no gain here (r01: 4.11 vs 4.18 ms) -- splitting a level
             // into per-t tables loses the x-locality of the plain layout (16 consecutive x share a 128-B line)
-            sn_hash_encode<16, (PREC == 1 ? SN_HASH_GROUP_H : 4)>(rsrc, p.scal, p.log2_t, q, feat);
+            sn_hash_encode<16, SN_HASH_GROUP>(rsrc, p.scal, p.log2_t, q, feat);
         }
         __builtin_amdgcn_sched_barrier(0);
         float h0, rgb[3];
