@@ -145,6 +145,47 @@ SN_DEV f32x2 sn_hash_blend(const f32x2 v[8], const float off[3]) {
     return f0312 * oz + f4756 * nz;
 }
 
+// Fused-kernel variants (same values, fewer instructions; the staged entry points keep the literal forms above so that
+// tests/test_gpu_stages.py can compare table rows and features bit for bit):
+//  * positions are normalised into [0, 1] before they get here, so floor == truncation (v_cvt_i32_f32) and x - floor(x) ==
+//    v_fract_f32(x), both exact;
+//  * the "ceil" corner is taken as floor + 1.  It differs from ceil(x) only when x is an integer, where its blend weight
+//    x - floor(x) is exactly 0, so the blended value is unchanged (table entries are finite) -- and (c + 1) * P == c * P + P
+//    turns the second multiply of each axis into an add;
+//  * the blend is a + w * (b - a) (one packed add + one packed FMA per lerp, no 1 - w): 1-ulp differences from the
+//    reference's a * w + b * (1 - w) association, far inside the 1e-3 budget of the rendered outputs.
+SN_DEV void sn_hash_corners_fast(const float q[3], float scale, uint32_t mask, SnHashLevel& hl) {
+    uint32_t f[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = q[a] * scale;
+        hl.off[a] = __builtin_amdgcn_fractf(x);
+        f[a] = (uint32_t)(int)x;
+    }
+    const uint32_t P1 = (2654435761u & mask) << 3, P2 = (805459861u & mask) << 3, m8 = mask << 3;
+    const uint32_t yf = __umul24(f[1], P1), zf = __umul24(f[2], P2), xf = f[0] << 3;
+    const uint32_t yc = yf + P1, zc = zf + P2, xc = xf + 8u;
+    hl.boff[0] = (xc ^ yc ^ zc) & m8;
+    hl.boff[1] = (xc ^ yf ^ zc) & m8;
+    hl.boff[2] = (xf ^ yf ^ zc) & m8;
+    hl.boff[3] = (xf ^ yc ^ zc) & m8;
+    hl.boff[4] = (xc ^ yc ^ zf) & m8;
+    hl.boff[5] = (xc ^ yf ^ zf) & m8;
+    hl.boff[6] = (xf ^ yf ^ zf) & m8;
+    hl.boff[7] = (xf ^ yc ^ zf) & m8;
+}
+
+SN_DEV f32x2 sn_hash_blend_fast(const f32x2 v[8], const float off[3]) {
+    const float ox = off[0], oy = off[1], oz = off[2];
+    const f32x2 f03 = (v[0] - v[3]) * ox + v[3];
+    const f32x2 f12 = (v[1] - v[2]) * ox + v[2];
+    const f32x2 f56 = (v[5] - v[6]) * ox + v[6];
+    const f32x2 f47 = (v[4] - v[7]) * ox + v[7];
+    const f32x2 f0312 = (f03 - f12) * oy + f12;
+    const f32x2 f4756 = (f47 - f56) * oy + f56;
+    return (f0312 - f4756) * oz + f4756;
+}
+
 // Buffer resource over a hash table (base must be wave-uniform: a kernel argument).
 SN_DEV __amdgpu_buffer_rsrc_t sn_table_rsrc(const float* table, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, (int)bytes, 0x00020000);
@@ -162,19 +203,21 @@ SN_DEV f32x2 sn_table_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, uint3
 // Encode one point over L levels -> feat[2L], level-major.  `scal` must be wave-uniform.
 // GROUP > 0 fences the instruction scheduler every GROUP levels: at most GROUP*8 gathers (GROUP*16 VGPRs) are in flight,
 // which keeps the fused kernels inside their register budget (the scheduler otherwise hoists all L*8 loads).
-template <int L, int GROUP = 0>
+// FAST selects the fused-kernel forms of the corner / blend arithmetic (see sn_hash_corners_fast).
+template <int L, int GROUP = 0, bool FAST = false>
 SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], float* feat) {
     const uint32_t mask = (1u << log2_t) - 1u;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         if (GROUP > 0 && l > 0 && (l % GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
         SnHashLevel hl;
-        sn_hash_corners(q, scal[l], mask, hl);
+        if (FAST) sn_hash_corners_fast(q, scal[l], mask, hl);
+        else sn_hash_corners(q, scal[l], mask, hl);
         const uint32_t lvl = ((uint32_t)l << log2_t) * 8u;
         f32x2 v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = sn_table_load(rsrc, hl.boff[k], lvl);
-        f32x2 e = sn_hash_blend(v, hl.off);
+        f32x2 e = FAST ? sn_hash_blend_fast(v, hl.off) : sn_hash_blend(v, hl.off);
         feat[2 * l] = e.x;
         feat[2 * l + 1] = e.y;
     }

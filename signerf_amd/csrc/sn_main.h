@@ -329,26 +329,39 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
     }
     // ---- colour layer 2 (two 32-row passes: halves the live accumulators, same MFMAs) + colour layer 3 on the VALU ----
     const int h = lane >> 5;
-    float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
+    // packed fp32 FMAs: even / odd rows accumulate in the two halves of a register pair, joined at the end
+    f32x2 q0[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, q1[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         f32x16 c0[1], c1[1];
         sn_mlp_layer_h<1, 4>(ldsb + SnMainImgH::WC2 + rt * 8192, tail + SnMainImgH::BC2 + rt * 32, op0, op1, c0, c1, lane);
         __builtin_amdgcn_sched_barrier(0);
+        f32x2 r0[8], r1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            r0[j] = f32x2{sn_relu(c0[0][2 * j]), sn_relu(c0[0][2 * j + 1])};
+            r1[j] = f32x2{sn_relu(c1[0][2 * j]), sn_relu(c1[0][2 * j + 1])};
+        }
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             const f32x4* w = (const f32x4*)(tail + SnMainImgH::W3 + (n * 2 + h) * 32);
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                f32x4 wv = w[rt * 4 + r4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    p0[n] = fmaf(wv[e], sn_relu(c0[0][r4 * 4 + e]), p0[n]);
-                    p1[n] = fmaf(wv[e], sn_relu(c1[0][r4 * 4 + e]), p1[n]);
-                }
+                const f32x4 wv = w[rt * 4 + r4];
+                const f32x2 wa = {wv.x, wv.y}, wb = {wv.z, wv.w};
+                q0[n] = wa * r0[2 * r4] + q0[n];
+                q1[n] = wa * r1[2 * r4] + q1[n];
+                q0[n] = wb * r0[2 * r4 + 1] + q0[n];
+                q1[n] = wb * r1[2 * r4 + 1] + q1[n];
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    float p0[3], p1[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        p0[n] = q0[n].x + q0[n].y;
+        p1[n] = q1[n].x + q1[n].y;
     }
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
@@ -483,7 +496,7 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
         } else {
             // plain table: the x-paired layout (sn_device.h) measured no gain here (r01: 4.11 vs 4.18 ms) -- splitting a level
             // into per-t tables loses the x-locality of the plain layout (16 consecutive x share a 128-B line)
-            sn_hash_encode<16, SN_HASH_GROUP>(rsrc, p.scal, p.log2_t, q, feat);
+            sn_hash_encode<16, SN_HASH_GROUP, true>(rsrc, p.scal, p.log2_t, q, feat);
         }
         __builtin_amdgcn_sched_barrier(0);
         float h0, rgb[3];
