@@ -317,9 +317,9 @@ WorkspacePlan plan_workspace(int height, int width, const SnRenderOpts& o) {
     w.prop_blocks = 0;
     if (o.num_proposal_iterations > 0) {
         off += align256((size_t)g.tiles_x * g.tiles_y * 64 * (o.num_nerf_samples + 1) * 4);
-        // persistent proposal waves: what the chip holds (256 CUs x 4 workgroups of SN_PROP_WAVES waves), at most one per tile
+        // persistent proposal waves: what the chip holds (256 CUs x SN_PROP_WG_PER_CU workgroups of SN_PROP_WAVES waves), at most one per tile
         const int ntiles = g.tiles_x * g.tiles_y;
-        w.prop_blocks = std::min((ntiles + SN_PROP_WAVES - 1) / SN_PROP_WAVES, 256 * 4);
+        w.prop_blocks = std::min((ntiles + SN_PROP_WAVES - 1) / SN_PROP_WAVES, 256 * SN_PROP_WG_PER_CU);
         w.off_prop_scratch = off;
         off += align256((size_t)w.prop_blocks * SN_PROP_WAVES * SN_PROP_SCRATCH_FLOATS * 4);
     }

@@ -68,6 +68,32 @@ SN_DEV bool sn_sample_q(const float o[3], const float d[3], float start, float e
     return sel;
 }
 
+// Fused-kernel form: the same map with v_rcp_f32 (1 ulp) instead of four IEEE divisions in the contraction.  Positions only
+// feed the fields (float work); the bins themselves (sn_euclid) stay strict.  Saves ~36 VALU instructions per sample.
+SN_DEV bool sn_sample_q_fast(const float o[3], const float d[3], float start, float end, float q[3]) {
+    const float t = (start + end) * 0.5f;
+    float p[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = fmaf(d[c], t, o[c]);
+    const float mag = fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2]));
+    if (!(mag < 1.0f)) {
+        const float r = __builtin_amdgcn_rcpf(mag);
+        const float k = (2.0f - r) * r;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[c] = k * p[c];
+    }
+    bool sel = true;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        q[c] = fmaf(p[c], 0.25f, 0.5f);
+        sel = sel && (q[c] > 0.0f) && (q[c] < 1.0f);
+    }
+    const float m = sel ? 1.0f : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[c] = q[c] * m;
+    return sel;
+}
+
 // Same, from a world position (stage-level field_forward).
 SN_DEV bool sn_position_q(const float pin[3], float q[3]) {
 #pragma clang fp contract(off)
@@ -249,8 +275,10 @@ SN_DEV f32x4 sn_pair_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t entry) {
     return o;
 }
 
-// Same result as sn_hash_encode (bit for bit), from the paired tables.
-template <int L, int GROUP = 0>
+// Same result as sn_hash_encode (bit for bit), from the paired tables.  FAST: the fused-kernel arithmetic of
+// sn_hash_corners_fast / sn_hash_blend_fast -- with "ceil = floor + 1" the pair's second half is always the wanted x + 1
+// corner, so the per-corner selects of the literal form disappear as well.
+template <int L, int GROUP = 0, bool FAST = false>
 SN_DEV void sn_hash_encode_pairs(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, const float* scal, int log2_t, const float q[3],
                                  float* feat) {
     const uint32_t mask = (1u << log2_t) - 1u;
@@ -259,7 +287,15 @@ SN_DEV void sn_hash_encode_pairs(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo&
         if (GROUP > 0 && l > 0 && (l % GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
         uint32_t f[3], c[3];
         float off[3];
-        {
+        if (FAST) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float x = q[a] * scal[l];
+                off[a] = __builtin_amdgcn_fractf(x);
+                f[a] = (uint32_t)(int)x;
+                c[a] = f[a] + 1u;
+            }
+        } else {
 #pragma clang fp contract(off)
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -271,7 +307,8 @@ SN_DEV void sn_hash_encode_pairs(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo&
             }
         }
         const uint32_t P1 = 2654435761u & mask, P2 = 805459861u & mask;  // see sn_hash_corners
-        const uint32_t yf = __umul24(f[1], P1), yc = __umul24(c[1], P1), zf = __umul24(f[2], P2), zc = __umul24(c[2], P2);
+        const uint32_t yf = __umul24(f[1], P1), zf = __umul24(f[2], P2);
+        const uint32_t yc = FAST ? yf + P1 : __umul24(c[1], P1), zc = FAST ? zf + P2 : __umul24(c[2], P2);
         const uint32_t t = (uint32_t)__builtin_ctz(~f[0]);  // trailing ones of xf (xf < 2^31, so ~xf != 0)
         const uint32_t base = pi.base[l] + (t << log2_t);
         // pair k: .xy = floor-x corner, .zw = ceil-x corner of (y?, z?)
@@ -279,7 +316,7 @@ SN_DEV void sn_hash_encode_pairs(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo&
         const f32x4 p_fc = sn_pair_load(prsrc, base + ((f[0] ^ yf ^ zc) & mask));  // corners 2 (ffc), 1 (cfc)
         const f32x4 p_ff = sn_pair_load(prsrc, base + ((f[0] ^ yf ^ zf) & mask));  // corners 6 (fff), 5 (cff)
         const f32x4 p_cf = sn_pair_load(prsrc, base + ((f[0] ^ yc ^ zf) & mask));  // corners 7 (fcf), 4 (ccf)
-        const bool same = c[0] == f[0];  // x on a grid plane: the ceil corner IS the floor corner
+        const bool same = !FAST && c[0] == f[0];  // x on a grid plane: the ceil corner IS the floor corner
         f32x2 v[8];
         v[3] = f32x2{p_cc.x, p_cc.y};
         v[0] = same ? v[3] : f32x2{p_cc.z, p_cc.w};
@@ -289,7 +326,7 @@ SN_DEV void sn_hash_encode_pairs(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo&
         v[5] = same ? v[6] : f32x2{p_ff.z, p_ff.w};
         v[7] = f32x2{p_cf.x, p_cf.y};
         v[4] = same ? v[7] : f32x2{p_cf.z, p_cf.w};
-        const f32x2 e = sn_hash_blend(v, off);
+        const f32x2 e = FAST ? sn_hash_blend_fast(v, off) : sn_hash_blend(v, off);
         feat[2 * l] = e.x;
         feat[2 * l + 1] = e.y;
     }

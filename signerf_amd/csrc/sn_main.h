@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
         const float t1 = MODE == 0 ? sn_euclid(p.sbins ? p.sbins[i + 1] : (float)(i + 1) / (float)S, s_near, s_far)
                                    : eb[(int64_t)(i + 1) * 64];
         float q[3];
-        const bool sel = sn_sample_q(o, d, t0, t1, q);
+        const bool sel = sn_sample_q_fast(o, d, t0, t1, q);
         float feat[32];
         if (ABLATE & 1) {
 #pragma unroll

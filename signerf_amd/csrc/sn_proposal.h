@@ -21,6 +21,9 @@
 
 #define SN_PROP_MAX_SAMPLES 256
 #define SN_PROP_WAVES 4
+#ifndef SN_PROP_WG_PER_CU
+#define SN_PROP_WG_PER_CU 5  // = waves per SIMD the kernel is compiled for (<= 96 VGPRs)
+#endif
 
 // proposal-net MLP pack (floats): W0 [16][10], b0 [16], W1 [16], b1
 #define SN_PROP_W0 0
@@ -33,11 +36,16 @@ struct SnScal5 {
     float v[5];
 };
 
-// pre-activation density of one proposal net at normalised position q
+// pre-activation density of one proposal net at normalised position q.
+// The MLP (10 -> 16 -> 1) stays on the VALU with wave-uniform weights from LDS.  Moving it to the matrix cores (exact fp32
+// v_mfma_f32_32x32x2_f32, weights as per-lane A registers, bias as a k-step: 11 MFMAs + 45 VALU instead of 187 VALU + 48 LDS
+// reads) was built and measured r01: instruction count -29 %, kernel 9 % SLOWER -- on gfx950 a SIMD's matrix pipe and VALU
+// do not run concurrently (tools/probes/overlap_probe.hip: MFMA-only 2.3 ms, FMA-only 1.8 ms, both 3.9 ms, from different
+// waves or interleaved in one), so 11 x 64 MFMA cycles simply replace 187 x 4 VALU cycles.
 SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, const SnScal5& scal, int log2_t, const float* __restrict__ w,
                         const float q[3]) {
     float feat[10];
-    sn_hash_encode_pairs<5>(prsrc, pi, scal.v, log2_t, q, feat);
+    sn_hash_encode_pairs<5, 0, true>(prsrc, pi, scal.v, log2_t, q, feat);
     float out = w[SN_PROP_B1];
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
@@ -172,7 +180,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
         asm volatile("" ::: "memory");
         const float e1 = sn_euclid(sb(i + 1), s_near, s_far);
         float q[3];
-        const bool sel = sn_sample_q(o, d, e0, e1, q);
+        const bool sel = sn_sample_q_fast(o, d, e0, e1, q);
         const float h0 = sn_prop_h0(rsrc, pi, scal, log2_t, wp, q);
         const float density = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
         float wt;
@@ -197,7 +205,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
     median_out = found ? median : mid;
 }
 
-__global__ __launch_bounds__(64 * SN_PROP_WAVES, 4) void sn_proposal_kernel(SnPropParams p) {
+__global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_proposal_kernel(SnPropParams p) {
     __shared__ SnPropLds L;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
