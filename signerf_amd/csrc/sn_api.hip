@@ -478,7 +478,9 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         const std::vector<float>* b1 = find(h, pre + "mlp.layers.1.bias", 1);
         if (!w0 || !b0 || !w1 || !b1) return fail(h, SN_ERR_STATE, "missing or mis-sized MLP parameter under " + pre);
         std::vector<float> pack(SN_PROP_PACK_FLOATS, 0.0f);
-        memcpy(pack.data() + SN_PROP_W0, w0->data(), 160 * 4);
+        // W0 is stored k-major ([k][n]) so that two neighbouring hidden units share a register pair (v_pk_fma_f32)
+        for (int n = 0; n < 16; ++n)
+            for (int k = 0; k < 10; ++k) pack[SN_PROP_W0 + k * 16 + n] = (*w0)[n * 10 + k];
         memcpy(pack.data() + SN_PROP_B0, b0->data(), 16 * 4);
         memcpy(pack.data() + SN_PROP_W1, w1->data(), 16 * 4);
         pack[SN_PROP_B1] = (*b1)[0];

@@ -376,6 +376,9 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
 // kernel
 // ------------------------------------------------------------------------------------------
 // levels whose gathers are in flight together (64 VGPRs of loads at 4) and the occupancy the kernels are compiled for (168 VGPRs)
+#ifndef SN_FAST_HASH
+#define SN_FAST_HASH true  // fused kernels use the reduced-instruction hash arithmetic (sn_hash_corners_fast)
+#endif
 #ifndef SN_HASH_GROUP
 #define SN_HASH_GROUP 4
 #endif
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
         } else {
             // plain table: the x-paired layout (sn_device.h) measured no gain here (r01: 4.11 vs 4.18 ms) -- splitting a level
             // into per-t tables loses the x-locality of the plain layout (16 consecutive x share a 128-B line)
-            sn_hash_encode<16, SN_HASH_GROUP, true>(rsrc, p.scal, p.log2_t, q, feat);
+            sn_hash_encode<16, SN_HASH_GROUP, SN_FAST_HASH>(rsrc, p.scal, p.log2_t, q, feat);
         }
         __builtin_amdgcn_sched_barrier(0);
         float h0, rgb[3];

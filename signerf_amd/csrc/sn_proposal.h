@@ -25,7 +25,7 @@
 #define SN_PROP_WG_PER_CU 5  // = waves per SIMD the kernel is compiled for (<= 96 VGPRs)
 #endif
 
-// proposal-net MLP pack (floats): W0 [16][10], b0 [16], W1 [16], b1
+// proposal-net MLP pack (floats): W0 [k=10][n=16] (k-major), b0 [16], W1 [16], b1
 #define SN_PROP_W0 0
 #define SN_PROP_B0 160
 #define SN_PROP_W1 176
@@ -46,14 +46,24 @@ SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, cons
                         const float q[3]) {
     float feat[10];
     sn_hash_encode_pairs<5, 0, true>(prsrc, pi, scal.v, log2_t, q, feat);
-    float out = w[SN_PROP_B1];
+    // hidden units in pairs: one v_pk_fma_f32 per (pair, k); every unit still sums bias, k = 0..9 in order with fused multiply-adds
+    const f32x2* w2 = (const f32x2*)w;
+    f32x2 a[8];
 #pragma unroll
-    for (int n = 0; n < 16; ++n) {
-        float a = w[SN_PROP_B0 + n];
+    for (int j = 0; j < 8; ++j) a[j] = w2[SN_PROP_B0 / 2 + j];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) a = fmaf(w[SN_PROP_W0 + n * 10 + k], feat[k], a);
-        out = fmaf(w[SN_PROP_W1 + n], sn_relu(a), out);
+    for (int k = 0; k < 10; ++k) {
+        const f32x2 fk = {feat[k], feat[k]};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = __builtin_elementwise_fma(w2[(SN_PROP_W0 + k * 16) / 2 + j], fk, a[j]);
     }
+    f32x2 o2 = {w[SN_PROP_B1], 0.0f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const f32x2 r = {sn_relu(a[j].x), sn_relu(a[j].y)};
+        o2 = __builtin_elementwise_fma(w2[SN_PROP_W1 / 2 + j], r, o2);
+    }
+    float out = o2.x + o2.y;
     // v_max-based ReLU launders NaN; the reference's field is NaN all the way for a NaN position
     if ((q[0] != q[0]) | (q[1] != q[1]) | (q[2] != q[2])) out = __builtin_nanf("");
     return out;

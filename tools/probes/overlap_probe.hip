@@ -33,22 +33,21 @@ __device__ float mfma_loop(int n, float seed) {
     return a0[0] + a1[1] + a2[2] + a3[3];
 }
 
+// 16 independent full-rate integer chains (v_xad_u32: not packable, 4 cycles per wave64 instruction): issue-bound VALU work
 __device__ float valu_loop(int n, float seed) {
-    float x0 = seed, x1 = seed + 1, x2 = seed + 2, x3 = seed + 3, x4 = seed + 4, x5 = seed + 5, x6 = seed + 6, x7 = seed + 7;
+    unsigned x[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) x[u] = (unsigned)seed * 977u + u;
     for (int i = 0; i < n; ++i) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            x0 = fmaf(x0, 1.0001f, 0.5f);
-            x1 = fmaf(x1, 1.0001f, 0.5f);
-            x2 = fmaf(x2, 1.0001f, 0.5f);
-            x3 = fmaf(x3, 1.0001f, 0.5f);
-            x4 = fmaf(x4, 1.0001f, 0.5f);
-            x5 = fmaf(x5, 1.0001f, 0.5f);
-            x6 = fmaf(x6, 1.0001f, 0.5f);
-            x7 = fmaf(x7, 1.0001f, 0.5f);
-        }
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = (x[u] ^ 0x9e3779b9u) + (x[(u + 1) & 15] | 1u);
     }
-    return x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+    unsigned t = 0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t ^= x[u];
+    return (float)t;
 }
 
 __device__ float gather_loop(const float* table, unsigned table_bytes, int n, unsigned wave) {
@@ -114,8 +113,8 @@ __global__ __launch_bounds__(256) void same_wave(int n, float* out) {
         ha[e] = (_Float16)seed;
         hb[e] = (_Float16)(seed * 0.5f);
     }
-    float x[8];
-    for (int u = 0; u < 8; ++u) x[u] = seed + u;
+    unsigned x[8];
+    for (int u = 0; u < 8; ++u) x[u] = (unsigned)threadIdx.x * 977u + u;
     for (int i = 0; i < n; ++i) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -126,12 +125,12 @@ __global__ __launch_bounds__(256) void same_wave(int n, float* out) {
             }
             if (DO_VALU) {
 #pragma unroll
-                for (int v = 0; v < NV / 4; ++v) x[v & 7] = fmaf(x[v & 7], 1.0001f, 0.5f);
+                for (int v = 0; v < NV / 4; ++v) x[v & 7] = (x[v & 7] ^ 0x9e3779b9u) + (x[(v + 1) & 7] | 1u);
             }
         }
     }
     float r = a0[0] + a1[1] + a2[2] + a3[3];
-    for (int u = 0; u < 8; ++u) r += x[u];
+    for (int u = 0; u < 8; ++u) r += (float)x[u];
     if (r == 123.456f) out[0] = r + pad[0];
 }
 
@@ -165,7 +164,7 @@ int main() {
     hipFuncSetAttribute((const void*)probe<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void*)probe<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void*)probe<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    // 4 MFMAs per iteration: f32 32x32x2 = 64 cycles each, f16 32x32x16 = 32 cycles each; VALU loop = 32 FMAs (128 cycles) per iteration
+    // 4 MFMAs per iteration: f32 32x32x2 = 64 cycles each, f16 32x32x16 = 32 cycles each; VALU loop = 32 integer ops per iteration
     run<0, 0>("f32 32x32x2 MFMA | VALU fma", 20000, 40000, table, table_bytes, out);
     run<1, 0>("f16 32x32x16 MFMA | VALU fma", 40000, 40000, table, table_bytes, out);
     run<0, 1>("f32 32x32x2 MFMA | 64-lane gathers", 20000, 20000, table, table_bytes, out);
