@@ -382,6 +382,13 @@ SN_DEV void sn_direction_encoding(const float d[3], int remap, float* c) {
 
 // ------------------------------------------------------------------------------------------
 // per-ray compositing state (A10 + A17), one ray per lane, samples visited front to back
+// exp for the fused kernels: v_exp_f32(x * log2 e), ~2 ulp plus |x| * 2^-24 relative (the libm form costs ~11 instructions;
+// a fused main-kernel sample evaluates 6 of them).  The staged entry points keep expf.
+template <bool FAST>
+SN_DEV float sn_exp(float x) {
+    return FAST ? __builtin_amdgcn_exp2f(x * 1.44269504088896341f) : expf(x);
+}
+
 // ------------------------------------------------------------------------------------------
 struct SnComposite {
     double cum_tau;   // cumsum(delta*density) -- torch-CPU cumsum accumulates fp32 data in fp64
@@ -405,14 +412,15 @@ struct SnComposite {
     }
 
     // One sample.  Returns the weight.
+    template <bool FAST = false>
     SN_DEV float step(int i, float start, float end, float density, float r, float g, float b) {
         float w, mid;
         {
 #pragma clang fp contract(off)
             float delta = end - start;
             float tau = delta * density;
-            float alpha = 1.0f - expf(-tau);
-            float trans = expf(-(float)cum_tau);
+            float alpha = 1.0f - sn_exp<FAST>(-tau);
+            float trans = sn_exp<FAST>(-(float)cum_tau);
             w = alpha * trans;
             if (w != w) w = 0.0f;  // nan_to_num
             cum_tau += (double)tau;

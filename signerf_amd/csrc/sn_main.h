@@ -154,7 +154,7 @@ SN_DEV void sn_main_field_f32(const float* __restrict__ lds, float* feat, const 
         float a = p0[n], b = p1[n];
         sn_swap_halves(a, b);  // lower: own tile-0 partial + upper's tile-0 partial; upper: tile 1
         float x = a + b + lds[SnMainImg::B3 + n];
-        rgb[n] = __builtin_amdgcn_rcpf(1.0f + expf(-x));  // v_rcp_f32 (1 ulp) instead of an IEEE divide: colours are fp work
+        rgb[n] = __builtin_amdgcn_rcpf(1.0f + sn_exp<true>(-x));  // v_exp_f32 / v_rcp_f32 (~1 ulp each) instead of libm exp and an IEEE divide
     }
 }
 
@@ -368,7 +368,7 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
         float a = p0[n], b = p1[n];
         sn_swap_halves(a, b);
         float x = a + b + tail[SnMainImgH::B3 + n];
-        rgb[n] = __builtin_amdgcn_rcpf(1.0f + expf(-x));  // v_rcp_f32 (1 ulp) instead of an IEEE divide: colours are fp work
+        rgb[n] = __builtin_amdgcn_rcpf(1.0f + sn_exp<true>(-x));  // v_exp_f32 / v_rcp_f32 (~1 ulp each) instead of libm exp and an IEEE divide
     }
 }
 
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
             sn_main_field_h((const char*)lds, feat, shh, lane, h0, rgb);
         }
         __builtin_amdgcn_sched_barrier(0);
-        float density = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
+        float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
         r = rgb[0];
         g = rgb[1];
         b = rgb[2];
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
             density = __builtin_nanf("");
             r = g = b = density;
         }
-        comp.step(i, t0, t1, density, r, g, b);
+        comp.step<true>(i, t0, t1, density, r, g, b);
         {
 #pragma clang fp contract(off)
             last_mid = (t0 + t1) / 2.0f;

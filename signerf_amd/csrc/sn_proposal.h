@@ -192,12 +192,12 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
         float q[3];
         const bool sel = sn_sample_q_fast(o, d, e0, e1, q);
         const float h0 = sn_prop_h0(rsrc, pi, scal, log2_t, wp, q);
-        const float density = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
+        const float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
         float wt;
         {
 #pragma clang fp contract(off)
             const float tau = (e1 - e0) * density;
-            wt = (1.0f - expf(-tau)) * expf(-(float)cum_tau);
+            wt = (1.0f - sn_exp<true>(-tau)) * sn_exp<true>(-(float)cum_tau);
             if (wt != wt) wt = 0.0f;
             cum_tau += (double)tau;
             mid = (e0 + e1) / 2.0f;
