@@ -177,6 +177,16 @@ int sn_aabb_mask_condition(const float* origins, const float* directions, const 
  * low 8 bits; NaN -> 0).  in: [n] fp32 device, out: [n] uint8 device. */
 int sn_tensor_to_uint8(const float* in, int64_t n, uint8_t* out, SnStream stream);
 
+/* ---- SURVEY §8(f) row 1, second half: the reference-sheet composition ------------------------------------------
+ * torch.nn.functional.interpolate(mode="bilinear", align_corners=False) from a [src_h, src_w, C] window to a [dst_h, dst_w, C]
+ * window of channel-last device images; windows are given by their first element and their ROW STRIDE in elements, so the same
+ * call does "downscale a view and paste it into its cell of the sheet" (signerf/datasetgenerator/datasetgenerator.py:526-539,
+ * 634-647) and "cut the edited cell out of the sheet and upscale it" (:577-586, 659).  src_u8 != 0: the source holds uint8
+ * 0/1 (the mask of sn_aabb_mask_condition; the reference's mask.float()).  threshold != 0: store (value > 0.5) as 1.0/0.0
+ * (mask_scaled, :527).  dst is fp32. */
+int sn_resize_bilinear(const void* src, int32_t src_u8, int32_t src_h, int32_t src_w, int64_t src_row_stride, int32_t channels,
+                       float* dst, int32_t dst_h, int32_t dst_w, int64_t dst_row_stride, int32_t threshold, SnStream stream);
+
 #ifdef __cplusplus
 }
 #endif

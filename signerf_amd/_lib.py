@@ -92,6 +92,8 @@ SIGNATURES = {
     "sn_composite": (C.c_int, [_FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
     "sn_pdf_sample": (C.c_int, [_FP, _FP, C.c_int64, C.c_int32, C.c_int32, _FP, C.c_float, _FP, _FP, C.c_void_p]),
     "sn_tensor_to_uint8": (C.c_int, [_FP, C.c_int64, _FP, C.c_void_p]),
+    "sn_resize_bilinear": (C.c_int, [_FP, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _FP, C.c_int32, C.c_int32, C.c_int64,
+                                      C.c_int32, C.c_void_p]),
     "sn_mask_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "sn_aabb_mask_condition": (C.c_int, [_FP, _FP, _FP, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(SnMaskOpts), _FP, _FP,
                                          C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -895,4 +895,28 @@ int sn_tensor_to_uint8(const float* in, int64_t n, uint8_t* out, SnStream stream
     return SN_OK;
 }
 
+int sn_resize_bilinear(const void* src, int32_t src_u8, int32_t src_h, int32_t src_w, int64_t src_row_stride, int32_t channels, float* dst,
+                       int32_t dst_h, int32_t dst_w, int64_t dst_row_stride, int32_t threshold, SnStream stream) {
+    if (!src || !dst || src_h < 1 || src_w < 1 || dst_h < 1 || dst_w < 1 || channels < 1 ||
+        src_row_stride < (int64_t)src_w * channels || dst_row_stride < (int64_t)dst_w * channels)
+        return fail(nullptr, SN_ERR_INVALID, "sn_resize_bilinear: bad argument");
+    SnResizeParams p;
+    p.src = src;
+    p.dst = dst;
+    p.src_u8 = src_u8 != 0;
+    p.src_h = src_h;
+    p.src_w = src_w;
+    p.dst_h = dst_h;
+    p.dst_w = dst_w;
+    p.channels = channels;
+    p.src_row_stride = src_row_stride;
+    p.dst_row_stride = dst_row_stride;
+    p.threshold = threshold != 0;
+    const int64_t n = (int64_t)dst_h * dst_w * channels;
+    hipLaunchKernelGGL(sn_resize_bilinear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_resize_bilinear launch: ") + hipGetErrorString(e));
+    return SN_OK;
+}
+
 }  // extern "C"

@@ -150,3 +150,53 @@ __global__ void sn_tensor_to_uint8_kernel(const float* __restrict__ in, int64_t 
     else iv = (int)v;
     out[i] = (uint8_t)(iv & 0xff);
 }
+
+// ------------------------------------------------------------------------------------------
+// F.interpolate(mode="bilinear", align_corners=False) between [h, w, C] windows of channel-last images (SURVEY §8(f) row 1:
+// the 1/2 downscale + paste into the reference sheet, datasetgenerator.py:526-539, and the upscale of the edited cell, :586).
+// PyTorch's arithmetic (ATen UpSample.h, area_pixel_compute_source_index + guard_index_and_lambda), fp32:
+//   scale = in / out;  src = max(fma(scale, dst + 0.5, -0.5), 0);  i0 = min(int(src), in - 1);  i1 = min(i0 + 1, in - 1);
+//   l1 = clamp(src - i0, 0, 1);  l0 = 1 - l1;   out = h0 * (w0 * p00 + w1 * p01) + h1 * (w0 * p10 + w1 * p11)
+// ------------------------------------------------------------------------------------------
+struct SnResizeParams {
+    const void* src;
+    float* dst;
+    int src_u8;  // source elements are uint8 (the 0/1 mask) instead of fp32
+    int src_h, src_w, dst_h, dst_w, channels;
+    int64_t src_row_stride, dst_row_stride;  // in elements
+    int threshold;                           // write (value > 0.5) as 1.0 / 0.0 (mask_scaled, :527)
+};
+
+SN_DEV void sn_resize_axis(int dst_index, int in_size, int out_size, int& i0, int& i1, float& l0, float& l1) {
+#pragma clang fp contract(off)
+    const float scale = (float)in_size / (float)out_size;
+    float src = fmaf(scale, (float)dst_index + 0.5f, -0.5f);  // one rounding, as the compiled ATen kernels (x86 FMA / nvcc fmad) do
+    if (src < 0.0f) src = 0.0f;
+    i0 = min((int)src, in_size - 1);
+    i1 = min(i0 + 1, in_size - 1);
+    l1 = fminf(fmaxf(src - (float)i0, 0.0f), 1.0f);
+    l0 = 1.0f - l1;
+}
+
+__global__ void sn_resize_bilinear_kernel(SnResizeParams p) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)p.dst_h * p.dst_w * p.channels;
+    if (i >= n) return;
+    const int c = (int)(i % p.channels);
+    const int x = (int)((i / p.channels) % p.dst_w);
+    const int y = (int)(i / ((int64_t)p.channels * p.dst_w));
+    int y0, y1, x0, x1;
+    float h0, h1, w0, w1;
+    sn_resize_axis(y, p.src_h, p.dst_h, y0, y1, h0, h1);
+    sn_resize_axis(x, p.src_w, p.dst_w, x0, x1, w0, w1);
+    auto at = [&](int yy, int xx) -> float {
+        const int64_t o = (int64_t)yy * p.src_row_stride + (int64_t)xx * p.channels + c;
+        return p.src_u8 ? (float)((const uint8_t*)p.src)[o] : ((const float*)p.src)[o];
+    };
+    const float top = w0 * at(y0, x0) + w1 * at(y0, x1);
+    const float bot = w0 * at(y1, x0) + w1 * at(y1, x1);
+    float v = h0 * top + h1 * bot;
+    if (p.threshold) v = v > 0.5f ? 1.0f : 0.0f;
+    p.dst[(int64_t)y * p.dst_row_stride + (int64_t)x * p.channels + c] = v;
+}

@@ -84,3 +84,32 @@ def pdf_sample(spacing_bins: Tensor, weights: Tensor, num_samples: int, histogra
         _lib.check(lib.sn_pdf_sample(_lib.ptr(sb), _lib.ptr(w), R, N, num_samples, _lib.ptr(u), C.c_float(histogram_padding),
                                      _lib.ptr(bins), _lib.ptr(inds), _lib.current_stream()), None, "sn_pdf_sample")
     return bins, inds
+
+
+def resize_bilinear(src: Tensor, out_h: int, out_w: int, threshold: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    """``F.interpolate(src.permute(2,0,1)[None], (out_h, out_w), mode="bilinear", align_corners=False)`` back in [H,W,C] form
+    (the reference's down/up-scale idiom, /root/reference/signerf/datasetgenerator/datasetgenerator.py:526-528,586,640-642,659).
+
+    src: [H,W,C] fp32, or uint8/bool (the 0/1 mask: the reference's ``mask.float()``); may be a window of a larger image
+    (``sheet[r0:r1, c0:c1, :]``).  threshold: return ``(value > 0.5)`` as 1.0/0.0 (``mask_scaled``).  out: optional
+    [out_h,out_w,C] fp32 destination, may itself be a window of a sheet -- the resize then IS the paste (:537-539)."""
+    lib = _lib.load()
+    if src.dtype == torch.bool:
+        src = src.view(torch.uint8) if src.is_contiguous() else src.to(torch.uint8)
+    if src.dtype not in (torch.float32, torch.uint8):
+        src = src.to(torch.float32)
+    H, W, Cn = src.shape
+    if src.stride(2) != 1 or src.stride(1) != Cn:
+        src = src.contiguous()
+    dev = src.device
+    if out is None:
+        with torch.cuda.device(dev):
+            out = torch.empty((out_h, out_w, Cn), dtype=torch.float32, device=dev)
+    if tuple(out.shape) != (out_h, out_w, Cn) or out.dtype != torch.float32 or out.stride(2) != 1 or out.stride(1) != Cn:
+        raise _lib.SignerfHipError("resize_bilinear: `out` must be a channel-last fp32 [out_h, out_w, C] window")
+    if not out.is_cuda or not src.is_cuda:
+        raise _lib.SignerfHipError("resize_bilinear: tensors must live on the GPU (there is no CPU path)")
+    with torch.cuda.device(dev):
+        _lib.check(lib.sn_resize_bilinear(src.data_ptr(), int(src.dtype == torch.uint8), H, W, src.stride(0), Cn, out.data_ptr(), out_h, out_w,
+                                          out.stride(0), int(bool(threshold)), _lib.current_stream()), None, "sn_resize_bilinear")
+    return out

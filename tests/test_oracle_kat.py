@@ -7,6 +7,7 @@ import torch
 
 from helpers import oracle_config, small_config
 from oracle import nerfacto as onf
+from oracle import signerf_utils as su
 from signerf_amd import scene
 
 
@@ -186,3 +187,22 @@ def test_dilate_single_pixel_reproduces_the_flipped_element():
     src2 = np.zeros((6, 6))
     src2[0, 0] = 1
     assert (su.dilate(src2, su.ellipse_element(3, 3)) > 0).sum() == 3
+
+
+def test_sheet_geometry_and_downscale_known_answers():
+    """datasetgenerator.py:497-502, 521-534: cell windows and the pad to a multiple of 8; a factor-2 bilinear downscale with
+    align_corners=False is the mean of each 2x2 block."""
+    from signerf_amd.datasetgenerator import DatasetGeneratorConfig, cell_window, sheet_geometry
+
+    cfg = DatasetGeneratorConfig(rows=2, cols=3, border_width_between_images=0)
+    assert sheet_geometry(cfg, 400, 400) == (800, 1200)
+    assert cell_window(cfg, 4, 400, 400) == (400, 800, 400, 800)
+    cfg = DatasetGeneratorConfig(rows=2, cols=3, border_width_between_images=5)
+    assert sheet_geometry(cfg, 401, 300) == (608, 1216)  # 605 -> 608, 1213 -> 1216
+    assert cell_window(cfg, 5, 401, 300) == (305, 605, 812, 1213)
+    t = torch.arange(4 * 6 * 1, dtype=torch.float32).reshape(4, 6, 1)
+    d = su.interpolate_hwc(t, 2, 3)
+    assert torch.equal(d[..., 0], torch.tensor([[3.5, 5.5, 7.5], [15.5, 17.5, 19.5]]))
+    img, msk, cnd = su.compose_reference_sheet([(torch.zeros(4, 4, 3), torch.ones(4, 4, 1, dtype=torch.bool), torch.full((4, 4, 1), 0.5))], 1, 2, 2, 2, 1)
+    assert img.shape == (8, 8, 3) and float(img[:2, :2].max()) == 0.0 and float(img[2:].min()) == 1.0
+    assert float(msk[:2, :2].min()) == 1.0 and float(msk.sum()) == 4.0 and float(cnd[:2, :2].min()) == 0.5
