@@ -187,7 +187,10 @@ def main():
                          "kernel": ("sn_render_main_kernel<0,%d>" % (0 if args.precision == "fp32" else 1)) if args.workload == "sheet64"
                          else "sn_proposal_kernel + sn_render_main_kernel<1,*> (whole render call)",
                          "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": W * H * bytes_per_ray},
+                         "algorithmic_bytes_per_launch": W * H * bytes_per_ray,
+                         "note": "frac > 1 means the algorithmic bytes never reach HBM: the hash table is served by L1/L2/Infinity "
+                                 "Cache (`traffic` = measured fabric bytes per launch); the kernel is bound by the L1 gather rate and "
+                                 "by SIMD issue (VALU + MFMA serialise on gfx950), see DESIGN.md K1"},
         }
         if not args.no_alt_precision:
             other = "fp32" if args.precision == "fp16x2" else "fp16x2"
