@@ -169,3 +169,42 @@ def test_state_dict_boundary(gpu):
     assert not torch.equal(a, c)
     groups = model.get_param_groups()
     assert set(groups) == {"proposal_networks", "fields"} and model.get_training_callbacks(None) == []
+
+
+def test_concurrent_renders_share_one_model(gpu):
+    """The reference renders from two host threads (GUI callback + viewer, interface.py:83-116, viewer.py:334-336).  Two
+    threads on two streams, one model / one library handle: scratch is per call, so every frame equals its sequential render."""
+    import threading
+
+    cfg = small_config(num_proposal_samples_per_ray=(48, 24), num_nerf_samples_per_ray=16)
+    model, _ = make_model(cfg, gpu)
+    c2w = scene.benchmark_cameras(8)
+    cams = Cameras(c2w[:, :3], 70.0, 70.0, 32.0, 24.0, 64, 48).to(gpu)
+    bundles = [cams[i].generate_rays(0) for i in range(4)]
+    expect = [{k: v.clone() for k, v in model.get_outputs_for_camera_ray_bundle(b).items()} for b in bundles]
+    torch.cuda.synchronize()
+    results, errors = {}, []
+
+    def worker(tid):
+        try:
+            stream = torch.cuda.Stream(device=gpu)
+            with torch.cuda.stream(stream):
+                for rep in range(6):
+                    for i in (range(4) if tid == 0 else reversed(range(4))):
+                        out = model.get_outputs_for_camera_ray_bundle(bundles[i])
+                        results[(tid, rep, i)] = {k: v.clone() for k, v in out.items()}
+            stream.synchronize()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    assert len(results) == 2 * 6 * 4
+    for (tid, rep, i), out in results.items():
+        for k in ("rgb", "depth", "accumulation"):
+            assert torch.equal(out[k], expect[i][k]), (tid, rep, i, k)
