@@ -101,3 +101,54 @@ def render_reference_sheet(model, cameras, group=None) -> Tensor:
         return out["rgb"], out["depth"]
 
     return render_cameras_sharded(render_fn, len(cameras), group)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Fallback of SURVEY §8(e): fewer cameras than GPUs, or one big frame -- contiguous row blocks of ONE image per rank.
+# ----------------------------------------------------------------------------------------------------------------------
+def row_blocks(height: int, world_size: int, align: int = 8) -> List[Tuple[int, int]]:
+    """[row0, row1) per rank: contiguous blocks whose sizes are multiples of `align` rows (the kernels' 8x8 pixel tiles) except
+    the last non-empty one, as equal as that allows; trailing ranks may get an empty block."""
+    units = (height + align - 1) // align
+    per, extra = divmod(units, world_size)
+    out, r = [], 0
+    for k in range(world_size):
+        n = (per + (1 if k < extra else 0)) * align
+        r1 = min(height, r + n)
+        out.append((r, r1))
+        r = r1
+    return out
+
+
+def gather_rows(local_rows: Tensor, blocks: Sequence[Tuple[int, int]], group=None) -> Tensor:
+    """All-gather row blocks of one image back into [H, W, C] on every rank (blocks padded to the tallest for the collective)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_rows
+    world = dist.get_world_size(group)
+    tallest = max(r1 - r0 for r0, r1 in blocks)
+    W, Cn = local_rows.shape[1], local_rows.shape[2]
+    pad = tallest - local_rows.shape[0]
+    if pad > 0:
+        local_rows = torch.cat([local_rows, local_rows.new_zeros((pad, W, Cn))], dim=0)
+    local_rows = local_rows.contiguous()
+    gathered = local_rows.new_empty((world * tallest, W, Cn))
+    dist.all_gather_into_tensor(gathered, local_rows, group=group)
+    return torch.cat([gathered[k * tallest : k * tallest + (r1 - r0)] for k, (r0, r1) in enumerate(blocks)], dim=0)
+
+
+def render_camera_row_sharded(model, camera, group=None) -> Tensor:
+    """One camera split into contiguous row blocks over the ranks (weights replicated), tiles all-gathered:
+    -> [H, W, 4] (rgb ++ median depth) on every rank, identical to a single-rank render -- rays are independent (§8(e));
+    the only per-chunk quantity of the path, the clip range of `expected_depth`, is not part of this tile."""
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    bundle = camera.generate_rays(camera_indices=0, aabb_box=model.render_aabb)  # ray generation is ~20 us for a full frame
+    H = bundle.origins.shape[0]
+    blocks = row_blocks(H, world)
+    r0, r1 = blocks[rank]
+    if r1 > r0:
+        out = model.get_outputs_for_camera_ray_bundle(bundle._map(lambda t: t[r0:r1].contiguous()))
+        local = torch.cat([out["rgb"], out["depth"]], dim=-1)
+    else:
+        local = bundle.origins.new_zeros((0, bundle.origins.shape[1], 4))
+    return gather_rows(local, blocks, group)

@@ -208,3 +208,25 @@ def test_concurrent_renders_share_one_model(gpu):
     for (tid, rep, i), out in results.items():
         for k in ("rgb", "depth", "accumulation"):
             assert torch.equal(out[k], expect[i][k]), (tid, rep, i, k)
+
+
+def test_row_blocks_render_equals_full_frame(gpu):
+    """SURVEY §8(e) fallback: a frame rendered as contiguous row blocks (what each rank does in render_camera_row_sharded) is
+    bit-identical to the full-frame render -- rgb, median depth, accumulation (rays are independent)."""
+    from signerf_amd import sheet
+
+    cfg = small_config(num_proposal_samples_per_ray=(48, 24), num_nerf_samples_per_ray=16)
+    model, _ = make_model(cfg, gpu)
+    c2w = scene.benchmark_cameras(8)
+    cam = Cameras(c2w[:, :3], 90.0, 90.0, 40.0, 30.0, 80, 60).to(gpu)[2]
+    full = sheet.render_camera_row_sharded(model, cam)  # single process: the plain render
+    b = cam.generate_rays(0)
+    ref = model.get_outputs_for_camera_ray_bundle(b)
+    assert torch.equal(full, torch.cat([ref["rgb"], ref["depth"]], dim=-1))
+    for world in (2, 3, 8):
+        parts = []
+        for r0, r1 in sheet.row_blocks(60, world):
+            if r1 > r0:
+                o = model.get_outputs_for_camera_ray_bundle(b._map(lambda t: t[r0:r1].contiguous()))
+                parts.append(torch.cat([o["rgb"], o["depth"]], dim=-1))
+        assert torch.equal(torch.cat(parts, dim=0), full), world
