@@ -230,3 +230,18 @@ def test_row_blocks_render_equals_full_frame(gpu):
                 o = model.get_outputs_for_camera_ray_bundle(b._map(lambda t: t[r0:r1].contiguous()))
                 parts.append(torch.cat([o["rgb"], o["depth"]], dim=-1))
         assert torch.equal(torch.cat(parts, dim=0), full), world
+
+
+@pytest.mark.parametrize("props", [0, 2])
+@pytest.mark.parametrize("W,H", [(1, 1), (1, 9), (9, 1), (70, 3), (9, 9), (64, 1)])
+def test_extreme_image_shapes(gpu, props, W, H):
+    """Frames smaller than / not a multiple of the 8x8 pixel tile, single rows and columns, a single ray."""
+    cfg = small_config(num_proposal_iterations=props, num_proposal_samples_per_ray=(24, 12) if props else (), num_nerf_samples_per_ray=8)
+    model, sd = make_model(cfg, gpu)
+    cam = Cameras(scene.benchmark_cameras(8)[:, :3], 30.0, 30.0, W / 2, H / 2, W, H).to(gpu)[1]
+    b = cam.generate_rays(0)
+    out = model.get_outputs_for_camera_ray_bundle(b)
+    ref = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg), b.origins.cpu(), b.directions.cpu())
+    assert out["rgb"].shape == (H, W, 3) and out["depth"].shape == (H, W, 1)
+    for k in ("rgb", "depth", "accumulation"):
+        assert rmse(out[k], ref[k]) <= RMSE_TOL, k
