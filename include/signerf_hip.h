@@ -54,7 +54,13 @@ typedef struct SnHashMlpDesc {
     int32_t hidden_dim;         /* 64 for the main field, 16 for proposal nets */
     int32_t num_layers;         /* must be 2 (one hidden layer) */
     int32_t out_dim;            /* 16 (1 + geo_feat_dim) main, 1 proposal */
-    float scalings[SN_MAX_LEVELS]; /* floor(base_res * growth**l), computed by the host exactly as HashEncoding does */
+    float scalings[SN_MAX_LEVELS]; /* grid_mode 0: floor(base_res * growth**l), computed by the host exactly as HashEncoding does;
+                                    * grid_mode 1: exp2f(l * log2f(growth)) * base_res - 1 (fp32), tiny-cuda-nn's grid_scale */
+    int32_t grid_mode;          /* 0 = nerfstudio's torch HashEncoding (every level hashed, ceil/floor corners);
+                                 * 1 = tiny-cuda-nn HashGrid semantics for `implementation="tcnn"` checkpoints (SURVEY §8(f) row 2;
+                                 *     x = fmaf(scale, q, 0.5), corners floor / floor + 1, dense indexing of the levels whose grid
+                                 *     fits 2^log2_hashmap_size rows).  The table is [L << log2_hashmap_size, F] in both modes; a
+                                 *     dense level's rows sit at the start of its slot (signerf_amd/tcnn_import.py).  UNPINNED. */
 } SnHashMlpDesc;
 
 /* Architecture of the nerfacto field + proposal nets (A0). */

@@ -53,6 +53,9 @@ class HashMLPConfig:
     hidden_dim: int = 64
     num_layers: int = 2
     out_dim: int = 16
+    grid: str = "torch"
+    """"torch": nerfstudio's HashEncoding fallback (A7, the parity target).  "tcnn": tiny-cuda-nn's grid (oracle/tcnn_layout.py,
+    UNPINNED); the parameters are then read from ``<prefix>.encoder.tcnn_grid`` ([rows, F], levels back to back)."""
 
 
 @dataclass
@@ -301,8 +304,14 @@ def mlp_forward(x: Tensor, params: Dict[str, Tensor], prefix: str, num_layers: i
 def density_field(params: Dict[str, Tensor], prefix: str, hcfg: HashMLPConfig, positions: Tensor, average_init_density: float):
     """positions [R,N,3] (world) -> density [R,N,1], mlp_out [R,N,out_dim], q, selector  (A6-A9)."""
     q, selector = normalized_positions(positions)
-    scalings = hash_scalings(hcfg.num_levels, hcfg.base_res, hcfg.max_res)
-    enc = hash_encode(q.view(-1, 3), params[f"{prefix}.encoder.hash_table"], scalings, hcfg.log2_hashmap_size)
+    if hcfg.grid == "tcnn":
+        from . import tcnn_layout
+
+        meta = tcnn_layout.grid_meta(hcfg.num_levels, hcfg.base_res, hcfg.max_res, hcfg.log2_hashmap_size, hcfg.features_per_level)
+        enc = tcnn_layout.grid_encode(q.view(-1, 3), params[f"{prefix}.encoder.tcnn_grid"], meta)
+    else:
+        scalings = hash_scalings(hcfg.num_levels, hcfg.base_res, hcfg.max_res)
+        enc = hash_encode(q.view(-1, 3), params[f"{prefix}.encoder.hash_table"], scalings, hcfg.log2_hashmap_size)
     h = mlp_forward(enc, params, f"{prefix}.mlp", hcfg.num_layers).view(*positions.shape[:-1], -1)
     density = average_init_density * torch.exp(h[..., 0:1])
     density = density * selector[..., None]

@@ -26,6 +26,7 @@ class SnHashMlpDesc(C.Structure):
         ("num_layers", C.c_int32),
         ("out_dim", C.c_int32),
         ("scalings", C.c_float * SN_MAX_LEVELS),
+        ("grid_mode", C.c_int32),
     ]
 
 

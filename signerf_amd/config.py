@@ -56,8 +56,9 @@ class NerfactoModelConfig(InstantiateConfig):
     average_init_density: float = 1.0
     eval_num_rays_per_chunk: int = 4096
     implementation: str = "torch"
-    """Which nerfstudio semantics to reproduce: "torch" (the CPU-runnable fallback; the parity target).
-    Only affects the SH input convention (SURVEY.md A13)."""
+    """Which nerfstudio semantics to reproduce: "torch" (the CPU-runnable fallback; the parity target of the render path) or
+    "tcnn" (tiny-cuda-nn: its hash-grid indexing, bias-free MLPs and SH input convention, SURVEY.md A7/A8/A13 and §8(f) row 2 --
+    for checkpoints trained with `ns-train nerfacto`; UNPINNED, see signerf_amd/tcnn_import.py)."""
     num_train_data: int = 50
     """Rows of the appearance embedding table (the new dataset's size; signerf_pipeline.py:110-111 drops the
     trained table, so eval uses the mean of a freshly initialised one)."""

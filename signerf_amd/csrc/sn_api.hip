@@ -77,8 +77,37 @@ bool check_hashmlp(const SnHashMlpDesc& d, int levels, int hidden, int out, std:
     else if (d.hidden_dim != hidden) why = "hidden_dim must be " + std::to_string(hidden);
     else if (d.num_layers != 2) why = "num_layers must be 2";
     else if (d.out_dim != out) why = "out_dim must be " + std::to_string(out);
+    else if (d.grid_mode != 0 && d.grid_mode != 1) why = "grid_mode must be 0 (torch HashEncoding) or 1 (tiny-cuda-nn)";
     else return true;
     return false;
+}
+
+// tiny-cuda-nn level table (grid_mode 1): resolution = ceil(scale) + 1; a level is dense when its whole grid fits the table
+SnGridLevels grid_levels(const SnHashMlpDesc& d) {
+    SnGridLevels g;
+    memset(&g, 0, sizeof(g));
+    if (d.grid_mode != 1) return g;
+    const uint64_t T = 1ull << d.log2_hashmap_size;
+    for (int l = 0; l < d.num_levels; ++l) {
+        const uint64_t res = (uint64_t)ceilf(d.scalings[l]) + 1;
+        const uint64_t n = res * res * res;
+        if (n <= T && res <= 255) g.packed[l >> 2] |= (uint32_t)res << ((l & 3) * 8);
+    }
+    return g;
+}
+
+// number of leading dense levels if the dense levels form a prefix of the level list, else -1
+int leading_dense(const SnHashMlpDesc& d) {
+    const SnGridLevels g = grid_levels(d);
+    int nd = 0;
+    bool ended = false;
+    for (int l = 0; l < d.num_levels; ++l) {
+        const bool dense = ((g.packed[l >> 2] >> ((l & 3) * 8)) & 0xffu) != 0u;
+        if (dense && ended) return -1;
+        if (dense) ++nd;
+        else ended = true;
+    }
+    return nd;
 }
 
 inline int rho(int r) { return (r & 3) + 8 * (r >> 2); }
@@ -603,6 +632,9 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
             pp.pinfo[i] = h->pinfo_prop[i];
             pp.pairs_bytes[i] = (uint32_t)h->pairs_prop[i].bytes;
             pp.wpack[i] = (const float*)h->wpack_prop[i].ptr;
+            pp.tables[i] = (const float*)h->table_prop[i].ptr;
+            pp.table_bytes[i] = (uint32_t)h->table_prop[i].bytes;
+            pp.grid[i] = grid_levels(d.proposals[i]);
             pp.log2_t[i] = d.proposals[i].log2_hashmap_size;
             for (int l = 0; l < 5; ++l) pp.scal[i][l] = d.proposals[i].scalings[l];
             pp.n_samples[i] = opts->num_proposal_samples[i];
@@ -612,7 +644,16 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
         pp.far_plane = opts->far_plane;
         pp.avg_density = d.average_init_density;
         pp.hist_pad = d.histogram_padding;
-        hipLaunchKernelGGL(sn_proposal_kernel, dim3((unsigned)wp.prop_blocks), dim3(64 * SN_PROP_WAVES), 0, st, pp);
+        const dim3 pgrid((unsigned)wp.prop_blocks), pblock(64 * SN_PROP_WAVES);
+        if (d.proposals[0].grid_mode == 1) {
+            // nerfacto's proposal nets (max_res 128 / 256, T = 2^17) have 3 and 2 leading dense levels; other shapes take the
+            // run-time form
+            const int nd0 = leading_dense(d.proposals[0]), nd1 = nprop > 1 ? leading_dense(d.proposals[1]) : 2;
+            if (nd0 == 3 && nd1 == 2) hipLaunchKernelGGL((sn_proposal_kernel<1, 3, 2>), pgrid, pblock, 0, st, pp);
+            else hipLaunchKernelGGL((sn_proposal_kernel<1, -1, -1>), pgrid, pblock, 0, st, pp);
+        } else {
+            hipLaunchKernelGGL((sn_proposal_kernel<0, -1, -1>), pgrid, pblock, 0, st, pp);
+        }
         SN_HIP(h, hipGetLastError());
     }
 
@@ -646,22 +687,39 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
     p.avg_density = d.average_init_density;
     p.sh_remap = d.sh_remap;
     p.chunk_rays = opts->chunk_rays;
+    p.grid = grid_levels(d.main_field);
     const int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
     const size_t lds_bytes = (size_t)SnMainImg::TOTAL * 4;
     const dim3 grid((unsigned)(gbx * gby)), block(256);
-#define SN_LAUNCH_MAIN(MODE, PREC, ABL) hipLaunchKernelGGL((sn_render_main_kernel<MODE, PREC, ABL>), grid, block, lds_bytes, st, p)
+#define SN_LAUNCH_MAIN(MODE, PREC, ABL, GRID, ND) \
+    hipLaunchKernelGGL((sn_render_main_kernel<MODE, PREC, ABL, GRID, ND>), grid, block, lds_bytes, st, p)
+#define SN_LAUNCH_MAIN_TCNN(MODE, PREC)                           \
+    switch (nd) {                                                 \
+        case 0: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 0); break;       \
+        case 1: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 1); break;       \
+        case 2: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 2); break;       \
+        case 3: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 3); break;       \
+        case 4: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 4); break;       \
+        case 5: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 5); break;       \
+        case 6: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 6); break;       \
+        case 7: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 7); break;       \
+        default: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, -1); break;     \
+    }
     const char* abl_env = getenv("SN_ABLATE");  // profiling only: non-zero gives WRONG images (see sn_main.h)
     const int ablate = abl_env ? atoi(abl_env) : 0;
     const bool split = opts->precision == 1;
-    if (ablate == 2 && nprop == 0) SN_LAUNCH_MAIN(0, 0, 2);
-    else if (ablate == 3 && nprop == 0) SN_LAUNCH_MAIN(0, 0, 3);
+    const bool tcnn = d.main_field.grid_mode == 1;
+    const int nd = tcnn ? leading_dense(d.main_field) : 0;
+    if (ablate == 2 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 0, 2, 0, -1);
+    else if (ablate == 3 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 0, 3, 0, -1);
     else if (nprop > 0) {
-        if (split) SN_LAUNCH_MAIN(1, 1, 0);
-        else SN_LAUNCH_MAIN(1, 0, 0);
+        if (split) { if (tcnn) { SN_LAUNCH_MAIN_TCNN(1, 1) } else SN_LAUNCH_MAIN(1, 1, 0, 0, -1); }
+        else { if (tcnn) { SN_LAUNCH_MAIN_TCNN(1, 0) } else SN_LAUNCH_MAIN(1, 0, 0, 0, -1); }
     } else {
-        if (split) SN_LAUNCH_MAIN(0, 1, 0);
-        else SN_LAUNCH_MAIN(0, 0, 0);
+        if (split) { if (tcnn) { SN_LAUNCH_MAIN_TCNN(0, 1) } else SN_LAUNCH_MAIN(0, 1, 0, 0, -1); }
+        else { if (tcnn) { SN_LAUNCH_MAIN_TCNN(0, 0) } else SN_LAUNCH_MAIN(0, 0, 0, 0, -1); }
     }
+#undef SN_LAUNCH_MAIN_TCNN
 #undef SN_LAUNCH_MAIN
     SN_HIP(h, hipGetLastError());
     if (expected_depth) {
@@ -692,7 +750,9 @@ int sn_hash_encode(SnHandle h, int32_t which, const float* q, int64_t n, float* 
     // Proposal nets: when the weights are finalized the features come from the x-paired tables (the production layout of K2);
     // SN_HASH_PLAIN=1 forces the plain table so that tests can check the two layouts against each other.
     const char* plain = getenv("SN_HASH_PLAIN");
-    const bool use_pairs = which >= 0 && h->finalized && !(plain && atoi(plain));
+    const bool use_pairs = which >= 0 && h->finalized && !(plain && atoi(plain)) && d.grid_mode == 0;
+    p.grid_mode = d.grid_mode;
+    p.grid = grid_levels(d);
     p.pairs = use_pairs ? (const float*)h->pairs_prop[which].ptr : nullptr;
     if (which >= 0) p.pinfo = h->pinfo_prop[which];
     else memset(&p.pinfo, 0, sizeof(p.pinfo));
@@ -724,6 +784,8 @@ int sn_field_forward(SnHandle h, int32_t which, const float* positions, const fl
         p.sh_remap = h->desc.sh_remap;
         p.density = density;
         p.rgb = rgb;
+        p.grid_mode = h->desc.main_field.grid_mode;
+        p.grid = grid_levels(h->desc.main_field);
         if (precision == 0)
             hipLaunchKernelGGL(sn_main_field_stage_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)SnMainImg::TOTAL * 4, st, p);
         else
@@ -740,6 +802,10 @@ int sn_field_forward(SnHandle h, int32_t which, const float* positions, const fl
         p.log2_t = h->desc.proposals[which].log2_hashmap_size;
         p.avg_density = h->desc.average_init_density;
         p.density = density;
+        p.table = (const float*)h->table_prop[which].ptr;
+        p.table_bytes = (uint32_t)h->table_prop[which].bytes;
+        p.grid_mode = h->desc.proposals[which].grid_mode;
+        p.grid = grid_levels(h->desc.proposals[which]);
         hipLaunchKernelGGL(sn_prop_field_stage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
     }
     SN_HIP(h, hipGetLastError());

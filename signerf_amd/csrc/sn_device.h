@@ -212,6 +212,60 @@ SN_DEV f32x2 sn_hash_blend_fast(const f32x2 v[8], const float off[3]) {
     return (f0312 - f4756) * oz + f4756;
 }
 
+// tiny-cuda-nn grid semantics (`implementation="tcnn"` checkpoints; UNPINNED -- oracle/tcnn_layout.py):
+// x = fmaf(scale, q, 0.5) with the library's real-valued per-level scale, corners floor(x) and floor(x) + 1, and a level whose
+// whole grid fits its table is indexed densely (x + y*res + z*res^2, wrapping modulo the level size as the library does),
+// otherwise with the same xor hash.  The tables keep this library's uniform [L][T] layout; the importer puts a dense level's
+// rows at the start of its slot.  The level table is wave-uniform (kernel arguments, 4 SGPRs).
+struct SnGridLevels {
+    uint32_t packed[SN_MAX_LEVELS_DEV / 4];  // 8 bits per level: its resolution if it is indexed densely, else 0 (dense => res <= 128)
+};
+SN_DEV uint32_t sn_grid_dense_res(const SnGridLevels& g, int l) {
+    uint32_t w = g.packed[l >> 2];
+    // opaque to the optimiser: otherwise the per-level resolution, its square and the level size of all 16 levels are hoisted
+    // out of the sample loop, 48 live SGPRs that spill into VGPR lanes (measured: 190 spilled VGPRs); 5 SALU ops per level instead
+    asm volatile("" : "+s"(w));
+    return (w >> ((l & 3) * 8)) & 0xffu;
+}
+
+// DENSE: 1 / 0 = the level is dense / hashed (known at compile time), -1 = decided at run time from dense_res (wave-uniform
+// branch; in the fused kernels that form spills ~190 VGPRs, so they are instantiated per number of leading dense levels).
+template <int DENSE>
+SN_DEV void sn_hash_corners_tcnn(const float q[3], float scale, uint32_t mask, uint32_t dense_res, SnHashLevel& hl) {
+    uint32_t f[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = fmaf(scale, q[a], 0.5f);
+        hl.off[a] = __builtin_amdgcn_fractf(x);
+        f[a] = (uint32_t)(int)x;
+    }
+    if (DENSE < 0 ? dense_res != 0u : DENSE == 1) {
+        const uint32_t r = dense_res, r2 = r * r;
+        const uint32_t dense_size = (r2 * r + 7u) & ~7u;  // rows of the level in the library's layout = the wrap modulus
+        const uint32_t i000 = f[0] + f[1] * r + f[2] * r2;
+        // nerfstudio corner order 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf with c = +1, f = +0 (x y z)
+        const uint32_t dx[8] = {1, 1, 0, 0, 1, 1, 0, 0}, dy[8] = {1, 0, 0, 1, 1, 0, 0, 1}, dz[8] = {1, 1, 1, 1, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t idx = i000 + dx[k] + dy[k] * r + dz[k] * r2;
+            idx = idx >= dense_size ? idx - dense_size : idx;  // index % size: idx < 2 * size always
+            hl.boff[k] = idx << 3;
+        }
+    } else {
+        const uint32_t P1 = (2654435761u & mask) << 3, P2 = (805459861u & mask) << 3, m8 = mask << 3;
+        const uint32_t yf = __umul24(f[1], P1), zf = __umul24(f[2], P2), xf = f[0] << 3;
+        const uint32_t yc = yf + P1, zc = zf + P2, xc = xf + 8u;
+        hl.boff[0] = (xc ^ yc ^ zc) & m8;
+        hl.boff[1] = (xc ^ yf ^ zc) & m8;
+        hl.boff[2] = (xf ^ yf ^ zc) & m8;
+        hl.boff[3] = (xf ^ yc ^ zc) & m8;
+        hl.boff[4] = (xc ^ yc ^ zf) & m8;
+        hl.boff[5] = (xc ^ yf ^ zf) & m8;
+        hl.boff[6] = (xf ^ yf ^ zf) & m8;
+        hl.boff[7] = (xf ^ yc ^ zf) & m8;
+    }
+}
+
 // Buffer resource over a hash table (base must be wave-uniform: a kernel argument).
 SN_DEV __amdgpu_buffer_rsrc_t sn_table_rsrc(const float* table, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, (int)bytes, 0x00020000);
@@ -229,15 +283,24 @@ SN_DEV f32x2 sn_table_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, uint3
 // Encode one point over L levels -> feat[2L], level-major.  `scal` must be wave-uniform.
 // GROUP > 0 fences the instruction scheduler every GROUP levels: at most GROUP*8 gathers (GROUP*16 VGPRs) are in flight,
 // which keeps the fused kernels inside their register budget (the scheduler otherwise hoists all L*8 loads).
-// FAST selects the fused-kernel forms of the corner / blend arithmetic (see sn_hash_corners_fast).
-template <int L, int GROUP = 0, bool FAST = false>
-SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], float* feat) {
+// ARITH: 0 = the literal torch-path arithmetic, 1 = its fused-kernel form (sn_hash_corners_fast), 2 = tiny-cuda-nn grid
+// semantics (sn_hash_corners_tcnn; `grid` must then point at the level table).
+// ND (ARITH 2 only): levels [0, ND) are dense and the rest hashed, fixed at compile time; -1 = per-level run-time decision.
+template <int L, int GROUP = 0, int ARITH = 0, int ND = -1>
+SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], float* feat,
+                           const SnGridLevels* grid = nullptr) {
+    constexpr bool FAST = ARITH != 0;
     const uint32_t mask = (1u << log2_t) - 1u;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         if (GROUP > 0 && l > 0 && (l % GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
         SnHashLevel hl;
-        if (FAST) sn_hash_corners_fast(q, scal[l], mask, hl);
+        if (ARITH == 2) {
+            if (ND < 0) sn_hash_corners_tcnn<-1>(q, scal[l], mask, sn_grid_dense_res(*grid, l), hl);
+            else if (l < ND) sn_hash_corners_tcnn<1>(q, scal[l], mask, sn_grid_dense_res(*grid, l), hl);
+            else sn_hash_corners_tcnn<0>(q, scal[l], mask, 0u, hl);
+        }
+        else if (ARITH == 1) sn_hash_corners_fast(q, scal[l], mask, hl);
         else sn_hash_corners(q, scal[l], mask, hl);
         const uint32_t lvl = ((uint32_t)l << log2_t) * 8u;
         f32x2 v[8];

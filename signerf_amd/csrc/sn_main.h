@@ -409,6 +409,7 @@ struct SnMainParams {
     float near_plane, far_plane, avg_density;
     int sh_remap;
     int chunk_rays;
+    SnGridLevels grid;  // tiny-cuda-nn grid mode only (GRID = 1)
 };
 
 // XCD-aware, bijective block remap: the dispatcher places block b on XCD b % 8 (observed); give each
@@ -424,7 +425,9 @@ SN_DEV int sn_xcd_remap(int b, int n) {
 // ABLATE (profiling only, images are WRONG when non-zero; selected by the SN_ABLATE environment variable): 2 = hash phase
 // only (no MLP: density / colour faked from the features), 3 = VALU only (no table gathers either).  Measured r01:
 // full 7.7 ms, hash-only 2.8-3.0 ms (= the L1 tag-lookup floor), VALU-only 1.4 ms; the 204.8 M fp32 MFMAs alone are 5.6 ms.
-template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int PREC /*0 fp32 MFMA, 1 fp16 hi+lo split MFMA*/, int ABLATE = 0>
+template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int PREC /*0 fp32 MFMA, 1 fp16 hi+lo split MFMA*/, int ABLATE = 0,
+          int GRID = 0 /*0 nerfstudio torch-path hash grid, 1 tiny-cuda-nn grid semantics*/,
+          int ND = -1 /*GRID 1: number of leading dense levels, fixed at compile time (-1: run-time decision per level)*/>
 __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_kernel(SnMainParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
         } else {
             // plain table: the x-paired layout (sn_device.h) measured no gain here (r01: 4.11 vs 4.18 ms) -- splitting a level
             // into per-t tables loses the x-locality of the plain layout (16 consecutive x share a 128-B line)
-            sn_hash_encode<16, SN_HASH_GROUP, SN_FAST_HASH>(rsrc, p.scal, p.log2_t, q, feat);
+            sn_hash_encode<16, SN_HASH_GROUP, (GRID ? 2 : (SN_FAST_HASH ? 1 : 0)), ND>(rsrc, p.scal, p.log2_t, q, feat, &p.grid);
         }
         __builtin_amdgcn_sched_barrier(0);
         float h0, rgb[3];

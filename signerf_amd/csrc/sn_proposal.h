@@ -42,10 +42,14 @@ struct SnScal5 {
 // reads) was built and measured r01: instruction count -29 %, kernel 9 % SLOWER -- on gfx950 a SIMD's matrix pipe and VALU
 // do not run concurrently (tools/probes/overlap_probe.hip: MFMA-only 2.3 ms, FMA-only 1.8 ms, both 3.9 ms, from different
 // waves or interleaved in one), so 11 x 64 MFMA cycles simply replace 187 x 4 VALU cycles.
+// GRID = 1 (tiny-cuda-nn grid semantics): `prsrc` is the PLAIN table of the net and `grid` its level table; the x-paired
+// layout relies on the xor hash and is only used for the torch-path grids.
+template <int GRID = 0, int ND = -1>
 SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, const SnScal5& scal, int log2_t, const float* __restrict__ w,
-                        const float q[3]) {
+                        const float q[3], const SnGridLevels* grid = nullptr) {
     float feat[10];
-    sn_hash_encode_pairs<5, 0, true>(prsrc, pi, scal.v, log2_t, q, feat);
+    if (GRID == 1) sn_hash_encode<5, 0, 2, ND>(prsrc, scal.v, log2_t, q, feat, grid);
+    else sn_hash_encode_pairs<5, 0, true>(prsrc, pi, scal.v, log2_t, q, feat);
     // hidden units in pairs: one v_pk_fma_f32 per (pair, k); every unit still sums bias, k = 0..9 in order with fused multiply-adds
     const f32x2* w2 = (const f32x2*)w;
     f32x2 a[8];
@@ -138,6 +142,9 @@ struct SnPropParams {
     float* ebins_out;                     // [tile][n_final+1][64]
     float* prop_depth[SN_MAX_PROPOSALS];  // [H*W] or null
     float* scratch;                       // [n_waves][SN_PROP_SCRATCH_FLOATS]
+    const float* tables[SN_MAX_PROPOSALS];     // plain tables (tiny-cuda-nn grid mode)
+    uint32_t table_bytes[SN_MAX_PROPOSALS];
+    SnGridLevels grid[SN_MAX_PROPOSALS];
     const float* pairs[SN_MAX_PROPOSALS];  // x-paired tables (sn_device.h)
     SnPairInfo pinfo[SN_MAX_PROPOSALS];
     uint32_t pairs_bytes[SN_MAX_PROPOSALS];
@@ -169,14 +176,14 @@ struct SnPropLds {
 
 // One proposal level for this lane's ray: density net LV at the N samples whose spacing bins are sb(0..N); writes the
 // weights to w[i * 64] and returns sum(w + pad) (fp64) and the level's median depth.
-template <int LV, typename SB>
+template <int LV, int GRID, int ND, typename SB>
 SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* __restrict__ w, int N, const float o[3], const float d[3], float s_near,
                           float s_far, double& sum_wp, float& median_out) {
     SnScal5 scal;
 #pragma unroll
     for (int l = 0; l < 5; ++l) scal.v[l] = p.scal[LV][l];
     const int log2_t = p.log2_t[LV];
-    const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.pairs[LV], p.pairs_bytes[LV]);
+    const __amdgpu_buffer_rsrc_t rsrc = GRID == 1 ? sn_table_rsrc(p.tables[LV], p.table_bytes[LV]) : sn_table_rsrc(p.pairs[LV], p.pairs_bytes[LV]);
     SnPairInfo pi;
 #pragma unroll
     for (int l = 0; l < 5; ++l) pi.base[l] = p.pinfo[LV].base[l];
@@ -191,7 +198,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
         const float e1 = sn_euclid(sb(i + 1), s_near, s_far);
         float q[3];
         const bool sel = sn_sample_q_fast(o, d, e0, e1, q);
-        const float h0 = sn_prop_h0(rsrc, pi, scal, log2_t, wp, q);
+        const float h0 = sn_prop_h0<GRID, ND>(rsrc, pi, scal, log2_t, wp, q, &p.grid[LV]);
         const float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
         float wt;
         {
@@ -215,6 +222,8 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
     median_out = found ? median : mid;
 }
 
+// GRID 1: ND0 / ND1 = leading dense levels of the two nets (-1: run-time decision per level)
+template <int GRID, int ND0 = -1, int ND1 = -1>
 __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_proposal_kernel(SnPropParams p) {
     __shared__ SnPropLds L;
     const int tid = threadIdx.x;
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
         // level 0: the initial (uniform in s) sampler
         double sum_wp;
         float med;
-        sn_prop_level<0>(p, L.wpack[0], [&](int i) { return L.sb0[i]; }, W, n0, o, d, s_near, s_far, sum_wp, med);
+        sn_prop_level<0, GRID, ND0>(p, L.wpack[0], [&](int i) { return L.sb0[i]; }, W, n0, o, d, s_near, s_far, sum_wp, med);
         if (valid && p.prop_depth[0]) p.prop_depth[0][pix] = med;
         SnPdfNorm nm;
         nm.set(sum_wp, n0);
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
             const int n1 = p.n_samples[1];
             sn_pdf_lane(W, 64, n0, n1, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; },
                         [&](int j, float v, int) { B0[(int64_t)j * 64] = v; });
-            sn_prop_level<1>(p, L.wpack[1], [&](int i) { return B0[(int64_t)i * 64]; }, W, n1, o, d, s_near, s_far, sum_wp, med);
+            sn_prop_level<1, GRID, ND1>(p, L.wpack[1], [&](int i) { return B0[(int64_t)i * 64]; }, W, n1, o, d, s_near, s_far, sum_wp, med);
             if (valid && p.prop_depth[1]) p.prop_depth[1][pix] = med;
             nm.set(sum_wp, n1);
             sn_pdf_lane(W, 64, n1, p.n_final, L.u[1], p.hist_pad, nm, [&](int i) { return B0[(int64_t)i * 64]; },
@@ -296,6 +305,10 @@ struct SnPropStageParams {
     int log2_t;
     float avg_density;
     float* density;
+    const float* table;  // plain table + level table: tiny-cuda-nn grid mode (grid_mode != 0)
+    uint32_t table_bytes;
+    int grid_mode;
+    SnGridLevels grid;
 };
 
 __global__ void sn_prop_field_stage_kernel(SnPropStageParams p) {
@@ -307,8 +320,9 @@ __global__ void sn_prop_field_stage_kernel(SnPropStageParams p) {
     SnScal5 scal;
 #pragma unroll
     for (int l = 0; l < 5; ++l) scal.v[l] = p.scal[l];
-    const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.pairs, p.pairs_bytes);
-    const float h0 = sn_prop_h0(rsrc, p.pinfo, scal, p.log2_t, p.wpack, q);
+    float h0;
+    if (p.grid_mode) h0 = sn_prop_h0<1, -1>(sn_table_rsrc(p.table, p.table_bytes), p.pinfo, scal, p.log2_t, p.wpack, q, &p.grid);
+    else h0 = sn_prop_h0<0, -1>(sn_table_rsrc(p.pairs, p.pairs_bytes), p.pinfo, scal, p.log2_t, p.wpack, q);
     if (i < p.n) p.density[i] = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
 }
 

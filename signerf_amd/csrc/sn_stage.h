@@ -131,6 +131,8 @@ struct SnHashStageParams {
     const float* pairs;  // x-paired tables: when non-null the features come from them (must equal the plain path bit for bit)
     SnPairInfo pinfo;
     uint32_t pairs_bytes;
+    int grid_mode;       // 1: tiny-cuda-nn grid semantics (level table in `grid`)
+    SnGridLevels grid;
 };
 
 __global__ void sn_hash_encode_kernel(SnHashStageParams p) {
@@ -141,7 +143,8 @@ __global__ void sn_hash_encode_kernel(SnHashStageParams p) {
     const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table, ((uint32_t)p.num_levels << p.log2_t) * 8u);
     for (int l = 0; l < p.num_levels; ++l) {
         SnHashLevel hl;
-        sn_hash_corners(q, p.scal[l], mask, hl);
+        if (p.grid_mode) sn_hash_corners_tcnn<-1>(q, p.scal[l], mask, sn_grid_dense_res(p.grid, l), hl);
+        else sn_hash_corners(q, p.scal[l], mask, hl);
         const uint32_t lvl = ((uint32_t)l << p.log2_t) * 8u;
         f32x2 v[8];
 #pragma unroll
@@ -149,7 +152,7 @@ __global__ void sn_hash_encode_kernel(SnHashStageParams p) {
             v[k] = sn_table_load(rsrc, hl.boff[k], lvl);
             if (p.indices) p.indices[(i * p.num_levels + l) * 8 + k] = (int32_t)((hl.boff[k] >> 3) + ((uint32_t)l << p.log2_t));
         }
-        f32x2 e = sn_hash_blend(v, hl.off);
+        f32x2 e = p.grid_mode ? sn_hash_blend_fast(v, hl.off) : sn_hash_blend(v, hl.off);
         if (!p.pairs) {
             p.features[i * 2 * p.num_levels + 2 * l] = e.x;
             p.features[i * 2 * p.num_levels + 2 * l + 1] = e.y;
@@ -179,6 +182,8 @@ struct SnFieldStageParams {
     int sh_remap;
     float* density;  // [n]
     float* rgb;      // [n,3] or null
+    int grid_mode;   // 1: tiny-cuda-nn grid semantics
+    SnGridLevels grid;
 };
 
 template <int PREC>
@@ -205,7 +210,8 @@ __global__ __launch_bounds__(256, 2) void sn_main_field_stage_kernel(SnFieldStag
     const bool sel = sn_position_q(pos, q);
     const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table, (16u << p.log2_t) * 8u);
     float feat[32];
-    sn_hash_encode<16>(rsrc, p.scal, p.log2_t, q, feat);
+    if (p.grid_mode) sn_hash_encode<16, 0, 2>(rsrc, p.scal, p.log2_t, q, feat, &p.grid);
+    else sn_hash_encode<16>(rsrc, p.scal, p.log2_t, q, feat);
     float h0, rgb[3];
     if (PREC == 0) sn_main_field_f32(lds, feat, sh, lane, h0, rgb);
     else sn_main_field_h((const char*)lds, feat, shh, lane, h0, rgb);

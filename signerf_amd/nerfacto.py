@@ -37,18 +37,29 @@ class HashEncoding(nn.Module):
     """Parameters of nerfstudio's HashEncoding (torch path): ``hash_table`` [L*T, F]."""
 
     def __init__(self, num_levels: int, min_res: int, max_res: int, log2_hashmap_size: int, features_per_level: int = 2,
-                 hash_init_scale: float = 0.001):
+                 hash_init_scale: float = 0.001, implementation: str = "torch"):
         super().__init__()
         self.num_levels, self.min_res, self.max_res = num_levels, min_res, max_res
         self.log2_hashmap_size, self.features_per_level = log2_hashmap_size, features_per_level
+        # "tcnn": tiny-cuda-nn grid semantics (SURVEY §8(f) row 2).  The table keeps the uniform [L * 2^log2_T, F] shape; a level
+        # that tiny-cuda-nn indexes densely uses the first next_multiple(res^3, 8) rows of its slot (signerf_amd/tcnn_import.py).
+        self.implementation = implementation
         table = torch.rand(size=((2**log2_hashmap_size) * num_levels, features_per_level)) * 2 - 1
         self.hash_table = nn.Parameter(table * hash_init_scale)
 
+    @property
+    def grid_mode(self) -> int:
+        return 0 if self.implementation == "torch" else 1
+
     def scalings(self) -> Tensor:
-        """floor(min_res * growth**level), evaluated exactly as HashEncoding.__init__ does (numpy float64 growth
-        factor raised to an int64 torch tensor -> fp32)."""
-        levels = torch.arange(self.num_levels)
+        """torch: floor(min_res * growth**level), evaluated exactly as HashEncoding.__init__ does (numpy float64 growth factor
+        raised to an int64 torch tensor -> fp32).  tcnn: the library's grid_scale(), exp2f(level * log2f(growth)) * base - 1."""
         growth = np.exp((np.log(self.max_res) - np.log(self.min_res)) / (self.num_levels - 1)) if self.num_levels > 1 else 1
+        if self.implementation != "torch":
+            log2_g = np.log2(np.float32(growth), dtype=np.float32)
+            lv = np.arange(self.num_levels, dtype=np.float32)
+            return torch.from_numpy(np.exp2(lv * log2_g, dtype=np.float32) * np.float32(self.min_res) - np.float32(1.0))
+        levels = torch.arange(self.num_levels)
         return torch.floor(self.min_res * growth**levels).to(torch.float32)
 
 
@@ -62,9 +73,10 @@ class MLP(nn.Module):
 
 
 class MLPWithHashEncoding(nn.Module):
-    def __init__(self, num_levels, min_res, max_res, log2_hashmap_size, features_per_level, num_layers, layer_width, out_dim):
+    def __init__(self, num_levels, min_res, max_res, log2_hashmap_size, features_per_level, num_layers, layer_width, out_dim,
+                 implementation: str = "torch"):
         super().__init__()
-        self.encoder = HashEncoding(num_levels, min_res, max_res, log2_hashmap_size, features_per_level)
+        self.encoder = HashEncoding(num_levels, min_res, max_res, log2_hashmap_size, features_per_level, implementation=implementation)
         self.mlp = MLP(num_levels * features_per_level, num_layers, layer_width, out_dim)
 
 
@@ -84,7 +96,8 @@ class NerfactoField(nn.Module):
         super().__init__()
         self.geo_feat_dim = 15
         self.mlp_base = MLPWithHashEncoding(config.num_levels, config.base_res, config.max_res, config.log2_hashmap_size,
-                                            config.features_per_level, 2, config.hidden_dim, 1 + self.geo_feat_dim)
+                                            config.features_per_level, 2, config.hidden_dim, 1 + self.geo_feat_dim,
+                                            implementation=config.implementation)
         self.embedding_appearance = Embedding(num_images, config.appearance_embed_dim)
         self.mlp_head = MLP(16 + self.geo_feat_dim + config.appearance_embed_dim, 3, config.hidden_dim_color, 3)
 
@@ -93,10 +106,11 @@ class HashMLPDensityField(nn.Module):
     """Parameters of a proposal network (row a9)."""
 
     def __init__(self, hidden_dim=16, log2_hashmap_size=17, num_levels=5, max_res=128, base_res=16, features_per_level=2,
-                 use_linear=False, **_):
+                 use_linear=False, implementation="torch", **_):
         super().__init__()
         assert not use_linear, "use_linear proposal nets are not supported"
-        self.mlp_base = MLPWithHashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level, 2, hidden_dim, 1)
+        self.mlp_base = MLPWithHashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level, 2, hidden_dim, 1,
+                                            implementation=implementation)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -110,6 +124,7 @@ def _desc_of(enc: HashEncoding, hidden_dim: int, out_dim: int) -> _lib.SnHashMlp
     d.hidden_dim = hidden_dim
     d.num_layers = 2
     d.out_dim = out_dim
+    d.grid_mode = enc.grid_mode
     sc = enc.scalings().tolist()
     for i in range(_lib.SN_MAX_LEVELS):
         d.scalings[i] = sc[i] if i < len(sc) else 0.0
@@ -145,7 +160,7 @@ class NerfactoModel(nn.Module):
         self.proposal_networks = nn.ModuleList()
         for i in range(cfg.num_proposal_iterations):
             args = cfg.proposal_net_args_list[min(i, len(cfg.proposal_net_args_list) - 1)]
-            self.proposal_networks.append(HashMLPDensityField(**args))
+            self.proposal_networks.append(HashMLPDensityField(**args, implementation=cfg.implementation))
 
     @property
     def device(self):
@@ -162,6 +177,10 @@ class NerfactoModel(nn.Module):
         raise NotImplementedError("training losses are outside the render path (SURVEY.md §2 row 8)")
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        if any(k.endswith(".params") for k in state_dict):  # a tiny-cuda-nn checkpoint (flat parameter vectors)
+            from .tcnn_import import convert_tcnn_state_dict
+
+            state_dict = convert_tcnn_state_dict(state_dict, self.config)
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         self._weights_dirty = True
         return out

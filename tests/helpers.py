@@ -16,8 +16,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def oracle_config(cfg: NerfactoModelConfig) -> onf.NerfactoConfig:
+    grid = "torch" if cfg.implementation == "torch" else "tcnn"
     props = tuple(
-        onf.HashMLPConfig(a["num_levels"], a.get("base_res", 16), a["max_res"], a["log2_hashmap_size"], 2, a["hidden_dim"], 2, 1)
+        onf.HashMLPConfig(a["num_levels"], a.get("base_res", 16), a["max_res"], a["log2_hashmap_size"], 2, a["hidden_dim"], 2, 1, grid)
         for a in cfg.proposal_net_args_list[: cfg.num_proposal_iterations]
     )
     return onf.NerfactoConfig(
@@ -31,7 +32,7 @@ def oracle_config(cfg: NerfactoModelConfig) -> onf.NerfactoConfig:
         hidden_dim_color=cfg.hidden_dim_color,
         sh_remap="torch" if cfg.implementation == "torch" else "tcnn",
         main=onf.HashMLPConfig(cfg.num_levels, cfg.base_res, cfg.max_res, cfg.log2_hashmap_size, cfg.features_per_level,
-                               cfg.hidden_dim, 2, 16),
+                               cfg.hidden_dim, 2, 16, grid),
         proposals=props,
     )
 
@@ -61,3 +62,57 @@ def make_model(cfg, device, seed=0, **scene_kw):
 
 def rmse(a: torch.Tensor, b: torch.Tensor) -> float:
     return float(torch.sqrt(torch.mean((a.double().cpu() - b.double().cpu()) ** 2)))
+
+
+# ---- tiny-cuda-nn layout: synthetic checkpoints in the flat-vector layout -------------------------------
+def synthetic_tcnn_checkpoint(cfg, seed=0, base_gain=2.0, head_gain=3.0, num_images=50):
+    """A random "ns-train nerfacto" style state dict: one flat fp32 vector per tiny-cuda-nn module (network matrices, then grid
+    rows), sized from the oracle's level table; bias-free nets, so opacity comes from cfg.average_init_density."""
+    from oracle import tcnn_layout as tl
+
+    g = torch.Generator().manual_seed(seed)
+
+    def net(in_dim, width, layers, out_dim, gain):
+        parts = []
+        for r, c in tl.mlp_shapes(in_dim, width, layers, out_dim):
+            parts.append((torch.randn(r, c, generator=g) * (gain / c**0.5)).reshape(-1))
+        return torch.cat(parts)
+
+    def grid(levels, base, mx, log2_t):
+        meta = tl.grid_meta(levels, base, mx, log2_t)
+        return (torch.rand(meta.n_rows * 2, generator=g) * 2 - 1)
+
+    sd = {}
+    sd["field.mlp_base.tcnn_encoding.params"] = torch.cat([net(2 * cfg.num_levels, cfg.hidden_dim, 2, 16, base_gain),
+                                                           grid(cfg.num_levels, cfg.base_res, cfg.max_res, cfg.log2_hashmap_size)])
+    sd["field.mlp_head.tcnn_encoding.params"] = net(16 + 15 + cfg.appearance_embed_dim, cfg.hidden_dim_color, 3, 3, head_gain)
+    for i in range(cfg.num_proposal_iterations):
+        a = cfg.proposal_net_args_list[min(i, len(cfg.proposal_net_args_list) - 1)]
+        sd[f"proposal_networks.{i}.mlp_base.tcnn_encoding.params"] = torch.cat(
+            [net(2 * a["num_levels"], a["hidden_dim"], 2, 1, base_gain), grid(a["num_levels"], a.get("base_res", 16), a["max_res"], a["log2_hashmap_size"])])
+    sd["field.embedding_appearance.embedding.weight"] = torch.randn(num_images, cfg.appearance_embed_dim, generator=g)
+    return sd
+
+
+def oracle_params_from_tcnn(sd, cfg):
+    """The oracle's own unpacking of such a checkpoint (oracle/tcnn_layout.py) -- independent of signerf_amd/tcnn_import.py."""
+    from oracle import tcnn_layout as tl
+
+    out = {"field.embedding_appearance.embedding.weight": sd["field.embedding_appearance.embedding.weight"]}
+
+    def stack(prefix, levels, base, mx, log2_t, width, out_dim):
+        flat = sd[prefix + ".tcnn_encoding.params"]
+        n_net = tl.mlp_n_params(2 * levels, width, 2, out_dim)
+        for k, v in tl.mlp_unpack(flat[:n_net], 2 * levels, width, 2, out_dim, pad_value=0.0).items():
+            out[f"{prefix}.mlp.{k}"] = v
+        meta = tl.grid_meta(levels, base, mx, log2_t)
+        out[f"{prefix}.encoder.tcnn_grid"] = flat[n_net:].reshape(meta.n_rows, 2)
+
+    stack("field.mlp_base", cfg.num_levels, cfg.base_res, cfg.max_res, cfg.log2_hashmap_size, cfg.hidden_dim, 16)
+    for k, v in tl.mlp_unpack(sd["field.mlp_head.tcnn_encoding.params"], 16 + 15 + cfg.appearance_embed_dim, cfg.hidden_dim_color, 3, 3,
+                              pad_value=1.0).items():
+        out[f"field.mlp_head.{k}"] = v
+    for i in range(cfg.num_proposal_iterations):
+        a = cfg.proposal_net_args_list[min(i, len(cfg.proposal_net_args_list) - 1)]
+        stack(f"proposal_networks.{i}.mlp_base", a["num_levels"], a.get("base_res", 16), a["max_res"], a["log2_hashmap_size"], a["hidden_dim"], 1)
+    return out

@@ -1,0 +1,119 @@
+"""SURVEY §8(f) row 2 on the GPU: tiny-cuda-nn grid semantics + checkpoint import, against the oracle's independent restatement of
+the library's layout (oracle/tcnn_layout.py).  UNPINNED against the real library (absent here) -- these tests pin the HIP kernels
+and the importer to that restatement."""
+import pytest
+import torch
+
+from helpers import make_model, oracle_config, oracle_params_from_tcnn, rmse, small_config, synthetic_tcnn_checkpoint
+from oracle import nerfacto as onf
+from oracle import tcnn_layout as tl
+from signerf_amd import Cameras, ops, scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _tcnn_model(gpu, seed=0, **kw):
+    kw.setdefault("average_init_density", 3.0)
+    cfg = small_config(implementation="tcnn", **kw)
+    sd = synthetic_tcnn_checkpoint(cfg, seed=seed)
+    model = cfg.setup()
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    return cfg, sd, model.to(gpu).eval()
+
+
+@pytest.mark.parametrize("which", [-1, 0, 1])
+def test_tcnn_hash_encode_rows_and_features(gpu, which):
+    cfg, sd, model = _tcnn_model(gpu)
+    a = None if which < 0 else cfg.proposal_net_args_list[which]
+    levels, base, mx, log2_t = ((cfg.num_levels, cfg.base_res, cfg.max_res, cfg.log2_hashmap_size) if which < 0 else
+                                (a["num_levels"], a.get("base_res", 16), a["max_res"], a["log2_hashmap_size"]))
+    meta = tl.grid_meta(levels, base, mx, log2_t)
+    assert any(meta.dense) and not all(meta.dense)  # both index forms are exercised
+    g = torch.Generator().manual_seed(11 + which)
+    q = torch.rand(4096, 3, generator=g)
+    q[:64] = torch.rand(64, 3, generator=g) * 0.02 + 0.98  # the far faces: dense levels wrap there
+    q[64:128] = torch.rand(64, 3, generator=g) * 0.02
+    feat, idx = ops.hash_encode(model, q.to(gpu), which, return_indices=True)
+    prefix = "field.mlp_base" if which < 0 else f"proposal_networks.{which}.mlp_base"
+    params = oracle_params_from_tcnn(sd, cfg)
+    ref = tl.grid_encode(q, params[f"{prefix}.encoder.tcnn_grid"], meta)
+    assert float((feat.cpu() - ref).abs().max()) <= 2e-6
+    # table rows, corner by corner (nerfstudio corner order of the stage output: 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf)
+    T = 1 << log2_t
+    order = [(1, 1, 1), (1, 0, 1), (0, 0, 1), (0, 1, 1), (1, 1, 0), (1, 0, 0), (0, 0, 0), (0, 1, 0)]
+    for level in range(levels):
+        pos = (q.double() * meta.scales[level] + 0.5).float()
+        base_c = torch.floor(pos).to(torch.int64)
+        for k, (dx, dy, dz) in enumerate(order):
+            rows = tl.grid_rows(meta, level, base_c + torch.tensor([dx, dy, dz]))
+            assert torch.equal(idx[:, level, k].cpu().to(torch.int64) - level * T, rows), (level, k)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x2"])
+def test_tcnn_field_forward(gpu, precision):
+    cfg, sd, model = _tcnn_model(gpu, precision=precision)
+    params = oracle_params_from_tcnn(sd, cfg)
+    ocfg = oracle_config(cfg)
+    g = torch.Generator().manual_seed(3)
+    pos = (torch.rand(2048, 3, generator=g) * 2 - 1) * torch.tensor([1.0, 1.0, 1.0])
+    pos[:256] *= 4.0  # contracted region
+    d = torch.nn.functional.normalize(torch.randn(2048, 3, generator=g), dim=-1)
+    dens, rgb = ops.field_forward(model, pos.to(gpu), d.to(gpu))
+    o_d, h, _, _ = onf.density_field(params, "field.mlp_base", ocfg.main, pos[:, None, :], ocfg.average_init_density)
+    o_rgb = onf.field_rgb(params, ocfg, d, h)[:, 0]
+    rel = ((dens.cpu() - o_d[:, 0, 0]).abs() / o_d[:, 0, 0].clamp_min(1e-6)).max()
+    assert float(rel) <= 2e-4, float(rel)
+    assert float((rgb.cpu() - o_rgb).abs().max()) <= 2e-5
+    assert float(o_rgb.std()) > 0.05
+    for which in range(cfg.num_proposal_iterations):
+        pd, _ = ops.field_forward(model, pos.to(gpu), None, which)
+        o_pd, _, _, _ = onf.density_field(params, f"proposal_networks.{which}.mlp_base", ocfg.proposals[which], pos[:, None, :],
+                                          ocfg.average_init_density)
+        rel = ((pd.cpu() - o_pd[:, 0, 0]).abs() / o_pd[:, 0, 0].clamp_min(1e-6)).max()
+        assert float(rel) <= 2e-4, (which, float(rel))
+
+
+@pytest.mark.parametrize("props,precision", [(0, "fp16x2"), (2, "fp16x2"), (2, "fp32"), (0, "fp32")])
+def test_tcnn_render_matches_oracle(gpu, props, precision):
+    cfg, sd, model = _tcnn_model(gpu, precision=precision, num_proposal_iterations=props,
+                                 num_proposal_samples_per_ray=(48, 24) if props else (), num_nerf_samples_per_ray=16)
+    params = oracle_params_from_tcnn(sd, cfg)
+    H, W = 40, 56
+    cam = Cameras(scene.benchmark_cameras(8)[:, :3], 60.0, 60.0, W / 2, H / 2, W, H).to(gpu)[2]
+    b = cam.generate_rays(0)
+    out = model.get_outputs_for_camera_ray_bundle(b)
+    ref = onf.get_outputs_for_camera_ray_bundle(params, oracle_config(cfg), b.origins.cpu(), b.directions.cpu())
+    e = {k: rmse(out[k], ref[k]) for k in ("rgb", "depth", "accumulation")}
+    print("tcnn render", props, precision, {k: f"{v:.2e}" for k, v in e.items()})
+    assert all(v <= 1e-3 for v in e.values()), e
+    assert float(ref["rgb"].std()) > 0.05 and float(ref["depth"].std()) > 0.01  # non-vacuous
+
+
+def test_tcnn_checkpoint_needs_tcnn_model(gpu):
+    cfg = small_config()  # implementation="torch"
+    sd = synthetic_tcnn_checkpoint(small_config(implementation="tcnn"))
+    with pytest.raises(ValueError):
+        cfg.setup().load_state_dict(sd, strict=False)
+
+
+def test_tcnn_render_full_size_grids(gpu):
+    """nerfacto's real grid sizes (main T = 2^19: 5 leading dense levels; proposal nets T = 2^17: 3 and 2) -- the shapes the
+    kernels are specialised for at compile time."""
+    cfg = scene.proposal_config()
+    cfg.implementation = "tcnn"
+    cfg.average_init_density = 3.0
+    sd = synthetic_tcnn_checkpoint(cfg, seed=2)
+    model = cfg.setup()
+    model.load_state_dict(sd, strict=False)
+    model = model.to(gpu).eval()
+    params = oracle_params_from_tcnn(sd, cfg)
+    H, W = 24, 40
+    cam = Cameras(scene.benchmark_cameras(8)[:, :3], 50.0, 50.0, W / 2, H / 2, W, H).to(gpu)[5]
+    b = cam.generate_rays(0)
+    out = model.get_outputs_for_camera_ray_bundle(b)
+    ref = onf.get_outputs_for_camera_ray_bundle(params, oracle_config(cfg), b.origins.cpu(), b.directions.cpu())
+    e = {k: rmse(out[k], ref[k]) for k in ("rgb", "depth", "accumulation")}
+    print("tcnn full-size render", {k: f"{v:.2e}" for k, v in e.items()})
+    assert all(v <= 1e-3 for v in e.values()), e
+    assert float(ref["rgb"].std()) > 0.05

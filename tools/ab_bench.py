@@ -23,12 +23,15 @@ def main():
     ap.add_argument("--config", default="bench")
     ap.add_argument("--precision", default="fp32")
     ap.add_argument("--size", type=int, default=800)
+    ap.add_argument("--implementation", default="torch", help='"tcnn": tiny-cuda-nn grid semantics (weights stay at their random init)')
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = scene.benchmark_config(64) if a.config == "bench" else scene.proposal_config()
     cfg.precision = a.precision
+    cfg.implementation = a.implementation
     model = cfg.setup()
-    model.load_state_dict(scene.synthetic_state_dict(cfg), strict=False)
+    if a.implementation == "torch":
+        model.load_state_dict(scene.synthetic_state_dict(cfg), strict=False)
     model = model.to(dev).eval()
     W = H = a.size
     cam = Cameras(scene.benchmark_cameras(8)[:, :3], float(W), float(W), W / 2, H / 2, W, H).to(dev)[0]
