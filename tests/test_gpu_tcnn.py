@@ -117,3 +117,18 @@ def test_tcnn_render_full_size_grids(gpu):
     print("tcnn full-size render", {k: f"{v:.2e}" for k, v in e.items()})
     assert all(v <= 1e-3 for v in e.values()), e
     assert float(ref["rgb"].std()) > 0.05
+
+
+def test_tcnn_all_levels_dense_runtime_path(gpu):
+    """A grid whose 16 levels are all dense (max_res 64, T = 2^19): more leading dense levels than the compile-time variants
+    cover, so the kernels take the per-level run-time decision."""
+    cfg, sd, model = _tcnn_model(gpu, seed=7, log2_hashmap_size=19, max_res=64, num_proposal_iterations=0, num_nerf_samples_per_ray=24)
+    assert all(tl.grid_meta(16, 16, 64, 19).dense)
+    params = oracle_params_from_tcnn(sd, cfg)
+    H, W = 24, 32
+    cam = Cameras(scene.benchmark_cameras(8)[:, :3], 40.0, 40.0, W / 2, H / 2, W, H).to(gpu)[4]
+    b = cam.generate_rays(0)
+    out = model.get_outputs_for_camera_ray_bundle(b)
+    ref = onf.get_outputs_for_camera_ray_bundle(params, oracle_config(cfg), b.origins.cpu(), b.directions.cpu())
+    assert rmse(out["rgb"], ref["rgb"]) <= 1e-3 and rmse(out["depth"], ref["depth"]) <= 1e-3
+    assert float(ref["rgb"].std()) > 0.02
