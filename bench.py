@@ -91,7 +91,13 @@ def main():
 
     from signerf_amd import Cameras, build, scene, sheet
 
-    build.build(verbose=False)
+    # The library ships prebuilt with the snapshot (__graft_entry__.build()).  Only a missing file is rebuilt, by local rank 0
+    # alone -- N ranks recompiling into one path at the same time would race.
+    if not os.path.exists(build.LIB_PATH):
+        if local_rank == 0:
+            build.build(verbose=False)
+        if world > 1:
+            dist.barrier()
     if args.workload == "sheet64":
         args.width, args.height, args.samples = args.width or 800, args.height or 800, args.samples or 64
         cfg = scene.benchmark_config(args.samples)
