@@ -83,8 +83,12 @@ def _unpack_grid(flat: Tensor, num_levels: int, base_res: int, max_res: int, log
     return table
 
 
+def _hits(sd: Dict[str, Tensor], module: str) -> List[str]:
+    return [k for k in sd if re.fullmatch(re.escape(module) + r"\.[A-Za-z_]+\.params", k)]
+
+
 def _find(sd: Dict[str, Tensor], module: str) -> Tensor:
-    hits = [k for k in sd if re.fullmatch(re.escape(module) + r"\.[A-Za-z_]+\.params", k)]
+    hits = _hits(sd, module)
     if len(hits) != 1:
         raise KeyError(f"expected exactly one '<{module}>.<attr>.params' vector in the checkpoint, found {hits}")
     return sd[hits[0]].detach().to("cpu", torch.float32).reshape(-1)
@@ -98,9 +102,17 @@ def convert_tcnn_state_dict(sd: Dict[str, Tensor], config, quantize_fp16: bool =
     out: Dict[str, Tensor] = {k: v for k, v in sd.items() if not k.endswith(".params")}
 
     def stack(prefix: str, levels: int, base: int, mx: int, log2_t: int, feats: int, width: int, out_dim: int):
-        flat = _find(sd, prefix)
-        n_net = _unpack_mlp(flat, f"{prefix}.mlp", levels * feats, width, 2, out_dim, 0.0, out)
-        out[f"{prefix}.encoder.hash_table"] = _unpack_grid(flat[n_net:], levels, base, mx, log2_t, feats)
+        if _hits(sd, prefix):  # one fused NetworkWithInputEncoding vector: network first, then the grid
+            flat = _find(sd, prefix)
+            n_net = _unpack_mlp(flat, f"{prefix}.mlp", levels * feats, width, 2, out_dim, 0.0, out)
+            grid = flat[n_net:]
+        else:                  # separate Encoding and Network modules (<prefix>.encoder.<attr>.params, <prefix>.mlp.<attr>.params)
+            net = _find(sd, f"{prefix}.mlp")
+            used = _unpack_mlp(net, f"{prefix}.mlp", levels * feats, width, 2, out_dim, 1.0, out)  # a plain Network pads with ones
+            if used != net.numel():
+                raise ValueError(f"{prefix}.mlp vector has {net.numel()} values, expected {used}")
+            grid = _find(sd, f"{prefix}.encoder")
+        out[f"{prefix}.encoder.hash_table"] = _unpack_grid(grid, levels, base, mx, log2_t, feats)
 
     stack("field.mlp_base", config.num_levels, config.base_res, config.max_res, config.log2_hashmap_size, config.features_per_level,
           config.hidden_dim, 16)

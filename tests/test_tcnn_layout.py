@@ -74,3 +74,18 @@ def test_importer_agrees_with_the_oracle_unpacking():
         convert_tcnn_state_dict(bad, cfg)
     with pytest.raises(ValueError):
         convert_tcnn_state_dict(sd, small_config())
+
+
+def test_importer_accepts_separate_encoding_and_network_vectors():
+    """Some nerfstudio versions keep the grid and the MLP of a field as two tiny-cuda-nn modules instead of one fused one."""
+    cfg = small_config(implementation="tcnn", num_proposal_iterations=0)
+    sd = synthetic_tcnn_checkpoint(cfg, seed=9)
+    fused = convert_tcnn_state_dict(sd, cfg)
+    flat = sd.pop("field.mlp_base.tcnn_encoding.params")
+    n_net = tl.mlp_n_params(2 * cfg.num_levels, cfg.hidden_dim, 2, 16)
+    sd["field.mlp_base.mlp.tcnn_encoding.params"] = flat[:n_net]
+    sd["field.mlp_base.encoder.tcnn_encoding.params"] = flat[n_net:]
+    split = convert_tcnn_state_dict(sd, cfg)
+    assert set(split) == set(fused)
+    for k in fused:
+        assert torch.equal(split[k], fused[k]), k  # 32 grid features need no input padding, so the two forms coincide
