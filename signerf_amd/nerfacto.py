@@ -302,6 +302,15 @@ class NerfactoModel(nn.Module):
         return {k: v.view(H, W, -1) for k, v in out.items()}
 
     @torch.no_grad()
+    def get_outputs_for_camera(self, camera, obb_box=None) -> Dict[str, Tensor]:
+        """nerfstudio's ``Model.get_outputs_for_camera`` [NS], the call the viewer's render thread makes on the shared model
+        (/root/reference/signerf/interface/viewer.py:334-336): rays of camera 0, then the whole-image
+        render -- the same kernels at the viewer's resolution.  ``obb_box`` (viewer crop) is not supported."""
+        if obb_box is not None:
+            raise NotImplementedError("oriented crop boxes (viewer crop) are not part of the render path")
+        return self.get_outputs_for_camera_ray_bundle(camera.generate_rays(camera_indices=0, aabb_box=self.render_aabb))
+
+    @torch.no_grad()
     def get_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
         """Flat bundle [R,...] -> dict of [R,C]."""
         R = len(ray_bundle)

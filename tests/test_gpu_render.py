@@ -245,3 +245,15 @@ def test_extreme_image_shapes(gpu, props, W, H):
     assert out["rgb"].shape == (H, W, 3) and out["depth"].shape == (H, W, 1)
     for k in ("rgb", "depth", "accumulation"):
         assert rmse(out[k], ref[k]) <= RMSE_TOL, k
+
+
+def test_get_outputs_for_camera_is_the_two_call_path(gpu):
+    """The viewer's entry point (viewer.py:334-336 -> Model.get_outputs_for_camera) equals generate_rays + render."""
+    cfg = small_config(num_proposal_samples_per_ray=(32, 16), num_nerf_samples_per_ray=12)
+    model, _ = make_model(cfg, gpu)
+    cam = Cameras(scene.benchmark_cameras(8)[:, :3], 50.0, 50.0, 20.0, 15.0, 40, 30).to(gpu)[6]
+    a = model.get_outputs_for_camera(cam)
+    b = model.get_outputs_for_camera_ray_bundle(cam.generate_rays(0))
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    with pytest.raises(NotImplementedError):
+        model.get_outputs_for_camera(cam, obb_box=object())
