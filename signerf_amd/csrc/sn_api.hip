@@ -49,6 +49,7 @@ struct SnContext {
     DevBuf wimg_main;                   // SnMainImg (fp32 MFMA operands)
     DevBuf wimg_main_h;                 // SnMainImgH (fp16 hi+lo MFMA operands)
     DevBuf wpack_prop[SN_MAX_PROPOSALS]; // SnPropPack
+    bool dense_pairs_ok = true;  // tcnn grids: every dense level is shorter than its slot (room for the wrap row, sn_finalize_weights)
     bool finalized = false;
 };
 
@@ -94,6 +95,27 @@ SnGridLevels grid_levels(const SnHashMlpDesc& d) {
         if (n <= T && res <= 255) g.packed[l >> 2] |= (uint32_t)res << ((l & 3) * 8);
     }
     return g;
+}
+
+// tiny-cuda-nn dense levels: copy row 0 of the level behind its last row, so that a 16-byte read at the last row returns the
+// wrapped x + 1 corner (sn_hash_level_dense_pairs).  Returns false if some dense level fills its whole slot (no room).
+bool write_wrap_rows(const SnHashMlpDesc& d, const DevBuf& table, hipStream_t st) {
+    if (d.grid_mode != 1) return true;
+    const SnGridLevels g = grid_levels(d);
+    const uint64_t T = 1ull << d.log2_hashmap_size;
+    bool ok = true;
+    for (int l = 0; l < d.num_levels; ++l) {
+        const uint64_t r = (g.packed[l >> 2] >> ((l & 3) * 8)) & 0xffu;
+        if (!r) continue;
+        const uint64_t size = ((r * r * r + 7) / 8) * 8;
+        if (size >= T) {
+            ok = false;
+            continue;
+        }
+        char* lvl = (char*)table.ptr + ((uint64_t)l * T) * 8;
+        (void)hipMemcpyAsync(lvl + size * 8, lvl, 8, hipMemcpyDeviceToDevice, st);
+    }
+    return ok;
 }
 
 // number of leading dense levels if the dense levels form a prefix of the level list, else -1
@@ -281,13 +303,17 @@ int build_pairs(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, DevBuf&
     const uint32_t T = 1u << d.log2_hashmap_size;
     uint64_t entries = 0;
     int n_t[SN_MAX_LEVELS];
+    const SnGridLevels gl = grid_levels(d);
     for (int l = 0; l < d.num_levels; ++l) {
         int bits = 0;
-        for (uint32_t s = (uint32_t)d.scalings[l]; s; s >>= 1) ++bits;
+        // largest floor coordinate: floor(scale) in the torch grid, at most ceil(scale) with tiny-cuda-nn's +0.5
+        for (uint32_t s = (uint32_t)ceilf(d.scalings[l]) + 1u; s; s >>= 1) ++bits;
         n_t[l] = bits + 1;
+        if (((gl.packed[l >> 2] >> ((l & 3) * 8)) & 0xffu) != 0u) n_t[l] = 0;  // dense tcnn level: read from the plain table
         info.base[l] = (uint32_t)entries;
         entries += (uint64_t)n_t[l] * T;
     }
+    if (entries == 0) entries = 1;
     for (int l = d.num_levels; l < SN_MAX_LEVELS; ++l) info.base[l] = 0;
     const uint64_t bytes = entries * 16;
     if (bytes >= (1ull << 32)) return fail(h, SN_ERR_INVALID, "paired hash tables exceed the 4 GiB buffer-descriptor range");
@@ -298,6 +324,7 @@ int build_pairs(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, DevBuf&
     }
     for (int l = 0; l < d.num_levels; ++l) {
         const uint64_t n = (uint64_t)n_t[l] * T;
+        if (n == 0) continue;
         hipLaunchKernelGGL(sn_build_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)table.ptr,
                            (float*)pairs.ptr, l, d.log2_hashmap_size, info.base[l], n_t[l]);
     }
@@ -519,8 +546,13 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         }
         SN_HIP(h, hipMemcpyAsync(h->wpack_prop[i].ptr, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, st));
     }
-    for (int i = 0; i < d.num_proposals; ++i)
+    bool wrap_ok = write_wrap_rows(d.main_field, h->table_main, st);
+    for (int i = 0; i < d.num_proposals; ++i) {
+        wrap_ok = write_wrap_rows(d.proposals[i], h->table_prop[i], st) && wrap_ok;
         if (int rc = build_pairs(h, d.proposals[i], h->table_prop[i], h->pairs_prop[i], h->pinfo_prop[i], st)) return rc;
+    }
+    h->dense_pairs_ok = wrap_ok;
+    SN_HIP(h, hipGetLastError());
     SN_HIP(h, hipStreamSynchronize(st));
     {
         std::lock_guard<std::mutex> g(h->mu);
@@ -649,7 +681,7 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
             // nerfacto's proposal nets (max_res 128 / 256, T = 2^17) have 3 and 2 leading dense levels; other shapes take the
             // run-time form
             const int nd0 = leading_dense(d.proposals[0]), nd1 = nprop > 1 ? leading_dense(d.proposals[1]) : 2;
-            if (nd0 == 3 && nd1 == 2) hipLaunchKernelGGL((sn_proposal_kernel<1, 3, 2>), pgrid, pblock, 0, st, pp);
+            if (nd0 == 3 && nd1 == 2 && h->dense_pairs_ok) hipLaunchKernelGGL((sn_proposal_kernel<1, 3, 2>), pgrid, pblock, 0, st, pp);
             else hipLaunchKernelGGL((sn_proposal_kernel<1, -1, -1>), pgrid, pblock, 0, st, pp);
         } else {
             hipLaunchKernelGGL((sn_proposal_kernel<0, -1, -1>), pgrid, pblock, 0, st, pp);
@@ -709,7 +741,7 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
     const int ablate = abl_env ? atoi(abl_env) : 0;
     const bool split = opts->precision == 1;
     const bool tcnn = d.main_field.grid_mode == 1;
-    const int nd = tcnn ? leading_dense(d.main_field) : 0;
+    const int nd = tcnn && h->dense_pairs_ok ? leading_dense(d.main_field) : -1;  // compile-time variants read dense levels as x-pairs
     if (ablate == 2 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 0, 2, 0, -1);
     else if (ablate == 3 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 0, 3, 0, -1);
     else if (nprop > 0) {

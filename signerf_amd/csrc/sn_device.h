@@ -283,9 +283,49 @@ SN_DEV f32x2 sn_table_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, uint3
 // Encode one point over L levels -> feat[2L], level-major.  `scal` must be wave-uniform.
 // GROUP > 0 fences the instruction scheduler every GROUP levels: at most GROUP*8 gathers (GROUP*16 VGPRs) are in flight,
 // which keeps the fused kernels inside their register budget (the scheduler otherwise hoists all L*8 loads).
+// One DENSE tiny-cuda-nn level with four 16-byte gathers instead of eight 8-byte ones: in a dense level the x + 1 corner is
+// the next row, so one dwordx4 at row i returns both x corners.  The wrap of the library (index % size) is kept: the base
+// row wraps with min(i, i - size), and the row after the level's last one holds a COPY of row 0 (written by
+// sn_finalize_weights; the host only selects this path when every dense level is shorter than its slot).
+SN_DEV f32x4 sn_table_load_pair(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, uint32_t level_off_bytes) {
+    typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+    u32x4_ r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, (int)level_off_bytes, 0);
+    return f32x4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+}
+
+SN_DEV f32x2 sn_hash_level_dense_pairs(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_off_bytes, const float q[3], float scale, uint32_t r) {
+    uint32_t f[3];
+    float off[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = fmaf(scale, q[a], 0.5f);
+        off[a] = __builtin_amdgcn_fractf(x);
+        f[a] = (uint32_t)(int)x;
+    }
+    const uint32_t r2 = r * r, size = (r2 * r + 7u) & ~7u;
+    const uint32_t i_ff = f[0] + f[1] * r + f[2] * r2;  // (x0, y0, z0)
+    const uint32_t i_cf = i_ff + r, i_fc = i_ff + r2, i_cc = i_ff + r + r2;  // (y1,z0), (y0,z1), (y1,z1)
+    auto wrap8 = [&](uint32_t i) { return min(i, i - size) << 3; };
+    const f32x4 p_cc = sn_table_load_pair(rsrc, wrap8(i_cc), level_off_bytes);
+    const f32x4 p_fc = sn_table_load_pair(rsrc, wrap8(i_fc), level_off_bytes);
+    const f32x4 p_ff = sn_table_load_pair(rsrc, wrap8(i_ff), level_off_bytes);
+    const f32x4 p_cf = sn_table_load_pair(rsrc, wrap8(i_cf), level_off_bytes);
+    f32x2 v[8];
+    v[3] = f32x2{p_cc.x, p_cc.y};
+    v[0] = f32x2{p_cc.z, p_cc.w};
+    v[2] = f32x2{p_fc.x, p_fc.y};
+    v[1] = f32x2{p_fc.z, p_fc.w};
+    v[6] = f32x2{p_ff.x, p_ff.y};
+    v[5] = f32x2{p_ff.z, p_ff.w};
+    v[7] = f32x2{p_cf.x, p_cf.y};
+    v[4] = f32x2{p_cf.z, p_cf.w};
+    return sn_hash_blend_fast(v, off);
+}
+
 // ARITH: 0 = the literal torch-path arithmetic, 1 = its fused-kernel form (sn_hash_corners_fast), 2 = tiny-cuda-nn grid
 // semantics (sn_hash_corners_tcnn; `grid` must then point at the level table).
 // ND (ARITH 2 only): levels [0, ND) are dense and the rest hashed, fixed at compile time; -1 = per-level run-time decision.
+// With ND >= 0 the dense levels use the paired 16-byte gathers of sn_hash_level_dense_pairs.
 template <int L, int GROUP = 0, int ARITH = 0, int ND = -1>
 SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], float* feat,
                            const SnGridLevels* grid = nullptr) {
@@ -294,6 +334,12 @@ SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int l
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         if (GROUP > 0 && l > 0 && (l % GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
+        if (ARITH == 2 && ND >= 0 && l < ND) {
+            const f32x2 e = sn_hash_level_dense_pairs(rsrc, ((uint32_t)l << log2_t) * 8u, q, scal[l], sn_grid_dense_res(*grid, l));
+            feat[2 * l] = e.x;
+            feat[2 * l + 1] = e.y;
+            continue;
+        }
         SnHashLevel hl;
         if (ARITH == 2) {
             if (ND < 0) sn_hash_corners_tcnn<-1>(q, scal[l], mask, sn_grid_dense_res(*grid, l), hl);
@@ -341,19 +387,21 @@ SN_DEV f32x4 sn_pair_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t entry) {
 // Same result as sn_hash_encode (bit for bit), from the paired tables.  FAST: the fused-kernel arithmetic of
 // sn_hash_corners_fast / sn_hash_blend_fast -- with "ceil = floor + 1" the pair's second half is always the wanted x + 1
 // corner, so the per-corner selects of the literal form disappear as well.
-template <int L, int GROUP = 0, bool FAST = false>
+// L0 / TCNN: levels [L0, L) only, with tiny-cuda-nn's position x = fmaf(scale, q, 0.5) -- the hashed levels of a tcnn grid
+// (their x + 1 corner is row ^ m_t exactly as in the torch grid, so the same paired tables serve them).
+template <int L, int GROUP = 0, bool FAST = false, int L0 = 0, bool TCNN = false>
 SN_DEV void sn_hash_encode_pairs(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, const float* scal, int log2_t, const float q[3],
                                  float* feat) {
     const uint32_t mask = (1u << log2_t) - 1u;
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
+    for (int l = L0; l < L; ++l) {
         if (GROUP > 0 && l > 0 && (l % GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
         uint32_t f[3], c[3];
         float off[3];
         if (FAST) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const float x = q[a] * scal[l];
+                const float x = TCNN ? fmaf(scal[l], q[a], 0.5f) : q[a] * scal[l];
                 off[a] = __builtin_amdgcn_fractf(x);
                 f[a] = (uint32_t)(int)x;
                 c[a] = f[a] + 1u;

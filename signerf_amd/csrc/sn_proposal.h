@@ -42,14 +42,22 @@ struct SnScal5 {
 // reads) was built and measured r01: instruction count -29 %, kernel 9 % SLOWER -- on gfx950 a SIMD's matrix pipe and VALU
 // do not run concurrently (tools/probes/overlap_probe.hip: MFMA-only 2.3 ms, FMA-only 1.8 ms, both 3.9 ms, from different
 // waves or interleaved in one), so 11 x 64 MFMA cycles simply replace 187 x 4 VALU cycles.
-// GRID = 1 (tiny-cuda-nn grid semantics): `prsrc` is the PLAIN table of the net and `grid` its level table; the x-paired
-// layout relies on the xor hash and is only used for the torch-path grids.
+// GRID = 1 (tiny-cuda-nn grid semantics): `plain` is the plain table of the net and `grid` its level table.  With the number of
+// leading dense levels ND known at compile time the dense levels read x-corner pairs straight from the plain table and the
+// hashed levels use the x-paired tables `prsrc` (built for those levels only); ND = -1 reads everything from the plain table.
 template <int GRID = 0, int ND = -1>
 SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, const SnScal5& scal, int log2_t, const float* __restrict__ w,
-                        const float q[3], const SnGridLevels* grid = nullptr) {
+                        const float q[3], const SnGridLevels* grid = nullptr, __amdgpu_buffer_rsrc_t plain = __amdgpu_buffer_rsrc_t()) {
     float feat[10];
-    if (GRID == 1) sn_hash_encode<5, 0, 2, ND>(prsrc, scal.v, log2_t, q, feat, grid);
-    else sn_hash_encode_pairs<5, 0, true>(prsrc, pi, scal.v, log2_t, q, feat);
+    if (GRID == 1 && ND >= 0) {
+        // dense levels: paired 16-byte gathers from the plain table; hashed levels: the x-paired tables
+        if (ND > 0) sn_hash_encode<(ND > 0 ? ND : 1), 0, 2, ND>(plain, scal.v, log2_t, q, feat, grid);
+        sn_hash_encode_pairs<5, 0, true, ND, true>(prsrc, pi, scal.v, log2_t, q, feat);
+    } else if (GRID == 1) {
+        sn_hash_encode<5, 0, 2, -1>(plain, scal.v, log2_t, q, feat, grid);
+    } else {
+        sn_hash_encode_pairs<5, 0, true>(prsrc, pi, scal.v, log2_t, q, feat);
+    }
     // hidden units in pairs: one v_pk_fma_f32 per (pair, k); every unit still sums bias, k = 0..9 in order with fused multiply-adds
     const f32x2* w2 = (const f32x2*)w;
     f32x2 a[8];
@@ -183,7 +191,8 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
 #pragma unroll
     for (int l = 0; l < 5; ++l) scal.v[l] = p.scal[LV][l];
     const int log2_t = p.log2_t[LV];
-    const __amdgpu_buffer_rsrc_t rsrc = GRID == 1 ? sn_table_rsrc(p.tables[LV], p.table_bytes[LV]) : sn_table_rsrc(p.pairs[LV], p.pairs_bytes[LV]);
+    const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.pairs[LV], p.pairs_bytes[LV]);
+    const __amdgpu_buffer_rsrc_t plain = sn_table_rsrc(p.tables[LV], p.table_bytes[LV]);
     SnPairInfo pi;
 #pragma unroll
     for (int l = 0; l < 5; ++l) pi.base[l] = p.pinfo[LV].base[l];
@@ -198,7 +207,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
         const float e1 = sn_euclid(sb(i + 1), s_near, s_far);
         float q[3];
         const bool sel = sn_sample_q_fast(o, d, e0, e1, q);
-        const float h0 = sn_prop_h0<GRID, ND>(rsrc, pi, scal, log2_t, wp, q, &p.grid[LV]);
+        const float h0 = sn_prop_h0<GRID, ND>(rsrc, pi, scal, log2_t, wp, q, &p.grid[LV], plain);
         const float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
         float wt;
         {
@@ -321,7 +330,7 @@ __global__ void sn_prop_field_stage_kernel(SnPropStageParams p) {
 #pragma unroll
     for (int l = 0; l < 5; ++l) scal.v[l] = p.scal[l];
     float h0;
-    if (p.grid_mode) h0 = sn_prop_h0<1, -1>(sn_table_rsrc(p.table, p.table_bytes), p.pinfo, scal, p.log2_t, p.wpack, q, &p.grid);
+    if (p.grid_mode) h0 = sn_prop_h0<1, -1>(sn_table_rsrc(p.pairs, p.pairs_bytes), p.pinfo, scal, p.log2_t, p.wpack, q, &p.grid, sn_table_rsrc(p.table, p.table_bytes));
     else h0 = sn_prop_h0<0, -1>(sn_table_rsrc(p.pairs, p.pairs_bytes), p.pinfo, scal, p.log2_t, p.wpack, q);
     if (i < p.n) p.density[i] = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
 }

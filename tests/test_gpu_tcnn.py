@@ -97,11 +97,13 @@ def test_tcnn_checkpoint_needs_tcnn_model(gpu):
         cfg.setup().load_state_dict(sd, strict=False)
 
 
-def test_tcnn_render_full_size_grids(gpu):
+@pytest.mark.parametrize("precision", ["fp16x2", "fp32"])
+def test_tcnn_render_full_size_grids(gpu, precision):
     """nerfacto's real grid sizes (main T = 2^19: 5 leading dense levels; proposal nets T = 2^17: 3 and 2) -- the shapes the
     kernels are specialised for at compile time."""
     cfg = scene.proposal_config()
     cfg.implementation = "tcnn"
+    cfg.precision = precision
     cfg.average_init_density = 3.0
     sd = synthetic_tcnn_checkpoint(cfg, seed=2)
     model = cfg.setup()
@@ -132,3 +134,19 @@ def test_tcnn_all_levels_dense_runtime_path(gpu):
     ref = onf.get_outputs_for_camera_ray_bundle(params, oracle_config(cfg), b.origins.cpu(), b.directions.cpu())
     assert rmse(out["rgb"], ref["rgb"]) <= 1e-3 and rmse(out["depth"], ref["depth"]) <= 1e-3
     assert float(ref["rgb"].std()) > 0.02
+
+
+def test_tcnn_dense_levels_as_x_pairs_with_room(gpu):
+    """Main grid T = 2^14 (2 leading dense levels, both shorter than their slot) and no proposal nets: the compile-time variant
+    that reads dense levels as 16-byte x-pairs, including the wrap row behind each dense level."""
+    cfg, sd, model = _tcnn_model(gpu, seed=5, num_proposal_iterations=0, num_nerf_samples_per_ray=32)
+    m = tl.grid_meta(cfg.num_levels, cfg.base_res, cfg.max_res, cfg.log2_hashmap_size)
+    assert m.dense[:3] == [True, True, False] and all(m.offsets[i + 1] - m.offsets[i] < (1 << cfg.log2_hashmap_size) for i in range(2))
+    params = oracle_params_from_tcnn(sd, cfg)
+    H, W = 32, 48
+    cam = Cameras(scene.benchmark_cameras(8)[:, :3], 45.0, 45.0, W / 2, H / 2, W, H).to(gpu)[1]
+    b = cam.generate_rays(0)
+    out = model.get_outputs_for_camera_ray_bundle(b)
+    ref = onf.get_outputs_for_camera_ray_bundle(params, oracle_config(cfg), b.origins.cpu(), b.directions.cpu())
+    e = {k: rmse(out[k], ref[k]) for k in ("rgb", "depth", "accumulation")}
+    assert all(v <= 1e-3 for v in e.values()), e
