@@ -49,9 +49,17 @@ struct SnContext {
     DevBuf wimg_main;                   // SnMainImg (fp32 MFMA operands)
     DevBuf wimg_main_h;                 // SnMainImgH (fp16 hi+lo MFMA operands)
     DevBuf wpack_prop[SN_MAX_PROPOSALS]; // SnPropPack
+    DevBuf dense_main;            // de-hashed copies of the coarse levels of a torch-path main grid (sn_device.h SnDenseCopy)
+    SnDenseCopy dense_info{};
+    SnGridLevels dense_res{};     // their resolutions R = scale + 2, packed like a tcnn level table
+    int nd_torch = 0;             // number of copied levels
     bool dense_pairs_ok = true;  // tcnn grids: every dense level is shorter than its slot (room for the wrap row, sn_finalize_weights)
     bool finalized = false;
 };
+
+#ifndef SN_DENSE_LEVELS_DEFAULT
+#define SN_DENSE_LEVELS_DEFAULT 8
+#endif
 
 namespace {
 
@@ -429,6 +437,7 @@ int sn_create(const SnFieldDesc* desc, SnHandle* out) {
 int sn_destroy(SnHandle h) {
     if (!h) return SN_OK;
     h->table_main.release();
+    h->dense_main.release();
     h->wimg_main.release();
     h->wimg_main_h.release();
     for (int i = 0; i < SN_MAX_PROPOSALS; ++i) {
@@ -545,6 +554,47 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
             h->wpack_prop[i].bytes = pack.size() * 4;
         }
         SN_HIP(h, hipMemcpyAsync(h->wpack_prop[i].ptr, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, st));
+    }
+    // torch grid: de-hashed copies of the coarse main-field levels (SN_DENSE_LEVELS of them, default 0 = off)
+    {
+        const char* e = getenv("SN_DENSE_LEVELS");
+        int want = e ? atoi(e) : SN_DENSE_LEVELS_DEFAULT;
+        want = std::max(0, std::min(want, 8));
+        h->nd_torch = 0;
+        memset(&h->dense_info, 0, sizeof(h->dense_info));
+        memset(&h->dense_res, 0, sizeof(h->dense_res));
+        if (d.main_field.grid_mode == 0 && want > 0) {
+            uint64_t bytes = 0;
+            uint32_t R[8];
+            int nd = 0;
+            for (int l = 0; l < want && l < d.main_field.num_levels; ++l) {
+                const uint64_t r = (uint64_t)d.main_field.scalings[l] + 2;
+                if (r > 255) break;
+                R[l] = (uint32_t)r;
+                h->dense_info.off[l] = (uint32_t)bytes;
+                bytes += (r * r * r + 1) * 8;  // one spare row: the last entry's 16-byte read stays inside the buffer
+                bytes = (bytes + 255) & ~255ull;
+                ++nd;
+            }
+            if (nd > 0) {
+                if (h->dense_main.bytes != bytes) {
+                    h->dense_main.release();
+                    SN_HIP(h, hipMalloc(&h->dense_main.ptr, bytes));
+                    h->dense_main.bytes = bytes;
+                }
+                SN_HIP(h, hipMemsetAsync(h->dense_main.ptr, 0, bytes, st));
+                for (int l = 0; l < nd; ++l) {
+                    const uint32_t n = R[l] * R[l] * R[l];
+                    hipLaunchKernelGGL(sn_build_dense_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)h->table_main.ptr,
+                                       (float*)((char*)h->dense_main.ptr + h->dense_info.off[l]), l, d.main_field.log2_hashmap_size, R[l]);
+                    h->dense_res.packed[l >> 2] |= R[l] << ((l & 3) * 8);
+                }
+                SN_HIP(h, hipGetLastError());
+                h->dense_info.base = (const float*)h->dense_main.ptr;
+                h->dense_info.bytes = (uint32_t)bytes;
+                h->nd_torch = nd;
+            }
+        }
     }
     bool wrap_ok = write_wrap_rows(d.main_field, h->table_main, st);
     for (int i = 0; i < d.num_proposals; ++i) {
@@ -720,6 +770,10 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
     p.sh_remap = d.sh_remap;
     p.chunk_rays = opts->chunk_rays;
     p.grid = grid_levels(d.main_field);
+    if (d.main_field.grid_mode == 0 && h->nd_torch > 0) {
+        p.grid = h->dense_res;
+        p.dense = h->dense_info;
+    }
     const int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
     const size_t lds_bytes = (size_t)SnMainImg::TOTAL * 4;
     const dim3 grid((unsigned)(gbx * gby)), block(256);
@@ -742,16 +796,25 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
     const bool split = opts->precision == 1;
     const bool tcnn = d.main_field.grid_mode == 1;
     const int nd = tcnn && h->dense_pairs_ok ? leading_dense(d.main_field) : -1;  // compile-time variants read dense levels as x-pairs
+#define SN_LAUNCH_MAIN_TORCH(MODE, PREC)                          \
+    switch (h->nd_torch) {                                        \
+        case 5: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 5); break;       \
+        case 6: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 6); break;       \
+        case 7: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 7); break;       \
+        case 8: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 8); break;       \
+        default: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, -1); break;     \
+    }
     if (ablate == 2 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 0, 2, 0, -1);
     else if (ablate == 3 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 0, 3, 0, -1);
     else if (nprop > 0) {
-        if (split) { if (tcnn) { SN_LAUNCH_MAIN_TCNN(1, 1) } else SN_LAUNCH_MAIN(1, 1, 0, 0, -1); }
-        else { if (tcnn) { SN_LAUNCH_MAIN_TCNN(1, 0) } else SN_LAUNCH_MAIN(1, 0, 0, 0, -1); }
+        if (split) { if (tcnn) { SN_LAUNCH_MAIN_TCNN(1, 1) } else { SN_LAUNCH_MAIN_TORCH(1, 1) } }
+        else { if (tcnn) { SN_LAUNCH_MAIN_TCNN(1, 0) } else { SN_LAUNCH_MAIN_TORCH(1, 0) } }
     } else {
-        if (split) { if (tcnn) { SN_LAUNCH_MAIN_TCNN(0, 1) } else SN_LAUNCH_MAIN(0, 1, 0, 0, -1); }
-        else { if (tcnn) { SN_LAUNCH_MAIN_TCNN(0, 0) } else SN_LAUNCH_MAIN(0, 0, 0, 0, -1); }
+        if (split) { if (tcnn) { SN_LAUNCH_MAIN_TCNN(0, 1) } else { SN_LAUNCH_MAIN_TORCH(0, 1) } }
+        else { if (tcnn) { SN_LAUNCH_MAIN_TCNN(0, 0) } else { SN_LAUNCH_MAIN_TORCH(0, 0) } }
     }
 #undef SN_LAUNCH_MAIN_TCNN
+#undef SN_LAUNCH_MAIN_TORCH
 #undef SN_LAUNCH_MAIN
     SN_HIP(h, hipGetLastError());
     if (expected_depth) {

@@ -322,13 +322,63 @@ SN_DEV f32x2 sn_hash_level_dense_pairs(__amdgpu_buffer_rsrc_t rsrc, uint32_t lev
     return sn_hash_blend_fast(v, off);
 }
 
+// De-hashed copies of the COARSE levels of a torch-path grid (an MI355X data layout, not a change of arithmetic):
+//     D_l[x + R y + R^2 z] = table[l][hash(x, y, z)],   R = scale_l + 2,   0 <= x, y, z <= scale_l + 1
+// built once by sn_finalize_weights.  In D_l the x + 1 corner is the next row, so a level costs four 16-byte gathers instead
+// of eight 8-byte ones and neighbouring voxels share cache lines.  Values are the table's own, so results are bit-identical
+// to the hashed reads.  Only levels with R <= 255 (packed 8-bit resolutions) and a few MB each are copied.
+struct SnDenseCopy {
+    const float* base;     // all copied levels, back to back
+    uint32_t bytes;
+    uint32_t off[8];       // byte offset of level l's copy (l < number of copied levels <= 8)
+};
+
+SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_off_bytes, const float q[3], float scale, uint32_t R) {
+    uint32_t f[3];
+    float off[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = q[a] * scale;
+        off[a] = __builtin_amdgcn_fractf(x);
+        f[a] = (uint32_t)(int)x;
+    }
+    const uint32_t R2 = R * R;
+    const uint32_t i_ff = f[0] + f[1] * R + f[2] * R2;
+    const uint32_t i_cf = i_ff + R, i_fc = i_ff + R2, i_cc = i_ff + R + R2;
+    const f32x4 p_cc = sn_table_load_pair(rsrc, i_cc << 3, level_off_bytes);
+    const f32x4 p_fc = sn_table_load_pair(rsrc, i_fc << 3, level_off_bytes);
+    const f32x4 p_ff = sn_table_load_pair(rsrc, i_ff << 3, level_off_bytes);
+    const f32x4 p_cf = sn_table_load_pair(rsrc, i_cf << 3, level_off_bytes);
+    f32x2 v[8];
+    v[3] = f32x2{p_cc.x, p_cc.y};
+    v[0] = f32x2{p_cc.z, p_cc.w};
+    v[2] = f32x2{p_fc.x, p_fc.y};
+    v[1] = f32x2{p_fc.z, p_fc.w};
+    v[6] = f32x2{p_ff.x, p_ff.y};
+    v[5] = f32x2{p_ff.z, p_ff.w};
+    v[7] = f32x2{p_cf.x, p_cf.y};
+    v[4] = f32x2{p_cf.z, p_cf.w};
+    return sn_hash_blend_fast(v, off);
+}
+
+// builds D_l for one level: one thread per entry
+__global__ void sn_build_dense_copy_kernel(const float* __restrict__ table, float* __restrict__ dense, int level, int log2_t, uint32_t R) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * R * R) return;
+    const uint32_t x = i % R, y = (i / R) % R, z = i / (R * R);
+    const uint32_t mask = (1u << log2_t) - 1u;
+    const uint32_t row = (x ^ (y * 2654435761u) ^ (z * 805459861u)) & mask;
+    const f32x2* lv = (const f32x2*)table + ((uint64_t)level << log2_t);
+    ((f32x2*)dense)[i] = lv[row];
+}
+
 // ARITH: 0 = the literal torch-path arithmetic, 1 = its fused-kernel form (sn_hash_corners_fast), 2 = tiny-cuda-nn grid
 // semantics (sn_hash_corners_tcnn; `grid` must then point at the level table).
 // ND (ARITH 2 only): levels [0, ND) are dense and the rest hashed, fixed at compile time; -1 = per-level run-time decision.
 // With ND >= 0 the dense levels use the paired 16-byte gathers of sn_hash_level_dense_pairs.
 template <int L, int GROUP = 0, int ARITH = 0, int ND = -1>
 SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], float* feat,
-                           const SnGridLevels* grid = nullptr) {
+                           const SnGridLevels* grid = nullptr, const SnDenseCopy* dense = nullptr) {
     constexpr bool FAST = ARITH != 0;
     const uint32_t mask = (1u << log2_t) - 1u;
 #pragma unroll
@@ -336,6 +386,12 @@ SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int l
         if (GROUP > 0 && l > 0 && (l % GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
         if (ARITH == 2 && ND >= 0 && l < ND) {
             const f32x2 e = sn_hash_level_dense_pairs(rsrc, ((uint32_t)l << log2_t) * 8u, q, scal[l], sn_grid_dense_res(*grid, l));
+            feat[2 * l] = e.x;
+            feat[2 * l + 1] = e.y;
+            continue;
+        }
+        if (ARITH == 1 && ND > 0 && l < ND && l < 8) {  // torch grid: de-hashed copy of a coarse level (R packed like a dense tcnn level)
+            const f32x2 e = sn_hash_level_dense_copy(sn_table_rsrc(dense->base, dense->bytes), dense->off[l], q, scal[l], sn_grid_dense_res(*grid, l));
             feat[2 * l] = e.x;
             feat[2 * l + 1] = e.y;
             continue;

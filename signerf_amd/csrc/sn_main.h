@@ -409,7 +409,8 @@ struct SnMainParams {
     float near_plane, far_plane, avg_density;
     int sh_remap;
     int chunk_rays;
-    SnGridLevels grid;  // tiny-cuda-nn grid mode only (GRID = 1)
+    SnGridLevels grid;  // GRID 1: dense-level resolutions of the tiny-cuda-nn grid; GRID 0, ND > 0: R of the de-hashed coarse copies
+    SnDenseCopy dense;  // GRID 0, ND > 0
 };
 
 // XCD-aware, bijective block remap: the dispatcher places block b on XCD b % 8 (observed); give each
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
         } else {
             // plain table: the x-paired layout (sn_device.h) measured no gain here (r01: 4.11 vs 4.18 ms) -- splitting a level
             // into per-t tables loses the x-locality of the plain layout (16 consecutive x share a 128-B line)
-            sn_hash_encode<16, SN_HASH_GROUP, (GRID ? 2 : (SN_FAST_HASH ? 1 : 0)), ND>(rsrc, p.scal, p.log2_t, q, feat, &p.grid);
+            sn_hash_encode<16, SN_HASH_GROUP, (GRID ? 2 : (SN_FAST_HASH ? 1 : 0)), ND>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense);
         }
         __builtin_amdgcn_sched_barrier(0);
         float h0, rgb[3];
