@@ -53,6 +53,10 @@ struct SnContext {
     SnDenseCopy dense_info{};
     SnGridLevels dense_res{};     // their resolutions R = scale + 2, packed like a tcnn level table
     int nd_torch = 0;             // number of copied levels
+    DevBuf dense_prop[SN_MAX_PROPOSALS];
+    SnDenseCopy dense_info_prop[SN_MAX_PROPOSALS]{};
+    SnGridLevels dense_res_prop[SN_MAX_PROPOSALS]{};
+    int nd_prop[SN_MAX_PROPOSALS] = {0, 0};
     bool dense_pairs_ok = true;  // tcnn grids: every dense level is shorter than its slot (room for the wrap row, sn_finalize_weights)
     bool finalized = false;
 };
@@ -103,6 +107,47 @@ SnGridLevels grid_levels(const SnHashMlpDesc& d) {
         if (n <= T && res <= 255) g.packed[l >> 2] |= (uint32_t)res << ((l & 3) * 8);
     }
     return g;
+}
+
+// De-hashed copies of the leading coarse levels of a torch-path grid (sn_device.h, SnDenseCopy).  A level is copied while its
+// resolution R = scale + 2 fits the packed 8 bits and its copy stays under 100 MB (a fine level's copy is R^3 / T times larger
+// than its hashed slot; measured r01: the main grid gains up to level 8, 18x).
+int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, int want, DevBuf& buf, SnDenseCopy& info, SnGridLevels& res,
+                       int& nd_out, hipStream_t st) {
+    nd_out = 0;
+    memset(&info, 0, sizeof(info));
+    memset(&res, 0, sizeof(res));
+    if (d.grid_mode != 0 || want <= 0 || !table.ptr) return SN_OK;
+    uint64_t bytes = 0;
+    uint32_t R[8];
+    int nd = 0;
+    for (int l = 0; l < want && l < d.num_levels && l < 8; ++l) {
+        const uint64_t r = (uint64_t)d.scalings[l] + 2;
+        if (r > 255 || r * r * r * 8 > 100ull * 1000 * 1000) break;
+        R[l] = (uint32_t)r;
+        info.off[l] = (uint32_t)bytes;
+        bytes += (r * r * r + 1) * 8;  // one spare row: the last entry's 16-byte read stays inside the buffer
+        bytes = (bytes + 255) & ~255ull;
+        ++nd;
+    }
+    if (nd == 0) return SN_OK;
+    if (buf.bytes != bytes) {
+        buf.release();
+        SN_HIP(h, hipMalloc(&buf.ptr, bytes));
+        buf.bytes = bytes;
+    }
+    SN_HIP(h, hipMemsetAsync(buf.ptr, 0, bytes, st));
+    for (int l = 0; l < nd; ++l) {
+        const uint32_t n = R[l] * R[l] * R[l];
+        hipLaunchKernelGGL(sn_build_dense_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)table.ptr,
+                           (float*)((char*)buf.ptr + info.off[l]), l, d.log2_hashmap_size, R[l]);
+        res.packed[l >> 2] |= R[l] << ((l & 3) * 8);
+    }
+    SN_HIP(h, hipGetLastError());
+    info.base = (const float*)buf.ptr;
+    info.bytes = (uint32_t)bytes;
+    nd_out = nd;
+    return SN_OK;
 }
 
 // tiny-cuda-nn dense levels: copy row 0 of the level behind its last row, so that a 16-byte read at the last row returns the
@@ -443,6 +488,7 @@ int sn_destroy(SnHandle h) {
     for (int i = 0; i < SN_MAX_PROPOSALS; ++i) {
         h->table_prop[i].release();
         h->pairs_prop[i].release();
+        h->dense_prop[i].release();
         h->wpack_prop[i].release();
     }
     delete h;
@@ -555,46 +601,16 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         }
         SN_HIP(h, hipMemcpyAsync(h->wpack_prop[i].ptr, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, st));
     }
-    // torch grid: de-hashed copies of the coarse main-field levels (SN_DENSE_LEVELS of them, default 0 = off)
+    // torch grids: de-hashed copies of the coarse levels (SN_DENSE_LEVELS caps the count; 0 = off)
     {
         const char* e = getenv("SN_DENSE_LEVELS");
-        int want = e ? atoi(e) : SN_DENSE_LEVELS_DEFAULT;
-        want = std::max(0, std::min(want, 8));
-        h->nd_torch = 0;
-        memset(&h->dense_info, 0, sizeof(h->dense_info));
-        memset(&h->dense_res, 0, sizeof(h->dense_res));
-        if (d.main_field.grid_mode == 0 && want > 0) {
-            uint64_t bytes = 0;
-            uint32_t R[8];
-            int nd = 0;
-            for (int l = 0; l < want && l < d.main_field.num_levels; ++l) {
-                const uint64_t r = (uint64_t)d.main_field.scalings[l] + 2;
-                if (r > 255) break;
-                R[l] = (uint32_t)r;
-                h->dense_info.off[l] = (uint32_t)bytes;
-                bytes += (r * r * r + 1) * 8;  // one spare row: the last entry's 16-byte read stays inside the buffer
-                bytes = (bytes + 255) & ~255ull;
-                ++nd;
-            }
-            if (nd > 0) {
-                if (h->dense_main.bytes != bytes) {
-                    h->dense_main.release();
-                    SN_HIP(h, hipMalloc(&h->dense_main.ptr, bytes));
-                    h->dense_main.bytes = bytes;
-                }
-                SN_HIP(h, hipMemsetAsync(h->dense_main.ptr, 0, bytes, st));
-                for (int l = 0; l < nd; ++l) {
-                    const uint32_t n = R[l] * R[l] * R[l];
-                    hipLaunchKernelGGL(sn_build_dense_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)h->table_main.ptr,
-                                       (float*)((char*)h->dense_main.ptr + h->dense_info.off[l]), l, d.main_field.log2_hashmap_size, R[l]);
-                    h->dense_res.packed[l >> 2] |= R[l] << ((l & 3) * 8);
-                }
-                SN_HIP(h, hipGetLastError());
-                h->dense_info.base = (const float*)h->dense_main.ptr;
-                h->dense_info.bytes = (uint32_t)bytes;
-                h->nd_torch = nd;
-            }
-        }
+        const int want = std::max(0, std::min(e ? atoi(e) : SN_DENSE_LEVELS_DEFAULT, 8));
+        if (int rc = build_dense_copies(h, d.main_field, h->table_main, want, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st))
+            return rc;
+        for (int i = 0; i < d.num_proposals; ++i)
+            if (int rc = build_dense_copies(h, d.proposals[i], h->table_prop[i], want, h->dense_prop[i], h->dense_info_prop[i],
+                                            h->dense_res_prop[i], h->nd_prop[i], st))
+                return rc;
     }
     bool wrap_ok = write_wrap_rows(d.main_field, h->table_main, st);
     for (int i = 0; i < d.num_proposals; ++i) {
@@ -717,6 +733,10 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
             pp.tables[i] = (const float*)h->table_prop[i].ptr;
             pp.table_bytes[i] = (uint32_t)h->table_prop[i].bytes;
             pp.grid[i] = grid_levels(d.proposals[i]);
+            if (d.proposals[i].grid_mode == 0 && h->nd_prop[i] > 0) {
+                pp.grid[i] = h->dense_res_prop[i];
+                pp.dense[i] = h->dense_info_prop[i];
+            }
             pp.log2_t[i] = d.proposals[i].log2_hashmap_size;
             for (int l = 0; l < 5; ++l) pp.scal[i][l] = d.proposals[i].scalings[l];
             pp.n_samples[i] = opts->num_proposal_samples[i];
@@ -733,6 +753,9 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
             const int nd0 = leading_dense(d.proposals[0]), nd1 = nprop > 1 ? leading_dense(d.proposals[1]) : 2;
             if (nd0 == 3 && nd1 == 2 && h->dense_pairs_ok) hipLaunchKernelGGL((sn_proposal_kernel<1, 3, 2>), pgrid, pblock, 0, st, pp);
             else hipLaunchKernelGGL((sn_proposal_kernel<1, -1, -1>), pgrid, pblock, 0, st, pp);
+        } else if (nprop == 2 && h->nd_prop[0] == 5 && h->nd_prop[1] == 4) {
+            // nerfacto's nets (max_res 128 / 256): every level but the finest of the second net has a de-hashed copy
+            hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4>), pgrid, pblock, 0, st, pp);
         } else {
             hipLaunchKernelGGL((sn_proposal_kernel<0, -1, -1>), pgrid, pblock, 0, st, pp);
         }

@@ -47,7 +47,8 @@ struct SnScal5 {
 // hashed levels use the x-paired tables `prsrc` (built for those levels only); ND = -1 reads everything from the plain table.
 template <int GRID = 0, int ND = -1>
 SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, const SnScal5& scal, int log2_t, const float* __restrict__ w,
-                        const float q[3], const SnGridLevels* grid = nullptr, __amdgpu_buffer_rsrc_t plain = __amdgpu_buffer_rsrc_t()) {
+                        const float q[3], const SnGridLevels* grid = nullptr, __amdgpu_buffer_rsrc_t plain = __amdgpu_buffer_rsrc_t(),
+                        const SnDenseCopy* dense = nullptr) {
     float feat[10];
     if (GRID == 1 && ND >= 0) {
         // dense levels: paired 16-byte gathers from the plain table; hashed levels: the x-paired tables
@@ -55,6 +56,10 @@ SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, cons
         sn_hash_encode_pairs<5, 0, true, ND, true>(prsrc, pi, scal.v, log2_t, q, feat);
     } else if (GRID == 1) {
         sn_hash_encode<5, 0, 2, -1>(plain, scal.v, log2_t, q, feat, grid);
+    } else if (ND > 0) {
+        // torch grid: levels [0, ND) from their de-hashed copies (4 gathers, 6 index instructions), the rest from the x-paired tables
+        sn_hash_encode<(ND > 0 ? ND : 1), 0, 1, ND>(plain, scal.v, log2_t, q, feat, grid, dense);
+        if (ND < 5) sn_hash_encode_pairs<5, 0, true, (ND > 0 && ND < 5 ? ND : 0)>(prsrc, pi, scal.v, log2_t, q, feat);
     } else {
         sn_hash_encode_pairs<5, 0, true>(prsrc, pi, scal.v, log2_t, q, feat);
     }
@@ -152,7 +157,8 @@ struct SnPropParams {
     float* scratch;                       // [n_waves][SN_PROP_SCRATCH_FLOATS]
     const float* tables[SN_MAX_PROPOSALS];     // plain tables (tiny-cuda-nn grid mode)
     uint32_t table_bytes[SN_MAX_PROPOSALS];
-    SnGridLevels grid[SN_MAX_PROPOSALS];
+    SnGridLevels grid[SN_MAX_PROPOSALS];       // tcnn: dense-level resolutions; torch with de-hashed copies: their R
+    SnDenseCopy dense[SN_MAX_PROPOSALS];       // torch grid, ND > 0: de-hashed copies of the leading levels
     const float* pairs[SN_MAX_PROPOSALS];  // x-paired tables (sn_device.h)
     SnPairInfo pinfo[SN_MAX_PROPOSALS];
     uint32_t pairs_bytes[SN_MAX_PROPOSALS];
@@ -207,7 +213,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
         const float e1 = sn_euclid(sb(i + 1), s_near, s_far);
         float q[3];
         const bool sel = sn_sample_q_fast(o, d, e0, e1, q);
-        const float h0 = sn_prop_h0<GRID, ND>(rsrc, pi, scal, log2_t, wp, q, &p.grid[LV], plain);
+        const float h0 = sn_prop_h0<GRID, ND>(rsrc, pi, scal, log2_t, wp, q, &p.grid[LV], plain, &p.dense[LV]);
         const float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
         float wt;
         {
