@@ -242,7 +242,7 @@ SN_DEV void sn_hash_corners_tcnn(const float q[3], float scale, uint32_t mask, u
     if (DENSE < 0 ? dense_res != 0u : DENSE == 1) {
         const uint32_t r = dense_res, r2 = r * r;
         const uint32_t dense_size = (r2 * r + 7u) & ~7u;  // rows of the level in the library's layout = the wrap modulus
-        const uint32_t i000 = f[0] + f[1] * r + f[2] * r2;
+        const uint32_t i000 = f[0] + __umul24(f[1], r) + __umul24(f[2], r2);
         // nerfstudio corner order 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf with c = +1, f = +0 (x y z)
         const uint32_t dx[8] = {1, 1, 0, 0, 1, 1, 0, 0}, dy[8] = {1, 0, 0, 1, 1, 0, 0, 1}, dz[8] = {1, 1, 1, 1, 0, 0, 0, 0};
 #pragma unroll
@@ -302,8 +302,10 @@ SN_DEV f32x2 sn_hash_level_dense_pairs(__amdgpu_buffer_rsrc_t rsrc, uint32_t lev
         off[a] = __builtin_amdgcn_fractf(x);
         f[a] = (uint32_t)(int)x;
     }
+    // r <= 255 and the coordinates are <= r, so every product fits 24 bits: full-rate v_mul_u32_u24 / v_mad_u32_u24 (v_mul_lo_u32
+    // is quarter rate)
     const uint32_t r2 = r * r, size = (r2 * r + 7u) & ~7u;
-    const uint32_t i_ff = f[0] + f[1] * r + f[2] * r2;  // (x0, y0, z0)
+    const uint32_t i_ff = f[0] + __umul24(f[1], r) + __umul24(f[2], r2);  // (x0, y0, z0)
     const uint32_t i_cf = i_ff + r, i_fc = i_ff + r2, i_cc = i_ff + r + r2;  // (y1,z0), (y0,z1), (y1,z1)
     auto wrap8 = [&](uint32_t i) { return min(i, i - size) << 3; };
     const f32x4 p_cc = sn_table_load_pair(rsrc, wrap8(i_cc), level_off_bytes);
@@ -342,8 +344,8 @@ SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t leve
         off[a] = __builtin_amdgcn_fractf(x);
         f[a] = (uint32_t)(int)x;
     }
-    const uint32_t R2 = R * R;
-    const uint32_t i_ff = f[0] + f[1] * R + f[2] * R2;
+    const uint32_t R2 = R * R;  // R <= 255: 24-bit products (full-rate multiplies)
+    const uint32_t i_ff = f[0] + __umul24(f[1], R) + __umul24(f[2], R2);
     const uint32_t i_cf = i_ff + R, i_fc = i_ff + R2, i_cc = i_ff + R + R2;
     const f32x4 p_cc = sn_table_load_pair(rsrc, i_cc << 3, level_off_bytes);
     const f32x4 p_fc = sn_table_load_pair(rsrc, i_fc << 3, level_off_bytes);
