@@ -182,13 +182,16 @@ struct SnMainImgH {
                          BC2 = SnMainImg::BC2 - SnMainImg::B1, W3 = SnMainImg::W3 - SnMainImg::B1, B3 = SnMainImg::B3 - SnMainImg::B1;
 };
 
-// two fp32 -> packed fp16 hi pair and lo pair
+// two fp32 -> packed fp16 hi pair and lo pair: hi = RTZ(a), lo = RTZ(a - hi).  The difference is formed by v_fma_mix_f32, which
+// reads the fp16 half straight out of the packed register (fma(hi16, -1.0, a) in fp32, exact) -- 4 instructions per pair
+// instead of mask, mask, convert, packed subtract, convert.  hipcc does not select fma_mix for this pattern, hence the asm
+// (a plain VALU instruction: no hazard class of its own; checked on hardware by tools/probes/mix_probe).
 SN_DEV void sn_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const float ah = __uint_as_float(__float_as_uint(a) & 0xffffe000u);
-    const float bh = __uint_as_float(__float_as_uint(b) & 0xffffe000u);
-    hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(ah, bh));
-    const f32x2 d = f32x2{a, b} - f32x2{ah, bh};  // one v_pk_add_f32
-    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(d.x, d.y));
+    hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+    float la, lb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hi), "v"(b));
+    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(la, lb));
 }
 
 struct SnOpH {  // one B operand (8 k-slots of one 32-sample tile), hi and lo parts
