@@ -344,13 +344,15 @@ SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t leve
         off[a] = __builtin_amdgcn_fractf(x);
         f[a] = (uint32_t)(int)x;
     }
-    const uint32_t R2 = R * R;  // R <= 255: 24-bit products (full-rate multiplies)
-    const uint32_t i_ff = f[0] + __umul24(f[1], R) + __umul24(f[2], R2);
-    const uint32_t i_cf = i_ff + R, i_fc = i_ff + R2, i_cc = i_ff + R + R2;
-    const f32x4 p_cc = sn_table_load_pair(rsrc, i_cc << 3, level_off_bytes);
-    const f32x4 p_fc = sn_table_load_pair(rsrc, i_fc << 3, level_off_bytes);
-    const f32x4 p_ff = sn_table_load_pair(rsrc, i_ff << 3, level_off_bytes);
-    const f32x4 p_cf = sn_table_load_pair(rsrc, i_cf << 3, level_off_bytes);
+    // byte offsets directly: the x8 is folded into the (wave-uniform) strides; R <= 255, so 8 R^2 and every product fit 24 bits
+    // (full-rate v_mul_u32_u24 / v_mad_u32_u24; v_mul_lo_u32 is quarter rate)
+    const uint32_t R8 = R << 3, R28 = (R * R) << 3;
+    const uint32_t b_ff = (f[0] << 3) + __umul24(f[1], R8) + __umul24(f[2], R28);
+    const uint32_t b_cf = b_ff + R8, b_fc = b_ff + R28, b_cc = b_ff + (R8 + R28);
+    const f32x4 p_cc = sn_table_load_pair(rsrc, b_cc, level_off_bytes);
+    const f32x4 p_fc = sn_table_load_pair(rsrc, b_fc, level_off_bytes);
+    const f32x4 p_ff = sn_table_load_pair(rsrc, b_ff, level_off_bytes);
+    const f32x4 p_cf = sn_table_load_pair(rsrc, b_cf, level_off_bytes);
     f32x2 v[8];
     v[3] = f32x2{p_cc.x, p_cc.y};
     v[0] = f32x2{p_cc.z, p_cc.w};
