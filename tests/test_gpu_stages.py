@@ -221,3 +221,25 @@ def test_pdf_sample(gpu, R, N, M):
     # a flipped tie still lands on (almost) the same bin value: the interpolant is continuous across a knot
     assert float((bins.cpu() - rb).abs().max()) <= 1e-5
     assert torch.all(bins[:, 1:] >= bins[:, :-1])
+
+
+def test_composite_nan_and_inf_inputs(gpu):
+    """torch.nan_to_num on the weights and on the per-sample colours (A10, A17): a NaN density zeroes its own and every later
+    weight of the ray (the cumulative optical depth is NaN from there on), an infinite density makes the sample opaque, NaN
+    colours count as 0."""
+    R, S = 64, 24
+    g = torch.Generator().manual_seed(9)
+    bins = torch.cumsum(torch.rand(R, S + 1, generator=g) * 0.1, dim=-1)
+    density = torch.exp(torch.randn(R, S, generator=g))
+    density[:16, 5] = float("nan")
+    density[16:32, 7] = float("inf")
+    rgb_s = torch.rand(R, S, 3, generator=g)
+    rgb_s[32:48, 3] = float("nan")
+    out = ops.composite(bins.to(gpu), density.to(gpu), rgb_s.to(gpu))
+    starts, ends = bins[:, :-1, None], bins[:, 1:, None]
+    w = onf.get_weights(ends - starts, density[..., None])
+    assert torch.isfinite(out["weights"]).all() and torch.isfinite(out["rgb"]).all()
+    assert float((out["weights"].cpu() - w[..., 0]).abs().max()) <= 2e-6
+    assert float(out["weights"][:16, 5:].abs().max()) == 0.0
+    assert float((out["rgb"].cpu() - onf.render_rgb(rgb_s, w)).abs().max()) <= 1e-5
+    assert float((out["accumulation"].cpu() - onf.render_accumulation(w)[:, 0]).abs().max()) <= 1e-5
