@@ -62,7 +62,7 @@ struct SnContext {
 };
 
 #ifndef SN_DENSE_LEVELS_DEFAULT
-#define SN_DENSE_LEVELS_DEFAULT 8
+#define SN_DENSE_LEVELS_DEFAULT 9
 #endif
 
 namespace {
@@ -119,9 +119,9 @@ int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, 
     memset(&res, 0, sizeof(res));
     if (d.grid_mode != 0 || want <= 0 || !table.ptr) return SN_OK;
     uint64_t bytes = 0;
-    uint32_t R[8];
+    uint32_t R[9];
     int nd = 0;
-    for (int l = 0; l < want && l < d.num_levels && l < 8; ++l) {
+    for (int l = 0; l < want && l < d.num_levels && l < 9; ++l) {
         const uint64_t r = (uint64_t)d.scalings[l] + 2;
         if (r > 255 || r * r * r * 8 > 100ull * 1000 * 1000) break;
         R[l] = (uint32_t)r;
@@ -604,7 +604,7 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
     // torch grids: de-hashed copies of the coarse levels (SN_DENSE_LEVELS caps the count; 0 = off)
     {
         const char* e = getenv("SN_DENSE_LEVELS");
-        const int want = std::max(0, std::min(e ? atoi(e) : SN_DENSE_LEVELS_DEFAULT, 8));
+        const int want = std::max(0, std::min(e ? atoi(e) : SN_DENSE_LEVELS_DEFAULT, 9));
         if (int rc = build_dense_copies(h, d.main_field, h->table_main, want, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st))
             return rc;
         for (int i = 0; i < d.num_proposals; ++i)
@@ -825,6 +825,7 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
         case 6: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 6); break;       \
         case 7: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 7); break;       \
         case 8: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 8); break;       \
+        case 9: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 9); break;       \
         default: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, -1); break;     \
     }
     if (ablate == 2 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 0, 2, 0, -1);

@@ -332,7 +332,7 @@ SN_DEV f32x2 sn_hash_level_dense_pairs(__amdgpu_buffer_rsrc_t rsrc, uint32_t lev
 struct SnDenseCopy {
     const float* base;     // all copied levels, back to back
     uint32_t bytes;
-    uint32_t off[8];       // byte offset of level l's copy (l < number of copied levels <= 8)
+    uint32_t off[9];       // byte offset of level l's copy (l < number of copied levels <= 9)
 };
 
 SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_off_bytes, const float q[3], float scale, uint32_t R) {
@@ -394,7 +394,7 @@ SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int l
             feat[2 * l + 1] = e.y;
             continue;
         }
-        if (ARITH == 1 && ND > 0 && l < ND && l < 8) {  // torch grid: de-hashed copy of a coarse level (R packed like a dense tcnn level)
+        if (ARITH == 1 && ND > 0 && l < ND && l < 9) {  // torch grid: de-hashed copy of a coarse level (R packed like a dense tcnn level)
             const f32x2 e = sn_hash_level_dense_copy(sn_table_rsrc(dense->base, dense->bytes), dense->off[l], q, scal[l], sn_grid_dense_res(*grid, l));
             feat[2 * l] = e.x;
             feat[2 * l + 1] = e.y;
