@@ -135,7 +135,9 @@ int sn_intersect_with_aabb(const float* origins, const float* directions, int64_
 size_t sn_workspace_bytes(SnHandle h, int32_t height, int32_t width, const SnRenderOpts* opts);
 /* origins/directions: [H,W,3]; nears/fars: [H,W,1] or NULL (collider).  Outputs (any may be NULL):
  * rgb [H,W,3], depth [H,W,1] (median), accumulation [H,W,1], expected_depth [H,W,1],
- * prop_depth_i [H,W,1].  Row-major ray order, identical to the reference's chunk loop. */
+ * prop_depth_i [H,W,1].  Row-major ray order, identical to the reference's chunk loop.  * Concurrency: calls may come from several host threads and HIP streams, on one handle or several; the library orders the
+ * renders of a process on the device (each waits for the previous render's completion event), see DESIGN.md "Open issue".
+ */
 int sn_render_rays(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars,
                    int32_t height, int32_t width, const SnRenderOpts* opts,
                    float* rgb, float* depth, float* accumulation, float* expected_depth,

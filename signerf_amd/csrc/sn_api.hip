@@ -67,6 +67,33 @@ struct SnContext {
 
 namespace {
 
+// Render calls of one process are chained on the device, whatever host threads / HIP streams they come from: each call makes its
+// stream wait for the previous render's completion event and records its own when it has enqueued its kernels.  Host threads
+// stay asynchronous; only the kernels are ordered (a render fills the chip anyway).  Reason (r01, tools/concurrency_probe.py):
+// with two renders in flight on two hardware queues, the fused proposal kernel returns wrong values in lanes 48-63 of a few
+// scattered 8x8 tiles per frame.  One queue at a time (GPU_MAX_HW_QUEUES=1) or this chain never shows it; fences, agent-scope
+// scratch accesses, a persistent workspace and separate handles do not help, and the stage kernels with the same arithmetic are
+// clean, so it is not a memory-ordering or host-side race -- the cause is open.
+struct RenderChain {
+    std::mutex mu;
+    hipEvent_t ev[16] = {};
+    bool recorded[16] = {};
+};
+RenderChain g_chain;
+
+struct RenderChainGuard {
+    hipStream_t st;
+    int dev;
+    std::unique_lock<std::mutex> lk;
+    RenderChainGuard(hipStream_t s, int d) : st(s), dev(d & 15), lk(g_chain.mu) {
+        if (g_chain.recorded[dev]) (void)hipStreamWaitEvent(st, g_chain.ev[dev], 0);
+    }
+    ~RenderChainGuard() {
+        if (!g_chain.ev[dev] && hipEventCreateWithFlags(&g_chain.ev[dev], hipEventDisableTiming) != hipSuccess) return;
+        if (hipEventRecord(g_chain.ev[dev], st) == hipSuccess) g_chain.recorded[dev] = true;
+    }
+};
+
 int fail(SnHandle h, int code, const std::string& msg) {
     if (h) {
         std::lock_guard<std::mutex> g(h->mu);
@@ -687,6 +714,7 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
     if (!opts->workspace || opts->workspace_bytes < wp.total)
         return fail(h, SN_ERR_WORKSPACE, "sn_render_rays: workspace too small, need " + std::to_string(wp.total) + " bytes");
     hipStream_t st = (hipStream_t)stream;
+    RenderChainGuard chain(st, h->device);  // orders this render after the previous one of the process, on the device
     char* ws = (char*)opts->workspace;
     const SnFieldDesc& d = h->desc;
     const TileGeom g = tile_geometry(height, width);

@@ -171,29 +171,36 @@ def test_state_dict_boundary(gpu):
     assert set(groups) == {"proposal_networks", "fields"} and model.get_training_callbacks(None) == []
 
 
-def test_concurrent_renders_share_one_model(gpu):
+@pytest.mark.parametrize("two_models", [False, True])
+def test_concurrent_renders_from_two_threads(gpu, two_models):
     """The reference renders from two host threads (GUI callback + viewer, interface.py:83-116, viewer.py:334-336).  Two
-    threads on two streams, one model / one library handle: scratch is per call, so every frame equals its sequential render."""
+    threads on two streams, one model (or two): every frame equals its sequential render.  The library chains renders on the
+    device (sn_api.hip, RenderChain): without the chain this test fails in lanes 48-63 of scattered tiles on the proposal path
+    (r01, tools/concurrency_probe.py)."""
     import threading
 
     cfg = small_config(num_proposal_samples_per_ray=(48, 24), num_nerf_samples_per_ray=16)
     model, _ = make_model(cfg, gpu)
+    model_b = make_model(cfg, gpu)[0] if two_models else model
     c2w = scene.benchmark_cameras(8)
-    cams = Cameras(c2w[:, :3], 70.0, 70.0, 32.0, 24.0, 64, 48).to(gpu)
+    cams = Cameras(c2w[:, :3], 280.0, 280.0, 128.0, 96.0, 256, 192).to(gpu)
     bundles = [cams[i].generate_rays(0) for i in range(4)]
     expect = [{k: v.clone() for k, v in model.get_outputs_for_camera_ray_bundle(b).items()} for b in bundles]
     torch.cuda.synchronize()
-    results, errors = {}, []
+    bad, errors = [], []
 
     def worker(tid):
         try:
+            m = model if tid == 0 else model_b
             stream = torch.cuda.Stream(device=gpu)
             with torch.cuda.stream(stream):
-                for rep in range(6):
+                for rep in range(12):
                     for i in (range(4) if tid == 0 else reversed(range(4))):
-                        out = model.get_outputs_for_camera_ray_bundle(bundles[i])
-                        results[(tid, rep, i)] = {k: v.clone() for k, v in out.items()}
-            stream.synchronize()
+                        out = m.get_outputs_for_camera_ray_bundle(bundles[i])
+                        stream.synchronize()
+                        for k in ("rgb", "depth", "accumulation", "prop_depth_1"):
+                            if not torch.equal(out[k], expect[i][k]):
+                                bad.append((tid, rep, i, k, int((out[k] != expect[i][k]).sum())))
         except Exception as e:  # pragma: no cover
             errors.append(e)
 
@@ -204,10 +211,7 @@ def test_concurrent_renders_share_one_model(gpu):
         t.join()
     torch.cuda.synchronize()
     assert not errors, errors
-    assert len(results) == 2 * 6 * 4
-    for (tid, rep, i), out in results.items():
-        for k in ("rgb", "depth", "accumulation"):
-            assert torch.equal(out[k], expect[i][k]), (tid, rep, i, k)
+    assert not bad, bad[:8]
 
 
 def test_row_blocks_render_equals_full_frame(gpu):
