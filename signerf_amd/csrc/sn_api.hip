@@ -86,7 +86,9 @@ struct RenderChainGuard {
     int dev;
     std::unique_lock<std::mutex> lk;
     RenderChainGuard(hipStream_t s, int d) : st(s), dev(d & 15), lk(g_chain.mu) {
-        if (g_chain.recorded[dev]) (void)hipStreamWaitEvent(st, g_chain.ev[dev], 0);
+        // SN_NO_RENDER_CHAIN=1 (diagnostics only, tools/concurrency_probe.py): leave concurrent renders unordered
+        static const bool off = getenv("SN_NO_RENDER_CHAIN") != nullptr;
+        if (g_chain.recorded[dev] && !off) (void)hipStreamWaitEvent(st, g_chain.ev[dev], 0);
     }
     ~RenderChainGuard() {
         if (!g_chain.ev[dev] && hipEventCreateWithFlags(&g_chain.ev[dev], hipEventDisableTiming) != hipSuccess) return;

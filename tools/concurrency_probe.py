@@ -12,7 +12,8 @@ ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=40);
 ap.add_argument("--size", type=int, default=64)
 ap.add_argument("--mode", default="shared", help="shared | two-models | serial (host lock around render+sync)"); a = ap.parse_args()
 gpu = torch.device("cuda", 0)
-cfg = small_config(num_proposal_iterations=a.props, num_proposal_samples_per_ray=(48, 24) if a.props else (), num_nerf_samples_per_ray=16)
+cfg = small_config(num_proposal_iterations=a.props, num_proposal_samples_per_ray=((48, 24) if a.props == 2 else (48,) if a.props == 1 else ()),
+                   num_nerf_samples_per_ray=16)
 model, _ = make_model(cfg, gpu)
 model2 = make_model(cfg, gpu)[0] if a.mode == 'two-models' else model
 glock = threading.Lock()
