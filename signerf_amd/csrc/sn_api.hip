@@ -62,7 +62,7 @@ struct SnContext {
 };
 
 #ifndef SN_DENSE_LEVELS_DEFAULT
-#define SN_DENSE_LEVELS_DEFAULT 9
+#define SN_DENSE_LEVELS_DEFAULT 11
 #endif
 
 namespace {
@@ -138,21 +138,23 @@ SnGridLevels grid_levels(const SnHashMlpDesc& d) {
     return g;
 }
 
-// De-hashed copies of the leading coarse levels of a torch-path grid (sn_device.h, SnDenseCopy).  A level is copied while its
-// resolution R = scale + 2 fits the packed 8 bits and its copy stays under 100 MB (a fine level's copy is R^3 / T times larger
-// than its hashed slot; measured r01: the main grid gains up to level 8, 18x).
-int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, int want, DevBuf& buf, SnDenseCopy& info, SnGridLevels& res,
-                       int& nd_out, hipStream_t st) {
+// De-hashed copies of the leading levels of a torch-path grid (sn_device.h, SnDenseCopy).  A level is copied while its copy
+// stays under `cap_mb` (a fine level's copy is R^3 / T times larger than its hashed slot) and 8 R^2 fits 24 bits.  Measured r01:
+// the main grid (T = 2^19, one pass of 48-64 samples per ray) still gains from level 10 (R = 408, 543 MB; same-box 3.85 / 3.55 /
+// 3.33 / 3.30 / 3.26 ms for 0 / 8 / 9 / 10 / 11 copied levels), the proposal nets (352 samples per ray over the coarse levels)
+// lose with the 137 MB copy of the second net's finest level (frame 18.8 vs 17.5 ms) -- hence the two caps.
+int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, int want, uint64_t cap_mb, DevBuf& buf, SnDenseCopy& info,
+                       SnGridLevels& res, int& nd_out, hipStream_t st) {
     nd_out = 0;
     memset(&info, 0, sizeof(info));
     memset(&res, 0, sizeof(res));
     if (d.grid_mode != 0 || want <= 0 || !table.ptr) return SN_OK;
     uint64_t bytes = 0;
-    uint32_t R[9];
+    uint32_t R[11];
     int nd = 0;
-    for (int l = 0; l < want && l < d.num_levels && l < 9; ++l) {
+    for (int l = 0; l < want && l < d.num_levels && l < 11; ++l) {
         const uint64_t r = (uint64_t)d.scalings[l] + 2;
-        if (r > 255 || r * r * r * 8 > 100ull * 1000 * 1000) break;
+        if (r > 1400 || r * r * r * 8 > cap_mb * 1000 * 1000) break;  // 8 R^2 must fit 24 bits
         R[l] = (uint32_t)r;
         info.off[l] = (uint32_t)bytes;
         bytes += (r * r * r + 1) * 8;  // one spare row: the last entry's 16-byte read stays inside the buffer
@@ -170,7 +172,7 @@ int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, 
         const uint32_t n = R[l] * R[l] * R[l];
         hipLaunchKernelGGL(sn_build_dense_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)table.ptr,
                            (float*)((char*)buf.ptr + info.off[l]), l, d.log2_hashmap_size, R[l]);
-        res.packed[l >> 2] |= R[l] << ((l & 3) * 8);
+        info.res[l] = R[l];
     }
     SN_HIP(h, hipGetLastError());
     info.base = (const float*)buf.ptr;
@@ -633,11 +635,11 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
     // torch grids: de-hashed copies of the coarse levels (SN_DENSE_LEVELS caps the count; 0 = off)
     {
         const char* e = getenv("SN_DENSE_LEVELS");
-        const int want = std::max(0, std::min(e ? atoi(e) : SN_DENSE_LEVELS_DEFAULT, 9));
-        if (int rc = build_dense_copies(h, d.main_field, h->table_main, want, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st))
+        const int want = std::max(0, std::min(e ? atoi(e) : SN_DENSE_LEVELS_DEFAULT, 11));
+        if (int rc = build_dense_copies(h, d.main_field, h->table_main, want, 600, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st))
             return rc;
         for (int i = 0; i < d.num_proposals; ++i)
-            if (int rc = build_dense_copies(h, d.proposals[i], h->table_prop[i], want, h->dense_prop[i], h->dense_info_prop[i],
+            if (int rc = build_dense_copies(h, d.proposals[i], h->table_prop[i], want, 100, h->dense_prop[i], h->dense_info_prop[i],
                                             h->dense_res_prop[i], h->nd_prop[i], st))
                 return rc;
     }
@@ -856,6 +858,8 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
         case 7: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 7); break;       \
         case 8: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 8); break;       \
         case 9: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 9); break;       \
+        case 10: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 10); break;     \
+        case 11: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 11); break;     \
         default: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, -1); break;     \
     }
     if (ablate == 2 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 0, 2, 0, -1);

@@ -328,11 +328,12 @@ SN_DEV f32x2 sn_hash_level_dense_pairs(__amdgpu_buffer_rsrc_t rsrc, uint32_t lev
 //     D_l[x + R y + R^2 z] = table[l][hash(x, y, z)],   R = scale_l + 2,   0 <= x, y, z <= scale_l + 1
 // built once by sn_finalize_weights.  In D_l the x + 1 corner is the next row, so a level costs four 16-byte gathers instead
 // of eight 8-byte ones and neighbouring voxels share cache lines.  Values are the table's own, so results are bit-identical
-// to the hashed reads.  Only levels with R <= 255 (packed 8-bit resolutions) and a few MB each are copied.
+// to the hashed reads.  Which levels are copied is the host's choice (sn_api.hip, build_dense_copies).
 struct SnDenseCopy {
     const float* base;     // all copied levels, back to back
     uint32_t bytes;
-    uint32_t off[9];       // byte offset of level l's copy (l < number of copied levels <= 9)
+    uint32_t off[11];      // byte offset of level l's copy (l < number of copied levels <= 11)
+    uint32_t res[11];      // R of level l
 };
 
 SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_off_bytes, const float q[3], float scale, uint32_t R) {
@@ -394,8 +395,10 @@ SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int l
             feat[2 * l + 1] = e.y;
             continue;
         }
-        if (ARITH == 1 && ND > 0 && l < ND && l < 9) {  // torch grid: de-hashed copy of a coarse level (R packed like a dense tcnn level)
-            const f32x2 e = sn_hash_level_dense_copy(sn_table_rsrc(dense->base, dense->bytes), dense->off[l], q, scal[l], sn_grid_dense_res(*grid, l));
+        if (ARITH == 1 && ND > 0 && l < ND && l < 11) {  // torch grid: de-hashed copy of a coarse level
+            uint32_t R = dense->res[l];
+            asm volatile("" : "+s"(R));  // keep the per-level strides out of the loop-invariant set (SGPR pressure, see sn_grid_dense_res)
+            const f32x2 e = sn_hash_level_dense_copy(sn_table_rsrc(dense->base, dense->bytes), dense->off[l], q, scal[l], R);
             feat[2 * l] = e.x;
             feat[2 * l + 1] = e.y;
             continue;
