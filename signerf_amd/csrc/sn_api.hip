@@ -69,11 +69,10 @@ namespace {
 
 // Render calls of one process are chained on the device, whatever host threads / HIP streams they come from: each call makes its
 // stream wait for the previous render's completion event and records its own when it has enqueued its kernels.  Host threads
-// stay asynchronous; only the kernels are ordered (a render fills the chip anyway).  Reason (r01, tools/concurrency_probe.py):
-// with two renders in flight on two hardware queues, the fused proposal kernel returns wrong values in lanes 48-63 of a few
-// scattered 8x8 tiles per frame.  One queue at a time (GPU_MAX_HW_QUEUES=1) or this chain never shows it; fences, agent-scope
-// scratch accesses, a persistent workspace and separate handles do not help, and the stage kernels with the same arithmetic are
-// clean, so it is not a memory-ordering or host-side race -- the cause is open.
+// stay asynchronous; only the kernels are ordered (a render fills the chip anyway).  History (r01, tools/concurrency_probe.py):
+// two renders in flight on two hardware queues corrupted lanes 48-63 of a few tiles per frame; the cause turned out to be an
+// instruction hazard in the proposal MLP that only the mixed-kernel issue pattern exposes (sn_proposal.h, sn_prop_h0) and is
+// fixed there.  The chain stays as a cheap second line of defence; SN_NO_RENDER_CHAIN=1 disables it (the tests run both ways).
 struct RenderChain {
     std::mutex mu;
     hipEvent_t ev[16] = {};
@@ -87,7 +86,7 @@ struct RenderChainGuard {
     std::unique_lock<std::mutex> lk;
     RenderChainGuard(hipStream_t s, int d) : st(s), dev(d & 15), lk(g_chain.mu) {
         // SN_NO_RENDER_CHAIN=1 (diagnostics only, tools/concurrency_probe.py): leave concurrent renders unordered
-        static const bool off = getenv("SN_NO_RENDER_CHAIN") != nullptr;
+        const bool off = getenv("SN_NO_RENDER_CHAIN") != nullptr;
         if (g_chain.recorded[dev] && !off) (void)hipStreamWaitEvent(st, g_chain.ev[dev], 0);
     }
     ~RenderChainGuard() {

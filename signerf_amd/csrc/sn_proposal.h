@@ -70,7 +70,15 @@ SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, cons
     for (int j = 0; j < 8; ++j) a[j] = w2[SN_PROP_B0 / 2 + j];
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
-        const f32x2 fk = {feat[k], feat[k]};
+        // gfx950 hazard found on hardware (r01, tools/concurrency_probe.py, tools/stage_concurrency_probe.py): feat[k] is one half of
+        // a register pair written by the blend's packed ops (v_pk_fma_f32); the packed FMAs below read it with an op_sel
+        // broadcast.  hipcc (ROCm 7.2) lets the two sit back to back, and when MFMA-heavy waves of ANOTHER kernel share the SIMD
+        // (two renders on two hardware queues) the consumer sees the pair's previous contents in lanes 48-63 (the last 16-lane
+        // pass) -- a few 8x8 tiles per frame.  The same family as the v_permlane32_swap hazard (sn_swap_halves).  A copy through a
+        // plain v_mov_b32 behind one wait state removes it (0 differences in the probes; ~100 000 per run without).
+        float fs;
+        asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(fs) : "v"(feat[k]));
+        const f32x2 fk = {fs, fs};
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = __builtin_elementwise_fma(w2[(SN_PROP_W0 + k * 16) / 2 + j], fk, a[j]);
     }

@@ -171,13 +171,18 @@ def test_state_dict_boundary(gpu):
     assert set(groups) == {"proposal_networks", "fields"} and model.get_training_callbacks(None) == []
 
 
-@pytest.mark.parametrize("two_models", [False, True])
-def test_concurrent_renders_from_two_threads(gpu, two_models):
+@pytest.mark.parametrize("two_models,chain", [(False, True), (True, True), (False, False), (True, False)])
+def test_concurrent_renders_from_two_threads(gpu, monkeypatch, two_models, chain):
     """The reference renders from two host threads (GUI callback + viewer, interface.py:83-116, viewer.py:334-336).  Two
-    threads on two streams, one model (or two): every frame equals its sequential render.  The library chains renders on the
-    device (sn_api.hip, RenderChain): without the chain this test fails in lanes 48-63 of scattered tiles on the proposal path
-    (r01, tools/concurrency_probe.py)."""
+    threads on two streams, one model (or two): every frame equals its sequential render -- with the library's device-side render
+    chain and, more importantly, WITHOUT it (SN_NO_RENDER_CHAIN): kernels of the two renders then overlap on the GPU, which is
+    what exposed the packed-FMA operand hazard of the proposal MLP (sn_proposal.h; ~100 000 wrong values per run before the fix)."""
     import threading
+
+    if chain:
+        monkeypatch.delenv("SN_NO_RENDER_CHAIN", raising=False)
+    else:
+        monkeypatch.setenv("SN_NO_RENDER_CHAIN", "1")
 
     cfg = small_config(num_proposal_samples_per_ray=(48, 24), num_nerf_samples_per_ray=16)
     model, _ = make_model(cfg, gpu)

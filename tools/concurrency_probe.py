@@ -16,21 +16,38 @@ cfg = small_config(num_proposal_iterations=a.props, num_proposal_samples_per_ray
                    num_nerf_samples_per_ray=16)
 model, _ = make_model(cfg, gpu)
 model2 = make_model(cfg, gpu)[0] if a.mode == 'two-models' else model
+if a.mode == 'vs-uniform':  # thread 1 renders with the uniform sampler (main kernel only), thread 0 with the proposal path
+    cfg_u = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=48)
+    model2 = make_model(cfg_u, gpu)[0]
 glock = threading.Lock()
 W, H = a.size, (a.size * 3) // 4
 cams = Cameras(scene.benchmark_cameras(8)[:, :3], 1.1 * W, 1.1 * W, W / 2, H / 2, W, H).to(gpu)
 bundles = [cams[i].generate_rays(0) for i in range(4)]
 expect = [{k: v.clone() for k, v in model.get_outputs_for_camera_ray_bundle(b).items()} for b in bundles]
+expect2 = expect if a.mode != 'vs-uniform' else [{k: v.clone() for k, v in model2.get_outputs_for_camera_ray_bundle(b).items()} for b in bundles]
 torch.cuda.synchronize()
 shown = []
 bad = collections.Counter(); lanes = collections.Counter(); lock = threading.Lock()
 def worker(tid):
     s = torch.cuda.Stream(device=gpu)
+    if a.mode.startswith('aggressor') and tid == 1:
+        import ctypes as C
+        from signerf_amd import _lib
+        lib = _lib.load(); kind = int(a.mode.split(':')[1]); buf = torch.zeros(16, device=gpu)
+        with torch.cuda.stream(s):
+            while not done.is_set():
+                for _ in range(8):
+                    lib.sn_debug_aggressor(kind, 2000, 2048, C.c_void_p(buf.data_ptr()), C.c_void_p(s.cuda_stream))
+                s.synchronize()
+        return
     if a.mode == 'other-work' and tid == 1:
         with torch.cuda.stream(s):
-            x = torch.rand(4096, 4096, device=gpu)
+            n = int(os.environ.get('SN_PROBE_MM', '4096'))
+            dt = torch.float16 if os.environ.get('SN_PROBE_MM_HALF') else torch.float32
+            x = torch.rand(64, n, n, device=gpu, dtype=dt) if n <= 512 else torch.rand(n, n, device=gpu, dtype=dt)
             while not done.is_set():
-                x = (x @ x).clamp_(0, 1) * 0.5 + 0.1
+                for _ in range(20):
+                    x = (x @ x).clamp_(0, 1) * 0.5 + 0.1
                 s.synchronize()
         return
     with torch.cuda.stream(s):
@@ -45,7 +62,8 @@ def worker(tid):
                     s.synchronize()
                 for k in ("prop_depth_0", "prop_depth_1", "expected_depth", "rgb", "depth", "accumulation"):
                     if k not in out: continue
-                    d = (out[k] != expect[i][k]).any(dim=-1)
+                    ex = expect if tid == 0 else expect2
+                    d = (out[k] != ex[i][k]).any(dim=-1)
                     n = int(d.sum())
                     if n:
                         with lock:
@@ -56,7 +74,7 @@ def worker(tid):
                                 shown.append(1)
                                 tiles = sorted({(y // 8, x // 8) for y, x in zip(ys.tolist(), xs.tolist())})
                                 print('   tiles (ty,tx):', tiles[:40], 'n_tiles', len(tiles), 'of', ((H + 7) // 8) * ((W + 7) // 8), flush=True)
-                            if sum(bad.values()) < 2000: print(f"thread {tid} rep {rep} cam {i} {k}: {n} pixels differ, max {float((out[k]-expect[i][k]).abs().max()):.3e}", flush=True)
+                            if sum(bad.values()) < 2000: print(f"thread {tid} rep {rep} cam {i} {k}: {n} pixels differ, max {float((out[k]-ex[i][k]).abs().max()):.3e}", flush=True)
 done = threading.Event()
 ts = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
 [t.start() for t in ts]; ts[0].join(); done.set(); ts[1].join()
