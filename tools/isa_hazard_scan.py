@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Static scan of the gfx950 ISA of csrc/sn_api.hip for the hazard family found on hardware in r01:
+a packed-fp32 VALU result (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 writing v[n:n+1]) consumed within `--window` instructions
+by a SWIZZLING reader of one of its halves: v_permlane32_swap, v_fma_mix_f32, or a v_pk_* whose op_sel / op_sel_hi differs from the
+plain packed form for that operand.  hipcc does not separate such pairs.  Prints every hit as kernel:line.
+
+    python tools/isa_hazard_scan.py [--window 2]
+"""
+import argparse, os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ap = argparse.ArgumentParser(); ap.add_argument("--window", type=int, default=2); a = ap.parse_args()
+out = os.path.join(tempfile.gettempdir(), "sn_api_scan.s")
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out,
+                os.path.join(ROOT, "signerf_amd/csrc/sn_api.hip")], check=True, stderr=subprocess.DEVNULL)
+reg = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)")
+
+
+def regs(tok):
+    m = reg.fullmatch(tok.strip().rstrip(","))
+    if not m:
+        return []
+    if m.group(1):
+        return list(range(int(m.group(1)), int(m.group(2)) + 1))
+    return [int(m.group(3))]
+
+
+hits, kernel, recent = 0, None, []  # recent: list of (age, set(regs)) of packed-fp32 results
+for ln, line in enumerate(open(out), 1):
+    t = line.strip()
+    m_k = re.match(r"(_Z\w+):", t)
+    if m_k:
+        kernel, recent = m_k.group(1), []
+        continue
+    if not t or t.startswith((";", ".")) or t.endswith(":"):
+        continue
+    op, _, rest = t.partition(" ")
+    if not (op.startswith("v_") or op.startswith("s_") or op.startswith("ds_") or op.startswith("buffer") or op.startswith("global")):
+        continue
+    ops = [x for x in rest.split(";")[0].replace(", ", ",").split(",")]
+    body = rest.split(";")[0]
+    swizzle = False
+    srcs = []
+    if op.startswith("v_permlane32_swap") or op.startswith("v_fma_mix"):
+        swizzle, srcs = True, sum((regs(x.split()[0]) for x in ops[(0 if "swap" in op else 1):] if x), [])
+    elif op.startswith("v_pk_") and op.endswith("_f32"):
+        m_sel = re.search(r"op_sel:\[([0-9,]+)\]", body)
+        m_hi = re.search(r"op_sel_hi:\[([0-9,]+)\]", body)
+        sel = [int(x) for x in m_sel.group(1).split(",")] if m_sel else [0, 0, 0]
+        hi = [int(x) for x in m_hi.group(1).split(",")] if m_hi else [1, 1, 1]
+        for i, x in enumerate(ops[1:4]):
+            r = regs(x.split()[0]) if x else []
+            if r and i < len(sel) and (sel[i] != 0 or hi[i] != 1):  # operand i does not read (lo, hi) as (lo, hi)
+                swizzle = True
+                srcs += r
+    if swizzle:
+        for age, rs, pl in recent:
+            if age <= a.window and rs & set(srcs):
+                hits += 1
+                print(f"{kernel}: line {ln}: {op} reads a half of the packed result of line {pl} ({age} instruction(s) earlier)")
+    recent = [(age + 1, rs, pl) for age, rs, pl in recent if age + 1 <= a.window]
+    if op in ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"):
+        recent.append((1, set(regs(ops[0].split()[0])), ln))
+print(f"{hits} suspicious pair(s) within {a.window} instruction(s)")
+sys.exit(1 if hits else 0)
