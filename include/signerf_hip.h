@@ -110,6 +110,7 @@ const char* sn_last_error(SnHandle h);
  *   field.mlp_base.encoder.hash_table                       [L*T, 2]
  *   field.mlp_base.mlp.layers.{0,1}.{weight,bias}
  *   field.mlp_head.layers.{0,1,2}.{weight,bias}
+ *   field.mlp_pred_normals.layers.{0,1,2}.{weight,bias}, field.field_head_pred_normals.net.{weight,bias}   (optional)
  *   field.embedding_appearance.mean                         [appearance_embed_dim] (mean over rows, A14)
  *   proposal_networks.{i}.mlp_base.encoder.hash_table       [L*T, 2]
  *   proposal_networks.{i}.mlp_base.mlp.layers.{0,1}.{weight,bias}
@@ -135,13 +136,24 @@ int sn_intersect_with_aabb(const float* origins, const float* directions, int64_
 size_t sn_workspace_bytes(SnHandle h, int32_t height, int32_t width, const SnRenderOpts* opts);
 /* origins/directions: [H,W,3]; nears/fars: [H,W,1] or NULL (collider).  Outputs (any may be NULL):
  * rgb [H,W,3], depth [H,W,1] (median), accumulation [H,W,1], expected_depth [H,W,1],
- * prop_depth_i [H,W,1].  Row-major ray order, identical to the reference's chunk loop.  * Concurrency: calls may come from several host threads and HIP streams, on one handle or several; the library orders the
- * renders of a process on the device (each waits for the previous render's completion event), see DESIGN.md "Open issue".
- */
+ * prop_depth_i [H,W,1].  Row-major ray order, identical to the reference's chunk loop.
+ * Concurrency: calls may come from several host threads and HIP streams, on one handle or several; the library orders the
+ * renders of a process on the device (each waits for the previous render's completion event), see DESIGN.md §5. */
 int sn_render_rays(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars,
                    int32_t height, int32_t width, const SnRenderOpts* opts,
                    float* rgb, float* depth, float* accumulation, float* expected_depth,
                    float* prop_depth_0, float* prop_depth_1, SnStream stream);
+
+/* ---- row a16 / §8(f) row 4: the `predict_normals=True` outputs (signerf_config.py:33) --------------------------- */
+/* "normals" (analytic: minus the normalised gradient of the pre-activation density w.r.t. the field's normalised sample
+ * location, weight-composited, renormalised, mapped to [0,1]) and "pred_normals" (the field's pred-normal MLP, same
+ * rendering), [H,W,3] each, either may be NULL.  A separate launch because DatasetGenerator.render_camera never reads them
+ * (datasetgenerator.py:700-701); same rays, options and workspace as sn_render_rays (the proposal sampler is re-run).
+ * pred_normals needs field.mlp_pred_normals.layers.{0,1,2}.{weight,bias} and field.field_head_pred_normals.net.{weight,bias}
+ * uploaded before sn_finalize_weights, else SN_ERR_STATE. */
+int sn_render_normals(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars,
+                      int32_t height, int32_t width, const SnRenderOpts* opts, float* normals, float* pred_normals,
+                      SnStream stream);
 
 /* ---- stage-level entry points (same device code as the fused kernels; used by parity tests) */
 /* which: -1 main field, i >= 0 proposal net i.  q: [n,3] normalised positions in [0,1).

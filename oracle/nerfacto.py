@@ -19,8 +19,9 @@ Decisions the builder had to take (confidence "L"):
     value the field hands it, i.e. on d' = (d + 1) / 2 (``sh_remap="torch"``).
     tinycudann maps d' back to [-1, 1] first (``sh_remap="tcnn"``).  Default
     is "torch" because the parity target is the CPU path.
-  * Normals (a16) are not produced: ``render_camera`` reads only ``rgb`` and
-    ``depth`` (datasetgenerator.py:700-701).
+  * Normals (a16; ``predict_normals=True``, signerf_config.py:33) are produced only when
+    ``NerfactoConfig.predict_normals`` is set: ``render_camera`` reads only ``rgb`` and ``depth``
+    (datasetgenerator.py:700-701), the viewer can show them.
 
 Tensor conventions: everything fp32 on CPU; a parameter set is a plain dict
 keyed by nerfstudio state-dict names (see ``signerf_amd.scene``).
@@ -75,6 +76,8 @@ class NerfactoConfig:
     hidden_dim_color: int = 64
     sh_levels: int = 4
     sh_remap: str = "torch"
+    predict_normals: bool = False
+    """signerf_config.py:33 sets it; adds "normals" (analytic) and "pred_normals" to the outputs (row a16)."""
     main: HashMLPConfig = field(
         default_factory=lambda: HashMLPConfig(16, 16, 2048, 19, 2, 64, 2, 16)
     )
@@ -422,6 +425,59 @@ def field_rgb(params: Dict[str, Tensor], cfg: NerfactoConfig, directions: Tensor
 
 
 # ----------------------------------------------------------------------------
+# row a16 -- normals (``predict_normals=True``, signerf_config.py:33; [NS-RECALL], unpinned like the rest)
+# ----------------------------------------------------------------------------
+
+
+def field_analytic_normals(params: Dict[str, Tensor], cfg: NerfactoConfig, positions: Tensor) -> Tensor:
+    """``Field.get_normals``: minus the normalised gradient of the PRE-activation density w.r.t. the field's
+    ``_sample_locations`` -- the contracted, [0,1]-normalised, selector-masked positions, not the world positions.
+    positions [R,N,3] (world) -> [R,N,3].  autograd through the hash grid = the gradient of the trilinear blend."""
+    hcfg = cfg.main
+    q, _ = normalized_positions(positions)
+    with torch.enable_grad():
+        q = q.detach().clone().requires_grad_(True)
+        if hcfg.grid == "tcnn":
+            from . import tcnn_layout
+
+            meta = tcnn_layout.grid_meta(hcfg.num_levels, hcfg.base_res, hcfg.max_res, hcfg.log2_hashmap_size, hcfg.features_per_level)
+            enc = tcnn_layout.grid_encode(q.view(-1, 3), params["field.mlp_base.encoder.tcnn_grid"], meta)
+        else:
+            scalings = hash_scalings(hcfg.num_levels, hcfg.base_res, hcfg.max_res)
+            enc = hash_encode(q.view(-1, 3), params["field.mlp_base.encoder.hash_table"], scalings, hcfg.log2_hashmap_size)
+        h0 = mlp_forward(enc, params, "field.mlp_base.mlp", hcfg.num_layers)[..., 0:1]
+        (g,) = torch.autograd.grad(h0, q, grad_outputs=torch.ones_like(h0))
+    return -torch.nn.functional.normalize(g.detach(), dim=-1)
+
+
+def nerf_encoding(x: Tensor, num_frequencies: int = 2, min_freq_exp: float = 0.0, max_freq_exp: float = 1.0) -> Tensor:
+    """NeRFEncoding (torch path) as NerfactoField builds its ``position_encoding``: sin(2 pi x 2^k) for all (axis, k), then the
+    same with a pi/2 phase.  [...,3] -> [..., 3 * F * 2]."""
+    scaled = 2.0 * math.pi * x
+    freqs = 2.0 ** torch.linspace(min_freq_exp, max_freq_exp, num_frequencies)
+    si = (scaled[..., None] * freqs).reshape(*scaled.shape[:-1], -1)
+    return torch.sin(torch.cat([si, si + math.pi / 2.0], dim=-1))
+
+
+def field_pred_normals(params: Dict[str, Tensor], cfg: NerfactoConfig, positions: Tensor, mlp_out: Tensor) -> Tensor:
+    """``NerfactoField.get_outputs`` pred-normal branch: [position encoding of the WORLD positions (12) | geo features (15)]
+    -> MLP 27->64->64->64 (ReLU, linear output) -> PredNormalsFieldHead (Linear 64->3, tanh, L2-normalise)."""
+    R, N = mlp_out.shape[:2]
+    geo = mlp_out[..., 1 : 1 + cfg.geo_feat_dim]
+    x = torch.cat([nerf_encoding(positions.reshape(-1, 3)), geo.reshape(R * N, -1)], dim=-1)
+    x = mlp_forward(x, params, "field.mlp_pred_normals", 3)
+    x = torch.nn.functional.linear(x, params["field.field_head_pred_normals.net.weight"], params["field.field_head_pred_normals.net.bias"])
+    return torch.nn.functional.normalize(torch.tanh(x), dim=-1).view(R, N, 3)
+
+
+def render_normals(normals: Tensor, weights: Tensor) -> Tensor:
+    """NormalsRenderer (normalize=True: v / (|v| + 1e-10)) followed by NormalsShader ((n + 1) / 2)."""
+    n = torch.sum(weights * normals, dim=-2)
+    n = n / (torch.linalg.vector_norm(n, dim=-1, keepdim=True) + 1e-10)
+    return (n + 1.0) / 2.0
+
+
+# ----------------------------------------------------------------------------
 # A17 -- renderers (row a17)
 # ----------------------------------------------------------------------------
 
@@ -507,6 +563,10 @@ def get_outputs(params: Dict[str, Tensor], cfg: NerfactoConfig, origins: Tensor,
     }
     for i, d in enumerate(prop_depths):
         out[f"prop_depth_{i}"] = d
+    if cfg.predict_normals:
+        out["normals"] = render_normals(field_analytic_normals(params, cfg, pos), weights)
+        if "field.mlp_pred_normals.layers.0.weight" in params:  # absent from converted tiny-cuda-nn checkpoints (tcnn_import)
+            out["pred_normals"] = render_normals(field_pred_normals(params, cfg, pos, h), weights)
     if return_debug:
         dbg.update({"median_index": med_idx, "weights": weights, "density": density, "rgb_samples": rgb_s,
                     "euclid_bins": ebins, "spacing_bins": sbins, "q": q, "selector": selector, "mlp_out": h})

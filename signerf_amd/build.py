@@ -18,7 +18,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libsignerf_hip.so")
 SOURCES = ["sn_api.hip"]
-HEADERS = ["sn_device.h", "sn_main.h", "sn_mask.h", "sn_proposal.h", "sn_stage.h", os.path.join("..", "..", "include", "signerf_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "signerf_hip.h")]
 ARCH = "gfx950"
 
 

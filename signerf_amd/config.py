@@ -52,6 +52,11 @@ class NerfactoModelConfig(InstantiateConfig):
     use_average_appearance_embedding: bool = True
     appearance_embed_dim: int = 32
     predict_normals: bool = False
+    compute_normals: str = "lazy"
+    """When ``predict_normals`` is set, the outputs hold "normals" and "pred_normals" (row a16).  "lazy" (default): they are
+    rendered -- by a separate kernel -- the first time one of the two keys is read from the returned dict, so
+    ``DatasetGenerator.render_camera``, which reads only rgb and depth (datasetgenerator.py:700-701), never pays for them;
+    "always": rendered with every call, as nerfstudio does; "never": the keys are absent."""
     disable_scene_contraction: bool = False
     average_init_density: float = 1.0
     eval_num_rays_per_chunk: int = 4096

@@ -17,6 +17,7 @@
 #include "sn_device.h"
 #include "sn_main.h"
 #include "sn_mask.h"
+#include "sn_normals.h"
 #include "sn_proposal.h"
 #include "sn_stage.h"
 
@@ -49,6 +50,8 @@ struct SnContext {
     DevBuf wimg_main;                   // SnMainImg (fp32 MFMA operands)
     DevBuf wimg_main_h;                 // SnMainImgH (fp16 hi+lo MFMA operands)
     DevBuf wpack_prop[SN_MAX_PROPOSALS]; // SnPropPack
+    DevBuf wimg_normals;                // SnNormImg (sn_normals.h); built when the weights are finalized
+    bool has_pred_normals = false;      // field.mlp_pred_normals.* / field.field_head_pred_normals.* were uploaded
     DevBuf dense_main;            // de-hashed copies of the coarse levels of a torch-path main grid (sn_device.h SnDenseCopy)
     SnDenseCopy dense_info{};
     SnGridLevels dense_res{};     // their resolutions R = scale + 2, packed like a tcnn level table
@@ -610,6 +613,55 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         h->wimg_main_h.bytes = imgh.size() * 4;
     }
     SN_HIP(h, hipMemcpyAsync(h->wimg_main_h.ptr, imgh.data(), imgh.size() * 4, hipMemcpyHostToDevice, st));
+    {
+        // Normals image (sn_normals.h): the density MLP of the main image, the pred-normal MLP (if uploaded) in the colour slots,
+        // and the transposed layer of the reverse pass.  The pred-normal MLP's last linear layer (64 -> 64, no activation) and
+        // PredNormalsFieldHead's Linear(64 -> 3) are multiplied together here.
+        const std::string pn = "field.mlp_pred_normals.layers.", hd = "field.field_head_pred_normals.net.";
+        const int pin = 12 + d.geo_feat_dim;
+        const std::vector<float>*w0 = find(h, pn + "0.weight", (size_t)64 * pin), *c0 = find(h, pn + "0.bias", 64),
+                                 *w1 = find(h, pn + "1.weight", 64 * 64), *c1 = find(h, pn + "1.bias", 64),
+                                 *w2 = find(h, pn + "2.weight", 64 * 64), *c2 = find(h, pn + "2.bias", 64),
+                                 *wh = find(h, hd + "weight", 3 * 64), *ch = find(h, hd + "bias", 3);
+        h->has_pred_normals = w0 && c0 && w1 && c1 && w2 && c2 && wh && ch;
+        SnFieldDesc dn = d;
+        dn.appearance_embed_dim = 0;
+        const int sh = d.sh_levels * d.sh_levels, cin_n = sh + d.geo_feat_dim;
+        std::vector<float> P1((size_t)64 * cin_n, 0.0f), z64(64, 0.0f), z6464(64 * 64, 0.0f), Wf(3 * 64, 0.0f), bf(3, 0.0f);
+        if (h->has_pred_normals) {
+            for (int n = 0; n < 64; ++n) {
+                for (int k = 0; k < 12; ++k) P1[(size_t)n * cin_n + k] = (*w0)[(size_t)n * pin + k];  // position encoding -> SH slots
+                for (int k = 0; k < d.geo_feat_dim; ++k) P1[(size_t)n * cin_n + sh + k] = (*w0)[(size_t)n * pin + 12 + k];
+            }
+            for (int n = 0; n < 3; ++n) {
+                double b = (*ch)[n];
+                for (int j = 0; j < 64; ++j) b += (double)(*wh)[n * 64 + j] * (double)(*c2)[j];
+                bf[n] = (float)b;
+                for (int k = 0; k < 64; ++k) {
+                    double a = 0.0;
+                    for (int j = 0; j < 64; ++j) a += (double)(*wh)[n * 64 + j] * (double)(*w2)[j * 64 + k];
+                    Wf[n * 64 + k] = (float)a;
+                }
+            }
+        }
+        std::vector<float> nimg = build_main_image(dn, t[0]->data(), t[1]->data(), t[2]->data(), t[3]->data(), P1.data(),
+                                                   h->has_pred_normals ? c0->data() : z64.data(),
+                                                   h->has_pred_normals ? w1->data() : z6464.data(),
+                                                   h->has_pred_normals ? c1->data() : z64.data(), Wf.data(), bf.data(), nullptr);
+        nimg.resize(SnNormImg::TOTAL, 0.0f);
+        // reverse pass: row f <- sum over hidden j of W1[j][f] * W2[0][j] * mask_j; slot (t, h) <-> hidden (t/16)*32 + rho(t%16) + 4h
+        for (int t32 = 0; t32 < 32; ++t32)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int f = lane & 31, hh = lane >> 5;
+                const int hid = (t32 / 16) * 32 + rho(t32 % 16) + 4 * hh;
+                nimg[SnNormImg::WB + ((t32 / 4) * 64 + lane) * 4 + (t32 % 4)] = (*t[0])[hid * 32 + f] * (*t[2])[hid];
+            }
+        if (!h->wimg_normals.ptr) {
+            SN_HIP(h, hipMalloc(&h->wimg_normals.ptr, nimg.size() * 4));
+            h->wimg_normals.bytes = nimg.size() * 4;
+        }
+        SN_HIP(h, hipMemcpyAsync(h->wimg_normals.ptr, nimg.data(), nimg.size() * 4, hipMemcpyHostToDevice, st));
+    }
     for (int i = 0; i < d.num_proposals; ++i) {
         const std::string pre = "proposal_networks." + std::to_string(i) + ".mlp_base.";
         if (!h->table_prop[i].ptr) return fail(h, SN_ERR_STATE, "missing " + pre + "encoder.hash_table");
@@ -704,6 +756,73 @@ size_t sn_workspace_bytes(SnHandle h, int32_t height, int32_t width, const SnRen
     return plan_workspace(height, width, *opts).total;
 }
 
+// K2: proposal sampler (rows a8-a12) -> final euclidean bins [tile][S+1][64] in the workspace.  Shared by the colour render and
+// the normals render.
+static int launch_proposals(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars,
+                            int32_t height, int32_t width, const SnRenderOpts* opts, const WorkspacePlan& wp, const TileGeom& g, char* ws,
+                            float* prop_depth_0, float* prop_depth_1, hipStream_t st, float** ebins_out) {
+    const SnFieldDesc& d = h->desc;
+    const int nprop = opts->num_proposal_iterations;
+    const float* d_sbins = opts->initial_spacing_bins;
+    float* d_ebins = (float*)(ws + wp.off_ebins);
+    SnPropParams pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.origins = origins;
+    pp.directions = directions;
+    pp.nears = nears;
+    pp.fars = fars;
+    pp.sbins0 = d_sbins;
+    for (int i = 0; i < SN_MAX_PROPOSALS; ++i) pp.pdf_u[i] = opts->pdf_u[i];
+    pp.ebins_out = d_ebins;
+    pp.scratch = (float*)(ws + wp.off_prop_scratch);
+    pp.prop_depth[0] = prop_depth_0;
+    pp.prop_depth[1] = prop_depth_1;
+    pp.height = height;
+    pp.width = width;
+    pp.tile_w_log2 = g.tw_log2;
+    pp.tile_h_log2 = g.th_log2;
+    pp.tiles_x = g.tiles_x;
+    pp.tiles_y = g.tiles_y;
+    pp.n_levels = nprop;
+    for (int i = 0; i < nprop; ++i) {
+        pp.pairs[i] = (const float*)h->pairs_prop[i].ptr;
+        pp.pinfo[i] = h->pinfo_prop[i];
+        pp.pairs_bytes[i] = (uint32_t)h->pairs_prop[i].bytes;
+        pp.wpack[i] = (const float*)h->wpack_prop[i].ptr;
+        pp.tables[i] = (const float*)h->table_prop[i].ptr;
+        pp.table_bytes[i] = (uint32_t)h->table_prop[i].bytes;
+        pp.grid[i] = grid_levels(d.proposals[i]);
+        if (d.proposals[i].grid_mode == 0 && h->nd_prop[i] > 0) {
+            pp.grid[i] = h->dense_res_prop[i];
+            pp.dense[i] = h->dense_info_prop[i];
+        }
+        pp.log2_t[i] = d.proposals[i].log2_hashmap_size;
+        for (int l = 0; l < 5; ++l) pp.scal[i][l] = d.proposals[i].scalings[l];
+        pp.n_samples[i] = opts->num_proposal_samples[i];
+    }
+    pp.n_final = opts->num_nerf_samples;
+    pp.near_plane = opts->near_plane;
+    pp.far_plane = opts->far_plane;
+    pp.avg_density = d.average_init_density;
+    pp.hist_pad = d.histogram_padding;
+    const dim3 pgrid((unsigned)wp.prop_blocks), pblock(64 * SN_PROP_WAVES);
+    if (d.proposals[0].grid_mode == 1) {
+        // nerfacto's proposal nets (max_res 128 / 256, T = 2^17) have 3 and 2 leading dense levels; other shapes take the
+        // run-time form
+        const int nd0 = leading_dense(d.proposals[0]), nd1 = nprop > 1 ? leading_dense(d.proposals[1]) : 2;
+        if (nd0 == 3 && nd1 == 2 && h->dense_pairs_ok) hipLaunchKernelGGL((sn_proposal_kernel<1, 3, 2>), pgrid, pblock, 0, st, pp);
+        else hipLaunchKernelGGL((sn_proposal_kernel<1, -1, -1>), pgrid, pblock, 0, st, pp);
+    } else if (nprop == 2 && h->nd_prop[0] == 5 && h->nd_prop[1] == 4) {
+        // nerfacto's nets (max_res 128 / 256): every level but the finest of the second net has a de-hashed copy
+        hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4>), pgrid, pblock, 0, st, pp);
+    } else {
+        hipLaunchKernelGGL((sn_proposal_kernel<0, -1, -1>), pgrid, pblock, 0, st, pp);
+    }
+    SN_HIP(h, hipGetLastError());
+    *ebins_out = d_ebins;
+    return SN_OK;
+}
+
 int sn_render_rays(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars, int32_t height,
                    int32_t width, const SnRenderOpts* opts, float* rgb, float* depth, float* accumulation, float* expected_depth,
                    float* prop_depth_0, float* prop_depth_1, SnStream stream) {
@@ -735,63 +854,9 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
     }
 
     float* d_ebins = nullptr;
-    if (nprop > 0) {
-        d_ebins = (float*)(ws + wp.off_ebins);
-        SnPropParams pp;
-        memset(&pp, 0, sizeof(pp));
-        pp.origins = origins;
-        pp.directions = directions;
-        pp.nears = nears;
-        pp.fars = fars;
-        pp.sbins0 = d_sbins;
-        for (int i = 0; i < SN_MAX_PROPOSALS; ++i) pp.pdf_u[i] = opts->pdf_u[i];
-        pp.ebins_out = d_ebins;
-        pp.scratch = (float*)(ws + wp.off_prop_scratch);
-        pp.prop_depth[0] = prop_depth_0;
-        pp.prop_depth[1] = prop_depth_1;
-        pp.height = height;
-        pp.width = width;
-        pp.tile_w_log2 = g.tw_log2;
-        pp.tile_h_log2 = g.th_log2;
-        pp.tiles_x = g.tiles_x;
-        pp.tiles_y = g.tiles_y;
-        pp.n_levels = nprop;
-        for (int i = 0; i < nprop; ++i) {
-            pp.pairs[i] = (const float*)h->pairs_prop[i].ptr;
-            pp.pinfo[i] = h->pinfo_prop[i];
-            pp.pairs_bytes[i] = (uint32_t)h->pairs_prop[i].bytes;
-            pp.wpack[i] = (const float*)h->wpack_prop[i].ptr;
-            pp.tables[i] = (const float*)h->table_prop[i].ptr;
-            pp.table_bytes[i] = (uint32_t)h->table_prop[i].bytes;
-            pp.grid[i] = grid_levels(d.proposals[i]);
-            if (d.proposals[i].grid_mode == 0 && h->nd_prop[i] > 0) {
-                pp.grid[i] = h->dense_res_prop[i];
-                pp.dense[i] = h->dense_info_prop[i];
-            }
-            pp.log2_t[i] = d.proposals[i].log2_hashmap_size;
-            for (int l = 0; l < 5; ++l) pp.scal[i][l] = d.proposals[i].scalings[l];
-            pp.n_samples[i] = opts->num_proposal_samples[i];
-        }
-        pp.n_final = opts->num_nerf_samples;
-        pp.near_plane = opts->near_plane;
-        pp.far_plane = opts->far_plane;
-        pp.avg_density = d.average_init_density;
-        pp.hist_pad = d.histogram_padding;
-        const dim3 pgrid((unsigned)wp.prop_blocks), pblock(64 * SN_PROP_WAVES);
-        if (d.proposals[0].grid_mode == 1) {
-            // nerfacto's proposal nets (max_res 128 / 256, T = 2^17) have 3 and 2 leading dense levels; other shapes take the
-            // run-time form
-            const int nd0 = leading_dense(d.proposals[0]), nd1 = nprop > 1 ? leading_dense(d.proposals[1]) : 2;
-            if (nd0 == 3 && nd1 == 2 && h->dense_pairs_ok) hipLaunchKernelGGL((sn_proposal_kernel<1, 3, 2>), pgrid, pblock, 0, st, pp);
-            else hipLaunchKernelGGL((sn_proposal_kernel<1, -1, -1>), pgrid, pblock, 0, st, pp);
-        } else if (nprop == 2 && h->nd_prop[0] == 5 && h->nd_prop[1] == 4) {
-            // nerfacto's nets (max_res 128 / 256): every level but the finest of the second net has a de-hashed copy
-            hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4>), pgrid, pblock, 0, st, pp);
-        } else {
-            hipLaunchKernelGGL((sn_proposal_kernel<0, -1, -1>), pgrid, pblock, 0, st, pp);
-        }
-        SN_HIP(h, hipGetLastError());
-    }
+    if (nprop > 0)
+        if (int rc = launch_proposals(h, origins, directions, nears, fars, height, width, opts, wp, g, ws, prop_depth_0, prop_depth_1, st, &d_ebins))
+            return rc;
 
     SnMainParams p;
     memset(&p, 0, sizeof(p));
@@ -879,6 +944,70 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
                            opts->chunk_rays, wp.n_chunks, expected_depth);
         SN_HIP(h, hipGetLastError());
     }
+    return SN_OK;
+}
+
+int sn_render_normals(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars, int32_t height,
+                      int32_t width, const SnRenderOpts* opts, float* normals, float* pred_normals, SnStream stream) {
+    if (!h) return SN_ERR_INVALID;
+    if (!origins || !directions || !opts || height <= 0 || width <= 0) return fail(h, SN_ERR_INVALID, "sn_render_normals: bad argument");
+    if ((nears == nullptr) != (fars == nullptr)) return fail(h, SN_ERR_INVALID, "sn_render_normals: nears and fars must both be given or both be NULL");
+    if (!h->finalized) return fail(h, SN_ERR_STATE, "sn_render_normals: weights not finalized");
+    if (pred_normals && !h->has_pred_normals)
+        return fail(h, SN_ERR_STATE, "sn_render_normals: field.mlp_pred_normals.* / field.field_head_pred_normals.net.* not uploaded");
+    std::string why;
+    if (!valid_opts(h->desc, *opts, why)) return fail(h, SN_ERR_INVALID, "sn_render_normals: " + why);
+    if (!normals && !pred_normals) return SN_OK;
+    const WorkspacePlan wp = plan_workspace(height, width, *opts);
+    if (!opts->workspace || opts->workspace_bytes < wp.total)
+        return fail(h, SN_ERR_WORKSPACE, "sn_render_normals: workspace too small, need " + std::to_string(wp.total) + " bytes");
+    hipStream_t st = (hipStream_t)stream;
+    RenderChainGuard chain(st, h->device);
+    char* ws = (char*)opts->workspace;
+    const SnFieldDesc& d = h->desc;
+    const TileGeom g = tile_geometry(height, width);
+    const int nprop = opts->num_proposal_iterations;
+    float* d_ebins = nullptr;
+    if (nprop > 0)
+        if (int rc = launch_proposals(h, origins, directions, nears, fars, height, width, opts, wp, g, ws, nullptr, nullptr, st, &d_ebins))
+            return rc;
+    SnNormalsParams p;
+    memset(&p, 0, sizeof(p));
+    p.origins = origins;
+    p.directions = directions;
+    p.nears = nears;
+    p.fars = fars;
+    p.sbins = opts->initial_spacing_bins;
+    p.ebins = d_ebins;
+    p.table = (const float*)h->table_main.ptr;
+    p.wimg = (const float*)h->wimg_normals.ptr;
+    p.normals = normals;
+    p.pred_normals = pred_normals;
+    for (int l = 0; l < 16; ++l) p.scal[l] = d.main_field.scalings[l];
+    p.height = height;
+    p.width = width;
+    p.n_samples = opts->num_nerf_samples;
+    p.tile_w_log2 = g.tw_log2;
+    p.tile_h_log2 = g.th_log2;
+    p.tiles_x = g.tiles_x;
+    p.tiles_y = g.tiles_y;
+    p.log2_t = d.main_field.log2_hashmap_size;
+    p.near_plane = opts->near_plane;
+    p.far_plane = opts->far_plane;
+    p.avg_density = d.average_init_density;
+    p.grid = grid_levels(d.main_field);
+    const int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
+    const size_t lds_bytes = (size_t)SnNormImg::TOTAL * 4;
+    const dim3 grid((unsigned)(gbx * gby)), block(256);
+    const bool tcnn = d.main_field.grid_mode == 1;
+    if (nprop > 0) {
+        if (tcnn) hipLaunchKernelGGL((sn_normals_kernel<1, 1>), grid, block, lds_bytes, st, p);
+        else hipLaunchKernelGGL((sn_normals_kernel<1, 0>), grid, block, lds_bytes, st, p);
+    } else {
+        if (tcnn) hipLaunchKernelGGL((sn_normals_kernel<0, 1>), grid, block, lds_bytes, st, p);
+        else hipLaunchKernelGGL((sn_normals_kernel<0, 0>), grid, block, lds_bytes, st, p);
+    }
+    SN_HIP(h, hipGetLastError());
     return SN_OK;
 }
 

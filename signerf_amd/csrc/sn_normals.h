@@ -1,0 +1,295 @@
+// sn_normals.h -- analytic and predicted normals of the main field.
+//
+// What the reference computes when `predict_normals=True` (/root/reference/signerf/signerf_config.py:33) [NS-RECALL]:
+//   normals      = -normalize(d h0 / d q)       h0 = PRE-activation density, q = the field's normalised sample location
+//   pred_normals = normalize(tanh(W_h . MLP_{27->64->64->64}([posenc(p_world) (12) | geo (15)]) + b_h))
+//   both rendered as  n = sum_i w_i n_i ;  n / (|n| + 1e-10) ;  (n + 1) / 2
+// `DatasetGenerator.render_camera` never reads them (datasetgenerator.py:700-701), so they are a SEPARATE, lazily launched
+// kernel: K1's register budget stays untouched and the generator does not pay for them.
+//
+// Same mapping as K1 (lane = ray, wave = 8x8 tile, one sample per lane per step), exact-fp32 MFMA MLPs in K1's register-chained
+// layout (sn_main.h).  Per wave-step:
+//   1. hash-encode (as K1), density MLP forward; the ReLU mask of layer 1 is kept;
+//   2. reverse mode for d h0 / d feat: h0 = W2[0,:] . relu(z1) + b, so  g_feat = W1^T (W2[0,:] * [z1 > 0]).  The host folds
+//      W2[0,:] into the transposed layer (image block WB), the B operand is the 0/1 mask in the layer-1 output layout, and one
+//      32-row MFMA pass gives g_feat; 16 permlane32 swaps bring the 32 values of a ray into its own lane;
+//   3. a second pass over the 16 levels re-gathers the corners (L1/L2 hits) and contracts the gradient of the trilinear blend
+//      with g_feat:  g_q = sum_l scale_l * (g_feat[2l] * d f0 / d off + g_feat[2l+1] * d f1 / d off);
+//   4. the pred-normal MLP has the shape of the colour MLP ([16 layer-2 rows | 16 per-lane inputs] -> 64 -> 64 -> 3): it runs
+//      through the SAME image slots and code path as the colour MLP, with the position encoding in the SH slots and its last
+//      two linear layers (64 -> 64, no activation, then the 64 -> 3 head) multiplied together on the host.
+#pragma once
+#include "sn_main.h"
+
+struct SnNormImg {  // float offsets.  [0, SnMainImg::TOTAL) has SnMainImg's layout, the pred-normal MLP in the colour slots
+    static constexpr int WB = SnMainImg::TOTAL;  // [rt=1][t4=8][64][4]: mask (64, layer-1 output order) -> d h0 / d feat (32 rows)
+    static constexpr int ZB = WB + 2048;         // its bias image: 32 zeros
+    static constexpr int TOTAL = ZB + 32;        // 12 740 floats = 50 960 B
+};
+
+struct SnNormalsParams {
+    const float* origins;
+    const float* directions;
+    const float* nears;
+    const float* fars;
+    const float* sbins;  // uniform mode
+    const float* ebins;  // bins mode: [tile][S+1][64]
+    const float* table;
+    const float* wimg;   // SnNormImg
+    float* normals;      // [H*W,3] or null
+    float* pred_normals; // [H*W,3] or null
+    float scal[16];
+    int height, width, n_samples;
+    int tile_w_log2, tile_h_log2, tiles_x, tiles_y;
+    int log2_t;
+    float near_plane, far_plane, avg_density;
+    SnGridLevels grid;
+};
+
+// NeRFEncoding(in_dim 3, 2 frequencies 2^0, 2^1): [sin(2 pi x_a 2^k)] for (a, k) a-major, then the same with a pi/2 phase.
+// v_sin_f32 takes its argument in revolutions, so sin(2 pi x 2^k) = v_sin(fract(x 2^k)): the power-of-two scaling and the
+// range reduction are exact (libm sinf's reduction path costs ~200 spilled registers here).
+SN_DEV void sn_position_encoding(const float p[3], float pe[12]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float rev = p[a] * (float)(1 << k);
+            pe[a * 2 + k] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev));
+            pe[6 + a * 2 + k] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev + 0.25f));
+        }
+}
+
+// tanh(x) = 1 - 2 / (exp(2x) + 1) with v_exp_f32 / v_rcp_f32 (exp overflow -> 1, underflow -> -1)
+SN_DEV float sn_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(sn_exp<true>(2.0f * x) + 1.0f); }
+
+// Forward of the density MLP + reverse-mode d h0 / d feat + pred-normal MLP for the wave's 64 samples.
+// feat[32]: this lane's hash features; pe[12]: its position encoding.  Out: this lane's h0, g_feat[32], pre-tanh pred normal x[3].
+SN_DEV void sn_normals_field(const float* __restrict__ lds, const float* feat, const float* pe, int lane, float& h0, float* gfeat,
+                             float x[3]) {
+    const bool upper = lane >= 32;
+    float op0[32], op1[32];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        float a = feat[2 * t], b = feat[2 * t + 1];
+        sn_swap_halves(a, b);
+        op0[t] = a;
+        op1[t] = b;
+    }
+    f32x16 a0[2], a1[2];
+    sn_mlp_layer_f32<2, 16>(lds + SnMainImg::W1, lds + SnMainImg::B1, op0, op1, a0, a1, lane);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            op0[rt * 16 + r] = sn_relu(a0[rt][r]);
+            op1[rt * 16 + r] = sn_relu(a1[rt][r]);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 g0[1], g1[1];
+    sn_mlp_layer_f32<1, 32>(lds + SnMainImg::W2, lds + SnMainImg::B2, op0, op1, g0, g1, lane);
+    h0 = upper ? g1[0][8] : g0[0][0];
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- d h0 / d feat: rows rho(r) + 4h of tile 0 / tile 1, then into the owning lane ----------------------------------
+    {
+        // torch's ReLU backward is grad * (z > 0), and relu(z) > 0 <=> z > 0: the mask replaces the activations in place
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            op0[k] = op0[k] > 0.0f ? 1.0f : 0.0f;
+            op1[k] = op1[k] > 0.0f ? 1.0f : 0.0f;
+        }
+        f32x16 b0[1], b1[1];
+        sn_mlp_layer_f32<1, 32>(lds + SnNormImg::WB, lds + SnNormImg::ZB, op0, op1, b0, b1, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = b0[0][r], b = b1[0][r];
+            sn_swap_halves(a, b);  // lower lane j: own tile-0 row rho(r), lane j+32's tile-0 row rho(r)+4; upper: tile 1
+            const int row = (r & 3) + 8 * (r >> 2);
+            gfeat[row] = a;
+            gfeat[row + 4] = b;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- pred-normal layer 1: (layer-2 rows 0..15 | position encoding in the SH slots) -> 64, ReLU --------------------------
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        op0[t] = g0[0][t];
+        op1[t] = g1[0][t];
+        float a = t < 6 ? pe[2 * t] : 0.0f, b = t < 6 ? pe[2 * t + 1] : 0.0f;
+        if (t < 6) sn_swap_halves(a, b);
+        op0[8 + t] = a;
+        op1[8 + t] = b;
+    }
+    sn_mlp_layer_f32<2, 16>(lds + SnMainImg::WC1, lds + SnMainImg::BC1, op0, op1, a0, a1, lane);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            op0[rt * 16 + r] = sn_relu(a0[rt][r]);
+            op1[rt * 16 + r] = sn_relu(a1[rt][r]);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    sn_mlp_layer_f32<2, 32>(lds + SnMainImg::WC2, lds + SnMainImg::BC2, op0, op1, a0, a1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- (layer 3 . head): 64 -> 3 on the VALU, as colour layer 3 ---------------------------------------------------------------
+    const int h = lane >> 5;
+    float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        const f32x4* w = (const f32x4*)(lds + SnMainImg::W3 + (n * 2 + h) * 32);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 wv = w[rt * 4 + r4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p0[n] = fmaf(wv[e], sn_relu(a0[rt][r4 * 4 + e]), p0[n]);
+                    p1[n] = fmaf(wv[e], sn_relu(a1[rt][r4 * 4 + e]), p1[n]);
+                }
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        float a = p0[n], b = p1[n];
+        sn_swap_halves(a, b);
+        x[n] = a + b + lds[SnMainImg::B3 + n];
+    }
+}
+
+// g_q += sum over levels of scale_l * (g_feat[2l], g_feat[2l+1]) . d(feature pair)/d(offset): the gradient of the trilinear
+// blend (sn_hash_blend's association) w.r.t. the in-voxel offset; floor / ceil carry no gradient.
+#ifndef SN_GRAD_GROUP
+#define SN_GRAD_GROUP 4
+#endif
+template <int GRID>
+SN_DEV void sn_hash_encode_grad(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], const float* gfeat,
+                                const SnGridLevels* grid, float g[3]) {
+    const uint32_t mask = (1u << log2_t) - 1u;
+    g[0] = g[1] = g[2] = 0.0f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+        if (l > 0 && (l % SN_GRAD_GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
+        SnHashLevel hl;
+        if (GRID) sn_hash_corners_tcnn<-1>(q, scal[l], mask, sn_grid_dense_res(*grid, l), hl);
+        else sn_hash_corners_fast(q, scal[l], mask, hl);
+        const uint32_t lvl = ((uint32_t)l << log2_t) * 8u;
+        f32x2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = sn_table_load(rsrc, hl.boff[k], lvl);
+        const float ox = hl.off[0], oy = hl.off[1], oz = hl.off[2];
+        const float nx = 1.0f - ox, ny = 1.0f - oy, nz = 1.0f - oz;
+        // corner order 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf; the "c" corner of an axis has weight off
+        f32x2 dx = ((v[0] - v[3]) * oy + (v[1] - v[2]) * ny) * oz + ((v[4] - v[7]) * oy + (v[5] - v[6]) * ny) * nz;
+        const f32x2 f03 = v[0] * ox + v[3] * nx, f12 = v[1] * ox + v[2] * nx;
+        const f32x2 f56 = v[5] * ox + v[6] * nx, f47 = v[4] * ox + v[7] * nx;
+        f32x2 dy = (f03 - f12) * oz + (f47 - f56) * nz;
+        f32x2 dz = (f03 * oy + f12 * ny) - (f47 * oy + f56 * ny);
+        if (!GRID) {
+            // torch path: where scale * q is an integer in fp32 (about 6e-4 of the samples: ulp(x) / 1 at the fine levels),
+            // ceil(x) == floor(x), both corners of that axis are the SAME table row and autograd sees no slope along it; the
+            // kernels fetch floor + 1 (value-identical, weight 0), so the slope is dropped explicitly
+            if (ox == 0.0f) dx = f32x2{0.0f, 0.0f};
+            if (oy == 0.0f) dy = f32x2{0.0f, 0.0f};
+            if (oz == 0.0f) dz = f32x2{0.0f, 0.0f};
+        }
+        const float ga = gfeat[2 * l] * scal[l], gb = gfeat[2 * l + 1] * scal[l];
+        g[0] = fmaf(ga, dx.x, fmaf(gb, dx.y, g[0]));
+        g[1] = fmaf(ga, dy.x, fmaf(gb, dy.y, g[1]));
+        g[2] = fmaf(ga, dz.x, fmaf(gb, dz.y, g[2]));
+    }
+}
+
+template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int GRID /*0 torch grid, 1 tiny-cuda-nn grid*/>
+// (the run-time dense / hashed branch of the tiny-cuda-nn grid needs more registers than 2 waves per SIMD leave: 1 wave there)
+__global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormalsParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    for (int i = tid * 4; i < SnNormImg::TOTAL; i += 256 * 4) *(f32x4*)(lds + i) = *(const f32x4*)(p.wimg + i);
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gbx = (p.tiles_x + 1) >> 1, gby = (p.tiles_y + 1) >> 1;
+    const int blk = sn_xcd_remap(blockIdx.x, gbx * gby);
+    const int tx = (blk % gbx) * 2 + (wave & 1);
+    const int ty = (blk / gbx) * 2 + (wave >> 1);
+    if (tx >= p.tiles_x || ty >= p.tiles_y) return;  // wave-uniform
+    const int tw = 1 << p.tile_w_log2;
+    const int px = (tx << p.tile_w_log2) + (lane & (tw - 1));
+    const int py = (ty << p.tile_h_log2) + (lane >> p.tile_w_log2);
+    const bool valid = px < p.width && py < p.height;
+    const int cx = min(px, p.width - 1), cy = min(py, p.height - 1);
+    const int64_t ray = (int64_t)cy * p.width + cx;
+    float o[3], d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = p.origins[ray * 3 + c];
+        d[c] = p.directions[ray * 3 + c];
+    }
+    const float near = p.nears ? p.nears[ray] : p.near_plane;
+    const float far = p.fars ? p.fars[ray] : p.far_plane;
+    const float s_near = sn_spacing(near), s_far = sn_spacing(far);
+    const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table, (16u << p.log2_t) * 8u);
+    const int S = p.n_samples;
+    const float* eb = nullptr;
+    if (MODE == 1) eb = p.ebins + ((int64_t)(ty * p.tiles_x + tx) * (S + 1)) * 64 + lane;
+
+    SnComposite comp;  // its colour channels carry the analytic normals
+    comp.init();
+    float pn[3] = {0.f, 0.f, 0.f};
+    float t0 = MODE == 0 ? sn_euclid(p.sbins ? p.sbins[0] : 0.0f, s_near, s_far) : eb[0];
+#pragma unroll 1
+    for (int i = 0; i < S; ++i) {
+        asm volatile("" ::: "memory");  // keeps the loop-invariant LDS weight reads inside the loop (sn_main.h)
+        const float t1 = MODE == 0 ? sn_euclid(p.sbins ? p.sbins[i + 1] : (float)(i + 1) / (float)S, s_near, s_far)
+                                   : eb[(int64_t)(i + 1) * 64];
+        float q[3];
+        // the STRICT position arithmetic (not K1's rcp form): the gradient is discontinuous across voxel faces, and a position
+        // one ulp off lands in the neighbouring voxel of a fine level about once per thousand samples
+        const bool sel = sn_sample_q(o, d, t0, t1, q);
+        float feat[32];
+        sn_hash_encode<16, 4, (GRID ? 2 : 1), -1>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, nullptr);
+        float pe[12];
+        {
+            const float tm = (t0 + t1) * 0.5f;
+            const float pw[3] = {fmaf(d[0], tm, o[0]), fmaf(d[1], tm, o[1]), fmaf(d[2], tm, o[2])};
+            sn_position_encoding(pw, pe);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float h0, gfeat[32], x[3];
+        sn_normals_field(lds, feat, pe, lane, h0, gfeat, x);
+        __builtin_amdgcn_sched_barrier(0);
+        float g[3];
+        // opaque copies of q: otherwise the compiler keeps the first pass's 128 corner offsets alive across the MLPs to reuse
+        // them here (~120 spilled registers) instead of recomputing them
+        asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]));
+        sn_hash_encode_grad<GRID>(rsrc, p.scal, p.log2_t, q, gfeat, &p.grid, g);
+        __builtin_amdgcn_sched_barrier(0);
+        // Field.get_normals: -F.normalize(grad) = -grad / max(|grad|, 1e-12)
+        const float gl = fmaxf(sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), 1e-12f);
+        const float an[3] = {-g[0] / gl, -g[1] / gl, -g[2] / gl};
+        // PredNormalsFieldHead: tanh, then F.normalize
+        const float tx3[3] = {sn_tanh(x[0]), sn_tanh(x[1]), sn_tanh(x[2])};
+        const float tl = fmaxf(sqrtf(tx3[0] * tx3[0] + tx3[1] * tx3[1] + tx3[2] * tx3[2]), 1e-12f);
+        const float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
+        const float w = comp.step<true>(i, t0, t1, density, an[0], an[1], an[2]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pn[c] = fmaf(w, tx3[c] / tl, pn[c]);
+        t0 = t1;
+    }
+    if (valid) {
+        const int64_t pix = (int64_t)py * p.width + px;
+        // NormalsRenderer (normalize=True): n / (|n| + 1e-10); NormalsShader: (n + 1) / 2
+        if (p.normals) {
+            const float l = sqrtf(comp.c[0] * comp.c[0] + comp.c[1] * comp.c[1] + comp.c[2] * comp.c[2]) + 1e-10f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p.normals[pix * 3 + c] = (comp.c[c] / l + 1.0f) / 2.0f;
+        }
+        if (p.pred_normals) {
+            const float l = sqrtf(pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2]) + 1e-10f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p.pred_normals[pix * 3 + c] = (pn[c] / l + 1.0f) / 2.0f;
+        }
+    }
+}

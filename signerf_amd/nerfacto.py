@@ -89,6 +89,14 @@ class Embedding(nn.Module):
         return self.embedding.weight.mean(dim)
 
 
+class PredNormalsFieldHead(nn.Module):
+    """Parameters of nerfstudio's PredNormalsFieldHead: ``net`` = Linear(in_dim, 3) (followed by tanh and L2 normalisation)."""
+
+    def __init__(self, in_dim: int):
+        super().__init__()
+        self.net = nn.Linear(in_dim, 3)
+
+
 class NerfactoField(nn.Module):
     """Parameters of nerfstudio's NerfactoField (A6-A9, A13-A15)."""
 
@@ -100,6 +108,9 @@ class NerfactoField(nn.Module):
                                             implementation=config.implementation)
         self.embedding_appearance = Embedding(num_images, config.appearance_embed_dim)
         self.mlp_head = MLP(16 + self.geo_feat_dim + config.appearance_embed_dim, 3, config.hidden_dim_color, 3)
+        if config.predict_normals:  # row a16: NeRFEncoding(2 frequencies) of the position (12) + geo features -> 64 -> 64 -> 64 -> head
+            self.mlp_pred_normals = MLP(12 + self.geo_feat_dim, 3, 64, 64)
+            self.field_head_pred_normals = PredNormalsFieldHead(64)
 
 
 class HashMLPDensityField(nn.Module):
@@ -111,6 +122,56 @@ class HashMLPDensityField(nn.Module):
         assert not use_linear, "use_linear proposal nets are not supported"
         self.mlp_base = MLPWithHashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level, 2, hidden_dim, 1,
                                             implementation=implementation)
+
+
+class LazyOutputs(dict):
+    """The outputs dict of a render whose "normals" / "pred_normals" entries (row a16) are rendered on first use: reading either
+    key, or enumerating the dict (keys / items / values / iteration / len / ``in``), launches the normals kernel once."""
+
+    _PENDING = ("normals", "pred_normals")
+
+    def __init__(self, base: Dict[str, Tensor], producer):
+        super().__init__(base)
+        self._producer = producer
+
+    def _materialise(self):
+        if self._producer is not None:
+            producer, self._producer = self._producer, None
+            super().update(producer())
+
+    def __missing__(self, key):
+        if key in self._PENDING and self._producer is not None:
+            self._materialise()
+            return super().__getitem__(key)
+        raise KeyError(key)
+
+    def get(self, key, default=None):
+        if key in self._PENDING:
+            self._materialise()
+        return super().get(key, default)
+
+    def __contains__(self, key):
+        return super().__contains__(key) or (key in self._PENDING and self._producer is not None)
+
+    def keys(self):
+        self._materialise()
+        return super().keys()
+
+    def items(self):
+        self._materialise()
+        return super().items()
+
+    def values(self):
+        self._materialise()
+        return super().values()
+
+    def __iter__(self):
+        self._materialise()
+        return super().__iter__()
+
+    def __len__(self):
+        self._materialise()
+        return super().__len__()
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -165,6 +226,12 @@ class NerfactoModel(nn.Module):
     @property
     def device(self):
         return self.device_indicator_param.device
+
+    @property
+    def _has_pred_normals(self) -> bool:
+        """The pred-normal MLP is rendered for torch-path models only: a tiny-cuda-nn checkpoint keeps it as a flat vector behind
+        tcnn's own frequency encoding, which tcnn_import does not convert (its analytic normals are rendered)."""
+        return self.config.predict_normals and self.config.implementation == "torch"
 
     # -- plugin surface the pipeline / trainer expect ---------------------------------------------------------
     def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
@@ -237,7 +304,8 @@ class NerfactoModel(nn.Module):
         with torch.cuda.device(self.device):
             sd = self.state_dict()
             for k, v in sd.items():
-                if k.endswith("hash_table") or ".mlp.layers." in k or k.startswith("field.mlp_head.layers."):
+                if (k.endswith("hash_table") or ".mlp.layers." in k or k.startswith("field.mlp_head.layers.")
+                        or (self._has_pred_normals and k.startswith(("field.mlp_pred_normals.layers.", "field.field_head_pred_normals.net.")))):
                     up(k, v)
             if self.config.appearance_embed_dim > 0:
                 if self.config.use_average_appearance_embedding:
@@ -298,8 +366,7 @@ class NerfactoModel(nn.Module):
         (median), "expected_depth", "prop_depth_i").  Rays are visited in the reference's row-major order; the
         reference's 32 768-ray chunking only survives in the expected-depth clip bounds (A17)."""
         H, W = camera_ray_bundle.origins.shape[:2]
-        out = self._render(camera_ray_bundle, H, W)
-        return {k: v.view(H, W, -1) for k, v in out.items()}
+        return self._with_normals(camera_ray_bundle, H, W, (H, W))
 
     @torch.no_grad()
     def get_outputs_for_camera(self, camera, obb_box=None) -> Dict[str, Tensor]:
@@ -314,11 +381,43 @@ class NerfactoModel(nn.Module):
     def get_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
         """Flat bundle [R,...] -> dict of [R,C]."""
         R = len(ray_bundle)
-        out = self._render(ray_bundle.flatten(), 1, R)
-        return {k: v.view(R, -1) for k, v in out.items()}
+        return self._with_normals(ray_bundle.flatten(), 1, R, (R,))
 
     def forward(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
         return self.get_outputs(ray_bundle)
+
+    def _with_normals(self, b: RayBundle, H: int, W: int, shape) -> Dict[str, Tensor]:
+        out = {k: v.view(*shape, -1) for k, v in self._render(b, H, W).items()}
+        mode = self.config.compute_normals if self.config.predict_normals else "never"
+        if mode == "never":
+            return out
+        if mode not in ("lazy", "always"):
+            raise ValueError(f"compute_normals must be 'lazy', 'always' or 'never', got {mode!r}")
+
+        def producer():
+            with torch.no_grad():
+                return {k: v.view(*shape, -1) for k, v in self._render_normals(b, H, W).items()}
+
+        if mode == "always":
+            out.update(producer())
+            return out
+        return LazyOutputs(out, producer)
+
+    def _render_normals(self, b: RayBundle, H: int, W: int) -> Dict[str, Tensor]:
+        """Row a16: "normals" (analytic) and "pred_normals", [H*W,3] each, by the separate normals kernel (csrc/sn_normals.h)."""
+        lib = self._ensure_engine()
+        dev = self.device
+        f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+        origins, directions, nears, fars = f32(b.origins), f32(b.directions), f32(b.nears), f32(b.fars)
+        with torch.cuda.device(dev):
+            o, keep = self._opts(H, W, lib)
+            normals = torch.empty((H * W, 3), dtype=torch.float32, device=dev)
+            pred = torch.empty((H * W, 3), dtype=torch.float32, device=dev) if self._has_pred_normals else None
+            st = lib.sn_render_normals(self._handle, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(nears), _lib.ptr(fars), H, W,
+                                       C.byref(o), _lib.ptr(normals), _lib.ptr(pred), _lib.current_stream())
+            _lib.check(st, self._handle, "sn_render_normals")
+            del keep
+        return {"normals": normals, "pred_normals": pred} if pred is not None else {"normals": normals}
 
     def _render(self, b: RayBundle, H: int, W: int) -> Dict[str, Tensor]:
         lib = self._ensure_engine()

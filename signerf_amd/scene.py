@@ -48,6 +48,16 @@ def synthetic_state_dict(config: NerfactoModelConfig, seed: int = 0, density_bia
     for i in range(config.num_proposal_iterations):
         a = config.proposal_net_args_list[min(i, len(config.proposal_net_args_list) - 1)]
         hash_mlp(f"proposal_networks.{i}.mlp_base", a["num_levels"], a["log2_hashmap_size"], a["hidden_dim"], 1, seed + 1 + i, base_gain)
+    if config.predict_normals:  # row a16: pred-normal MLP 27 -> 64 -> 64 -> 64 and PredNormalsFieldHead's Linear(64, 3)
+        torch.manual_seed(seed + 300)
+        dims = [12 + 15, 64, 64, 64]
+        for i in range(3):
+            lin = torch.nn.Linear(dims[i], dims[i + 1])
+            sd[f"field.mlp_pred_normals.layers.{i}.weight"] = lin.weight.detach().clone() * head_gain
+            sd[f"field.mlp_pred_normals.layers.{i}.bias"] = lin.bias.detach().clone()
+        lin = torch.nn.Linear(64, 3)
+        sd["field.field_head_pred_normals.net.weight"] = lin.weight.detach().clone() * head_gain
+        sd["field.field_head_pred_normals.net.bias"] = lin.bias.detach().clone()
     return sd
 
 

@@ -1,0 +1,92 @@
+"""Row a16 / §8(f) row 4: the `predict_normals=True` outputs (signerf_config.py:33) -- "normals" (analytic, reverse mode through
+the density MLP and the hash grid) and "pred_normals" -- against the CPU oracle (torch autograd).  Both are unit vectors mapped to
+[0, 1]; gate: per-pixel RMSE <= 1e-3, the north_star tolerance of the colour outputs."""
+import dataclasses
+
+import pytest
+import torch
+
+from helpers import make_model, oracle_config, rmse, small_config
+from oracle import nerfacto as onf
+from signerf_amd import Cameras, scene
+from signerf_amd.nerfacto import LazyOutputs
+
+pytestmark = pytest.mark.gpu
+RMSE_TOL = 1e-3
+
+
+def _pair(cfg, gpu, H, W, cam=0, focal=None):
+    model, sd = make_model(cfg, gpu)
+    focal = focal or float(W)
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], focal, focal, W / 2, H / 2, W, H).to(gpu)
+    bundle = cams[cam].generate_rays(camera_indices=0)
+    out = model.get_outputs_for_camera_ray_bundle(bundle)
+    ocfg = dataclasses.replace(oracle_config(cfg), predict_normals=True)
+    ref = onf.get_outputs_for_camera_ray_bundle(sd, ocfg, bundle.origins.cpu(), bundle.directions.cpu())
+    return model, out, ref
+
+
+def _check(out, ref, exact_bins=True):
+    for k in ("normals", "pred_normals"):
+        assert out[k].shape == ref[k].shape and out[k].dtype == torch.float32 and out[k].is_cuda, k
+        e = rmse(out[k], ref[k])
+        d = (out[k].cpu() - ref[k]).abs().max(dim=-1).values
+        print(f"{k}: rmse {e:.2e} max {float(d.max()):.2e}, pixels off by > 1e-3: {int((d > 1e-3).sum())}/{d.numel()}")
+        if exact_bins or k == "pred_normals":
+            assert e <= RMSE_TOL, k
+        else:
+            # With proposal nets the bins differ from the oracle's by ~1e-6 relative (K2's fused arithmetic), i.e. by ~2e-3 of a
+            # voxel at the finest level, and the analytic gradient is discontinuous across voxel faces: a sample that lands on the
+            # other side of one changes its normal by O(1) (measured: 5-10 % of the pixels hold such a sample).  Counted and
+            # bounded, as SURVEY §8(d) allows for documented ties; with identical bins (the other tests) the RMSE is ~3e-7.
+            assert float(d.median()) <= 3e-4 and float((d > 1e-3).float().mean()) <= 0.15 and e <= 3e-2, k
+        n = ref[k] * 2 - 1
+        assert float(ref[k].std()) > 0.05, "vacuous"                                    # directions vary over the image
+        assert torch.allclose(n.norm(dim=-1), torch.ones(n.shape[:-1]), atol=1e-4)      # unit vectors
+    assert rmse(out["rgb"], ref["rgb"]) <= RMSE_TOL
+
+
+def test_normals_uniform_sampler(gpu):
+    cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=32)
+    _, out, ref = _pair(cfg, gpu, 48, 56)
+    _check(out, ref)
+
+
+def test_normals_with_proposal_sampler_and_ragged_image(gpu):
+    cfg = small_config(num_proposal_samples_per_ray=(48, 24), num_nerf_samples_per_ray=16)
+    _, out, ref = _pair(cfg, gpu, 37, 43, cam=3)
+    _check(out, ref, exact_bins=False)
+
+
+def test_normals_full_tables(gpu):
+    """The benchmark field (L=16, T=2^19) at 64x64x64."""
+    cfg = scene.benchmark_config(64)
+    _, out, ref = _pair(cfg, gpu, 64, 64, cam=1, focal=64.0)
+    _check(out, ref)
+
+
+def test_normals_are_lazy(gpu, monkeypatch):
+    """The generator's reads (rgb, depth: datasetgenerator.py:700-701) never launch the normals kernel; the first read of either
+    normals key launches it once; compute_normals = "always" / "never" do what they say."""
+    cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=16)
+    model, _ = make_model(cfg, gpu)
+    calls = []
+    real = model._render_normals
+    monkeypatch.setattr(model, "_render_normals", lambda *a: (calls.append(1), real(*a))[1])
+    bundle = Cameras(scene.benchmark_cameras(8)[:, :3], 24.0, 24.0, 12.0, 12.0, 24, 24).to(gpu)[0].generate_rays(0)
+    out = model.get_outputs_for_camera_ray_bundle(bundle)
+    assert isinstance(out, LazyOutputs) and "normals" in out and "pred_normals" in out
+    _ = out["rgb"], out["depth"], out.get("accumulation")
+    assert calls == []
+    n = out["normals"]
+    assert calls == [1] and n.shape == (24, 24, 3)
+    assert out["pred_normals"].shape == (24, 24, 3) and calls == [1]
+    assert set(out) == {"rgb", "accumulation", "depth", "expected_depth", "normals", "pred_normals"}
+    model.config.compute_normals = "always"
+    out2 = model.get_outputs_for_camera_ray_bundle(bundle)
+    assert type(out2) is dict and calls == [1, 1] and torch.equal(out2["normals"], n)
+    model.config.compute_normals = "never"
+    assert "normals" not in model.get_outputs_for_camera_ray_bundle(bundle)
+    model.config.compute_normals = "lazy"
+    model.config.predict_normals = False
+    assert "normals" not in model.get_outputs_for_camera_ray_bundle(bundle)

@@ -60,7 +60,7 @@ def test_config2_reduced_96x96x64_full_tables(gpu, precision):
     model, sd = make_model(cfg, gpu)
     out, ref = _render_pair(cfg, model, sd, gpu, 96, 96, cam=1, focal=96.0)
     _check(out, ref)
-    assert set(out.keys()) == {"rgb", "accumulation", "depth", "expected_depth"}
+    assert set(out.keys()) == {"rgb", "accumulation", "depth", "expected_depth", "normals", "pred_normals"}  # predict_normals=True
 
 
 def test_ragged_image_and_aabb_nears_fars(gpu):

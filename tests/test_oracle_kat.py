@@ -206,3 +206,35 @@ def test_sheet_geometry_and_downscale_known_answers():
     img, msk, cnd = su.compose_reference_sheet([(torch.zeros(4, 4, 3), torch.ones(4, 4, 1, dtype=torch.bool), torch.full((4, 4, 1), 0.5))], 1, 2, 2, 2, 1)
     assert img.shape == (8, 8, 3) and float(img[:2, :2].max()) == 0.0 and float(img[2:].min()) == 1.0
     assert float(msk[:2, :2].min()) == 1.0 and float(msk.sum()) == 4.0 and float(cnd[:2, :2].min()) == 0.5
+
+
+def test_normals_outputs_are_unit_vectors_and_follow_finite_differences():
+    """Row a16: the analytic normal is minus the normalised gradient of the pre-activation density w.r.t. the NORMALISED sample
+    location; checked against central differences inside one voxel of a one-level grid (exact there: the blend is trilinear and
+    the MLP piecewise linear), and the rendered outputs are unit vectors mapped to [0, 1]."""
+    import dataclasses
+
+    cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=8)
+    sd = scene.synthetic_state_dict(cfg, seed=3)
+    ocfg = dataclasses.replace(oracle_config(cfg), predict_normals=True)
+    torch.manual_seed(0)
+    pos = (torch.rand(1, 64, 3) - 0.5) * 1.6   # inside the unit box: q = (p + 2) / 4, no contraction
+    n = onf.field_analytic_normals(sd, ocfg, pos)
+    assert torch.allclose(n.norm(dim=-1), torch.ones(1, 64), atol=1e-5)
+
+    def h0(p):
+        _, h, _, _ = onf.density_field(sd, "field.mlp_base", ocfg.main, p.float(), ocfg.average_init_density)
+        return h[..., 0].double()
+
+    eps = 2e-5   # well inside a voxel of the finest level for almost every point; q = p / 4 + 1/2
+    g = torch.stack([(h0(pos + eps * e) - h0(pos - eps * e)) / (2 * eps) for e in torch.eye(3)], dim=-1) * 4.0
+    fd = -torch.nn.functional.normalize(g, dim=-1).float()
+    cos = (fd * n).sum(-1)
+    assert float(cos.median()) > 0.99, float(cos.median())   # fp32 differences are noisy; the direction must agree
+
+    o = torch.tensor([[0.0, 0.0, 0.6]]).repeat(4, 1)
+    d = torch.nn.functional.normalize(torch.tensor([[0.1, 0.05, -1.0], [0.0, 0.2, -1.0], [-0.2, 0.0, -1.0], [0.1, -0.1, -1.0]]), dim=-1)
+    out = onf.get_outputs(sd, ocfg, o, d)
+    for k in ("normals", "pred_normals"):
+        v = out[k] * 2 - 1
+        assert out[k].shape == (4, 3) and torch.allclose(v.norm(dim=-1), torch.ones(4), atol=1e-4), k
