@@ -677,6 +677,23 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         memcpy(pack.data() + SN_PROP_B0, b0->data(), 16 * 4);
         memcpy(pack.data() + SN_PROP_W1, w1->data(), 16 * 4);
         pack[SN_PROP_B1] = (*b1)[0];
+        // matrix-core form (sn_prop_mlp_mfma): A[i = lane & 31][k = 8 (lane >> 5) + e], fp16 hi / lo (lo = RNE(x - hi)); k < 10:
+        // W0[i][k], k = 10: b0[i]; rows >= 16 and k > 10 are zero
+        {
+            uint16_t* ahi = (uint16_t*)(pack.data() + SN_PROP_MA_HI);
+            uint16_t* alo = (uint16_t*)(pack.data() + SN_PROP_MA_LO);
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int row = lane & 31, k = 8 * (lane >> 5) + e;
+                    float x = 0.0f;
+                    if (row < 16) x = k < 10 ? (*w0)[row * 10 + k] : (k == 10 ? (*b0)[row] : 0.0f);
+                    const uint16_t hi = f32_to_f16_rne(x);
+                    ahi[lane * 8 + e] = hi;
+                    alo[lane * 8 + e] = f32_to_f16_rne(x - f16_to_f32(hi));
+                }
+            for (int hh = 0; hh < 2; ++hh)
+                for (int r = 0; r < 8; ++r) pack[SN_PROP_MW1 + hh * 8 + r] = (*w1)[(r & 3) + 8 * (r >> 2) + 4 * hh];
+        }
         if (!h->wpack_prop[i].ptr) {
             SN_HIP(h, hipMalloc(&h->wpack_prop[i].ptr, pack.size() * 4));
             h->wpack_prop[i].bytes = pack.size() * 4;

@@ -12,12 +12,13 @@
 //     level, read back once) -- a 64 KB-per-wave LDS copy would cap occupancy at 2 waves per CU;
 //   * inverse-CDF resampling is a per-lane merge of the sorted u grid with the running CDF (searchsorted(right) == "all u in
 //     [cdf_i, cdf_{i+1})");
-//   * the tiny density MLP (10->16->1, 352 FLOP) runs on the VALU with wave-uniform weights from the scalar cache.
+//   * the tiny density MLP (10->16->1, 352 FLOP) runs on the matrix cores in split precision (sn_prop_mlp_mfma).
 // Waves are persistent over tiles (grid = what the chip holds) so the scratch is per wave, not per tile.  The final
 // sample bins are written in [tile][bin][lane=ray] order, exactly the order in which sn_render_main_kernel<1> reads them.
 #pragma once
 #include "../../include/signerf_hip.h"
 #include "sn_device.h"
+#include "sn_main.h"  // fp16 hi+lo split helpers (sn_split2, f16x8)
 
 #define SN_PROP_MAX_SAMPLES 256
 #define SN_PROP_WAVES 4
@@ -30,18 +31,92 @@
 #define SN_PROP_B0 160
 #define SN_PROP_W1 176
 #define SN_PROP_B1 192
-#define SN_PROP_PACK_FLOATS 196
+// ... followed by the matrix-core form of the same weights (SN_PROP_MFMA): the A operand of v_mfma_f32_32x32x16_f16 as fp16
+// hi / lo parts, [lane][8 halves] each -- A[i = lane & 31][k = 8 (lane >> 5) + e] = W0[i][k] (k < 10), b0[i] (k = 10), 0 --
+// and the layer-2 weights in accumulator order, [h][r] = W1[(r & 3) + 8 (r >> 2) + 4 h], r = 0..7
+#define SN_PROP_MA_HI 196
+#define SN_PROP_MA_LO 452
+#define SN_PROP_MW1 708
+#define SN_PROP_PACK_FLOATS 724
+#ifndef SN_PROP_MFMA
+#define SN_PROP_MFMA 1
+#endif
 
 struct SnScal5 {
     float v[5];
 };
 
+SN_DEV void sn_swap_halves_u(uint32_t& a, uint32_t& b) {
+    asm volatile("s_nop 1" : "+v"(a), "+v"(b));
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+
+// The 10 -> 16 -> 1 MLP of the wave's 64 samples on the matrix cores, split precision (sn_main.h): features as fp16 hi + lo,
+// three v_mfma_f32_32x32x16_f16 per 32-sample tile (hi.hi + hi.lo + lo.hi, fp32 accumulate) -- K = 16 holds the 10 features
+// and the bias slot in ONE k-step.  B operand of tile 0 (rays 0..31): lanes 0..31 carry k = 0..7 = their own features 0..7,
+// lanes 32..63 carry k = 8..15 = (feature 8, feature 9, 1.0, 0 ...) of ray lane - 32; tile 1 the other way round: one
+// permlane32_swap of (X, Y) per packed register gives both.  Layer 2 is 8 FMAs per lane and tile plus one swap.
+// 6 MFMAs (32 cycles each) + ~65 VALU instead of 187 VALU + 48 LDS reads.
+SN_DEV float sn_prop_mlp_mfma(const float* __restrict__ w, const float* feat, int lane) {
+    u32x4 xh, xl, yh = {0u, 0x00003c00u /* (1.0h, 0) -> the bias slot k = 10 */, 0u, 0u}, yl = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        uint32_t h, l;
+        sn_split2(feat[2 * m], feat[2 * m + 1], h, l);
+        xh[m] = h;
+        xl[m] = l;
+    }
+    {
+        uint32_t h, l;
+        sn_split2(feat[8], feat[9], h, l);
+        yh[0] = h;
+        yl[0] = l;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        uint32_t a = xh[m], b = yh[m];
+        sn_swap_halves_u(a, b);
+        xh[m] = a;  // tile 0
+        yh[m] = b;  // tile 1
+        a = xl[m];
+        b = yl[m];
+        sn_swap_halves_u(a, b);
+        xl[m] = a;
+        yl[m] = b;
+    }
+    const f16x8 ah = __builtin_bit_cast(f16x8, *(const u32x4*)(w + SN_PROP_MA_HI + lane * 4));
+    const f16x8 al = __builtin_bit_cast(f16x8, *(const u32x4*)(w + SN_PROP_MA_LO + lane * 4));
+    const f16x8 b0h = __builtin_bit_cast(f16x8, xh), b0l = __builtin_bit_cast(f16x8, xl);
+    const f16x8 b1h = __builtin_bit_cast(f16x8, yh), b1l = __builtin_bit_cast(f16x8, yl);
+    f32x16 c0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, c1 = c0;
+    SN_MFMA_H(c0, al, b0h);
+    SN_MFMA_H(c1, al, b1h);
+    SN_MFMA_H(c0, ah, b0l);
+    SN_MFMA_H(c1, ah, b1l);
+    SN_MFMA_H(c0, ah, b0h);
+    SN_MFMA_H(c1, ah, b1h);
+    // layer 2: this lane holds hidden units (r & 3) + 8 (r >> 2) + 4 h, r = 0..7, of its column in both tiles
+    const f32x4* w1 = (const f32x4*)(w + SN_PROP_MW1 + (lane >> 5) * 8);
+    const f32x4 wa = w1[0], wb = w1[1];
+    float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float wv = r < 4 ? wa[r] : wb[r - 4];
+        p0 = fmaf(wv, sn_relu(c0[r]), p0);
+        p1 = fmaf(wv, sn_relu(c1[r]), p1);
+    }
+    sn_swap_halves(p0, p1);  // lower lane j: both halves of tile 0, column j; upper lane: tile 1
+    return p0 + p1 + w[SN_PROP_B1];
+}
+
 // pre-activation density of one proposal net at normalised position q.
-// The MLP (10 -> 16 -> 1) stays on the VALU with wave-uniform weights from LDS.  Moving it to the matrix cores (exact fp32
-// v_mfma_f32_32x32x2_f32, weights as per-lane A registers, bias as a k-step: 11 MFMAs + 45 VALU instead of 187 VALU + 48 LDS
-// reads) was built and measured r01: instruction count -29 %, kernel 9 % SLOWER -- on gfx950 a SIMD's matrix pipe and VALU
-// do not run concurrently (tools/probes/overlap_probe.hip: MFMA-only 2.3 ms, FMA-only 1.8 ms, both 3.9 ms, from different
-// waves or interleaved in one), so 11 x 64 MFMA cycles simply replace 187 x 4 VALU cycles.
+// The MLP (10 -> 16 -> 1) runs on the matrix cores in split precision (sn_prop_mlp_mfma above; SN_PROP_MFMA=0 keeps the VALU form:
+// weights broadcast from LDS, two hidden units per v_pk_fma_f32).  History (r01): an exact-fp32 version (v_mfma_f32_32x32x2_f32,
+// 11 MFMAs x 64 cycles) was 9 % SLOWER than the VALU form -- on gfx950 a SIMD's matrix pipe and VALU do not run concurrently
+// (tools/probes/overlap_probe.hip), so MFMA cycles simply replace VALU cycles; the fp16 hi+lo form needs 6 MFMAs x 32 cycles for
+// the whole layer (K = 16 in one k-step) and measured 4 % faster on the 1080p nerfacto frame (17.5 -> 16.8 ms, same box).
 // GRID = 1 (tiny-cuda-nn grid semantics): `plain` is the plain table of the net and `grid` its level table.  With the number of
 // leading dense levels ND known at compile time the dense levels read x-corner pairs straight from the plain table and the
 // hashed levels use the x-paired tables `prsrc` (built for those levels only); ND = -1 reads everything from the plain table.
@@ -63,6 +138,9 @@ SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, cons
     } else {
         sn_hash_encode_pairs<5, 0, true>(prsrc, pi, scal.v, log2_t, q, feat);
     }
+#if SN_PROP_MFMA
+    float out = sn_prop_mlp_mfma(w, feat, (int)(threadIdx.x & 63));
+#else
     // hidden units in pairs: one v_pk_fma_f32 per (pair, k); every unit still sums bias, k = 0..9 in order with fused multiply-adds
     const f32x2* w2 = (const f32x2*)w;
     f32x2 a[8];
@@ -89,6 +167,7 @@ SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, cons
         o2 = __builtin_elementwise_fma(w2[SN_PROP_W1 / 2 + j], r, o2);
     }
     float out = o2.x + o2.y;
+#endif
     // v_max-based ReLU launders NaN; the reference's field is NaN all the way for a NaN position
     if ((q[0] != q[0]) | (q[1] != q[1]) | (q[2] != q[2])) out = __builtin_nanf("");
     return out;
@@ -248,7 +327,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
 // GRID 1: ND0 / ND1 = leading dense levels of the two nets (-1: run-time decision per level)
 template <int GRID, int ND0 = -1, int ND1 = -1>
 __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_proposal_kernel(SnPropParams p) {
-    __shared__ SnPropLds L;
+    __shared__ __attribute__((aligned(16))) SnPropLds L;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
