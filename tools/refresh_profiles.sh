@@ -1,0 +1,32 @@
+#!/bin/bash
+# End-of-round evidence run on the GPU box (from the repo root): bench lines, rocprofv3 kernel stats of the same commands, PMC passes
+# of K1 and K2, concurrency / determinism probes.  Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
+#   tools/refresh_profiles.sh <tag>
+set -u
+TAG=${1:-refresh}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$ROOT"
+timeout 600 python bench.py > "$OUT/bench_sheet64.json" 2> "$OUT/bench_sheet64.err"
+timeout 600 python bench.py --workload nerfacto1080 --steps 10 --warmup 2 > "$OUT/bench_nerfacto1080.json" 2> "$OUT/bench_nerfacto1080.err"
+timeout 300 python tools/normals_bench.py > "$OUT/normals_bench.txt" 2>&1
+timeout 300 python tools/normals_bench.py --workload nerfacto1080 >> "$OUT/normals_bench.txt" 2>&1
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_sheet64" -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/prof_sheet64.log" 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_nerfacto1080" -- python "$ROOT/bench.py" --workload nerfacto1080 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/prof_nerfacto1080.log" 2>&1)
+python tools/rocprof_summary.py "$OUT/prof_sheet64" > "$OUT/kernel_stats_sheet64.txt" 2>&1
+python tools/rocprof_summary.py "$OUT/prof_nerfacto1080" > "$OUT/kernel_stats_nerfacto1080.txt" 2>&1
+bash tools/pmc_passes.sh "$OUT/pmc_k1" > "$OUT/pmc_k1.log" 2>&1
+python tools/pmc_summary.py "$OUT/pmc_k1" "sn_render_main_kernel<0, 1" --json fp16x2 > "$OUT/pmc_k1_summary.txt" 2>&1
+cp profiles/traffic.json "$OUT/traffic.json"
+bash tools/pmc_passes_k2.sh "$OUT/pmc_k2" > "$OUT/pmc_k2.log" 2>&1
+python tools/pmc_summary.py "$OUT/pmc_k2" sn_proposal_kernel > "$OUT/pmc_k2_summary.txt" 2>&1
+for m in shared two-models vs-uniform; do
+  echo "== concurrency_probe --mode $m (SN_NO_RENDER_CHAIN=1)" >> "$OUT/probes.txt"
+  SN_NO_RENDER_CHAIN=1 timeout 300 python tools/concurrency_probe.py --mode $m 2>&1 | tail -3 >> "$OUT/probes.txt"
+done
+echo "== determinism_probe" >> "$OUT/probes.txt"
+timeout 300 python tools/determinism_probe.py 2>&1 | tail -3 >> "$OUT/probes.txt"
+# drop the bulky raw traces, keep the stats
+find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
+ls "$OUT"
