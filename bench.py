@@ -7,7 +7,8 @@
 A "step" = every rank renders ONE 800x800 camera of the 3x3 reference sheet (BASELINE.json configs[1]: synthetic nerfacto
 field, hash grid L=16 T=2^19, 64 samples/ray, no proposal nets; rank r renders camera r of circle_poses(8)) through
 Cameras.generate_rays -> Model.get_outputs_for_camera_ray_bundle, followed (N>1) by the RCCL all-gather of the finished
-[H,W,4] tiles.  Weak scaling: per-GPU work is fixed.  Inputs (weights, camera) are resident in HBM before the timed region.
+[H,W,4] tiles (started asynchronously: it overlaps the next step's render; all K gathers complete inside the timed region).
+Weak scaling: per-GPU work is fixed.  Inputs (weights, camera) are resident in HBM before the timed region.
 Prints ONE JSON line (see README / DESIGN.md "Measurement").
 """
 import argparse
@@ -137,6 +138,8 @@ def main():
         model.config.precision = old
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
+    pending = [None]  # the previous step's tile all-gather, still in flight
+
     def step(timed: bool):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
@@ -145,20 +148,33 @@ def main():
         out = model.get_outputs_for_camera_ray_bundle(bundle)
         e1.record()
         tile = torch.cat([out["rgb"], out["depth"]], dim=-1)[None]
-        if world > 1:
-            tile = sheet.gather_tiles(tile, world)
         if timed:
             render_ms.append((e0, e1))
-        return tile
+        if world == 1:
+            return tile
+        # depth-1 pipeline: this frame's all-gather (RCCL's own stream) overlaps the next frame's render; every gather is
+        # waited for inside the timed region (drain() below)
+        handle = sheet.gather_tiles_async(tile, world)
+        done = pending[0].wait() if pending[0] is not None else None
+        pending[0] = handle
+        return done
+
+    def drain():
+        if pending[0] is not None:
+            tiles = pending[0].wait()
+            pending[0] = None
+            return tiles
 
     for _ in range(args.warmup):
         step(False)
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tiles = step(True)
+    tiles = drain() if world > 1 else tiles
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -185,7 +201,7 @@ def main():
                        if args.workload == "sheet64" else
                        (f"BASELINE.json configs[3]: {W}x{H} rays, proposal nets 256 + 96 samples (L=5, T=2^17) + {S} main samples "
                         "(L=16, T=2^19), random-weight synthetic scene, one camera per GPU + tile all-gather"),
-                       "rays_per_gpu": W * H, "samples_per_ray": S, "parallelism": f"camera-sharded x{world}"},
+                       "rays_per_gpu": W * H, "samples_per_ray": S, "parallelism": f"camera-sharded x{world}" + (", tile all-gather overlapped with the next render" if world > 1 else "")},
             "ms_per_frame": elapsed / args.steps * 1e3,
             "rays_per_sec": world * W * H * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

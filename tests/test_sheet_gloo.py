@@ -148,3 +148,35 @@ def test_row_sharded_frame_matches_single_rank(tmp_path, world, H, W):
     assert sorted(covered) == blocks and blocks[0][0] == 0 and blocks[-1][1] == H
     assert all(b0[1] == b1[0] for b0, b1 in zip(blocks, blocks[1:]))
     assert all((b[1] - b[0]) % 8 == 0 for b in blocks[:-1])  # whole 8-row tile bands except the last block
+
+
+def _pipeline_worker(rank, world, port, steps, out_dir):
+    """bench.py's depth-1 pipeline: the gather of frame i is in flight while frame i + 1 is 'rendered'."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from signerf_amd import sheet
+
+    done, pending = [], None
+    for step in range(steps):
+        tile = torch.cat(_fake_render(100 * step + rank), dim=-1)[None]
+        handle = sheet.gather_tiles_async(tile, world)
+        if pending is not None:
+            done.append(pending.wait())
+        pending = handle
+    done.append(pending.wait())
+    torch.save(done, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gathers_deliver_every_frame_in_order(tmp_path):
+    world, steps = 2, 4
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), steps, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = torch.load(os.path.join(tmp_path, f"rank{r}.pt"))
+        assert len(got) == steps
+        for step, sheet_tiles in enumerate(got):
+            want = torch.stack([torch.cat(_fake_render(100 * step + k), dim=-1) for k in range(world)])
+            assert torch.equal(sheet_tiles, want), (r, step)
