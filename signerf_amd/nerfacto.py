@@ -173,6 +173,10 @@ class LazyOutputs(dict):
         self._materialise()
         return super().__len__()
 
+    def copy(self):
+        self._materialise()
+        return dict(self)
+
 
 # ------------------------------------------------------------------------------------------------------
 # the model
