@@ -204,6 +204,9 @@ def main():
                        "rays_per_gpu": W * H, "samples_per_ray": S, "parallelism": f"camera-sharded x{world}" + (", tile all-gather overlapped with the next render" if world > 1 else "")},
             "ms_per_frame": elapsed / args.steps * 1e3,
             "rays_per_sec": world * W * H * args.steps / elapsed,
+            # SURVEY §8(d) metric (3): every field evaluation of a ray (proposal nets + main field)
+            "field_evaluations_per_sec": world * W * H * (S + (sum(cfg.num_proposal_samples_per_ray[:cfg.num_proposal_iterations])
+                                                               if args.workload != "sheet64" else 0)) * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": measured_traffic(args.precision) if args.workload == "sheet64" else None,
                          "kernel": ("sn_render_main_kernel<0,%d>" % (0 if args.precision == "fp32" else 1)) if args.workload == "sheet64"

@@ -51,6 +51,7 @@ struct SnContext {
     DevBuf wimg_main_h;                 // SnMainImgH (fp16 hi+lo MFMA operands)
     DevBuf wpack_prop[SN_MAX_PROPOSALS]; // SnPropPack
     DevBuf wimg_normals;                // SnNormImg (sn_normals.h); built when the weights are finalized
+    DevBuf wimg_normals_h;              // SnNormImgH: its fp16 hi+lo form
     bool has_pred_normals = false;      // field.mlp_pred_normals.* / field.field_head_pred_normals.* were uploaded
     DevBuf dense_main;            // de-hashed copies of the coarse levels of a torch-path main grid (sn_device.h SnDenseCopy)
     SnDenseCopy dense_info{};
@@ -518,6 +519,8 @@ int sn_destroy(SnHandle h) {
     h->dense_main.release();
     h->wimg_main.release();
     h->wimg_main_h.release();
+    h->wimg_normals.release();
+    h->wimg_normals_h.release();
     for (int i = 0; i < SN_MAX_PROPOSALS; ++i) {
         h->table_prop[i].release();
         h->pairs_prop[i].release();
@@ -661,6 +664,30 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
             h->wimg_normals.bytes = nimg.size() * 4;
         }
         SN_HIP(h, hipMemcpyAsync(h->wimg_normals.ptr, nimg.data(), nimg.size() * 4, hipMemcpyHostToDevice, st));
+        // fp16 hi+lo form: the main-image builder on the same matrices, then the reverse-pass layer in k-slot order
+        // (slot (s, h, e) <-> hidden (s/2)*32 + rho(8 (s%2) + e) + 4h, as layer 2's input)
+        std::vector<float> nh = build_main_image_h(dn, t[0]->data(), t[2]->data(), P1.data(),
+                                                   h->has_pred_normals ? w1->data() : z6464.data(), nimg);
+        nh.resize(SnNormImgH::TOTAL_BYTES / 4, 0.0f);
+        {
+            uint16_t* hw = (uint16_t*)nh.data();
+            for (int s4 = 0; s4 < 4; ++s4)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int f = lane & 31, hh = lane >> 5;
+                        const int hid = (s4 / 2) * 32 + rho(8 * (s4 % 2) + e) + 4 * hh;
+                        const float w = (*t[0])[hid * 32 + f] * (*t[2])[hid];
+                        const uint16_t hi = f32_to_f16_rne(w), lo = f32_to_f16_rne(w - f16_to_f32(hi));
+                        const size_t off = (size_t)SnNormImgH::WB / 2 + ((size_t)(s4 * 2) * 64 + lane) * 8 + e;
+                        hw[off] = hi;
+                        hw[off + 512] = lo;
+                    }
+        }
+        if (!h->wimg_normals_h.ptr) {
+            SN_HIP(h, hipMalloc(&h->wimg_normals_h.ptr, nh.size() * 4));
+            h->wimg_normals_h.bytes = nh.size() * 4;
+        }
+        SN_HIP(h, hipMemcpyAsync(h->wimg_normals_h.ptr, nh.data(), nh.size() * 4, hipMemcpyHostToDevice, st));
     }
     for (int i = 0; i < d.num_proposals; ++i) {
         const std::string pre = "proposal_networks." + std::to_string(i) + ".mlp_base.";
@@ -997,7 +1024,8 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
     p.sbins = opts->initial_spacing_bins;
     p.ebins = d_ebins;
     p.table = (const float*)h->table_main.ptr;
-    p.wimg = (const float*)h->wimg_normals.ptr;
+    const bool split = opts->precision == 1;
+    p.wimg = (const float*)(split ? h->wimg_normals_h.ptr : h->wimg_normals.ptr);
     p.normals = normals;
     p.pred_normals = pred_normals;
     for (int l = 0; l < 16; ++l) p.scal[l] = d.main_field.scalings[l];
@@ -1014,16 +1042,18 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
     p.avg_density = d.average_init_density;
     p.grid = grid_levels(d.main_field);
     const int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
-    const size_t lds_bytes = (size_t)SnNormImg::TOTAL * 4;
+    const size_t lds_bytes = split ? (size_t)SnNormImgH::TOTAL_BYTES : (size_t)SnNormImg::TOTAL * 4;
     const dim3 grid((unsigned)(gbx * gby)), block(256);
     const bool tcnn = d.main_field.grid_mode == 1;
+#define SN_LAUNCH_NORMALS(MODE, GRID)                                                                        \
+    if (split) hipLaunchKernelGGL((sn_normals_kernel<MODE, GRID, 1>), grid, block, lds_bytes, st, p);        \
+    else hipLaunchKernelGGL((sn_normals_kernel<MODE, GRID, 0>), grid, block, lds_bytes, st, p)
     if (nprop > 0) {
-        if (tcnn) hipLaunchKernelGGL((sn_normals_kernel<1, 1>), grid, block, lds_bytes, st, p);
-        else hipLaunchKernelGGL((sn_normals_kernel<1, 0>), grid, block, lds_bytes, st, p);
+        if (tcnn) { SN_LAUNCH_NORMALS(1, 1); } else { SN_LAUNCH_NORMALS(1, 0); }
     } else {
-        if (tcnn) hipLaunchKernelGGL((sn_normals_kernel<0, 1>), grid, block, lds_bytes, st, p);
-        else hipLaunchKernelGGL((sn_normals_kernel<0, 0>), grid, block, lds_bytes, st, p);
+        if (tcnn) { SN_LAUNCH_NORMALS(0, 1); } else { SN_LAUNCH_NORMALS(0, 0); }
     }
+#undef SN_LAUNCH_NORMALS
     SN_HIP(h, hipGetLastError());
     return SN_OK;
 }

@@ -27,6 +27,12 @@ struct SnNormImg {  // float offsets.  [0, SnMainImg::TOTAL) has SnMainImg's lay
     static constexpr int TOTAL = ZB + 32;        // 12 740 floats = 50 960 B
 };
 
+// fp16x2 form: SnMainImgH (pred-normal MLP in the colour slots) followed by the reverse-pass layer in the same operand order
+struct SnNormImgH {
+    static constexpr int WB = SnMainImgH::TOTAL_BYTES;  // [s=4][hi|lo][lane][8 halves] = 8 KiB
+    static constexpr int TOTAL_BYTES = WB + 8192;       // 50 832
+};
+
 struct SnNormalsParams {
     const float* origins;
     const float* directions;
@@ -157,6 +163,129 @@ SN_DEV void sn_normals_field(const float* __restrict__ lds, const float* feat, c
     }
 }
 
+// Split-precision (fp16 hi + lo, sn_main.h) form of sn_normals_field: same layers through sn_mlp_layer_h.  The reverse pass reads
+// a 0 / 1 mask -- exact in fp16 with a zero lo part -- so it needs only two of the three product terms.
+SN_DEV void sn_normals_field_h(const char* __restrict__ ldsb, const float* feat, const float* pe, int lane, float& h0, float* gfeat,
+                               float x[3]) {
+    const bool upper = lane >= 32;
+    const float* tail = (const float*)(ldsb + SnMainImgH::FP32);
+    SnOpH op0[4], op1[4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = feat[16 * s + e], b = feat[16 * s + 8 + e];
+            sn_swap_halves(a, b);
+            v0[e] = a;
+            v1[e] = b;
+        }
+        op0[s].set(v0);
+        op1[s].set(v1);
+    }
+    f32x16 a0[2], a1[2];
+    sn_mlp_layer_h<2, 2>(ldsb + SnMainImgH::W1, tail + SnMainImgH::B1, op0, op1, a0, a1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    // ReLU mask of layer 1 as fp16 pairs (1.0h = 0x3c00), in the operand order of the next layer
+    u32x4 m0[4], m1[4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t lo0 = a0[rt][2 * j] > 0.0f ? 0x3c00u : 0u, hi0 = a0[rt][2 * j + 1] > 0.0f ? 0x3c000000u : 0u;
+            const uint32_t lo1 = a1[rt][2 * j] > 0.0f ? 0x3c00u : 0u, hi1 = a1[rt][2 * j + 1] > 0.0f ? 0x3c000000u : 0u;
+            m0[2 * rt + j / 4][j % 4] = lo0 | hi0;
+            m1[2 * rt + j / 4][j % 4] = lo1 | hi1;
+        }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        sn_acc_to_ops(a0[rt], true, op0[2 * rt], op0[2 * rt + 1]);
+        sn_acc_to_ops(a1[rt], true, op1[2 * rt], op1[2 * rt + 1]);
+    }
+    f32x16 g0[1], g1[1];
+    sn_mlp_layer_h<1, 4>(ldsb + SnMainImgH::W2, tail + SnMainImgH::B2, op0, op1, g0, g1, lane);
+    h0 = upper ? g1[0][8] : g0[0][0];
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        f32x16 b0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b1 = b0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const char* base = ldsb + SnNormImgH::WB + ((s * 2) * 64 + lane) * 16;
+            const f16x8 ah = __builtin_bit_cast(f16x8, *(const u32x4*)base);
+            const f16x8 al = __builtin_bit_cast(f16x8, *(const u32x4*)(base + 1024));
+            const f16x8 k0 = __builtin_bit_cast(f16x8, m0[s]), k1 = __builtin_bit_cast(f16x8, m1[s]);
+            SN_MFMA_H(b0, al, k0);
+            SN_MFMA_H(b1, al, k1);
+            SN_MFMA_H(b0, ah, k0);
+            SN_MFMA_H(b1, ah, k1);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = b0[r], b = b1[r];
+            sn_swap_halves(a, b);
+            const int row = (r & 3) + 8 * (r >> 2);
+            gfeat[row] = a;
+            gfeat[row + 4] = b;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v0[e] = g0[0][e];
+            v1[e] = g1[0][e];
+        }
+        op0[0].set(v0);
+        op1[0].set(v1);
+        // slot (h, e) of k-step 1 <-> position-encoding component 8h + e (12 real, 4 zero)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = pe[e], b = e < 4 ? pe[8 + e] : 0.0f;
+            sn_swap_halves(a, b);
+            v0[e] = a;
+            v1[e] = b;
+        }
+        op0[1].set(v0);
+        op1[1].set(v1);
+    }
+    sn_mlp_layer_h<2, 2>(ldsb + SnMainImgH::WC1, tail + SnMainImgH::BC1, op0, op1, a0, a1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        sn_acc_to_ops(a0[rt], true, op0[2 * rt], op0[2 * rt + 1]);
+        sn_acc_to_ops(a1[rt], true, op1[2 * rt], op1[2 * rt + 1]);
+    }
+    const int h = lane >> 5;
+    float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        f32x16 c0[1], c1[1];
+        sn_mlp_layer_h<1, 4>(ldsb + SnMainImgH::WC2 + rt * 8192, tail + SnMainImgH::BC2 + rt * 32, op0, op1, c0, c1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const f32x4* w = (const f32x4*)(tail + SnMainImgH::W3 + (n * 2 + h) * 32);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 wv = w[rt * 4 + r4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p0[n] = fmaf(wv[e], sn_relu(c0[0][r4 * 4 + e]), p0[n]);
+                    p1[n] = fmaf(wv[e], sn_relu(c1[0][r4 * 4 + e]), p1[n]);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        float a = p0[n], b = p1[n];
+        sn_swap_halves(a, b);
+        x[n] = a + b + tail[SnMainImgH::B3 + n];
+    }
+}
+
 // g_q += sum over levels of scale_l * (g_feat[2l], g_feat[2l+1]) . d(feature pair)/d(offset): the gradient of the trilinear
 // blend (sn_hash_blend's association) w.r.t. the in-voxel offset; floor / ceil carry no gradient.
 #ifndef SN_GRAD_GROUP
@@ -200,12 +329,13 @@ SN_DEV void sn_hash_encode_grad(__amdgpu_buffer_rsrc_t rsrc, const float* scal, 
     }
 }
 
-template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int GRID /*0 torch grid, 1 tiny-cuda-nn grid*/>
+template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int GRID /*0 torch grid, 1 tiny-cuda-nn grid*/,
+          int PREC /*0 exact fp32 MFMA, 1 fp16 hi+lo split MFMA*/>
 // (the run-time dense / hashed branch of the tiny-cuda-nn grid needs more registers than 2 waves per SIMD leave: 1 wave there)
 __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormalsParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    for (int i = tid * 4; i < SnNormImg::TOTAL; i += 256 * 4) *(f32x4*)(lds + i) = *(const f32x4*)(p.wimg + i);
+    for (int i = tid * 4; i < (PREC ? SnNormImgH::TOTAL_BYTES / 4 : SnNormImg::TOTAL); i += 256 * 4) *(f32x4*)(lds + i) = *(const f32x4*)(p.wimg + i);
     __syncthreads();
 
     const int lane = tid & 63;
@@ -258,7 +388,8 @@ __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormals
         }
         __builtin_amdgcn_sched_barrier(0);
         float h0, gfeat[32], x[3];
-        sn_normals_field(lds, feat, pe, lane, h0, gfeat, x);
+        if (PREC) sn_normals_field_h((const char*)lds, feat, pe, lane, h0, gfeat, x);
+        else sn_normals_field(lds, feat, pe, lane, h0, gfeat, x);
         __builtin_amdgcn_sched_barrier(0);
         float g[3];
         // opaque copies of q: otherwise the compiler keeps the first pass's 128 corner offsets alive across the MLPs to reuse

@@ -46,8 +46,9 @@ def _check(out, ref, exact_bins=True):
     assert rmse(out["rgb"], ref["rgb"]) <= RMSE_TOL
 
 
-def test_normals_uniform_sampler(gpu):
-    cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=32)
+@pytest.mark.parametrize("precision", ["fp16x2", "fp32"])
+def test_normals_uniform_sampler(gpu, precision):
+    cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=32, precision=precision)
     _, out, ref = _pair(cfg, gpu, 48, 56)
     _check(out, ref)
 
@@ -58,9 +59,11 @@ def test_normals_with_proposal_sampler_and_ragged_image(gpu):
     _check(out, ref, exact_bins=False)
 
 
-def test_normals_full_tables(gpu):
-    """The benchmark field (L=16, T=2^19) at 64x64x64."""
+@pytest.mark.parametrize("precision", ["fp16x2", "fp32"])
+def test_normals_full_tables(gpu, precision):
+    """The benchmark field (L=16, T=2^19) at 64x64x64, both MFMA arithmetic modes of the normals kernel."""
     cfg = scene.benchmark_config(64)
+    cfg.precision = precision
     _, out, ref = _pair(cfg, gpu, 64, 64, cam=1, focal=64.0)
     _check(out, ref)
 
