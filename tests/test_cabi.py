@@ -110,3 +110,26 @@ def test_isa_has_no_packed_result_into_swizzle_pairs():
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "isa_hazard_scan.py")
     r = subprocess.run([sys.executable, tool, "--window", "2"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_lazy_outputs_dict_semantics():
+    """signerf_amd.nerfacto.LazyOutputs: the normals entries are produced once, on first use, and only then."""
+    from signerf_amd.nerfacto import LazyOutputs
+
+    calls = []
+
+    def producer():
+        calls.append(1)
+        return {"normals": "n", "pred_normals": "p"}
+
+    d = LazyOutputs({"rgb": 1, "depth": 2}, producer)
+    assert d["rgb"] == 1 and d.get("depth") == 2 and d.get("missing", 7) == 7 and calls == []
+    assert "normals" in d and "pred_normals" in d and "other" not in d and calls == []
+    with pytest.raises(KeyError):
+        d["other"]
+    assert d["pred_normals"] == "p" and calls == [1]
+    assert d["normals"] == "n" and calls == [1]
+    assert set(d) == {"rgb", "depth", "normals", "pred_normals"} and len(d) == 4 and calls == [1]
+    e = LazyOutputs({"rgb": 1}, producer)
+    assert dict(e.items()) == {"rgb": 1, "normals": "n", "pred_normals": "p"} and calls == [1, 1]
+    assert LazyOutputs({"rgb": 1}, producer).copy() == {"rgb": 1, "normals": "n", "pred_normals": "p"}

@@ -30,16 +30,6 @@ shown = []
 bad = collections.Counter(); lanes = collections.Counter(); lock = threading.Lock()
 def worker(tid):
     s = torch.cuda.Stream(device=gpu)
-    if a.mode.startswith('aggressor') and tid == 1:
-        import ctypes as C
-        from signerf_amd import _lib
-        lib = _lib.load(); kind = int(a.mode.split(':')[1]); buf = torch.zeros(16, device=gpu)
-        with torch.cuda.stream(s):
-            while not done.is_set():
-                for _ in range(8):
-                    lib.sn_debug_aggressor(kind, 2000, 2048, C.c_void_p(buf.data_ptr()), C.c_void_p(s.cuda_stream))
-                s.synchronize()
-        return
     if a.mode == 'other-work' and tid == 1:
         with torch.cuda.stream(s):
             n = int(os.environ.get('SN_PROBE_MM', '4096'))
