@@ -217,6 +217,18 @@ def main():
                                  "Cache (`traffic` = measured fabric bytes per launch); the kernel is bound by the L1 gather rate and "
                                  "by SIMD issue (VALU + MFMA serialise on gfx950), see DESIGN.md K1"},
         }
+        if args.workload == "sheet64":
+            # Secondary view (north_star: "MFMA utilisation against gfx950 peak"): matrix-core instructions issued per launch are
+            # fixed by the kernel (per wave-step of 64 samples: 120 v_mfma_f32_32x32x16_f16 in split precision, 320
+            # v_mfma_f32_32x32x2_f32 in exact fp32; rocprofv3 SQ_INSTS_MFMA agrees, profiles/) -- issued flops / kernel time
+            # against the dense peak of that MFMA type (MI355X_MICROARCH.md: 2.5 PFLOP/s f16, 157.3 TFLOP/s f32-input).
+            per_step, flop, peak = (120, 2 * 32 * 32 * 16, 2500.0) if args.precision == "fp16x2" else (320, 2 * 32 * 32 * 2, 157.3)
+            issued = (W * H * S / 64) * per_step * flop
+            line["roofline_mfma"] = {"bound": "mfma", "achieved": issued / (kernel_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                     "frac": issued / (kernel_ms * 1e-3) / 1e12 / peak,
+                                     "algorithmic_tflops": W * H * S * 22784 / (kernel_ms * 1e-3) / 1e12,
+                                     "note": "issued MFMA flops (3-term fp16 split, 32-row tile padding) = matrix-pipe busy fraction; "
+                                             "algorithmic = 22 784 FLOP per sample (SURVEY 8(d))"}
         if not args.no_alt_precision:
             other = "fp32" if args.precision == "fp16x2" else "fp16x2"
             ms = kernel_ms_of(other)
