@@ -970,7 +970,10 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
         case 11: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 11); break;     \
         default: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, -1); break;     \
     }
-    if (ablate == 2 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 0, 2, 0, -1);
+    if (ablate == 12 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 1, 2, 0, 11);        // fp16x2 kernel: hash phase (11 de-hashed levels) only
+    else if (ablate == 14 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 1, 4, 0, -1);   // fp16x2 kernel: MLP phase only
+    else if (ablate == 13 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 1, 3, 0, -1);   // fp16x2 kernel: hash VALU only (no gathers, no MLP)
+    else if (ablate == 2 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 0, 2, 0, -1);
     else if (ablate == 3 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 0, 3, 0, -1);
     else if (nprop > 0) {
         if (split) { if (tcnn) { SN_LAUNCH_MAIN_TCNN(1, 1) } else { SN_LAUNCH_MAIN_TORCH(1, 1) } }

@@ -488,7 +488,10 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
         float q[3];
         const bool sel = sn_sample_q_fast(o, d, t0, t1, q);
         float feat[32];
-        if (ABLATE & 1) {
+        if (ABLATE & 4) {  // no hash phase at all: the MLP phase alone
+#pragma unroll
+            for (int k = 0; k < 32; ++k) feat[k] = q[k % 3] + 0.01f * (float)k;
+        } else if (ABLATE & 1) {
 #pragma unroll
             for (int l = 0; l < 16; ++l) {
                 SnHashLevel hl;
