@@ -165,6 +165,8 @@ def main():
             pending[0] = None
             return tiles
 
+    model._ensure_engine()  # library load, weight upload and de-hashed copies are set-up, not a step (matters only for --warmup 0)
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step(False)
     drain()
