@@ -93,3 +93,26 @@ def test_normals_are_lazy(gpu, monkeypatch):
     model.config.compute_normals = "lazy"
     model.config.predict_normals = False
     assert "normals" not in model.get_outputs_for_camera_ray_bundle(bundle)
+
+
+def test_normals_flat_bundle_with_aabb_nears_fars(gpu):
+    """`Model.get_outputs` on a flat [R] bundle (a 1 x R frame for the kernels) whose nears / fars come from render_aabb: the
+    normals kernel honours per-ray bounds and sub-tile shapes exactly like the colour kernel."""
+    from signerf_amd import SceneBox
+
+    cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=24)
+    model, sd = make_model(cfg, gpu)
+    box = SceneBox(aabb=torch.tensor([[-0.15, -0.12, -0.1], [0.12, 0.15, 0.1]]))
+    cam = Cameras(scene.benchmark_cameras(8)[:, :3], 40.0, 40.0, 17.0, 11.0, 34, 22).to(gpu)[5]
+    bundle = cam.generate_rays(camera_indices=0, aabb_box=box)
+    flat = bundle.flatten()
+    out = model.get_outputs(flat)
+    ocfg = dataclasses.replace(oracle_config(cfg), predict_normals=True)
+    ref = onf.get_outputs(sd, ocfg, flat.origins.cpu(), flat.directions.cpu(), flat.nears.cpu(), flat.fars.cpu())
+    hit = (flat.fars.cpu() < 1e9).squeeze(-1)     # rays that miss the box carry the 1e10 sentinel (NaN positions): compare the hits
+    assert int(hit.sum()) > 50
+    for k in ("normals", "pred_normals"):
+        assert out[k].shape == (34 * 22, 3)
+        e = rmse(out[k][hit.to(gpu)], ref[k][hit])
+        print(f"{k} (flat bundle, aabb bounds): rmse {e:.2e}")
+        assert e <= RMSE_TOL, k
