@@ -132,6 +132,13 @@ int sn_generate_rays(const float* c2w, float fx, float fy, float cx, float cy, i
 int sn_intersect_with_aabb(const float* origins, const float* directions, int64_t n_rays, const float* aabb,
                            float* nears, float* fars, SnStream stream);
 
+/* ---- viewer crop: nerfstudio's intersect_obb, reached from Model.get_outputs_for_camera(camera, obb_box)
+ * (signerf/interface/viewer.py:334-336 runs nerfstudio's render thread on the shared model) ----------------------------- */
+/* world2box: 12 host floats, the 3x4 row-major inverse of the box pose [R | T]; size: 3 host floats (S).  nears/fars: [n_rays],
+ * clamped to [0, 1e10]; a ray that misses gets 1e10 for both. */
+int sn_intersect_obb(const float* origins, const float* directions, int64_t n_rays, const float* world2box, const float* size,
+                     float* nears, float* fars, SnStream stream);
+
 /* ---- rows a6-a17: Model.get_outputs_for_camera_ray_bundle (datasetgenerator.py:694) ------ */
 size_t sn_workspace_bytes(SnHandle h, int32_t height, int32_t width, const SnRenderOpts* opts);
 /* origins/directions: [H,W,3]; nears/fars: [H,W,1] or NULL (collider).  Outputs (any may be NULL):

@@ -158,6 +158,35 @@ def intersect_aabb_ns(origins: Tensor, directions: Tensor, aabb: Tensor, max_bou
 
 
 # ----------------------------------------------------------------------------
+# viewer crop: nerfstudio.utils.math.intersect_aabb / intersect_obb [NS-RECALL]
+# ----------------------------------------------------------------------------
+
+
+def intersect_aabb(origins: Tensor, directions: Tensor, aabb: Tensor, max_bound: float = 1e10, invalid_value: float = 1e10):
+    """origins / directions [N,3], aabb [6] (min xyz, max xyz) -> t_min, t_max [N]: clamped slab test, misses -> invalid_value."""
+    tx_min = (aabb[:3] - origins) / directions
+    tx_max = (aabb[3:] - origins) / directions
+    t_min = torch.stack((tx_min, tx_max)).amin(dim=0).amax(dim=-1)
+    t_max = torch.stack((tx_min, tx_max)).amax(dim=0).amin(dim=-1)
+    t_min = torch.clamp(t_min, min=0, max=max_bound)
+    t_max = torch.clamp(t_max, min=0, max=max_bound)
+    cond = t_max <= t_min
+    return torch.where(cond, invalid_value, t_min), torch.where(cond, invalid_value, t_max)
+
+
+def intersect_obb(origins: Tensor, directions: Tensor, R: Tensor, T: Tensor, S: Tensor):
+    """Rays into the frame of the oriented box (pose [R | T], side lengths S), then intersect_aabb against [-S/2, S/2]."""
+    H = torch.eye(4)
+    H[:3, :3] = R
+    H[:3, 3] = T
+    H_world2bbox = torch.inverse(H)
+    o = torch.cat((origins, torch.ones_like(origins[..., :1])), dim=-1)
+    o = torch.matmul(H_world2bbox, o.T).T[..., :3]
+    d = torch.matmul(H_world2bbox[:3, :3], directions.T).T
+    return intersect_aabb(o, d, torch.cat((-S / 2, S / 2)))
+
+
+# ----------------------------------------------------------------------------
 # A3 / A4 -- collider and the initial (uniform-in-s) sampler (rows a7, a8)
 # ----------------------------------------------------------------------------
 

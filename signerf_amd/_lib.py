@@ -85,6 +85,7 @@ SIGNATURES = {
     "sn_generate_rays": (C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                    _FP, _FP, _FP, _FP, C.POINTER(C.c_float), _FP, _FP, C.c_void_p]),
     "sn_intersect_with_aabb": (C.c_int, [_FP, _FP, C.c_int64, C.POINTER(C.c_float), _FP, _FP, C.c_void_p]),
+    "sn_intersect_obb": (C.c_int, [_FP, _FP, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float), _FP, _FP, C.c_void_p]),
     "sn_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SnRenderOpts)]),
     "sn_render_rays": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.POINTER(SnRenderOpts),
                                  _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),

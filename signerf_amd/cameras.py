@@ -29,6 +29,15 @@ class SceneBox:
 
 
 @dataclass
+class OrientedBox:
+    """nerfstudio's ``OrientedBox`` (the viewer's crop box): rotation ``R`` [3,3], translation ``T`` [3], side lengths ``S`` [3]."""
+
+    R: Tensor
+    T: Tensor
+    S: Tensor
+
+
+@dataclass
 class RayBundle:
     """A bundle of rays.  For a full-image bundle every tensor is [H,W,C]."""
 
@@ -153,11 +162,13 @@ class Cameras:
         return cam
 
     # -- row a5 ------------------------------------------------------------------------------------------
-    def generate_rays(self, camera_indices: int = 0, aabb_box: Optional[SceneBox] = None, **_unused) -> RayBundle:
+    def generate_rays(self, camera_indices: int = 0, aabb_box: Optional[SceneBox] = None, obb_box: Optional[OrientedBox] = None,
+                      **_unused) -> RayBundle:
         """Full-image ray bundle of one camera, generated on the GPU.
 
         ``camera_indices`` selects the camera of a batch (a 0-dim camera accepts only 0).  With ``aabb_box`` the
-        bundle carries nears/fars from nerfstudio's clamped slab test, and the model's collider is then skipped.
+        bundle carries nears/fars from nerfstudio's clamped slab test, and the model's collider is then skipped; ``obb_box`` (the
+        viewer's crop, used when no ``aabb_box`` is given) does the same in the box's frame (nerfstudio's ``intersect_obb``).
         """
         if not isinstance(camera_indices, int):
             raise NotImplementedError("only integer camera_indices are supported (the SIGNeRF call site passes 0)")
@@ -184,6 +195,17 @@ class Cameras:
                                       _lib.ptr(pixel_area), _lib.ptr(dnorm), aabb_arr, _lib.ptr(nears), _lib.ptr(fars),
                                       _lib.current_stream())
             _lib.check(st, None, "sn_generate_rays")
+            if aabb_box is None and obb_box is not None:
+                pose = torch.eye(4, dtype=torch.float64)
+                pose[:3, :3] = obb_box.R.detach().to("cpu", torch.float64)
+                pose[:3, 3] = obb_box.T.detach().to("cpu", torch.float64).reshape(3)
+                w2b = torch.linalg.inv(pose)[:3].to(torch.float32).reshape(-1).tolist()
+                size = obb_box.S.detach().to("cpu", torch.float32).reshape(3).tolist()
+                nears = torch.empty((H, W, 1), dtype=torch.float32, device=dev)
+                fars = torch.empty((H, W, 1), dtype=torch.float32, device=dev)
+                st = lib.sn_intersect_obb(_lib.ptr(origins), _lib.ptr(directions), H * W, (C.c_float * 12)(*w2b), (C.c_float * 3)(*size),
+                                          _lib.ptr(nears), _lib.ptr(fars), _lib.current_stream())
+                _lib.check(st, None, "sn_intersect_obb")
         cam_idx = torch.full((H, W, 1), i, dtype=torch.int64, device=dev)
         return RayBundle(origins=origins, directions=directions, pixel_area=pixel_area, camera_indices=cam_idx,
                          nears=nears, fars=fars, metadata={"directions_norm": dnorm})

@@ -795,6 +795,21 @@ int sn_intersect_with_aabb(const float* origins, const float* directions, int64_
     return SN_OK;
 }
 
+int sn_intersect_obb(const float* origins, const float* directions, int64_t n_rays, const float* world2box, const float* size,
+                     float* nears, float* fars, SnStream stream) {
+    if (!origins || !directions || !world2box || !size || !nears || !fars || n_rays < 0)
+        return fail(nullptr, SN_ERR_INVALID, "sn_intersect_obb: bad argument");
+    if (n_rays == 0) return SN_OK;
+    SnObb box;
+    memcpy(box.w2b, world2box, sizeof(box.w2b));
+    for (int c = 0; c < 3; ++c) box.half[c] = size[c] / 2.0f;
+    hipLaunchKernelGGL(sn_intersect_obb_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, origins,
+                       directions, n_rays, box, nears, fars);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_intersect_obb launch: ") + hipGetErrorString(e));
+    return SN_OK;
+}
+
 size_t sn_workspace_bytes(SnHandle h, int32_t height, int32_t width, const SnRenderOpts* opts) {
     if (!h || !opts || height <= 0 || width <= 0 || opts->chunk_rays < 1) return 0;
     return plan_workspace(height, width, *opts).total;

@@ -118,6 +118,38 @@ __global__ void sn_intersect_with_aabb_kernel(const float* origins, const float*
 }
 
 // ------------------------------------------------------------------------------------------
+// viewer crop: nerfstudio's intersect_obb [NS] -- rays into the box frame (world2box = inverse of [R | T]),
+// then the clamped slab test of intersect_aabb against [-S/2, S/2]; invalid -> 1e10 for both
+// ------------------------------------------------------------------------------------------
+struct SnObb {
+    float w2b[12];  // 3x4 row-major
+    float half[3];
+};
+
+__global__ void sn_intersect_obb_kernel(const float* origins, const float* directions, int64_t n, SnObb box, float* nears, float* fars) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float o[3] = {origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2]};
+    const float d[3] = {directions[i * 3], directions[i * 3 + 1], directions[i * 3 + 2]};
+    float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* m = box.w2b + 4 * c;
+        const float ob = ((m[0] * o[0] + m[1] * o[1]) + m[2] * o[2]) + m[3];
+        const float db = (m[0] * d[0] + m[1] * d[1]) + m[2] * d[2];
+        const float a = (-box.half[c] - ob) / db, b = (box.half[c] - ob) / db;
+        tmin = fmaxf(tmin, fminf(a, b));
+        tmax = fminf(tmax, fmaxf(a, b));
+    }
+    tmin = fminf(fmaxf(tmin, 0.0f), 1e10f);
+    tmax = fminf(fmaxf(tmax, 0.0f), 1e10f);
+    if (tmax <= tmin) tmin = tmax = 1e10f;
+    nears[i] = tmin;
+    fars[i] = tmax;
+}
+
+// ------------------------------------------------------------------------------------------
 // row a13: hash encoding of explicit normalised positions
 // ------------------------------------------------------------------------------------------
 struct SnHashStageParams {

@@ -376,10 +376,9 @@ class NerfactoModel(nn.Module):
     def get_outputs_for_camera(self, camera, obb_box=None) -> Dict[str, Tensor]:
         """nerfstudio's ``Model.get_outputs_for_camera`` [NS], the call the viewer's render thread makes on the shared model
         (/root/reference/signerf/interface/viewer.py:334-336): rays of camera 0, then the whole-image
-        render -- the same kernels at the viewer's resolution.  ``obb_box`` (viewer crop) is not supported."""
-        if obb_box is not None:
-            raise NotImplementedError("oriented crop boxes (viewer crop) are not part of the render path")
-        return self.get_outputs_for_camera_ray_bundle(camera.generate_rays(camera_indices=0, aabb_box=self.render_aabb))
+        render -- the same kernels at the viewer's resolution.  ``obb_box`` (the viewer's crop box) bounds the rays through
+        nerfstudio's ``intersect_obb`` (``Cameras.generate_rays(obb_box=...)``)."""
+        return self.get_outputs_for_camera_ray_bundle(camera.generate_rays(camera_indices=0, aabb_box=self.render_aabb, obb_box=obb_box))
 
     @torch.no_grad()
     def get_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:

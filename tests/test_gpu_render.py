@@ -264,5 +264,36 @@ def test_get_outputs_for_camera_is_the_two_call_path(gpu):
     a = model.get_outputs_for_camera(cam)
     b = model.get_outputs_for_camera_ray_bundle(cam.generate_rays(0))
     assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
-    with pytest.raises(NotImplementedError):
-        model.get_outputs_for_camera(cam, obb_box=object())
+
+
+def test_viewer_crop_box_bounds_the_rays(gpu):
+    """`get_outputs_for_camera(camera, obb_box)` (the viewer's crop): nears / fars from nerfstudio's intersect_obb in the box frame,
+    checked against the oracle; an axis-aligned box gives the aabb path's bounds; the render then equals the oracle's on those rays."""
+    import math
+
+    from signerf_amd import OrientedBox
+
+    cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=24, predict_normals=False)
+    model, sd = make_model(cfg, gpu)
+    cam = Cameras(scene.benchmark_cameras(8)[:, :3], 60.0, 60.0, 24.0, 18.0, 48, 36).to(gpu)[2]
+    a = math.radians(25.0)
+    R = torch.tensor([[math.cos(a), -math.sin(a), 0.0], [math.sin(a), math.cos(a), 0.0], [0.0, 0.0, 1.0]])
+    box = OrientedBox(R=R, T=torch.tensor([0.02, -0.03, 0.01]), S=torch.tensor([0.3, 0.2, 0.25]))
+    b = cam.generate_rays(0, obb_box=box)
+    o, d = b.origins.cpu().reshape(-1, 3), b.directions.cpu().reshape(-1, 3)
+    t0, t1 = onf.intersect_obb(o, d, box.R, box.T, box.S)
+    hit = t1 < 1e9
+    assert 100 < int(hit.sum()) < hit.numel()
+    assert torch.equal(b.nears.cpu().reshape(-1) >= 1e9, ~hit)                      # the same rays miss
+    assert torch.allclose(b.nears.cpu().reshape(-1)[hit], t0[hit], rtol=2e-5, atol=1e-6)
+    assert torch.allclose(b.fars.cpu().reshape(-1)[hit], t1[hit], rtol=2e-5, atol=1e-6)
+    # axis-aligned box == the aabb path
+    eye = OrientedBox(R=torch.eye(3), T=torch.zeros(3), S=torch.tensor([0.3, 0.2, 0.25]))
+    e = cam.generate_rays(0, obb_box=eye)
+    f = cam.generate_rays(0, aabb_box=SceneBox(aabb=torch.tensor([[-0.15, -0.1, -0.125], [0.15, 0.1, 0.125]])))
+    assert torch.allclose(e.nears, f.nears, rtol=1e-6) and torch.allclose(e.fars, f.fars, rtol=1e-6)
+    # the render inside the crop
+    out = model.get_outputs_for_camera(cam, obb_box=box)
+    ref = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg), b.origins.cpu(), b.directions.cpu(), b.nears.cpu(), b.fars.cpu())
+    m = hit.view(36, 48)
+    assert rmse(out["rgb"].cpu()[m], ref["rgb"][m]) <= RMSE_TOL and rmse(out["depth"].cpu()[m], ref["depth"][m]) <= RMSE_TOL
