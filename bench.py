@@ -55,7 +55,13 @@ def cpu_baseline(cfg, sd, width, height, samples, crop=200):
     t = time.perf_counter()
     onf.get_outputs_for_camera_ray_bundle(sd, ocfg, o, d)
     dt = time.perf_counter() - t
-    return {"value": crop * crop * samples / dt, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+    cpu = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next(ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    return {"value": crop * crop * samples / dt, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port", "host_cpu": cpu,
             "sample": f"centred {crop}x{crop} crop of the {width}x{height}x{samples} frame, {dt:.1f} s, torch CPU fp32 oracle",
             "ms_per_frame_extrapolated": dt * 1e3 * (width * height) / (crop * crop)}
 
