@@ -153,9 +153,9 @@ int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, 
     memset(&res, 0, sizeof(res));
     if (d.grid_mode != 0 || want <= 0 || !table.ptr) return SN_OK;
     uint64_t bytes = 0;
-    uint32_t R[11];
+    uint32_t R[12];
     int nd = 0;
-    for (int l = 0; l < want && l < d.num_levels && l < 11; ++l) {
+    for (int l = 0; l < want && l < d.num_levels && l < 12; ++l) {
         const uint64_t r = (uint64_t)d.scalings[l] + 2;
         if (r > 1400 || r * r * r * 8 > cap_mb * 1000 * 1000) break;  // 8 R^2 must fit 24 bits
         R[l] = (uint32_t)r;
@@ -730,8 +730,10 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
     // torch grids: de-hashed copies of the coarse levels (SN_DENSE_LEVELS caps the count; 0 = off)
     {
         const char* e = getenv("SN_DENSE_LEVELS");
-        const int want = std::max(0, std::min(e ? atoi(e) : SN_DENSE_LEVELS_DEFAULT, 11));
-        if (int rc = build_dense_copies(h, d.main_field, h->table_main, want, 600, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st))
+        const int want = std::max(0, std::min(e ? atoi(e) : SN_DENSE_LEVELS_DEFAULT, 12));
+        const char* cap_env = getenv("SN_DENSE_CAP_MB");  // per-level size cap of the main grid's copies (experiments)
+        const uint64_t cap_main = cap_env ? (uint64_t)std::max(1, atoi(cap_env)) : 600;
+        if (int rc = build_dense_copies(h, d.main_field, h->table_main, want, cap_main, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st))
             return rc;
         for (int i = 0; i < d.num_proposals; ++i)
             if (int rc = build_dense_copies(h, d.proposals[i], h->table_prop[i], want, 100, h->dense_prop[i], h->dense_info_prop[i],
@@ -983,6 +985,7 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
         case 9: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 9); break;       \
         case 10: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 10); break;     \
         case 11: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 11); break;     \
+        case 12: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 12); break;     \
         default: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, -1); break;     \
     }
     if (ablate == 12 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 1, 2, 0, 11);        // fp16x2 kernel: hash phase (11 de-hashed levels) only

@@ -332,8 +332,8 @@ SN_DEV f32x2 sn_hash_level_dense_pairs(__amdgpu_buffer_rsrc_t rsrc, uint32_t lev
 struct SnDenseCopy {
     const float* base;     // all copied levels, back to back
     uint32_t bytes;
-    uint32_t off[11];      // byte offset of level l's copy (l < number of copied levels <= 11)
-    uint32_t res[11];      // R of level l
+    uint32_t off[12];      // byte offset of level l's copy (l < number of copied levels <= 12)
+    uint32_t res[12];      // R of level l
 };
 
 SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_off_bytes, const float q[3], float scale, uint32_t R) {
@@ -395,7 +395,7 @@ SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int l
             feat[2 * l + 1] = e.y;
             continue;
         }
-        if (ARITH == 1 && ND > 0 && l < ND && l < 11) {  // torch grid: de-hashed copy of a coarse level
+        if (ARITH == 1 && ND > 0 && l < ND && l < 12) {  // torch grid: de-hashed copy of a coarse level
             uint32_t R = dense->res[l];
             asm volatile("" : "+s"(R));  // keep the per-level strides out of the loop-invariant set (SGPR pressure, see sn_grid_dense_res)
             const f32x2 e = sn_hash_level_dense_copy(sn_table_rsrc(dense->base, dense->bytes), dense->off[l], q, scal[l], R);
