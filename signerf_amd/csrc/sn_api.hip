@@ -147,7 +147,7 @@ SnGridLevels grid_levels(const SnHashMlpDesc& d) {
 // 3.33 / 3.30 / 3.26 ms for 0 / 8 / 9 / 10 / 11 copied levels), the proposal nets (352 samples per ray over the coarse levels)
 // lose with the 137 MB copy of the second net's finest level (frame 18.8 vs 17.5 ms) -- hence the two caps.
 int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, int want, uint64_t cap_mb, DevBuf& buf, SnDenseCopy& info,
-                       SnGridLevels& res, int& nd_out, hipStream_t st) {
+                       SnGridLevels& res, int& nd_out, hipStream_t st, int n_sets = 1) {
     nd_out = 0;
     memset(&info, 0, sizeof(info));
     memset(&res, 0, sizeof(res));
@@ -165,21 +165,27 @@ int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, 
         ++nd;
     }
     if (nd == 0) return SN_OK;
+    // orientation sets (y-fast, z-fast) behind the x-fast one, as long as 32-bit buffer offsets reach them
+    const uint64_t set_bytes = bytes;
+    if (n_sets > 1 && set_bytes * (uint64_t)n_sets >= 0xf0000000ull) n_sets = 1;
+    bytes = set_bytes * (uint64_t)n_sets;
     if (buf.bytes != bytes) {
         buf.release();
         SN_HIP(h, hipMalloc(&buf.ptr, bytes));
         buf.bytes = bytes;
     }
     SN_HIP(h, hipMemsetAsync(buf.ptr, 0, bytes, st));
-    for (int l = 0; l < nd; ++l) {
-        const uint32_t n = R[l] * R[l] * R[l];
-        hipLaunchKernelGGL(sn_build_dense_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)table.ptr,
-                           (float*)((char*)buf.ptr + info.off[l]), l, d.log2_hashmap_size, R[l]);
-        info.res[l] = R[l];
-    }
+    for (int set = 0; set < n_sets; ++set)
+        for (int l = 0; l < nd; ++l) {
+            const uint32_t n = R[l] * R[l] * R[l];
+            hipLaunchKernelGGL(sn_build_dense_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)table.ptr,
+                               (float*)((char*)buf.ptr + (uint64_t)set * set_bytes + info.off[l]), l, d.log2_hashmap_size, R[l], set);
+            info.res[l] = R[l];
+        }
     SN_HIP(h, hipGetLastError());
     info.base = (const float*)buf.ptr;
     info.bytes = (uint32_t)bytes;
+    info.perm_stride = n_sets > 1 ? (uint32_t)set_bytes : 0u;
     nd_out = nd;
     return SN_OK;
 }
@@ -733,7 +739,9 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         const int want = std::max(0, std::min(e ? atoi(e) : SN_DENSE_LEVELS_DEFAULT, 12));
         const char* cap_env = getenv("SN_DENSE_CAP_MB");  // per-level size cap of the main grid's copies (experiments)
         const uint64_t cap_main = cap_env ? (uint64_t)std::max(1, atoi(cap_env)) : 600;
-        if (int rc = build_dense_copies(h, d.main_field, h->table_main, want, cap_main, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st))
+        const char* pe = getenv("SN_DENSE_ORIENT");  // 0: only the x-fast set of copies
+        const int sets = (pe && atoi(pe) == 0) ? 1 : 3;
+        if (int rc = build_dense_copies(h, d.main_field, h->table_main, want, cap_main, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st, sets))
             return rc;
         for (int i = 0; i < d.num_proposals; ++i)
             if (int rc = build_dense_copies(h, d.proposals[i], h->table_prop[i], want, 100, h->dense_prop[i], h->dense_info_prop[i],

@@ -334,6 +334,10 @@ struct SnDenseCopy {
     uint32_t bytes;
     uint32_t off[12];      // byte offset of level l's copy (l < number of copied levels <= 12)
     uint32_t res[12];      // R of level l
+    // Orientation copies (main grid): the same levels again with the y (k = 1) or z (k = 2) axis as the fast one, at byte offset
+    // k * perm_stride; 0 = only the x-fast set exists.  A wave picks the set whose fast axis is the grid axis along which its
+    // pixel row moves (sn_render_main_kernel): the 8 lanes of a tile row then read neighbouring entries instead of 8 far rows.
+    uint32_t perm_stride;
 };
 
 SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_off_bytes, const float q[3], float scale, uint32_t R) {
@@ -367,10 +371,13 @@ SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t leve
 }
 
 // builds D_l for one level: one thread per entry
-__global__ void sn_build_dense_copy_kernel(const float* __restrict__ table, float* __restrict__ dense, int level, int log2_t, uint32_t R) {
+// perm: 0 = entry i holds grid point (x, y, z) = (i % R, i / R % R, i / R^2); 1 = the roles of x and y swapped; 2 = x and z swapped
+__global__ void sn_build_dense_copy_kernel(const float* __restrict__ table, float* __restrict__ dense, int level, int log2_t, uint32_t R,
+                                           int perm) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R * R * R) return;
-    const uint32_t x = i % R, y = (i / R) % R, z = i / (R * R);
+    const uint32_t c0 = i % R, c1 = (i / R) % R, c2 = i / (R * R);
+    const uint32_t x = perm == 1 ? c1 : (perm == 2 ? c2 : c0), y = perm == 1 ? c0 : c1, z = perm == 2 ? c0 : c2;
     const uint32_t mask = (1u << log2_t) - 1u;
     const uint32_t row = (x ^ (y * 2654435761u) ^ (z * 805459861u)) & mask;
     const f32x2* lv = (const f32x2*)table + ((uint64_t)level << log2_t);
@@ -383,7 +390,8 @@ __global__ void sn_build_dense_copy_kernel(const float* __restrict__ table, floa
 // With ND >= 0 the dense levels use the paired 16-byte gathers of sn_hash_level_dense_pairs.
 template <int L, int GROUP = 0, int ARITH = 0, int ND = -1>
 SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], float* feat,
-                           const SnGridLevels* grid = nullptr, const SnDenseCopy* dense = nullptr) {
+                           const SnGridLevels* grid = nullptr, const SnDenseCopy* dense = nullptr, const float* qdense = nullptr,
+                           uint32_t dense_set_off = 0u) {
     constexpr bool FAST = ARITH != 0;
     const uint32_t mask = (1u << log2_t) - 1u;
 #pragma unroll
@@ -398,7 +406,8 @@ SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int l
         if (ARITH == 1 && ND > 0 && l < ND && l < 12) {  // torch grid: de-hashed copy of a coarse level
             uint32_t R = dense->res[l];
             asm volatile("" : "+s"(R));  // keep the per-level strides out of the loop-invariant set (SGPR pressure, see sn_grid_dense_res)
-            const f32x2 e = sn_hash_level_dense_copy(sn_table_rsrc(dense->base, dense->bytes), dense->off[l], q, scal[l], R);
+            // qdense / dense_set_off: the position with its axes in the order of the orientation set this wave reads (or q, set 0)
+            const f32x2 e = sn_hash_level_dense_copy(sn_table_rsrc(dense->base, dense->bytes), dense->off[l] + dense_set_off, qdense ? qdense : q, scal[l], R);
             feat[2 * l] = e.x;
             feat[2 * l + 1] = e.y;
             continue;
