@@ -390,7 +390,7 @@ class NerfactoModel(nn.Module):
         return self.get_outputs(ray_bundle)
 
     def _with_normals(self, b: RayBundle, H: int, W: int, shape) -> Dict[str, Tensor]:
-        out = {k: v.view(*shape, -1) for k, v in self._render(b, H, W).items()}
+        out = {k: v.view(*shape, v.shape[-1]) for k, v in self._render(b, H, W).items()}
         mode = self.config.compute_normals if self.config.predict_normals else "never"
         if mode == "never":
             return out
@@ -399,7 +399,7 @@ class NerfactoModel(nn.Module):
 
         def producer():
             with torch.no_grad():
-                return {k: v.view(*shape, -1) for k, v in self._render_normals(b, H, W).items()}
+                return {k: v.view(*shape, v.shape[-1]) for k, v in self._render_normals(b, H, W).items()}
 
         if mode == "always":
             out.update(producer())
@@ -410,6 +410,9 @@ class NerfactoModel(nn.Module):
         """Row a16: "normals" (analytic) and "pred_normals", [H*W,3] each, by the separate normals kernel (csrc/sn_normals.h)."""
         lib = self._ensure_engine()
         dev = self.device
+        if H * W == 0:
+            z = torch.empty((0, 3), dtype=torch.float32, device=dev)
+            return {"normals": z, "pred_normals": z.clone()} if self._has_pred_normals else {"normals": z}
         f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
         origins, directions, nears, fars = f32(b.origins), f32(b.directions), f32(b.nears), f32(b.fars)
         with torch.cuda.device(dev):
@@ -424,6 +427,11 @@ class NerfactoModel(nn.Module):
 
     def _render(self, b: RayBundle, H: int, W: int) -> Dict[str, Tensor]:
         lib = self._ensure_engine()
+        if H * W == 0:  # an empty bundle renders to empty outputs, as the reference's chunk loop does
+            z = lambda c: torch.empty((0, c), dtype=torch.float32, device=self.device)  # noqa: E731
+            out = {"rgb": z(3), "accumulation": z(1), "depth": z(1), "expected_depth": z(1)}
+            out.update({f"prop_depth_{i}": z(1) for i in range(self.config.num_proposal_iterations)})
+            return out
         dev = self.device
         f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
         origins, directions, nears, fars = f32(b.origins), f32(b.directions), f32(b.nears), f32(b.fars)

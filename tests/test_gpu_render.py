@@ -324,3 +324,14 @@ def test_orientation_sets_of_the_dehashed_copies_agree(gpu, monkeypatch):
         out = three.get_outputs_for_camera_ray_bundle(b)
         assert rmse(out["rgb"], ref["rgb"]) <= 1e-6 and rmse(out["accumulation"], ref["accumulation"]) <= 1e-6
         assert float((out["depth"] != ref["depth"]).float().mean()) <= 0.002   # median-index ties only
+
+
+def test_empty_bundle_renders_to_empty_outputs(gpu):
+    """A bundle with no rays (an empty row-major slice, as the reference's chunk loop can produce): every output is [0, C]."""
+    cfg = small_config(num_proposal_samples_per_ray=(24, 12), num_nerf_samples_per_ray=8)
+    model, _ = make_model(cfg, gpu)
+    b = Cameras(scene.benchmark_cameras(8)[:, :3], 30.0, 30.0, 8.0, 8.0, 16, 16).to(gpu)[1].generate_rays(0)
+    empty = b.get_row_major_sliced_ray_bundle(5, 5)
+    out = model.get_outputs(empty)
+    assert out["rgb"].shape == (0, 3) and out["depth"].shape == (0, 1) and out["prop_depth_1"].shape == (0, 1)
+    assert out["normals"].shape == (0, 3) and out["pred_normals"].shape == (0, 3)
