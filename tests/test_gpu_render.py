@@ -335,3 +335,20 @@ def test_empty_bundle_renders_to_empty_outputs(gpu):
     out = model.get_outputs(empty)
     assert out["rgb"].shape == (0, 3) and out["depth"].shape == (0, 1) and out["prop_depth_1"].shape == (0, 1)
     assert out["normals"].shape == (0, 3) and out["pred_normals"].shape == (0, 3)
+
+
+@pytest.mark.parametrize("props", [0, 2])
+def test_4k_frame_indexing(gpu, props):
+    """Largest frame a viewer asks for (3840 x 2160 = 8.3 M rays; 129 600 tiles): a band of rows rendered on its own is bit-identical to
+    the same rows of the full frame (rays are independent), i.e. tile / bin / pixel indexing holds at that size."""
+    cfg = small_config(num_proposal_iterations=props, num_proposal_samples_per_ray=(16, 8) if props else (), num_nerf_samples_per_ray=6,
+                       predict_normals=False)
+    model, _ = make_model(cfg, gpu)
+    W, H = 3840, 2160
+    b = Cameras(scene.benchmark_cameras(8)[:, :3], 2000.0, 2000.0, W / 2, H / 2, W, H).to(gpu)[3].generate_rays(0)
+    full = model.get_outputs_for_camera_ray_bundle(b)
+    assert full["rgb"].shape == (H, W, 3) and torch.isfinite(full["rgb"]).all() and torch.isfinite(full["depth"]).all()
+    for r0 in (0, 1072, 2152):
+        band = model.get_outputs_for_camera_ray_bundle(b._map(lambda t: t[r0:r0 + 8].contiguous()))
+        for k in ("rgb", "depth", "accumulation"):
+            assert torch.equal(band[k], full[k][r0:r0 + 8]), (r0, k)
