@@ -352,3 +352,19 @@ def test_4k_frame_indexing(gpu, props):
         band = model.get_outputs_for_camera_ray_bundle(b._map(lambda t: t[r0:r0 + 8].contiguous()))
         for k in ("rgb", "depth", "accumulation"):
             assert torch.equal(band[k], full[k][r0:r0 + 8]), (r0, k)
+
+
+def test_unsupported_options_fail_loudly(gpu):
+    """Error behaviour of the boundary: int status + sn_last_error text -> SignerfHipError, never a silent fallback."""
+    from signerf_amd import _lib
+
+    cfg = small_config(num_proposal_samples_per_ray=(300, 12), num_nerf_samples_per_ray=8)   # 300 > the kernel's 256-sample scratch
+    model, _ = make_model(cfg, gpu)
+    b = Cameras(scene.benchmark_cameras(8)[:, :3], 30.0, 30.0, 8.0, 8.0, 16, 16).to(gpu)[0].generate_rays(0)
+    with pytest.raises(_lib.SignerfHipError, match="num_proposal_samples out of range"):
+        model.get_outputs_for_camera_ray_bundle(b)
+    with pytest.raises(_lib.SignerfHipError, match="GPU"):
+        cfg2 = small_config(num_proposal_iterations=0)
+        cfg2.setup().get_outputs_for_camera_ray_bundle(b)        # a model left on the CPU: no CPU path
+    with pytest.raises(_lib.SignerfHipError):
+        small_config(hidden_dim=32).setup().to(gpu).get_outputs_for_camera_ray_bundle(b)   # an MLP width the kernels are not built for
