@@ -221,6 +221,11 @@ class NerfactoModel(nn.Module):
         cfg = self.config
         if cfg.disable_scene_contraction:
             raise NotImplementedError("only the L-inf scene contraction path is built")
+        # the kernels implement the values SIGNeRF runs with (nerfacto's defaults); anything else must not render silently wrong
+        if cfg.background_color != "last_sample":
+            raise NotImplementedError(f"background_color={cfg.background_color!r}: only 'last_sample' (nerfacto's default) is built")
+        if cfg.proposal_initial_sampler != "piecewise":
+            raise NotImplementedError(f"proposal_initial_sampler={cfg.proposal_initial_sampler!r}: only 'piecewise' is built")
         self.field = NerfactoField(cfg, self.num_train_data)
         self.proposal_networks = nn.ModuleList()
         for i in range(cfg.num_proposal_iterations):

@@ -133,3 +133,13 @@ def test_lazy_outputs_dict_semantics():
     e = LazyOutputs({"rgb": 1}, producer)
     assert dict(e.items()) == {"rgb": 1, "normals": "n", "pred_normals": "p"} and calls == [1, 1]
     assert LazyOutputs({"rgb": 1}, producer).copy() == {"rgb": 1, "normals": "n", "pred_normals": "p"}
+
+
+def test_unbuilt_config_values_are_rejected_at_model_set_up():
+    """Values of nerfstudio's config that the kernels do not implement raise instead of rendering something else."""
+    from signerf_amd import SIGNeRFModelConfig
+
+    for kw in ({"background_color": "black"}, {"proposal_initial_sampler": "uniform"}, {"disable_scene_contraction": True}):
+        with pytest.raises(NotImplementedError):
+            SIGNeRFModelConfig(**kw).setup()
+    SIGNeRFModelConfig(log2_hashmap_size=12).setup()   # the defaults build (CPU-side module set-up only)
