@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tl = _torch_lib_dir()
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-no-hip-rt",
-           "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Rpass-analysis=kernel-resource-usage",
+           "-fno-slp-vectorize", "-mllvm", "-disable-vector-combine", "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Rpass-analysis=kernel-resource-usage",
            *extra_flags,
            *[os.path.join(CSRC, s) for s in SOURCES],
            "-o", LIB_PATH, f"-L{tl}", "-lamdhip64", f"-Wl,-rpath,{tl}", "-Wl,-rpath,/opt/rocm/lib"]

@@ -202,14 +202,25 @@ SN_DEV void sn_hash_corners_fast(const float q[3], float scale, uint32_t mask, S
 }
 
 SN_DEV f32x2 sn_hash_blend_fast(const f32x2 v[8], const float off[3]) {
+    // Plain (un-packed) fp32 instructions ON PURPOSE.  Measured r02 (tools/probes/overlap2_probe.hip, profiles/r02_overlap2_probe.txt):
+    // on gfx950 v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 are mutually exclusive with the matrix pipe of their SIMD -- a packed op
+    // waits for the MFMA in flight (of ANY wave of the SIMD) and the next MFMA waits for it -- while plain VALU ops (v_fma_f32,
+    // v_sub_f32, integer, conversions) issue beside a running v_mfma_f32_32x32x16_f16 for free.  In the fused kernels the blend of one
+    // wave runs beside the MLP of the others, so 2 plain ops beat 1 packed op.  (The library is built with -fno-slp-vectorize so that
+    // hipcc does not re-pack them.)
     const float ox = off[0], oy = off[1], oz = off[2];
-    const f32x2 f03 = (v[0] - v[3]) * ox + v[3];
-    const f32x2 f12 = (v[1] - v[2]) * ox + v[2];
-    const f32x2 f56 = (v[5] - v[6]) * ox + v[6];
-    const f32x2 f47 = (v[4] - v[7]) * ox + v[7];
-    const f32x2 f0312 = (f03 - f12) * oy + f12;
-    const f32x2 f4756 = (f47 - f56) * oy + f56;
-    return (f0312 - f4756) * oz + f4756;
+    f32x2 out;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float f03 = fmaf(v[0][c] - v[3][c], ox, v[3][c]);
+        const float f12 = fmaf(v[1][c] - v[2][c], ox, v[2][c]);
+        const float f56 = fmaf(v[5][c] - v[6][c], ox, v[6][c]);
+        const float f47 = fmaf(v[4][c] - v[7][c], ox, v[7][c]);
+        const float f0312 = fmaf(f03 - f12, oy, f12);
+        const float f4756 = fmaf(f47 - f56, oy, f56);
+        out[c] = fmaf(f0312 - f4756, oz, f4756);
+    }
+    return out;
 }
 
 // tiny-cuda-nn grid semantics (`implementation="tcnn"` checkpoints; UNPINNED -- oracle/tcnn_layout.py):

@@ -187,6 +187,10 @@ struct SnMainImgH {
 // instead of mask, mask, convert, packed subtract, convert.  hipcc does not select fma_mix for this pattern, hence the asm
 // (a plain VALU instruction: no hazard class of its own; checked on hardware by tools/probes/mix_probe).
 SN_DEV void sn_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+#ifdef SN_PROBE_NOSPLIT  // tools/probes/mlp_probe.hip: the MFMA part of the MLP alone (no instruction, dependencies kept)
+    asm volatile("" : "=v"(hi), "=v"(lo) : "v"(a), "v"(b));
+    return;
+#endif
     hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
     float la, lb;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la) : "v"(hi), "v"(a));
@@ -207,7 +211,9 @@ struct SnOpH {  // one B operand (8 k-slots of one 32-sample tile), hi and lo pa
     }
 };
 
+#ifndef SN_MFMA_H  // (tools/probes/mlp_probe.hip overrides it to time the VALU part of the MLP alone)
 #define SN_MFMA_H(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, ACC, 0, 0, 0)
+#endif
 
 template <int RT, int KS>
 SN_DEV void sn_mlp_layer_h(const char* __restrict__ wimg, const float* __restrict__ bimg, const SnOpH* op0, const SnOpH* op1,
@@ -233,6 +239,9 @@ SN_DEV void sn_mlp_layer_h(const char* __restrict__ wimg, const float* __restric
         const f16x8 bh0 = __builtin_bit_cast(f16x8, op0[s].hi), bl0 = __builtin_bit_cast(f16x8, op0[s].lo);
         const f16x8 bh1 = __builtin_bit_cast(f16x8, op1[s].hi), bl1 = __builtin_bit_cast(f16x8, op1[s].lo);
         // small terms first, then hi.hi; independent accumulators interleaved
+#ifdef SN_MFMA_PRIO  // experiment (tools/probes/mlp_probe.hip): raise the wave's priority around its MFMA cluster
+        __builtin_amdgcn_s_setprio(SN_MFMA_PRIO);
+#endif
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             SN_MFMA_H(acc0[rt], al[rt], bh0);
@@ -248,6 +257,9 @@ SN_DEV void sn_mlp_layer_h(const char* __restrict__ wimg, const float* __restric
             SN_MFMA_H(acc0[rt], ah[rt], bh0);
             SN_MFMA_H(acc1[rt], ah[rt], bh1);
         }
+#ifdef SN_MFMA_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
 }
 
@@ -332,18 +344,19 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
     }
     // ---- colour layer 2 (two 32-row passes: halves the live accumulators, same MFMAs) + colour layer 3 on the VALU ----
     const int h = lane >> 5;
-    // packed fp32 FMAs: even / odd rows accumulate in the two halves of a register pair, joined at the end
-    f32x2 q0[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, q1[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    // plain fp32 FMAs (NOT v_pk_fma_f32: packed fp32 ops are mutually exclusive with the matrix pipe on gfx950 and would stall
+    // behind the other waves' MFMAs -- tools/probes/overlap2_probe.hip); two accumulators per channel and tile for issue distance
+    float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         f32x16 c0[1], c1[1];
         sn_mlp_layer_h<1, 4>(ldsb + SnMainImgH::WC2 + rt * 8192, tail + SnMainImgH::BC2 + rt * 32, op0, op1, c0, c1, lane);
         __builtin_amdgcn_sched_barrier(0);
-        f32x2 r0[8], r1[8];
+        float r0[16], r1[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            r0[j] = f32x2{sn_relu(c0[0][2 * j]), sn_relu(c0[0][2 * j + 1])};
-            r1[j] = f32x2{sn_relu(c1[0][2 * j]), sn_relu(c1[0][2 * j + 1])};
+        for (int j = 0; j < 16; ++j) {
+            r0[j] = sn_relu(c0[0][j]);
+            r1[j] = sn_relu(c1[0][j]);
         }
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
@@ -351,20 +364,14 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const f32x4 wv = w[rt * 4 + r4];
-                const f32x2 wa = {wv.x, wv.y}, wb = {wv.z, wv.w};
-                q0[n] = wa * r0[2 * r4] + q0[n];
-                q1[n] = wa * r1[2 * r4] + q1[n];
-                q0[n] = wb * r0[2 * r4 + 1] + q0[n];
-                q1[n] = wb * r1[2 * r4 + 1] + q1[n];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p0[n] = fmaf(wv[e], r0[4 * r4 + e], p0[n]);
+                    p1[n] = fmaf(wv[e], r1[4 * r4 + e], p1[n]);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-    }
-    float p0[3], p1[3];
-#pragma unroll
-    for (int n = 0; n < 3; ++n) {
-        p0[n] = q0[n].x + q0[n].y;
-        p1[n] = q1[n].x + q1[n].y;
     }
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
