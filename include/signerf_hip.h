@@ -162,7 +162,10 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
                       int32_t height, int32_t width, const SnRenderOpts* opts, float* normals, float* pred_normals,
                       SnStream stream);
 
-/* ---- stage-level entry points (same device code as the fused kernels; used by parity tests) */
+/* ---- stage-level entry points (used by parity tests).  They run the LITERAL torch-path arithmetic (IEEE divisions in the
+ * contraction, floor / ceil corners, the reference's blend association, expf); the fused kernels behind sn_render_rays run the
+ * reduced-instruction forms of the same maps (v_rcp_f32 contraction, truncation + fract corners with "ceil = floor + 1", lerp-form
+ * blend, v_exp_f32) and read the coarse levels from de-hashed copies -- what THEY fetch is checked through sn_render_rays_debug. */
 /* which: -1 main field, i >= 0 proposal net i.  q: [n,3] normalised positions in [0,1).
  * features: [n, L*F] level-major; indices (nullable): [n, L, 8] int32 table rows incl. level offset,
  * corner order as nerfstudio's hashed_0..7 (row a13). */
@@ -181,6 +184,49 @@ int sn_composite(const float* euclid_bins, const float* density, const float* rg
  * u: [M+1] device floats (the eval-mode grid). */
 int sn_pdf_sample(const float* spacing_bins, const float* weights, int64_t n_rays, int32_t n_in, int32_t n_out,
                   const float* u, float histogram_padding, float* new_bins, int32_t* inds, SnStream stream);
+
+/* ---- test instrumentation of the FUSED kernels (SURVEY.md §8(d) parity gate: "bit-exact: hash corner coords & table indices,
+ * PDF searchsorted indices and median-depth index ... count and report ties") -----------------------------------------------
+ * sn_render_rays_debug is sn_render_rays with the production kernels instantiated with their DUMP flag: every ray-sample records
+ * what it fetched, from the registers that feed the loads.  It exists for the default kernel variants only (torch grid,
+ * 11 de-hashed main levels; proposal nets with 5 + 4 de-hashed levels) and returns SN_ERR_INVALID otherwise.  Any pointer may be NULL.
+ * A fetch record is 8 uint32 words per (ray, sample, level):
+ *   hashed level read from the plain table   words 0..7 = byte offset (row * 8) of the 8 corner rows within the level,
+ *                                            nerfstudio corner order 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf
+ *                                            (x y z; the kernels take the "c" corner as floor + 1: it differs from ceil only where the
+ *                                            coordinate is an integer, i.e. where that corner's blend weight is exactly 0);
+ *   level read from its de-hashed copy       words 0..3 = byte offset, within the buffer of copies, of the four 16-byte fetches
+ *                                            (y1 z1), (y0 z1), (y0 z0), (y1 z0), each holding the x0 and x0 + 1 entries;
+ *                                            word 4 = 0xD0000000 | orientation set (0 x-fast, 1 y-fast, 2 z-fast);
+ *   level read from the x-paired tables      words 0..3 = 16-byte entry number of the four fetches (same order), each holding row r
+ *                                            and row r ^ (2^(t+1) - 1); word 4 = 0xA0000000 | t.
+ * sn_debug_layout / sn_debug_read expose the layout and the contents of those derived buffers so that a test can map every record
+ * back to rows of the uploaded hash table and check the copies against it. */
+typedef struct SnDebugDump {
+    uint32_t* main_fetch;                    /* [H*W][num_nerf_samples][16][8] */
+    float* main_q;                           /* [H*W][num_nerf_samples][3] the normalised positions the main kernel hashed */
+    int32_t* median_index;                   /* [H*W] index of the median-depth sample (row a17) */
+    uint32_t* prop_fetch[SN_MAX_PROPOSALS];  /* [H*W][num_proposal_samples[k]][5][8] */
+    float* prop_q[SN_MAX_PROPOSALS];         /* [H*W][num_proposal_samples[k]][3] the normalised positions proposal net k hashed */
+    int32_t* pdf_index[SN_MAX_PROPOSALS];    /* [H*W][m_k + 1]: PDFSampler's searchsorted(cdf, u, right) of resampling step k */
+} SnDebugDump;
+int sn_render_rays_debug(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars,
+                         int32_t height, int32_t width, const SnRenderOpts* opts,
+                         float* rgb, float* depth, float* accumulation, float* expected_depth,
+                         float* prop_depth_0, float* prop_depth_1, const SnDebugDump* dump, SnStream stream);
+typedef struct SnDebugLayout {
+    int32_t n_dense;                   /* leading levels that are read from de-hashed copies */
+    uint32_t dense_res[12];            /* R of level l: entry (c0, c1, c2) sits at c0 + R c1 + R^2 c2 */
+    uint32_t dense_off[12];            /* byte offset of level l's copy within one orientation set */
+    uint32_t dense_set_stride;         /* bytes between orientation sets (0: only the x-fast set exists) */
+    uint64_t dense_bytes;              /* size of the buffer of copies */
+    uint32_t pair_base[SN_MAX_LEVELS]; /* which >= 0: first 16-byte entry of level l's t = 0 paired table (table t follows at t << log2_T) */
+    uint64_t pair_bytes;
+} SnDebugLayout;
+/* which: -1 main field, i >= 0 proposal net i. */
+int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out);
+/* what: 0 = the buffer of de-hashed copies, 1 = the x-paired tables (proposal nets).  dst: device pointer, bytes must match. */
+int sn_debug_read(SnHandle h, int32_t which, int32_t what, void* dst, size_t bytes, SnStream stream);
 
 /* ---- the mask + condition step after the render, "aabb" masking mode ------------------
  * (signerf/datasetgenerator/datasetgenerator.py:758-818).  Stays on the device: no cv2 round trip (:776-778), no host sync on

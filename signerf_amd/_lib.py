@@ -73,6 +73,29 @@ class SnMaskOpts(C.Structure):
     ]
 
 
+class SnDebugDump(C.Structure):
+    _fields_ = [
+        ("main_fetch", C.c_void_p),
+        ("main_q", C.c_void_p),
+        ("median_index", C.c_void_p),
+        ("prop_fetch", C.c_void_p * SN_MAX_PROPOSALS),
+        ("prop_q", C.c_void_p * SN_MAX_PROPOSALS),
+        ("pdf_index", C.c_void_p * SN_MAX_PROPOSALS),
+    ]
+
+
+class SnDebugLayout(C.Structure):
+    _fields_ = [
+        ("n_dense", C.c_int32),
+        ("dense_res", C.c_uint32 * 12),
+        ("dense_off", C.c_uint32 * 12),
+        ("dense_set_stride", C.c_uint32),
+        ("dense_bytes", C.c_uint64),
+        ("pair_base", C.c_uint32 * SN_MAX_LEVELS),
+        ("pair_bytes", C.c_uint64),
+    ]
+
+
 # name -> (restype, argtypes).  Must list every symbol include/signerf_hip.h declares
 # (tests/test_cabi.py checks the two against each other).
 _FP = C.c_void_p  # device pointer
@@ -89,6 +112,10 @@ SIGNATURES = {
     "sn_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SnRenderOpts)]),
     "sn_render_rays": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.POINTER(SnRenderOpts),
                                  _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
+    "sn_render_rays_debug": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.POINTER(SnRenderOpts),
+                                       _FP, _FP, _FP, _FP, _FP, _FP, C.POINTER(SnDebugDump), C.c_void_p]),
+    "sn_debug_layout": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(SnDebugLayout)]),
+    "sn_debug_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _FP, C.c_size_t, C.c_void_p]),
     "sn_render_normals": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.POINTER(SnRenderOpts), _FP, _FP, C.c_void_p]),
     "sn_hash_encode": (C.c_int, [C.c_void_p, C.c_int32, _FP, C.c_int64, _FP, _FP, C.c_void_p]),
     "sn_field_forward": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, C.c_void_p]),

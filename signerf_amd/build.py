@@ -20,6 +20,11 @@ LIB_PATH = os.path.join(PKG_DIR, "libsignerf_hip.so")
 SOURCES = ["sn_api.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "signerf_hip.h")]
 ARCH = "gfx950"
+# Code-generation flags of the device code (tools/isa_hazard_scan.py compiles with the same ones).
+#   -fno-slp-vectorize, -disable-vector-combine: keep hipcc from packing neighbouring fp32 operations into v_pk_fma_f32 /
+#   v_pk_add_f32 / v_pk_mul_f32.  Measured r02 (tools/probes/overlap2_probe.hip): on gfx950 packed-fp32 VALU instructions are
+#   mutually exclusive with the matrix pipe of their SIMD, plain ones issue beside a running f16 MFMA.
+CODEGEN_FLAGS = ["-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-disable-vector-combine"]
 
 
 def _torch_lib_dir() -> str:
@@ -41,8 +46,8 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tl = _torch_lib_dir()
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-no-hip-rt",
-           "-fno-slp-vectorize", "-mllvm", "-disable-vector-combine", "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Rpass-analysis=kernel-resource-usage",
+    cmd = [hipcc, f"--offload-arch={ARCH}", *CODEGEN_FLAGS, "-fPIC", "-shared", "-no-hip-rt",
+           "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Rpass-analysis=kernel-resource-usage",
            *extra_flags,
            *[os.path.join(CSRC, s) for s in SOURCES],
            "-o", LIB_PATH, f"-L{tl}", "-lamdhip64", f"-Wl,-rpath,{tl}", "-Wl,-rpath,/opt/rocm/lib"]

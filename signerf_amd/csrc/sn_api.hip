@@ -829,7 +829,7 @@ size_t sn_workspace_bytes(SnHandle h, int32_t height, int32_t width, const SnRen
 // the normals render.
 static int launch_proposals(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars,
                             int32_t height, int32_t width, const SnRenderOpts* opts, const WorkspacePlan& wp, const TileGeom& g, char* ws,
-                            float* prop_depth_0, float* prop_depth_1, hipStream_t st, float** ebins_out) {
+                            float* prop_depth_0, float* prop_depth_1, hipStream_t st, float** ebins_out, const SnDebugDump* dump = nullptr) {
     const SnFieldDesc& d = h->desc;
     const int nprop = opts->num_proposal_iterations;
     const float* d_sbins = opts->initial_spacing_bins;
@@ -875,6 +875,17 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     pp.avg_density = d.average_init_density;
     pp.hist_pad = d.histogram_padding;
     const dim3 pgrid((unsigned)wp.prop_blocks), pblock(64 * SN_PROP_WAVES);
+    if (dump) {
+        // the instrumented instantiation exists for the production variant of nerfacto's proposal nets only
+        if (!(d.proposals[0].grid_mode == 0 && nprop == 2 && h->nd_prop[0] == 5 && h->nd_prop[1] == 4))
+            return fail(h, SN_ERR_INVALID, "sn_render_rays_debug: the proposal-kernel dump exists for the default variant only (torch grid, 2 nets, 5 + 4 de-hashed levels)");
+        for (int i = 0; i < SN_MAX_PROPOSALS; ++i) {
+            pp.dump_fetch[i] = dump->prop_fetch[i];
+            pp.dump_pdf[i] = dump->pdf_index[i];
+            pp.dump_q[i] = dump->prop_q[i];
+        }
+        hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4, true>), pgrid, pblock, 0, st, pp);
+    } else
     if (d.proposals[0].grid_mode == 1) {
         // nerfacto's proposal nets (max_res 128 / 256, T = 2^17) have 3 and 2 leading dense levels; other shapes take the
         // run-time form
@@ -892,9 +903,9 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     return SN_OK;
 }
 
-int sn_render_rays(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars, int32_t height,
-                   int32_t width, const SnRenderOpts* opts, float* rgb, float* depth, float* accumulation, float* expected_depth,
-                   float* prop_depth_0, float* prop_depth_1, SnStream stream) {
+static int render_rays_impl(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars, int32_t height,
+                            int32_t width, const SnRenderOpts* opts, float* rgb, float* depth, float* accumulation, float* expected_depth,
+                            float* prop_depth_0, float* prop_depth_1, const SnDebugDump* dump, SnStream stream) {
     if (!h) return SN_ERR_INVALID;
     if (!origins || !directions || !opts || height <= 0 || width <= 0) return fail(h, SN_ERR_INVALID, "sn_render_rays: bad argument");
     if ((nears == nullptr) != (fars == nullptr)) return fail(h, SN_ERR_INVALID, "sn_render_rays: nears and fars must both be given or both be NULL");
@@ -924,7 +935,7 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
 
     float* d_ebins = nullptr;
     if (nprop > 0)
-        if (int rc = launch_proposals(h, origins, directions, nears, fars, height, width, opts, wp, g, ws, prop_depth_0, prop_depth_1, st, &d_ebins))
+        if (int rc = launch_proposals(h, origins, directions, nears, fars, height, width, opts, wp, g, ws, prop_depth_0, prop_depth_1, st, &d_ebins, dump))
             return rc;
 
     SnMainParams p;
@@ -996,6 +1007,21 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
         case 12: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 12); break;     \
         default: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, -1); break;     \
     }
+    if (dump) {
+        // instrumented instantiations: the production variant (torch grid, 11 de-hashed levels), both samplers, both precisions
+        if (tcnn || h->nd_torch != 11)
+            return fail(h, SN_ERR_INVALID, "sn_render_rays_debug: the main-kernel dump exists for the default variant only (torch grid, 11 de-hashed levels)");
+        p.dump_fetch = dump->main_fetch;
+        p.dump_q = dump->main_q;
+        p.dump_median = dump->median_index;
+        if (nprop > 0) {
+            if (split) hipLaunchKernelGGL((sn_render_main_kernel<1, 1, 0, 0, 11, true>), grid, block, lds_bytes, st, p);
+            else hipLaunchKernelGGL((sn_render_main_kernel<1, 0, 0, 0, 11, true>), grid, block, lds_bytes, st, p);
+        } else {
+            if (split) hipLaunchKernelGGL((sn_render_main_kernel<0, 1, 0, 0, 11, true>), grid, block, lds_bytes, st, p);
+            else hipLaunchKernelGGL((sn_render_main_kernel<0, 0, 0, 0, 11, true>), grid, block, lds_bytes, st, p);
+        }
+    } else
     if (ablate == 12 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 1, 2, 0, 11);        // fp16x2 kernel: hash phase (11 de-hashed levels) only
     else if (ablate == 14 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 1, 4, 0, -1);   // fp16x2 kernel: MLP phase only
     else if (ablate == 13 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 1, 3, 0, -1);   // fp16x2 kernel: hash VALU only (no gathers, no MLP)
@@ -1017,6 +1043,54 @@ int sn_render_rays(SnHandle h, const float* origins, const float* directions, co
                            opts->chunk_rays, wp.n_chunks, expected_depth);
         SN_HIP(h, hipGetLastError());
     }
+    return SN_OK;
+}
+
+int sn_render_rays(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars, int32_t height,
+                   int32_t width, const SnRenderOpts* opts, float* rgb, float* depth, float* accumulation, float* expected_depth,
+                   float* prop_depth_0, float* prop_depth_1, SnStream stream) {
+    return render_rays_impl(h, origins, directions, nears, fars, height, width, opts, rgb, depth, accumulation, expected_depth, prop_depth_0,
+                            prop_depth_1, nullptr, stream);
+}
+
+int sn_render_rays_debug(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars, int32_t height,
+                         int32_t width, const SnRenderOpts* opts, float* rgb, float* depth, float* accumulation, float* expected_depth,
+                         float* prop_depth_0, float* prop_depth_1, const SnDebugDump* dump, SnStream stream) {
+    if (!dump) return fail(h, SN_ERR_INVALID, "sn_render_rays_debug: null dump");
+    return render_rays_impl(h, origins, directions, nears, fars, height, width, opts, rgb, depth, accumulation, expected_depth, prop_depth_0,
+                            prop_depth_1, dump, stream);
+}
+
+int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out) {
+    if (!h || !out) return fail(h, SN_ERR_INVALID, "sn_debug_layout: null argument");
+    if (which < -1 || which >= h->desc.num_proposals) return fail(h, SN_ERR_INVALID, "sn_debug_layout: bad field selector");
+    if (!h->finalized) return fail(h, SN_ERR_STATE, "sn_debug_layout: weights not finalized");
+    memset(out, 0, sizeof(*out));
+    const SnDenseCopy& dc = which < 0 ? h->dense_info : h->dense_info_prop[which];
+    out->n_dense = which < 0 ? h->nd_torch : h->nd_prop[which];
+    for (int l = 0; l < 12; ++l) {
+        out->dense_res[l] = dc.res[l];
+        out->dense_off[l] = dc.off[l];
+    }
+    out->dense_set_stride = dc.perm_stride;
+    out->dense_bytes = which < 0 ? h->dense_main.bytes : h->dense_prop[which].bytes;
+    if (which >= 0) {
+        for (int l = 0; l < SN_MAX_LEVELS; ++l) out->pair_base[l] = h->pinfo_prop[which].base[l];
+        out->pair_bytes = h->pairs_prop[which].bytes;
+    }
+    return SN_OK;
+}
+
+int sn_debug_read(SnHandle h, int32_t which, int32_t what, void* dst, size_t bytes, SnStream stream) {
+    if (!h || !dst) return fail(h, SN_ERR_INVALID, "sn_debug_read: null argument");
+    if (which < -1 || which >= h->desc.num_proposals) return fail(h, SN_ERR_INVALID, "sn_debug_read: bad field selector");
+    if (!h->finalized) return fail(h, SN_ERR_STATE, "sn_debug_read: weights not finalized");
+    const DevBuf* src = nullptr;
+    if (what == 0) src = which < 0 ? &h->dense_main : &h->dense_prop[which];
+    else if (what == 1 && which >= 0) src = &h->pairs_prop[which];
+    if (!src || !src->ptr) return fail(h, SN_ERR_INVALID, "sn_debug_read: no such buffer");
+    if (bytes != src->bytes) return fail(h, SN_ERR_INVALID, "sn_debug_read: expected " + std::to_string(src->bytes) + " bytes");
+    SN_HIP(h, hipMemcpyAsync(dst, src->ptr, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SN_OK;
 }
 

@@ -351,7 +351,10 @@ struct SnDenseCopy {
     uint32_t perm_stride;
 };
 
-SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_off_bytes, const float q[3], float scale, uint32_t R) {
+// rec (test instrumentation, sn_render_rays_debug): where non-null, receives the byte offsets of the four 16-byte fetches
+// (order: y1 z1, y0 z1, y0 z0, y1 z0 -- each returns the x0 and x0 + 1 entries) within the buffer of copies.
+SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_off_bytes, const float q[3], float scale, uint32_t R,
+                                      uint32_t* rec = nullptr) {
     uint32_t f[3];
     float off[3];
 #pragma unroll
@@ -365,6 +368,12 @@ SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t leve
     const uint32_t R8 = R << 3, R28 = (R * R) << 3;
     const uint32_t b_ff = (f[0] << 3) + __umul24(f[1], R8) + __umul24(f[2], R28);
     const uint32_t b_cf = b_ff + R8, b_fc = b_ff + R28, b_cc = b_ff + (R8 + R28);
+    if (rec) {
+        rec[0] = b_cc + level_off_bytes;
+        rec[1] = b_fc + level_off_bytes;
+        rec[2] = b_ff + level_off_bytes;
+        rec[3] = b_cf + level_off_bytes;
+    }
     const f32x4 p_cc = sn_table_load_pair(rsrc, b_cc, level_off_bytes);
     const f32x4 p_fc = sn_table_load_pair(rsrc, b_fc, level_off_bytes);
     const f32x4 p_ff = sn_table_load_pair(rsrc, b_ff, level_off_bytes);
@@ -399,10 +408,14 @@ __global__ void sn_build_dense_copy_kernel(const float* __restrict__ table, floa
 // semantics (sn_hash_corners_tcnn; `grid` must then point at the level table).
 // ND (ARITH 2 only): levels [0, ND) are dense and the rest hashed, fixed at compile time; -1 = per-level run-time decision.
 // With ND >= 0 the dense levels use the paired 16-byte gathers of sn_hash_level_dense_pairs.
-template <int L, int GROUP = 0, int ARITH = 0, int ND = -1>
+// DUMP / rec (test instrumentation behind sn_render_rays_debug; include/signerf_hip.h "SnDebugDump"): where `rec` is non-null the
+// lane records, per level, the 8 words that identify what it fetched: a hashed level -> the byte offsets of its 8 rows within the
+// level, nerfstudio corner order; a de-hashed level -> words 0..3 = byte offsets of the four 16-byte fetches within the buffer of
+// copies, word 4 = 0xD0000000 | orientation set.  Taken from the very registers that feed the loads.
+template <int L, int GROUP = 0, int ARITH = 0, int ND = -1, bool DUMP = false>
 SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], float* feat,
                            const SnGridLevels* grid = nullptr, const SnDenseCopy* dense = nullptr, const float* qdense = nullptr,
-                           uint32_t dense_set_off = 0u) {
+                           uint32_t dense_set_off = 0u, uint32_t* rec = nullptr) {
     constexpr bool FAST = ARITH != 0;
     const uint32_t mask = (1u << log2_t) - 1u;
 #pragma unroll
@@ -418,7 +431,12 @@ SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int l
             uint32_t R = dense->res[l];
             asm volatile("" : "+s"(R));  // keep the per-level strides out of the loop-invariant set (SGPR pressure, see sn_grid_dense_res)
             // qdense / dense_set_off: the position with its axes in the order of the orientation set this wave reads (or q, set 0)
-            const f32x2 e = sn_hash_level_dense_copy(sn_table_rsrc(dense->base, dense->bytes), dense->off[l] + dense_set_off, qdense ? qdense : q, scal[l], R);
+            const f32x2 e = sn_hash_level_dense_copy(sn_table_rsrc(dense->base, dense->bytes), dense->off[l] + dense_set_off, qdense ? qdense : q, scal[l], R,
+                                                     DUMP && rec ? rec + 8 * l : nullptr);
+            if (DUMP && rec) {
+                rec[8 * l + 4] = 0xD0000000u | (dense->perm_stride ? dense_set_off / dense->perm_stride : 0u);
+                rec[8 * l + 5] = rec[8 * l + 6] = rec[8 * l + 7] = 0u;
+            }
             feat[2 * l] = e.x;
             feat[2 * l + 1] = e.y;
             continue;
@@ -435,6 +453,10 @@ SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int l
         f32x2 v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = sn_table_load(rsrc, hl.boff[k], lvl);
+        if (DUMP && rec) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rec[8 * l + k] = hl.boff[k];
+        }
         f32x2 e = FAST ? sn_hash_blend_fast(v, hl.off) : sn_hash_blend(v, hl.off);
         feat[2 * l] = e.x;
         feat[2 * l + 1] = e.y;
@@ -472,9 +494,11 @@ SN_DEV f32x4 sn_pair_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t entry) {
 // corner, so the per-corner selects of the literal form disappear as well.
 // L0 / TCNN: levels [L0, L) only, with tiny-cuda-nn's position x = fmaf(scale, q, 0.5) -- the hashed levels of a tcnn grid
 // (their x + 1 corner is row ^ m_t exactly as in the torch grid, so the same paired tables serve them).
-template <int L, int GROUP = 0, bool FAST = false, int L0 = 0, bool TCNN = false>
+// DUMP / rec: as in sn_hash_encode; a level read from the paired tables records words 0..3 = the 16-byte ENTRY numbers of its four
+// fetches (order: y1 z1, y0 z1, y0 z0, y1 z0), word 4 = 0xA0000000 | t.
+template <int L, int GROUP = 0, bool FAST = false, int L0 = 0, bool TCNN = false, bool DUMP = false>
 SN_DEV void sn_hash_encode_pairs(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, const float* scal, int log2_t, const float q[3],
-                                 float* feat) {
+                                 float* feat, uint32_t* rec = nullptr) {
     const uint32_t mask = (1u << log2_t) - 1u;
 #pragma unroll
     for (int l = L0; l < L; ++l) {
@@ -506,10 +530,20 @@ SN_DEV void sn_hash_encode_pairs(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo&
         const uint32_t t = (uint32_t)__builtin_ctz(~f[0]);  // trailing ones of xf (xf < 2^31, so ~xf != 0)
         const uint32_t base = pi.base[l] + (t << log2_t);
         // pair k: .xy = floor-x corner, .zw = ceil-x corner of (y?, z?)
-        const f32x4 p_cc = sn_pair_load(prsrc, base + ((f[0] ^ yc ^ zc) & mask));  // corners 3 (fcc), 0 (ccc)
-        const f32x4 p_fc = sn_pair_load(prsrc, base + ((f[0] ^ yf ^ zc) & mask));  // corners 2 (ffc), 1 (cfc)
-        const f32x4 p_ff = sn_pair_load(prsrc, base + ((f[0] ^ yf ^ zf) & mask));  // corners 6 (fff), 5 (cff)
-        const f32x4 p_cf = sn_pair_load(prsrc, base + ((f[0] ^ yc ^ zf) & mask));  // corners 7 (fcf), 4 (ccf)
+        const uint32_t e_cc = base + ((f[0] ^ yc ^ zc) & mask), e_fc = base + ((f[0] ^ yf ^ zc) & mask);
+        const uint32_t e_ff = base + ((f[0] ^ yf ^ zf) & mask), e_cf = base + ((f[0] ^ yc ^ zf) & mask);
+        if (DUMP && rec) {
+            rec[8 * l + 0] = e_cc;
+            rec[8 * l + 1] = e_fc;
+            rec[8 * l + 2] = e_ff;
+            rec[8 * l + 3] = e_cf;
+            rec[8 * l + 4] = 0xA0000000u | t;
+            rec[8 * l + 5] = rec[8 * l + 6] = rec[8 * l + 7] = 0u;
+        }
+        const f32x4 p_cc = sn_pair_load(prsrc, e_cc);  // corners 3 (fcc), 0 (ccc)
+        const f32x4 p_fc = sn_pair_load(prsrc, e_fc);  // corners 2 (ffc), 1 (cfc)
+        const f32x4 p_ff = sn_pair_load(prsrc, e_ff);  // corners 6 (fff), 5 (cff)
+        const f32x4 p_cf = sn_pair_load(prsrc, e_cf);  // corners 7 (fcf), 4 (ccf)
         const bool same = !FAST && c[0] == f[0];  // x on a grid plane: the ceil corner IS the floor corner
         f32x2 v[8];
         v[3] = f32x2{p_cc.x, p_cc.y};

@@ -421,6 +421,10 @@ struct SnMainParams {
     int chunk_rays;
     SnGridLevels grid;  // GRID 1: dense-level resolutions of the tiny-cuda-nn grid; GRID 0, ND > 0: R of the de-hashed coarse copies
     SnDenseCopy dense;  // GRID 0, ND > 0
+    // test instrumentation (DUMP = 1 instantiations only; sn_render_rays_debug)
+    uint32_t* dump_fetch;  // [H*W][S][16][8] fetch records (sn_hash_encode) or null
+    float* dump_q;         // [H*W][S][3] normalised positions that were hashed, or null
+    int32_t* dump_median;  // [H*W] median index, or null
 };
 
 // XCD-aware, bijective block remap: the dispatcher places block b on XCD b % 8 (observed); give each
@@ -438,7 +442,8 @@ SN_DEV int sn_xcd_remap(int b, int n) {
 // full 7.7 ms, hash-only 2.8-3.0 ms (= the L1 tag-lookup floor), VALU-only 1.4 ms; the 204.8 M fp32 MFMAs alone are 5.6 ms.
 template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int PREC /*0 fp32 MFMA, 1 fp16 hi+lo split MFMA*/, int ABLATE = 0,
           int GRID = 0 /*0 nerfstudio torch-path hash grid, 1 tiny-cuda-nn grid semantics*/,
-          int ND = -1 /*GRID 1: number of leading dense levels, fixed at compile time (-1: run-time decision per level)*/>
+          int ND = -1 /*GRID 1: number of leading dense levels, fixed at compile time (-1: run-time decision per level)*/,
+          bool DUMP = false /*test instrumentation: record what every sample fetches (SnMainParams::dump_*)*/>
 __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_kernel(SnMainParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -528,8 +533,18 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
             // plain table: the x-paired layout (sn_device.h) measured no gain here (r01: 4.11 vs 4.18 ms) -- splitting a level
             // into per-t tables loses the x-locality of the plain layout (16 consecutive x share a 128-B line)
             const float qd[3] = {dsel == 1 ? q[1] : (dsel == 2 ? q[2] : q[0]), dsel == 1 ? q[0] : q[1], dsel == 2 ? q[0] : q[2]};
-            sn_hash_encode<16, SN_HASH_GROUP, (GRID ? 2 : (SN_FAST_HASH ? 1 : 0)), ND>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, qd,
-                                                                                      dense_set_off);
+            uint32_t* rec = nullptr;
+            if (DUMP && valid) {
+                const size_t smp = (size_t)ray * (size_t)S + (size_t)i;
+                if (p.dump_fetch) rec = p.dump_fetch + smp * 128;
+                if (p.dump_q) {
+                    p.dump_q[smp * 3 + 0] = q[0];
+                    p.dump_q[smp * 3 + 1] = q[1];
+                    p.dump_q[smp * 3 + 2] = q[2];
+                }
+            }
+            sn_hash_encode<16, SN_HASH_GROUP, (GRID ? 2 : (SN_FAST_HASH ? 1 : 0)), ND, DUMP>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, qd,
+                                                                                            dense_set_off, rec);
         }
         __builtin_amdgcn_sched_barrier(0);
         float h0, rgb[3];
@@ -578,6 +593,7 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
             p.rgb[pix * 3 + 2] = out_rgb[2];
         }
         if (p.depth) p.depth[pix] = depth;
+        if (DUMP && p.dump_median) p.dump_median[pix] = comp.median_idx;
         if (p.acc) p.acc[pix] = acc;
         if (p.exp_raw) p.exp_raw[pix] = exp_raw;
     }

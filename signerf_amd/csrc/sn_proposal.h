@@ -120,10 +120,10 @@ SN_DEV float sn_prop_mlp_mfma(const float* __restrict__ w, const float* feat, in
 // GRID = 1 (tiny-cuda-nn grid semantics): `plain` is the plain table of the net and `grid` its level table.  With the number of
 // leading dense levels ND known at compile time the dense levels read x-corner pairs straight from the plain table and the
 // hashed levels use the x-paired tables `prsrc` (built for those levels only); ND = -1 reads everything from the plain table.
-template <int GRID = 0, int ND = -1>
+template <int GRID = 0, int ND = -1, bool DUMP = false>
 SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, const SnScal5& scal, int log2_t, const float* __restrict__ w,
                         const float q[3], const SnGridLevels* grid = nullptr, __amdgpu_buffer_rsrc_t plain = __amdgpu_buffer_rsrc_t(),
-                        const SnDenseCopy* dense = nullptr) {
+                        const SnDenseCopy* dense = nullptr, uint32_t* rec = nullptr) {
     float feat[10];
     if (GRID == 1 && ND >= 0) {
         // dense levels: paired 16-byte gathers from the plain table; hashed levels: the x-paired tables
@@ -133,10 +133,10 @@ SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, cons
         sn_hash_encode<5, 0, 2, -1>(plain, scal.v, log2_t, q, feat, grid);
     } else if (ND > 0) {
         // torch grid: levels [0, ND) from their de-hashed copies (4 gathers, 6 index instructions), the rest from the x-paired tables
-        sn_hash_encode<(ND > 0 ? ND : 1), 0, 1, ND>(plain, scal.v, log2_t, q, feat, grid, dense);
-        if (ND < 5) sn_hash_encode_pairs<5, 0, true, (ND > 0 && ND < 5 ? ND : 0)>(prsrc, pi, scal.v, log2_t, q, feat);
+        sn_hash_encode<(ND > 0 ? ND : 1), 0, 1, ND, DUMP>(plain, scal.v, log2_t, q, feat, grid, dense, nullptr, 0u, rec);
+        if (ND < 5) sn_hash_encode_pairs<5, 0, true, (ND > 0 && ND < 5 ? ND : 0), false, DUMP>(prsrc, pi, scal.v, log2_t, q, feat, rec);
     } else {
-        sn_hash_encode_pairs<5, 0, true>(prsrc, pi, scal.v, log2_t, q, feat);
+        sn_hash_encode_pairs<5, 0, true, 0, false, DUMP>(prsrc, pi, scal.v, log2_t, q, feat, rec);
     }
 #if SN_PROP_MFMA
     float out = sn_prop_mlp_mfma(w, feat, (int)(threadIdx.x & 63));
@@ -241,6 +241,10 @@ struct SnPropParams {
     const float* pdf_u[SN_MAX_PROPOSALS]; // u grid of resampling step k, or null ((j + 0.5) / (m + 1))
     float* ebins_out;                     // [tile][n_final+1][64]
     float* prop_depth[SN_MAX_PROPOSALS];  // [H*W] or null
+    // test instrumentation (DUMP = 1 instantiations only; sn_render_rays_debug)
+    uint32_t* dump_fetch[SN_MAX_PROPOSALS];  // [H*W][n_samples[k]][5][8] fetch records of net k, or null
+    float* dump_q[SN_MAX_PROPOSALS];         // [H*W][n_samples[k]][3] hashed positions of net k, or null
+    int32_t* dump_pdf[SN_MAX_PROPOSALS];     // [H*W][m_k + 1] searchsorted index of every u of resampling step k, or null
     float* scratch;                       // [n_waves][SN_PROP_SCRATCH_FLOATS]
     const float* tables[SN_MAX_PROPOSALS];     // plain tables (tiny-cuda-nn grid mode)
     uint32_t table_bytes[SN_MAX_PROPOSALS];
@@ -277,9 +281,9 @@ struct SnPropLds {
 
 // One proposal level for this lane's ray: density net LV at the N samples whose spacing bins are sb(0..N); writes the
 // weights to w[i * 64] and returns sum(w + pad) (fp64) and the level's median depth.
-template <int LV, int GRID, int ND, typename SB>
+template <int LV, int GRID, int ND, bool DUMP, typename SB>
 SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* __restrict__ w, int N, const float o[3], const float d[3], float s_near,
-                          float s_far, double& sum_wp, float& median_out) {
+                          float s_far, double& sum_wp, float& median_out, int64_t dump_ray = -1) {
     SnScal5 scal;
 #pragma unroll
     for (int l = 0; l < 5; ++l) scal.v[l] = p.scal[LV][l];
@@ -300,7 +304,17 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
         const float e1 = sn_euclid(sb(i + 1), s_near, s_far);
         float q[3];
         const bool sel = sn_sample_q_fast(o, d, e0, e1, q);
-        const float h0 = sn_prop_h0<GRID, ND>(rsrc, pi, scal, log2_t, wp, q, &p.grid[LV], plain, &p.dense[LV]);
+        uint32_t* rec = nullptr;
+        if (DUMP && dump_ray >= 0) {
+            const size_t smp = (size_t)dump_ray * (size_t)N + (size_t)i;
+            if (p.dump_fetch[LV]) rec = p.dump_fetch[LV] + smp * 40;
+            if (p.dump_q[LV]) {
+                p.dump_q[LV][smp * 3 + 0] = q[0];
+                p.dump_q[LV][smp * 3 + 1] = q[1];
+                p.dump_q[LV][smp * 3 + 2] = q[2];
+            }
+        }
+        const float h0 = sn_prop_h0<GRID, ND, DUMP>(rsrc, pi, scal, log2_t, wp, q, &p.grid[LV], plain, &p.dense[LV], rec);
         const float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
         float wt;
         {
@@ -325,7 +339,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
 }
 
 // GRID 1: ND0 / ND1 = leading dense levels of the two nets (-1: run-time decision per level)
-template <int GRID, int ND0 = -1, int ND1 = -1>
+template <int GRID, int ND0 = -1, int ND1 = -1, bool DUMP = false>
 __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_proposal_kernel(SnPropParams p) {
     __shared__ __attribute__((aligned(16))) SnPropLds L;
     const int tid = threadIdx.x;
@@ -374,22 +388,33 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
         // level 0: the initial (uniform in s) sampler
         double sum_wp;
         float med;
-        sn_prop_level<0, GRID, ND0>(p, L.wpack[0], [&](int i) { return L.sb0[i]; }, W, n0, o, d, s_near, s_far, sum_wp, med);
+        const int64_t dump_ray = DUMP && valid ? pix : -1;
+        sn_prop_level<0, GRID, ND0, DUMP>(p, L.wpack[0], [&](int i) { return L.sb0[i]; }, W, n0, o, d, s_near, s_far, sum_wp, med, dump_ray);
         if (valid && p.prop_depth[0]) p.prop_depth[0][pix] = med;
         SnPdfNorm nm;
         nm.set(sum_wp, n0);
+        // DUMP: the searchsorted index of every u (PDFSampler's `inds`), as the merge found it
+        auto dump_idx = [&](int k, int m, int j, int idx) {
+            if (DUMP && dump_ray >= 0 && p.dump_pdf[k]) p.dump_pdf[k][(size_t)dump_ray * (size_t)(m + 1) + (size_t)j] = idx;
+        };
         if (p.n_levels == 1) {
-            sn_pdf_lane(W, 64, n0, p.n_final, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; },
-                        [&](int j, float v, int) { eb_tile[(int64_t)j * 64] = sn_euclid(v, s_near, s_far); });
+            sn_pdf_lane(W, 64, n0, p.n_final, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; }, [&](int j, float v, int idx) {
+                eb_tile[(int64_t)j * 64] = sn_euclid(v, s_near, s_far);
+                dump_idx(0, p.n_final, j, idx);
+            });
         } else {
             const int n1 = p.n_samples[1];
-            sn_pdf_lane(W, 64, n0, n1, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; },
-                        [&](int j, float v, int) { B0[(int64_t)j * 64] = v; });
-            sn_prop_level<1, GRID, ND1>(p, L.wpack[1], [&](int i) { return B0[(int64_t)i * 64]; }, W, n1, o, d, s_near, s_far, sum_wp, med);
+            sn_pdf_lane(W, 64, n0, n1, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; }, [&](int j, float v, int idx) {
+                B0[(int64_t)j * 64] = v;
+                dump_idx(0, n1, j, idx);
+            });
+            sn_prop_level<1, GRID, ND1, DUMP>(p, L.wpack[1], [&](int i) { return B0[(int64_t)i * 64]; }, W, n1, o, d, s_near, s_far, sum_wp, med, dump_ray);
             if (valid && p.prop_depth[1]) p.prop_depth[1][pix] = med;
             nm.set(sum_wp, n1);
-            sn_pdf_lane(W, 64, n1, p.n_final, L.u[1], p.hist_pad, nm, [&](int i) { return B0[(int64_t)i * 64]; },
-                        [&](int j, float v, int) { eb_tile[(int64_t)j * 64] = sn_euclid(v, s_near, s_far); });
+            sn_pdf_lane(W, 64, n1, p.n_final, L.u[1], p.hist_pad, nm, [&](int i) { return B0[(int64_t)i * 64]; }, [&](int j, float v, int idx) {
+                eb_tile[(int64_t)j * 64] = sn_euclid(v, s_near, s_far);
+                dump_idx(1, p.n_final, j, idx);
+            });
         }
         (void)B1;
     }

@@ -113,3 +113,78 @@ def resize_bilinear(src: Tensor, out_h: int, out_w: int, threshold: bool = False
         _lib.check(lib.sn_resize_bilinear(src.data_ptr(), int(src.dtype == torch.uint8), H, W, src.stride(0), Cn, out.data_ptr(), out_h, out_w,
                                           out.stride(0), int(bool(threshold)), _lib.current_stream()), None, "sn_resize_bilinear")
     return out
+
+
+# ---- test instrumentation of the fused kernels (include/signerf_hip.h "SnDebugDump") -----------------------------------------
+def render_rays_debug(model, ray_bundle, want=("main_fetch", "main_q", "median_index", "prop_fetch", "prop_q", "pdf_index")):
+    """``Model.get_outputs_for_camera_ray_bundle`` through ``sn_render_rays_debug``: the production kernels instantiated with their
+    DUMP flag.  Returns (outputs, dump): outputs = {"rgb","depth","accumulation","expected_depth"} [H,W,C]; dump holds
+    "main_fetch" [H*W,S,16,8] int64 (uint32 words), "main_q" [H*W,S,3], "median_index" [H*W] int32, "prop_fetch_k" [H*W,N_k,5,8], "prop_q_k" [H*W,N_k,3],
+    "pdf_index_k" [H*W,M_k+1] int32 -- see the header for the record format."""
+    lib = model._ensure_engine()
+    H, W = ray_bundle.origins.shape[:2]
+    dev = model.device
+    cfg = model.config
+    f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+    o, d, nears, fars = f32(ray_bundle.origins), f32(ray_bundle.directions), f32(ray_bundle.nears), f32(ray_bundle.fars)
+    n = H * W
+    S = cfg.num_nerf_samples_per_ray
+    nprop = cfg.num_proposal_iterations
+    with torch.cuda.device(dev):
+        opts, keep = model._opts(H, W, lib)
+        new = lambda c: torch.empty((n, c), dtype=torch.float32, device=dev)  # noqa: E731
+        rgb, depth, acc, exp = new(3), new(1), new(1), new(1)
+        dump = _lib.SnDebugDump()
+        t = {}
+        if "main_fetch" in want:
+            t["main_fetch"] = torch.full((n, S, 16, 8), -1, dtype=torch.int32, device=dev)
+            dump.main_fetch = t["main_fetch"].data_ptr()
+        if "main_q" in want:
+            t["main_q"] = torch.full((n, S, 3), float("nan"), dtype=torch.float32, device=dev)
+            dump.main_q = t["main_q"].data_ptr()
+        if "median_index" in want:
+            t["median_index"] = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            dump.median_index = t["median_index"].data_ptr()
+        counts = list(cfg.num_proposal_samples_per_ray[:nprop]) + [S]
+        for k in range(nprop):
+            if "prop_fetch" in want:
+                t[f"prop_fetch_{k}"] = torch.full((n, counts[k], 5, 8), -1, dtype=torch.int32, device=dev)
+                dump.prop_fetch[k] = t[f"prop_fetch_{k}"].data_ptr()
+            if "prop_q" in want:
+                t[f"prop_q_{k}"] = torch.full((n, counts[k], 3), float("nan"), dtype=torch.float32, device=dev)
+                dump.prop_q[k] = t[f"prop_q_{k}"].data_ptr()
+            if "pdf_index" in want:
+                t[f"pdf_index_{k}"] = torch.full((n, counts[k + 1] + 1), -1, dtype=torch.int32, device=dev)
+                dump.pdf_index[k] = t[f"pdf_index_{k}"].data_ptr()
+        st = lib.sn_render_rays_debug(model._handle, _lib.ptr(o), _lib.ptr(d), _lib.ptr(nears), _lib.ptr(fars), H, W, C.byref(opts),
+                                      _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc), _lib.ptr(exp), None, None, C.byref(dump),
+                                      _lib.current_stream())
+        _lib.check(st, model._handle, "sn_render_rays_debug")
+        torch.cuda.synchronize(dev)
+        del keep
+    out = {"rgb": rgb.view(H, W, 3), "depth": depth.view(H, W, 1), "accumulation": acc.view(H, W, 1), "expected_depth": exp.view(H, W, 1)}
+    for k in list(t):
+        if "fetch" in k:  # uint32 words -> int64 so that the 0xA/0xD tags stay positive
+            t[k] = t[k].to(torch.int64) & 0xFFFFFFFF
+    return out, t
+
+
+def debug_layout(model, which: int = -1) -> dict:
+    """Layout of the derived gather buffers of one field (sn_debug_layout)."""
+    lib = model._ensure_engine()
+    lay = _lib.SnDebugLayout()
+    _lib.check(lib.sn_debug_layout(model._handle, which, C.byref(lay)), model._handle, "sn_debug_layout")
+    return {"n_dense": lay.n_dense, "dense_res": list(lay.dense_res), "dense_off": list(lay.dense_off), "dense_set_stride": lay.dense_set_stride,
+            "dense_bytes": lay.dense_bytes, "pair_base": list(lay.pair_base), "pair_bytes": lay.pair_bytes}
+
+
+def debug_read(model, which: int, what: int) -> Tensor:
+    """Contents of the de-hashed copies (what = 0) or the x-paired tables (what = 1) as a flat fp32 tensor on the model's device."""
+    lib = model._ensure_engine()
+    lay = debug_layout(model, which)
+    nbytes = lay["dense_bytes"] if what == 0 else lay["pair_bytes"]
+    with torch.cuda.device(model.device):
+        buf = torch.empty((nbytes // 4,), dtype=torch.float32, device=model.device)
+        _lib.check(lib.sn_debug_read(model._handle, which, what, buf.data_ptr(), nbytes, _lib.current_stream()), model._handle, "sn_debug_read")
+        torch.cuda.synchronize(model.device)
+    return buf

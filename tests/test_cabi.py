@@ -49,6 +49,8 @@ int main(void) {
          offsetof(SnFieldDesc, average_init_density), offsetof(SnFieldDesc, num_proposals));
   printf("%zu %zu %zu %zu %zu\n", offsetof(SnRenderOpts, num_nerf_samples), offsetof(SnRenderOpts, chunk_rays),
          offsetof(SnRenderOpts, workspace), offsetof(SnRenderOpts, initial_spacing_bins), offsetof(SnRenderOpts, pdf_u));
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(SnDebugDump), offsetof(SnDebugDump, prop_q), offsetof(SnDebugDump, pdf_index),
+         sizeof(SnDebugLayout), offsetof(SnDebugLayout, dense_bytes), offsetof(SnDebugLayout, pair_bytes));
   return 0;
 }
 """
@@ -61,7 +63,9 @@ int main(void) {
             _lib.SnHashMlpDesc.scalings.offset, _lib.SnFieldDesc.proposals.offset, _lib.SnFieldDesc.average_init_density.offset,
             _lib.SnFieldDesc.num_proposals.offset,
             _lib.SnRenderOpts.num_nerf_samples.offset, _lib.SnRenderOpts.chunk_rays.offset, _lib.SnRenderOpts.workspace.offset,
-            _lib.SnRenderOpts.initial_spacing_bins.offset, _lib.SnRenderOpts.pdf_u.offset]
+            _lib.SnRenderOpts.initial_spacing_bins.offset, _lib.SnRenderOpts.pdf_u.offset,
+            C.sizeof(_lib.SnDebugDump), _lib.SnDebugDump.prop_q.offset, _lib.SnDebugDump.pdf_index.offset,
+            C.sizeof(_lib.SnDebugLayout), _lib.SnDebugLayout.dense_bytes.offset, _lib.SnDebugLayout.pair_bytes.offset]
     assert got == want
 
 

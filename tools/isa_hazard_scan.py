@@ -11,7 +11,10 @@ import argparse, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ap = argparse.ArgumentParser(); ap.add_argument("--window", type=int, default=2); a = ap.parse_args()
 out = os.path.join(tempfile.gettempdir(), "sn_api_scan.s")
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out,
+sys.path.insert(0, ROOT)
+from signerf_amd.build import CODEGEN_FLAGS  # noqa: E402  (the scan must see the code the library is built from)
+
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *CODEGEN_FLAGS, "-S", "--cuda-device-only", "-o", out,
                 os.path.join(ROOT, "signerf_amd/csrc/sn_api.hip")], check=True, stderr=subprocess.DEVNULL)
 reg = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)")
 
