@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- ray-samples/s and ms/frame of the reference-sheet render path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 300 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = every rank renders ONE 800x800 camera of the 3x3 reference sheet (BASELINE.json configs[1]: synthetic nerfacto
@@ -9,11 +9,21 @@ field, hash grid L=16 T=2^19, 64 samples/ray, no proposal nets; rank r renders c
 Cameras.generate_rays -> Model.get_outputs_for_camera_ray_bundle, followed (N>1) by the RCCL all-gather of the finished
 [H,W,4] tiles (started asynchronously: it overlaps the next step's render; all K gathers complete inside the timed region).
 Weak scaling: per-GPU work is fixed.  Inputs (weights, camera) are resident in HBM before the timed region.
-Prints ONE JSON line (see README / DESIGN.md "Measurement").
+Prints ONE JSON line (see DESIGN.md "Measurement"):
+  value            whole-job ray-samples/s over the K timed steps (wall clock between barriers + device syncs, max over ranks)
+  kernel_ms        HIP-event time of every timed render call on its launch stream: mean / median / min / max / p05 / p95
+  roofline         the hardware issue roof that binds the dominant kernel (K1 sn_render_main_kernel), as a fraction < 1: instruction
+                   counts per wave-step come from the disassembly of the loaded library (tools/kernel_counts.py), the clock from
+                   sn_clock_probe running beside the renders; `roofs` lists every roof considered
+  roofline_hbm     the SURVEY §8(d) line: algorithmic bytes (1024 B per main-field sample) over the 8 TB/s HBM peak.  It exceeds 1
+                   because the 64 MiB table is served by L1/L2/Infinity Cache; `traffic` = fabric bytes per launch from the rocprofv3
+                   PMC passes committed under profiles/ (labelled with the commit they were taken at)
+  cpu_baseline     the CPU oracle (a port of nerfstudio's torch fallback) on bounded samples of configs 2, 1 and 4, rank 0, N = 1
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -25,52 +35,106 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_MAIN_SAMPLE = 1024.0  # 16 levels x 8 corners x 2 features x 4 B
+N_CUS, N_SIMDS = 256, 1024      # MI355X_MICROARCH.md chip-level parameters
+VALU_ISSUE_CYCLES = 4.0         # one VALU / MFMA issue slot per SIMD every 4 cycles (measured 3.86 with several waves, profiles/r02_overlap2_probe.txt)
+GATHER_MIN_CYCLES = 16.0        # a 64-lane gather costs the CU's L1/TA >= 16 cycles (4 lanes per clock), DESIGN.md "What the L1 charges"
+MFMA_F16_CYCLES = 32.0          # v_mfma_f32_32x32x16_f16 pipe time per SIMD
+MFMA_F32_CYCLES = 64.0          # v_mfma_f32_32x32x2_f32
 
 
 def measured_traffic(precision):
-    """HBM-side bytes per launch of the dominant kernel, from the committed PMC pass (profiles/traffic.json, written by
-    tools/pmc_summary.py --json from TCC_EA0_RDREQ_{32,64,128}B + WRITE_SIZE; bench.py cannot run rocprofv3 on itself)."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json, written by
+    tools/pmc_summary.py --json: TCC_EA0_RDREQ_{32,64,128}B + WRITE_SIZE).  bench.py cannot run rocprofv3 on itself, so the entry
+    carries the commit it was profiled at and the line says so."""
     try:
-        with open(path) as f:
-            return json.load(f).get(precision, {}).get("bytes_per_launch")
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            e = json.load(f).get(precision, {})
+            return e.get("bytes_per_launch"), e.get("commit", "r01 (ae42c63)")
     except (OSError, ValueError):
-        return None
+        return None, None
 
 
-def cpu_baseline(cfg, sd, width, height, samples, crop=200):
-    """The CPU oracle (a port: nerfstudio's own CPU path cannot be installed) timed on a centred crop of the same frame."""
+def physical_cores():
+    """(physical cores, logical CPUs) of the host."""
+    pairs, phys, core = set(), None, None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("physical id"):
+                    phys = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":")[1].strip()
+                elif not ln.strip() and phys is not None and core is not None:
+                    pairs.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        logical = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    n = len(pairs) or max(1, logical // 2)
+    return min(n, logical), logical
+
+
+def cpu_baseline(main_cfg, main_sd, width, height, samples):
+    """The CPU oracle (kind "port": nerfstudio itself cannot be installed here) timed on bounded samples of the BASELINE
+    configurations: a centred crop of the headline frame (config 2), config 1 in full, a 240x135 crop of config 4.
+    Threads = physical cores, set explicitly."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import oracle_config
+    from helpers import oracle_config, small_config
     from oracle import nerfacto as onf
     from signerf_amd import scene
 
-    c2w = scene.benchmark_cameras(8)[0]
-    rays = onf.generate_rays(c2w[:3], float(width), float(width), width / 2, height / 2, height, width)
-    y0, x0 = (height - crop) // 2, (width - crop) // 2
-    o = rays["origins"][y0:y0 + crop, x0:x0 + crop].contiguous()
-    d = rays["directions"][y0:y0 + crop, x0:x0 + crop].contiguous()
-    ocfg = oracle_config(cfg)
-    onf.get_outputs_for_camera_ray_bundle(sd, ocfg, o[:32], d[:32])  # warm-up
-    t = time.perf_counter()
-    onf.get_outputs_for_camera_ray_bundle(sd, ocfg, o, d)
-    dt = time.perf_counter() - t
+    cores, logical = physical_cores()
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(cores)
     cpu = "unknown CPU"
     try:
         with open("/proc/cpuinfo") as f:
             cpu = next(ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name"))
     except (OSError, StopIteration):
         pass
-    return {"value": crop * crop * samples / dt, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port", "host_cpu": cpu,
-            "sample": f"centred {crop}x{crop} crop of the {width}x{height}x{samples} frame, {dt:.1f} s, torch CPU fp32 oracle",
-            "ms_per_frame_extrapolated": dt * 1e3 * (width * height) / (crop * crop)}
+
+    def timed(cfg, sd, W, H, focal, crop_w, crop_h, cam=0, chunk=None):
+        c2w = scene.benchmark_cameras(8)[cam]
+        rays = onf.generate_rays(c2w[:3], focal, focal, W / 2, H / 2, H, W)
+        y0, x0 = (H - crop_h) // 2, (W - crop_w) // 2
+        o = rays["origins"][y0:y0 + crop_h, x0:x0 + crop_w].contiguous()
+        d = rays["directions"][y0:y0 + crop_h, x0:x0 + crop_w].contiguous()
+        ocfg = oracle_config(cfg)
+        onf.get_outputs_for_camera_ray_bundle(sd, ocfg, o[:8, :8].contiguous(), d[:8, :8].contiguous())  # warm-up
+        t = time.perf_counter()
+        onf.get_outputs_for_camera_ray_bundle(sd, ocfg, o, d, chunk=chunk)
+        return time.perf_counter() - t
+
+    crop = 200  # BASELINE.md §2
+    dt2 = timed(main_cfg, main_sd, width, height, float(width), crop, crop)
+    out = {"value": crop * crop * samples / dt2, "unit": "ray-samples/s", "cores": cores, "threads": cores, "logical_cpus": logical,
+           "kind": "port", "host_cpu": cpu,
+           "sample": f"config 2: centred {crop}x{crop} crop of the {width}x{height}x{samples} frame, {dt2:.1f} s, torch CPU fp32 oracle",
+           "ms_per_frame_extrapolated": dt2 * 1e3 * (width * height) / (crop * crop), "others": []}
+    c1 = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=32)
+    dt1 = timed(c1, scene.synthetic_state_dict(c1, seed=0), 64, 64, 64.0, 64, 64)
+    out["others"].append({"config": "config 1: 64x64 image, 32 samples/ray, in full", "seconds": dt1, "ray_samples_per_s": 64 * 64 * 32 / dt1,
+                          "ms_per_frame": dt1 * 1e3})
+    c4 = scene.proposal_config()
+    sd4 = scene.synthetic_state_dict(c4, seed=0)
+    dt4 = timed(c4, sd4, 1920, 1080, 1.2 * 1080, 240, 135, chunk=8192)  # chunked: bounds the oracle's memory (352 proposal samples per ray)
+    n4 = 240 * 135
+    out["others"].append({"config": "config 4: centred 240x135 crop of the 1920x1080 frame, proposal nets 256 + 96 + 48 main samples", "seconds": dt4,
+                          "ray_samples_per_s": n4 * 48 / dt4, "field_evaluations_per_s": n4 * 400 / dt4,
+                          "ms_per_frame_extrapolated": dt4 * 1e3 * (1920 * 1080) / n4})
+    torch.set_num_threads(old_threads)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default 300: >= 0.9 s of render at ~3 ms per frame)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="sheet64", choices=["sheet64", "nerfacto1080"],
                     help="sheet64 = BASELINE.json configs[1] (the metric's configuration, default); "
                          "nerfacto1080 = configs[3]: 1920x1080, 2 proposal nets (256 + 96 samples) + 48 main samples")
@@ -79,7 +143,10 @@ def main():
     ap.add_argument("--samples", type=int, default=None)
     ap.add_argument("--precision", default="fp16x2", choices=["fp32", "fp16x2"],
                     help="MFMA arithmetic of the tiny MLPs: fp16x2 = fp32 operands split into fp16 hi+lo, fp32 accumulate "
-                         "(measured error identical to exact fp32 MFMA, tests/test_gpu_stages.py); fp32 = exact fp32 MFMA")
+                         "(error equals exact fp32 MFMA inside the validated operand range, tests/test_gpu_precision.py); fp32 = exact fp32 MFMA")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1: nccl = RCCL over xGMI (the real thing); gloo = host-staged gathers, for dry "
+                         "runs of the N > 1 code on a box with fewer GPUs than ranks (ranks then share GPUs)")
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the extra (untimed-region) run of the other precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -90,13 +157,21 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    shared_gpu = world > n_dev
+    if shared_gpu and args.backend == "nccl":
+        sys.exit(f"{world} ranks on {n_dev} GPU(s): RCCL needs one GPU per rank (use --backend gloo for a dry run)")
+    dev_index = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
-    from signerf_amd import Cameras, build, scene, sheet
+    from signerf_amd import Cameras, _lib, build, scene, sheet
 
     # The library ships prebuilt with the snapshot (__graft_entry__.build()).  Only a missing file is rebuilt, by local rank 0
     # alone -- N ranks recompiling into one path at the same time would race.
@@ -127,7 +202,7 @@ def main():
 
     render_ms = []
 
-    def kernel_ms_of(precision: str, n: int = 5) -> float:
+    def kernel_ms_of(precision: str, n: int = 10) -> float:
         """Mean HIP-event time of the render call in another arithmetic mode (outside the timed region)."""
         old = model.config.precision
         model.config.precision = precision
@@ -143,6 +218,21 @@ def main():
         torch.cuda.synchronize()
         model.config.precision = old
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+    def sustained_clock_ghz(frames: int = 12) -> float:
+        """Shader clock the chip sustains under this render: sn_clock_probe's one wave on a side stream counts shader cycles against
+        the constant-rate wall clock while `frames` renders run on the main stream."""
+        lib = _lib.load()
+        ms = statistics.median(a.elapsed_time(b) for a, b in render_ms) if render_ms else 5.0
+        out = torch.zeros(3, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        _lib.check(lib.sn_clock_probe(out.data_ptr(), min(0.9, max(0.005, frames * ms * 1e-3 * 0.8)), side.cuda_stream), None, "sn_clock_probe")
+        for _ in range(frames):
+            model.get_outputs_for_camera_ray_bundle(cam.generate_rays(camera_indices=0, aabb_box=model.render_aabb))
+        torch.cuda.synchronize()
+        cyc, ticks, rate = (int(x) for x in out.tolist())
+        return cyc / (ticks / rate) / 1e9 if ticks > 0 and rate > 0 else float("nan")
 
     pending = [None]  # the previous step's tile all-gather, still in flight
 
@@ -188,44 +278,98 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        assert tiles is not None and tuple(tiles.shape) == (world, H, W, 4), "the gathered sheet must hold one tile per rank"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = sum(a.elapsed_time(b) for a, b in render_ms) / max(len(render_ms), 1)
+    per_step = sorted(a.elapsed_time(b) for a, b in render_ms)
+    kernel_ms = sum(per_step) / max(len(per_step), 1)
 
     if rank == 0:
+        n_steps = len(per_step)
+        pct = lambda q: per_step[min(n_steps - 1, int(q * n_steps))]  # noqa: E731
+        k_med = statistics.median(per_step)
         samples_per_step = world * W * H * S
         value = samples_per_step * args.steps / elapsed
-        achieved = (W * H * bytes_per_ray) / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": "ray-samples/sec (%dx%d reference-sheet camera render)" % (W, H),
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else
-                     "f32 (MLP operands carried as fp16 hi+lo pairs on the matrix cores, f32 accumulate; measured error equals exact-f32 MFMA)",
+                     "f32 (MLP operands carried as fp16 hi+lo pairs on the matrix cores, f32 accumulate; fp32-grade for |operands| in "
+                     "[2^-13, 65504], guarded by sn_finalize_weights -- tests/test_gpu_precision.py)",
             "data": "synthetic",
             "config": {"workload": (f"BASELINE.json configs[1]: {W}x{H} rays x {S} samples/ray, nerfacto hash grid L=16 T=2^19 F=2, "
                                     "no proposal nets, random-weight synthetic scene, one camera per GPU + tile all-gather")
                        if args.workload == "sheet64" else
                        (f"BASELINE.json configs[3]: {W}x{H} rays, proposal nets 256 + 96 samples (L=5, T=2^17) + {S} main samples "
                         "(L=16, T=2^19), random-weight synthetic scene, one camera per GPU + tile all-gather"),
-                       "rays_per_gpu": W * H, "samples_per_ray": S, "parallelism": f"camera-sharded x{world}" + (", tile all-gather overlapped with the next render" if world > 1 else "")},
+                       "rays_per_gpu": W * H, "samples_per_ray": S,
+                       "parallelism": f"camera-sharded x{world}" + (", tile all-gather overlapped with the next render" if world > 1 else ""),
+                       "backend": (args.backend if world > 1 else None), "ranks_share_a_gpu": shared_gpu},
             "ms_per_frame": elapsed / args.steps * 1e3,
+            "timed_region_s": elapsed,
+            "kernel_ms": {"mean": kernel_ms, "median": k_med, "min": per_step[0], "max": per_step[-1], "p05": pct(0.05), "p95": pct(0.95), "n": n_steps,
+                          "what": "HIP-event time of each timed render call on its launch stream (K1 + two memsets + the clip kernel; + K2 with proposal nets)"},
             "rays_per_sec": world * W * H * args.steps / elapsed,
             # SURVEY §8(d) metric (3): every field evaluation of a ray (proposal nets + main field)
             "field_evaluations_per_sec": world * W * H * (S + (sum(cfg.num_proposal_samples_per_ray[:cfg.num_proposal_iterations])
                                                                if args.workload != "sheet64" else 0)) * args.steps / elapsed,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": measured_traffic(args.precision) if args.workload == "sheet64" else None,
-                         "kernel": ("sn_render_main_kernel<0,%d>" % (0 if args.precision == "fp32" else 1)) if args.workload == "sheet64"
-                         else "sn_proposal_kernel + sn_render_main_kernel<1,*> (whole render call)",
-                         "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": W * H * bytes_per_ray,
-                         "note": "frac > 1 means the algorithmic bytes never reach HBM: the hash table is served by L1/L2/Infinity "
-                                 "Cache (`traffic` = measured fabric bytes per launch); the kernel is bound by the L1 gather rate and "
-                                 "by SIMD issue (VALU + MFMA serialise on gfx950), see DESIGN.md K1"},
         }
+        achieved_gbps = (W * H * bytes_per_ray) / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_commit = measured_traffic(args.precision) if args.workload == "sheet64" else (None, None)
+        line["roofline_hbm"] = {
+            "bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved_gbps / HBM_PEAK_GBPS,
+            "traffic": traffic, "traffic_profiled_at": traffic_commit,
+            "kernel": ("sn_render_main_kernel<0,%d>" % (0 if args.precision == "fp32" else 1)) if args.workload == "sheet64"
+            else "sn_proposal_kernel + sn_render_main_kernel<1,*> (whole render call)",
+            "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": W * H * bytes_per_ray,
+            "note": "SURVEY 8(d)'s definition (1024 algorithmic bytes per main-field sample).  frac > 1 is NOT a fraction of a binding "
+                    "roof: the 64 MiB table never leaves L1/L2/Infinity Cache (`traffic` = fabric bytes per launch from the committed "
+                    "rocprofv3 PMC passes, ~0.17x the algorithmic bytes).  The roofs that bind are in `roofline`."}
         if args.workload == "sheet64":
+            # The issue roofs of K1.  Per wave-step (64 samples) the kernel issues a fixed instruction mix -- counted from the
+            # disassembly of the library that is loaded -- and every resource below serves one such instruction per so many cycles.
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import kernel_counts
+
+                cnt = kernel_counts.loop_counts("sn_render_main_kernelILi0ELi%dELi0ELi0ELi11ELb0E" % (0 if args.precision == "fp32" else 1))
+            except Exception as e:  # noqa: BLE001  (no llvm-objdump: the roofs are then unavailable, the throughput line is not)
+                cnt = {"error": repr(e)}
+            clock = sustained_clock_ghz()
+            if "valu" in cnt and clock == clock:
+                wave_steps = W * H * S / 64.0
+                t_kernel = k_med * 1e-3
+                mfma_cyc = MFMA_F32_CYCLES if args.precision == "fp32" else MFMA_F16_CYCLES
+                n_gather = cnt.get("gather", cnt["vmem_load"])
+                roofs = {
+                    "simd-issue": {"per_wave_step": cnt["valu"] + cnt["mfma"], "cycles_each": VALU_ISSUE_CYCLES, "units": N_SIMDS,
+                                   "what": "VALU + MFMA instructions through the one vector issue port of a SIMD"},
+                    "l1-gather-issue": {"per_wave_step": n_gather, "cycles_each": GATHER_MIN_CYCLES, "units": N_CUS,
+                                        "what": "64-lane buffer_load gathers through the CU's texture-address / L1 path"},
+                    "matrix-pipe": {"per_wave_step": cnt["mfma"], "cycles_each": mfma_cyc, "units": N_SIMDS,
+                                    "what": "MFMA instructions through the SIMD's matrix pipe"},
+                }
+                for r in roofs.values():
+                    r["achieved"] = r["per_wave_step"] * wave_steps / t_kernel / 1e9                  # G instructions / s, whole chip
+                    r["peak"] = r["units"] * clock / r["cycles_each"]                                # G instructions / s at the sustained clock
+                    r["frac"] = r["achieved"] / r["peak"]
+                    r["roof_ms"] = r["per_wave_step"] * wave_steps * r["cycles_each"] / (r["units"] * clock * 1e9) * 1e3
+                bound = max(roofs, key=lambda k: roofs[k]["frac"])
+                line["roofline"] = {
+                    "bound": bound, "achieved": roofs[bound]["achieved"], "peak": roofs[bound]["peak"], "unit": "G wave-instructions/s",
+                    "frac": roofs[bound]["frac"], "traffic": traffic, "traffic_profiled_at": traffic_commit,
+                    "kernel": cnt["kernel"], "kernel_ms": k_med, "sustained_clock_ghz": clock,
+                    "instructions_per_wave_step": {k: cnt[k] for k in ("valu", "mfma", "vmem_load", "lds", "packed_f32") if k in cnt} | {"gather": n_gather},
+                    "roofs": roofs,
+                    "note": "bound = the hardware resource with the largest busy fraction at the clock the chip sustains under this kernel "
+                            "(power-limited, well below the 2.4 GHz peak).  The matrix pipe hides plain VALU issued beside it only in part "
+                            "(profiles/r02_overlap2_probe.txt, r02_mlp_probe.txt), so the simd-issue and matrix-pipe fractions sum to more "
+                            "than 1 and neither reaches it."}
+            else:
+                line["roofline"] = {"bound": "simd-issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None,
+                                    "traffic": traffic, "error": cnt.get("error", "clock probe failed")}
             # Secondary view (north_star: "MFMA utilisation against gfx950 peak"): matrix-core instructions issued per launch are
             # fixed by the kernel (per wave-step of 64 samples: 120 v_mfma_f32_32x32x16_f16 in split precision, 320
             # v_mfma_f32_32x32x2_f32 in exact fp32; rocprofv3 SQ_INSTS_MFMA agrees, profiles/) -- issued flops / kernel time
@@ -235,17 +379,20 @@ def main():
             line["roofline_mfma"] = {"bound": "mfma", "achieved": issued / (kernel_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                                      "frac": issued / (kernel_ms * 1e-3) / 1e12 / peak,
                                      "algorithmic_tflops": W * H * S * 22784 / (kernel_ms * 1e-3) / 1e12,
-                                     "note": "issued MFMA flops (3-term fp16 split, 32-row tile padding) = matrix-pipe busy fraction; "
-                                             "algorithmic = 22 784 FLOP per sample (SURVEY 8(d))"}
+                                     "note": "issued MFMA flops (3-term fp16 split, 32-row tile padding) = matrix-pipe busy fraction at the 2.4 GHz "
+                                             "peak clock; algorithmic = 22 784 FLOP per sample (SURVEY 8(d))"}
+        else:
+            line["roofline"] = dict(line["roofline_hbm"])
         if not args.no_alt_precision:
             other = "fp32" if args.precision == "fp16x2" else "fp16x2"
             ms = kernel_ms_of(other)
             line["alt_precision"] = {"precision": other, "kernel_ms": ms, "ray_samples_per_s_per_gpu": W * H * S / (ms * 1e-3),
-                                     "roofline_frac": (W * H * bytes_per_ray) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                                     "roofline_hbm_frac": (W * H * bytes_per_ray) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         if world == 1 and not args.no_cpu_baseline and args.workload == "sheet64":
             line["cpu_baseline"] = cpu_baseline(cfg, sd, W, H, S)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

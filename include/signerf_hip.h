@@ -228,6 +228,12 @@ int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out);
 /* what: 0 = the buffer of de-hashed copies, 1 = the x-paired tables (proposal nets).  dst: device pointer, bytes must match. */
 int sn_debug_read(SnHandle h, int32_t which, int32_t what, void* dst, size_t bytes, SnStream stream);
 
+/* ---- measurement aid (bench.py's issue roofs need the clock the chip actually sustains under the render) ------------------
+ * Enqueues a ONE-WAVE kernel that idles for `seconds` (<= 1) of the device's constant-rate wall clock and reports how many shader
+ * cycles passed meanwhile: out[0] = shader cycles (s_memtime), out[1] = wall-clock ticks (s_memrealtime), out[2] = wall-clock
+ * rate in Hz.  out: 3 x uint64 in DEVICE memory.  Launch it on a side stream just before the renders to be clocked. */
+int sn_clock_probe(uint64_t* out, double seconds, SnStream stream);
+
 /* ---- the mask + condition step after the render, "aabb" masking mode ------------------
  * (signerf/datasetgenerator/datasetgenerator.py:758-818).  Stays on the device: no cv2 round trip (:776-778), no host sync on
  * `torch.sum(visible_mask) > 1e-6` (:770). */

@@ -1094,6 +1094,33 @@ int sn_debug_read(SnHandle h, int32_t which, int32_t what, void* dst, size_t byt
     return SN_OK;
 }
 
+// one wave: shader-clock cycles (s_memtime) elapsed while the constant-rate wall clock (s_memrealtime) advances by `ticks`
+__global__ void sn_clock_probe_kernel(unsigned long long* out, unsigned long long ticks) {
+    const unsigned long long r0 = wall_clock64();
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    while (wall_clock64() - r0 < ticks) __builtin_amdgcn_s_sleep(32);
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    const unsigned long long r1 = wall_clock64();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
+}
+
+int sn_clock_probe(uint64_t* out, double seconds, SnStream stream) {
+    if (!out || !(seconds > 0.0) || seconds > 1.0) return fail(nullptr, SN_ERR_INVALID, "sn_clock_probe: bad argument (0 < seconds <= 1)");
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+        return fail(nullptr, SN_ERR_HIP, "sn_clock_probe: cannot read the wall-clock rate of the device");
+    const unsigned long long rate = (unsigned long long)khz * 1000ull;
+    const unsigned long long ticks = (unsigned long long)(seconds * (double)rate);
+    hipLaunchKernelGGL(sn_clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out, ticks);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out + 2, &rate, 8, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_clock_probe: ") + hipGetErrorString(e));
+    return SN_OK;
+}
+
 int sn_render_normals(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars, int32_t height,
                       int32_t width, const SnRenderOpts* opts, float* normals, float* pred_normals, SnStream stream) {
     if (!h) return SN_ERR_INVALID;

@@ -21,17 +21,25 @@ def shard_indices(n_items: int, world_size: int, rank: int) -> List[int]:
     return list(range(rank, n_items, world_size))
 
 
+def _stage_through_host(t: Tensor, group=None) -> bool:
+    """gloo has no all-gather for device tensors: with that backend (single-GPU debugging, the world-2 tests that put both ranks on
+    one GPU) GPU tiles are staged through the host.  RCCL ("nccl") gathers device memory directly over xGMI."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 class TileGather:
     """An all-gather of tiles in flight (``gather_tiles_async``).  ``wait()`` orders the caller's stream behind the collective
     (RCCL: a stream wait, the host does not block) and returns the tiles in item order."""
 
-    def __init__(self, work, gathered: Tensor, n_items: int):
-        self._work, self._gathered, self._n_items = work, gathered, n_items
+    def __init__(self, work, gathered: Tensor, n_items: int, device=None):
+        self._work, self._gathered, self._n_items, self._device = work, gathered, n_items, device
 
     def wait(self) -> Tensor:
         if self._work is not None:
             self._work.wait()
             self._work = None
+        if self._device is not None:  # staged through the host (gloo): back to the GPU the tiles came from
+            self._gathered, self._device = self._gathered.to(self._device), None
         g = self._gathered
         if g.dim() == 4:  # single process: already [n_items, H, W, C]
             return g
@@ -53,9 +61,12 @@ def gather_tiles_async(local_tiles: Tensor, n_items: int, group=None) -> TileGat
     if pad > 0:
         local_tiles = torch.cat([local_tiles, local_tiles.new_zeros((pad, *local_tiles.shape[1:]))], dim=0)
     local_tiles = local_tiles.contiguous()
+    device = None
+    if _stage_through_host(local_tiles, group):
+        device, local_tiles = local_tiles.device, local_tiles.cpu()
     gathered = local_tiles.new_empty((world, per, *local_tiles.shape[1:]))
     work = dist.all_gather_into_tensor(gathered.view(world * per, *local_tiles.shape[1:]), local_tiles, group=group, async_op=True)
-    return TileGather(work, gathered, n_items)
+    return TileGather(work, gathered, n_items, device)
 
 
 def gather_tiles(local_tiles: Tensor, n_items: int, group=None) -> Tensor:
@@ -87,7 +98,7 @@ def render_cameras_sharded(render_fn: Callable[[int], Tuple[Tensor, Tensor]], n_
     if world > 1:
         shape = torch.tensor(list(local.shape[1:]) if local is not None else [0, 0, 0], dtype=torch.int64)
         dev = local.device if local is not None else _default_device()
-        shape = shape.to(dev)
+        shape = shape.to(dev if dist.get_backend(group) != "gloo" else "cpu")
         dist.broadcast(shape, src=0, group=group)
         if local is None:
             local = torch.zeros((0, *shape.tolist()), dtype=torch.float32, device=dev)
@@ -156,8 +167,13 @@ def gather_rows(local_rows: Tensor, blocks: Sequence[Tuple[int, int]], group=Non
     if pad > 0:
         local_rows = torch.cat([local_rows, local_rows.new_zeros((pad, W, Cn))], dim=0)
     local_rows = local_rows.contiguous()
+    device = None
+    if _stage_through_host(local_rows, group):
+        device, local_rows = local_rows.device, local_rows.cpu()
     gathered = local_rows.new_empty((world * tallest, W, Cn))
     dist.all_gather_into_tensor(gathered, local_rows, group=group)
+    if device is not None:
+        gathered = gathered.to(device)
     return torch.cat([gathered[k * tallest : k * tallest + (r1 - r0)] for k, (r0, r1) in enumerate(blocks)], dim=0)
 
 

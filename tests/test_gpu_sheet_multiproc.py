@@ -1,0 +1,101 @@
+"""BASELINE.json configs[2] with REAL renders crossing a process boundary (VERDICT r01 "What's missing" #2): two processes, each
+with its own HIP context, library handle and weight upload, render the cameras they own through the reference's two calls and
+exchange the finished tiles -- `sheet.render_reference_sheet` on the 8 `circle_poses` cameras (camera i -> rank i % 2) and
+`sheet.render_camera_row_sharded` on one camera.  The GPU box has one GPU, so both ranks sit on cuda:0 and the process group is
+gloo (tiles staged through the host; RCCL refuses two ranks on one device) -- the sharding, ownership, gather and re-ordering code is
+the code that runs over RCCL.  Every rank must end up with the sheet a single process renders, bit for bit.
+Also a world-2 dry run of bench.py's N > 1 branch (same arrangement), so that code has executed."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir, size):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import make_model
+    from signerf_amd import Cameras, scene, sheet
+
+    cfg = scene.benchmark_config(64)            # configs[1]'s field: L=16, T=2^19, 64 samples, no proposal nets
+    model, _ = make_model(cfg, dev)
+    model.eval()
+    W = H = size
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], float(W), float(W), W / 2, H / 2, W, H).to(dev)
+    rendered = []
+    orig = model.get_outputs_for_camera_ray_bundle
+
+    def counting(bundle):
+        rendered.append(tuple(bundle.origins.shape[:2]))
+        return orig(bundle)
+
+    model.get_outputs_for_camera_ray_bundle = counting
+    tiles = sheet.render_reference_sheet(model, cams)                 # [8, H, W, 4], every rank
+    n_sheet = len(rendered)
+    rows = sheet.render_camera_row_sharded(model, cams[2])            # [H, W, 4], every rank
+    row_shapes = rendered[n_sheet:]
+    model.get_outputs_for_camera_ray_bundle = orig
+    # what ONE process renders, in this process
+    local = []
+    for i in range(8):
+        out = model.get_outputs_for_camera_ray_bundle(cams[i].generate_rays(camera_indices=0, aabb_box=model.render_aabb))
+        local.append(torch.cat([out["rgb"], out["depth"]], dim=-1))
+    local = torch.stack(local)
+    torch.cuda.synchronize()
+    torch.save({"tiles": tiles.cpu(), "rows": rows.cpu(), "local": local.cpu(), "n_sheet_renders": n_sheet, "row_shapes": row_shapes},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reference_sheet_rendered_by_two_processes(gpu, tmp_path):
+    world, size = 2, 160
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), size), nprocs=world, join=True)
+    got = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    single = got[0]["local"]
+    assert single.shape == (8, size, size, 4) and float(single[..., :3].std()) > 0.05          # a non-trivial sheet
+    for r in range(world):
+        assert got[r]["n_sheet_renders"] == 4                                                 # camera i -> rank i % 2: four each
+        assert torch.equal(got[r]["local"], single)                                           # the two processes render identically
+        assert torch.equal(got[r]["tiles"], single), f"rank {r}: gathered sheet differs from the single-process sheet"
+        assert torch.equal(got[r]["rows"], single[2]), f"rank {r}: row-sharded camera differs from the single-process render"
+        assert got[r]["row_shapes"] == [(size // 2, size)]                                    # half the rows each (8-row bands)
+
+
+def test_bench_n2_branch_dry_run(gpu, tmp_path):
+    """bench.py --gpus 2 under torch.distributed.run with both ranks on the one GPU (gloo): the N > 1 code path -- process-group
+    set-up, camera-per-rank, the depth-1 gather pipeline, drain, barrier, max-over-ranks timing, the JSON line -- runs once."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--backend", "gloo", "--width", "200", "--height", "200", "--no-cpu-baseline", "--no-alt-precision"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                                                  # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["config"]["ranks_share_a_gpu"] is True
+    assert d["config"]["backend"] == "gloo" and "camera-sharded x2" in d["config"]["parallelism"]
+    assert d["value"] > 0 and abs(d["value"] - 2 * 200 * 200 * 64 * 4 / d["timed_region_s"]) / d["value"] < 1e-6   # whole-job aggregate
+    assert "cpu_baseline" not in d                                                            # N = 1 only

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Static instruction counts of the sample loop of a kernel in libsignerf_hip.so -- the constants `bench.py`'s issue roofs are
+built from ("from constants the kernel fixes").
+
+The gfx950 code object is extracted from the library that is actually loaded (llvm-objdump --offloading), the kernel is
+disassembled, its sample loop is taken to be the backward branch with the largest span, and the instructions between the branch
+target and the branch are counted by issue class.  Every instruction of the loop body is issued once per wave-step (the few
+exec-masked regions inside it -- the contraction branch, NaN restore -- are issued whatever the mask), so these are the per-wave-step
+issue counts; rocprofv3's SQ_INSTS_VALU / SQ_INSTS_MFMA / SQ_INSTS_VMEM_RD per wave-step (profiles/) agree with them.
+
+    python tools/kernel_counts.py [mangled-kernel-name-substring]
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "signerf_amd", "libsignerf_hip.so")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def _code_object(lib: str, workdir: str) -> str:
+    dst = os.path.join(workdir, os.path.basename(lib))
+    if os.path.lexists(dst):
+        os.remove(dst)
+    os.symlink(lib, dst)
+    subprocess.run([OBJDUMP, "--offloading", os.path.basename(lib)], cwd=workdir, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for f in os.listdir(workdir):
+        if "amdgcn" in f and "gfx950" in f:
+            return os.path.join(workdir, f)
+    raise RuntimeError("no gfx950 code object in " + lib)
+
+
+def classify(op: str) -> str:
+    if op.startswith("v_mfma") or op.startswith("v_smfma"):
+        return "mfma"
+    if op.startswith(("buffer_load", "global_load", "flat_load", "scratch_load")):
+        return "vmem_load"
+    if op.startswith(("buffer_store", "global_store", "flat_store", "scratch_store", "buffer_atomic", "global_atomic")):
+        return "vmem_store"
+    if op.startswith("ds_"):
+        return "lds"
+    if op.startswith("v_"):
+        return "valu"
+    if op.startswith(("s_waitcnt", "s_nop", "s_sleep", "s_barrier", "s_setprio")):
+        return "wait"
+    if op.startswith(("s_load", "s_buffer_load", "s_memtime", "s_memrealtime")):
+        return "smem"
+    if op.startswith(("s_cbranch", "s_branch", "s_setpc", "s_endpgm")):
+        return "branch"
+    if op.startswith("s_"):
+        return "salu"
+    return "other"
+
+
+def loop_counts(kernel_substr: str, lib: str = LIB) -> dict:
+    """{"kernel": mangled name, "valu", "mfma", "vmem_load", "lds", "salu", ..., "packed_f32": n, "loop_bytes": n}"""
+    with tempfile.TemporaryDirectory() as wd:
+        co = _code_object(lib, wd)
+        syms = subprocess.run([OBJDUMP, "-t", co], capture_output=True, text=True, check=True).stdout
+        names = [ln.split()[-1] for ln in syms.splitlines() if kernel_substr in ln and " F " in ln and ".text" in ln]
+        names = [n for n in names if not n.endswith(".kd")]
+        if len(names) != 1:
+            raise RuntimeError(f"{kernel_substr!r} matches {len(names)} kernels: {names[:4]}")
+        dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f"--disassemble-symbols={names[0]}", co], capture_output=True, text=True,
+                             check=True).stdout
+    insts = []  # (address, opcode, text)
+    for ln in dis.splitlines():
+        m = re.match(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", ln)
+        if m:
+            insts.append((int(m.group(3), 16), m.group(1), ln))
+    base = insts[0][0]
+    best = None
+    for addr, op, ln in insts:
+        if op.startswith(("s_branch", "s_cbranch")):
+            m = re.search(r"\+0x([0-9a-fA-F]+)>", ln)
+            if m:
+                tgt = base + int(m.group(1), 16)
+                if tgt < addr and (best is None or addr - tgt > best[1] - best[0]):
+                    best = (tgt, addr)
+    if best is None:
+        raise RuntimeError("no backward branch in " + names[0])
+    out = {"kernel": names[0], "loop_bytes": best[1] - best[0]}
+    for addr, op, ln in insts:
+        if best[0] <= addr <= best[1]:
+            c = classify(op)
+            out[c] = out.get(c, 0) + 1
+            if op.startswith("v_pk_") and op.endswith("_f32"):
+                out["packed_f32"] = out.get("packed_f32", 0) + 1
+            if op.startswith(("buffer_load_dwordx2", "buffer_load_dwordx4")):  # the hash-grid gathers (spill reloads are scratch_load)
+                out["gather"] = out.get("gather", 0) + 1
+    for k in ("valu", "mfma", "vmem_load", "lds", "packed_f32", "gather"):
+        out.setdefault(k, 0)
+    return out
+
+
+if __name__ == "__main__":
+    pat = sys.argv[1] if len(sys.argv) > 1 else "sn_render_main_kernelILi0ELi1ELi0ELi0ELi11ELb0E"
+    print(loop_counts(pat))
