@@ -974,7 +974,8 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
         p.dense = h->dense_info;
     }
     const int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
-    const size_t lds_bytes = (size_t)SnMainImg::TOTAL * 4;
+    // weight image + (uniform sampler) the frame's S + 1 euclidean bins
+    const size_t lds_bytes = (size_t)SnMainImg::TOTAL * 4 + (nprop == 0 ? ((size_t)opts->num_nerf_samples + 1 + 3) / 4 * 16 : 0);
     const dim3 grid((unsigned)(gbx * gby)), block(256);
 #define SN_LAUNCH_MAIN(MODE, PREC, ABL, GRID, ND) \
     hipLaunchKernelGGL((sn_render_main_kernel<MODE, PREC, ABL, GRID, ND>), grid, block, lds_bytes, st, p)

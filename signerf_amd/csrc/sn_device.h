@@ -367,17 +367,19 @@ SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t leve
     // (full-rate v_mul_u32_u24 / v_mad_u32_u24; v_mul_lo_u32 is quarter rate)
     const uint32_t R8 = R << 3, R28 = (R * R) << 3;
     const uint32_t b_ff = (f[0] << 3) + __umul24(f[1], R8) + __umul24(f[2], R28);
-    const uint32_t b_cf = b_ff + R8, b_fc = b_ff + R28, b_cc = b_ff + (R8 + R28);
+    // the y + 1 / z + 1 strides are wave-uniform: they ride in the buffer instruction's SCALAR offset (3 s_add per level on the
+    // scalar port) instead of three per-lane v_add
+    const uint32_t o_cf = level_off_bytes + R8, o_fc = level_off_bytes + R28, o_cc = level_off_bytes + (R8 + R28);
     if (rec) {
-        rec[0] = b_cc + level_off_bytes;
-        rec[1] = b_fc + level_off_bytes;
+        rec[0] = b_ff + o_cc;
+        rec[1] = b_ff + o_fc;
         rec[2] = b_ff + level_off_bytes;
-        rec[3] = b_cf + level_off_bytes;
+        rec[3] = b_ff + o_cf;
     }
-    const f32x4 p_cc = sn_table_load_pair(rsrc, b_cc, level_off_bytes);
-    const f32x4 p_fc = sn_table_load_pair(rsrc, b_fc, level_off_bytes);
+    const f32x4 p_cc = sn_table_load_pair(rsrc, b_ff, o_cc);
+    const f32x4 p_fc = sn_table_load_pair(rsrc, b_ff, o_fc);
     const f32x4 p_ff = sn_table_load_pair(rsrc, b_ff, level_off_bytes);
-    const f32x4 p_cf = sn_table_load_pair(rsrc, b_cf, level_off_bytes);
+    const f32x4 p_cf = sn_table_load_pair(rsrc, b_ff, o_cf);
     f32x2 v[8];
     v[3] = f32x2{p_cc.x, p_cc.y};
     v[0] = f32x2{p_cc.z, p_cc.w};

@@ -449,6 +449,15 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
     const int tid = threadIdx.x;
     // both weight images are SnMainImg::TOTAL floats (42 640 B)
     for (int i = tid * 4; i < SnMainImg::TOTAL; i += 256 * 4) *(f32x4*)(lds + i) = *(const f32x4*)(p.wimg + i);
+    // Uniform sampler without per-ray nears / fars (the collider's constants): the S + 1 euclidean bins are the same for every ray
+    // of the frame.  They are computed once per workgroup -- with the same strict arithmetic, so bit-identical -- and read back as
+    // LDS broadcasts, instead of ~20 VALU instructions (an IEEE division among them) per lane and step.
+    float* etab = lds + SnMainImg::TOTAL;
+    const bool shared_bins = MODE == 0 && p.nears == nullptr;
+    if (shared_bins) {
+        const float sn = sn_spacing(p.near_plane), sf = sn_spacing(p.far_plane);
+        for (int i = tid; i <= p.n_samples; i += 256) etab[i] = sn_euclid(p.sbins ? p.sbins[i] : (float)i / (float)p.n_samples, sn, sf);
+    }
     __syncthreads();
 
     const int lane = tid & 63;
@@ -498,7 +507,7 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
 
     SnComposite comp;
     comp.init();
-    float t0 = MODE == 0 ? sn_euclid(p.sbins ? p.sbins[0] : 0.0f, s_near, s_far) : eb[0];
+    float t0 = MODE == 0 ? (shared_bins ? etab[0] : sn_euclid(p.sbins ? p.sbins[0] : 0.0f, s_near, s_far)) : eb[0];
     float first_mid = 0.f, last_mid = 0.f;
     float r = 0.f, g = 0.f, b = 0.f;
 #pragma unroll 1
@@ -506,7 +515,7 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
         // The LDS weight reads are loop-invariant; LICM would hoist them all (368 VGPRs) and spill.  A compiler-only
         // memory clobber per iteration keeps them inside the loop.
         asm volatile("" ::: "memory");
-        const float t1 = MODE == 0 ? sn_euclid(p.sbins ? p.sbins[i + 1] : (float)(i + 1) / (float)S, s_near, s_far)
+        const float t1 = MODE == 0 ? (shared_bins ? etab[i + 1] : sn_euclid(p.sbins ? p.sbins[i + 1] : (float)(i + 1) / (float)S, s_near, s_far))
                                    : eb[(int64_t)(i + 1) * 64];
         float q[3];
         const bool sel = sn_sample_q_fast(o, d, t0, t1, q);

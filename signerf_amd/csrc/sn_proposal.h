@@ -272,6 +272,7 @@ struct SnPropParams {
 // shared per-workgroup LDS: the sampler grids
 struct SnPropLds {
     float sb0[SN_PROP_MAX_SAMPLES + 4];
+    float eb0[SN_PROP_MAX_SAMPLES + 4];  // euclidean bins of the initial sampler when the frame has no per-ray nears / fars (same for every ray)
     float u[SN_MAX_PROPOSALS][SN_PROP_MAX_SAMPLES + 4];
     // MLP weight packs.  They are wave-uniform, but the per-iteration compiler memory clobber (needed against LICM) makes
     // hipcc fetch global weights with VECTOR loads -- 49 extra TA instructions per sample, more than the 40 hash gathers
@@ -281,9 +282,10 @@ struct SnPropLds {
 
 // One proposal level for this lane's ray: density net LV at the N samples whose spacing bins are sb(0..N); writes the
 // weights to w[i * 64] and returns sum(w + pad) (fp64) and the level's median depth.
+// eb_shared: LV 0 only -- the level's euclidean bins from LDS (frames without per-ray nears / fars), else null
 template <int LV, int GRID, int ND, bool DUMP, typename SB>
 SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* __restrict__ w, int N, const float o[3], const float d[3], float s_near,
-                          float s_far, double& sum_wp, float& median_out, int64_t dump_ray = -1) {
+                          float s_far, double& sum_wp, float& median_out, int64_t dump_ray = -1, const float* eb_shared = nullptr) {
     SnScal5 scal;
 #pragma unroll
     for (int l = 0; l < 5; ++l) scal.v[l] = p.scal[LV][l];
@@ -296,12 +298,12 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
     double cum_tau = 0.0, cum_w = 0.0, swp = 0.0;
     bool found = false;
     float median = 0.0f, mid = 0.0f;
-    float e0 = sn_euclid(sb(0), s_near, s_far);
+    float e0 = eb_shared ? eb_shared[0] : sn_euclid(sb(0), s_near, s_far);
 #pragma unroll 1
     for (int i = 0; i < N; ++i) {
         // keep the (loop-invariant) MLP weight loads inside the loop: hoisted, they cost ~200 registers (see sn_main.h)
         asm volatile("" ::: "memory");
-        const float e1 = sn_euclid(sb(i + 1), s_near, s_far);
+        const float e1 = eb_shared ? eb_shared[i + 1] : sn_euclid(sb(i + 1), s_near, s_far);
         float q[3];
         const bool sel = sn_sample_q_fast(o, d, e0, e1, q);
         uint32_t* rec = nullptr;
@@ -347,7 +349,12 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // sampler grids -> LDS (per-lane indexed later)
     const int n0 = p.n_samples[0];
-    for (int i = tid; i <= n0; i += 64 * SN_PROP_WAVES) L.sb0[i] = p.sbins0 ? p.sbins0[i] : (float)i / (float)n0;
+    const bool shared_bins = p.nears == nullptr;
+    for (int i = tid; i <= n0; i += 64 * SN_PROP_WAVES) {
+        const float sb = p.sbins0 ? p.sbins0[i] : (float)i / (float)n0;
+        L.sb0[i] = sb;
+        if (shared_bins) L.eb0[i] = sn_euclid(sb, sn_spacing(p.near_plane), sn_spacing(p.far_plane));  // the same strict arithmetic as per lane
+    }
     for (int k = 0; k < p.n_levels; ++k) {
         const int m = k + 1 < p.n_levels ? p.n_samples[k + 1] : p.n_final;
         for (int j = tid; j <= m; j += 64 * SN_PROP_WAVES) {
@@ -389,7 +396,8 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
         double sum_wp;
         float med;
         const int64_t dump_ray = DUMP && valid ? pix : -1;
-        sn_prop_level<0, GRID, ND0, DUMP>(p, L.wpack[0], [&](int i) { return L.sb0[i]; }, W, n0, o, d, s_near, s_far, sum_wp, med, dump_ray);
+        sn_prop_level<0, GRID, ND0, DUMP>(p, L.wpack[0], [&](int i) { return L.sb0[i]; }, W, n0, o, d, s_near, s_far, sum_wp, med, dump_ray,
+                                          shared_bins ? L.eb0 : nullptr);
         if (valid && p.prop_depth[0]) p.prop_depth[0][pix] = med;
         SnPdfNorm nm;
         nm.set(sum_wp, n0);
