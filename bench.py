@@ -296,8 +296,9 @@ def main():
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else
-                     "f32 (MLP operands carried as fp16 hi+lo pairs on the matrix cores, f32 accumulate; fp32-grade for |operands| in "
-                     "[2^-13, 65504], guarded by sn_finalize_weights -- tests/test_gpu_precision.py)",
+                     "f32 (MLP operands carried as fp16 hi+lo pairs on the matrix cores, f32 accumulate; every layer range-conditioned into "
+                     "fp16's [2^-3, 65504] by exact power-of-two scales at sn_finalize_weights, exact-fp32 MFMA fallback otherwise; validated "
+                     "against exact fp32 for tables x1..1e-5, weights x0.05 and activations > 65504: tests/test_gpu_precision.py)",
             "data": "synthetic",
             "config": {"workload": (f"BASELINE.json configs[1]: {W}x{H} rays x {S} samples/ray, nerfacto hash grid L=16 T=2^19 F=2, "
                                     "no proposal nets, random-weight synthetic scene, one camera per GPU + tile all-gather")

@@ -162,6 +162,14 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
                       int32_t height, int32_t width, const SnRenderOpts* opts, float* normals, float* pred_normals,
                       SnStream stream);
 
+/* SnRenderOpts.precision = 1 (split fp16) is a REQUEST.  sn_finalize_weights conditions every layer of the split-precision MLPs into
+ * fp16's range with exact power-of-two scales derived from the uploaded parameters (bounds of the activations over all inputs with
+ * |feature| <= max|table row|), which keeps the arithmetic fp32-grade for tables and weights of any magnitude; if a conditioned weight
+ * still leaves the fp16 range the handle renders such requests with the exact-fp32 MFMA path instead.  Returns the precision that
+ * `requested` resolves to (0 or 1) for kernel 0 = sn_render_rays / sn_field_forward, 1 = sn_render_normals (which splits
+ * unconditioned operands and therefore falls back as soon as max|table row| < 1/8 or an activation bound exceeds 65504); -1 on error. */
+int sn_effective_precision(SnHandle h, int32_t requested, int32_t kernel);
+
 /* ---- stage-level entry points (used by parity tests).  They run the LITERAL torch-path arithmetic (IEEE divisions in the
  * contraction, floor / ceil corners, the reference's blend association, expf); the fused kernels behind sn_render_rays run the
  * reduced-instruction forms of the same maps (v_rcp_f32 contraction, truncation + fract corners with "ceil = floor + 1", lerp-form
@@ -222,6 +230,8 @@ typedef struct SnDebugLayout {
     uint64_t dense_bytes;              /* size of the buffer of copies */
     uint32_t pair_base[SN_MAX_LEVELS]; /* which >= 0: first 16-byte entry of level l's t = 0 paired table (table t follows at t << log2_T) */
     uint64_t pair_bytes;
+    float feature_scale;               /* the copies / paired tables hold table rows TIMES this power of two (range conditioning of the
+                                        * split-precision MLPs; the first layer's weights carry its inverse) */
 } SnDebugLayout;
 /* which: -1 main field, i >= 0 proposal net i. */
 int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out);

@@ -93,6 +93,7 @@ class SnDebugLayout(C.Structure):
         ("dense_bytes", C.c_uint64),
         ("pair_base", C.c_uint32 * SN_MAX_LEVELS),
         ("pair_bytes", C.c_uint64),
+        ("feature_scale", C.c_float),
     ]
 
 
@@ -117,6 +118,7 @@ SIGNATURES = {
     "sn_debug_layout": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(SnDebugLayout)]),
     "sn_debug_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _FP, C.c_size_t, C.c_void_p]),
     "sn_clock_probe": (C.c_int, [_FP, C.c_double, C.c_void_p]),
+    "sn_effective_precision": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "sn_render_normals": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.POINTER(SnRenderOpts), _FP, _FP, C.c_void_p]),
     "sn_hash_encode": (C.c_int, [C.c_void_p, C.c_int32, _FP, C.c_int64, _FP, _FP, C.c_void_p]),
     "sn_field_forward": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, C.c_void_p]),

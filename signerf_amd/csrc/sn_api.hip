@@ -62,6 +62,12 @@ struct SnContext {
     SnGridLevels dense_res_prop[SN_MAX_PROPOSALS]{};
     int nd_prop[SN_MAX_PROPOSALS] = {0, 0};
     bool dense_pairs_ok = true;  // tcnn grids: every dense level is shorter than its slot (room for the wrap row, sn_finalize_weights)
+    // Range conditioning of the split-precision (fp16 hi + lo) MLPs, decided by sn_finalize_weights (plan_split_scales):
+    float feat_scale_main = 1.0f;                      // power of two carried by the main grid's de-hashed copies (1 for tcnn grids)
+    float feat_scale_prop[SN_MAX_PROPOSALS] = {1.0f, 1.0f};  // ... by a proposal net's de-hashed copies and paired tables
+    bool split_ok = true;        // false: some scaled weight leaves the fp16 range -> precision 1 requests render with exact fp32 MFMA
+    std::string split_why;
+    bool normals_split_ok = true;  // the normals kernel splits UNconditioned operands: allowed only while table and bounds sit in range
     bool finalized = false;
 };
 
@@ -147,7 +153,7 @@ SnGridLevels grid_levels(const SnHashMlpDesc& d) {
 // 3.33 / 3.30 / 3.26 ms for 0 / 8 / 9 / 10 / 11 copied levels), the proposal nets (352 samples per ray over the coarse levels)
 // lose with the 137 MB copy of the second net's finest level (frame 18.8 vs 17.5 ms) -- hence the two caps.
 int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, int want, uint64_t cap_mb, DevBuf& buf, SnDenseCopy& info,
-                       SnGridLevels& res, int& nd_out, hipStream_t st, int n_sets = 1) {
+                       SnGridLevels& res, int& nd_out, hipStream_t st, int n_sets = 1, float scale = 1.0f) {
     nd_out = 0;
     memset(&info, 0, sizeof(info));
     memset(&res, 0, sizeof(res));
@@ -179,7 +185,7 @@ int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, 
         for (int l = 0; l < nd; ++l) {
             const uint32_t n = R[l] * R[l] * R[l];
             hipLaunchKernelGGL(sn_build_dense_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)table.ptr,
-                               (float*)((char*)buf.ptr + (uint64_t)set * set_bytes + info.off[l]), l, d.log2_hashmap_size, R[l], set);
+                               (float*)((char*)buf.ptr + (uint64_t)set * set_bytes + info.off[l]), l, d.log2_hashmap_size, R[l], set, scale);
             info.res[l] = R[l];
         }
     SN_HIP(h, hipGetLastError());
@@ -385,6 +391,89 @@ std::vector<float> build_main_image_h(const SnFieldDesc& d, const float* W1, con
     return out;
 }
 
+// ---- range conditioning of the split-precision MLPs ---------------------------------------------------------------------------
+// Every fp32 operand of the "fp16x2" path is carried as fp16 hi + lo.  That is fp32-grade (2^-22 relative) only while the operand sits
+// in [2^-3, 65504]: below, lo drops into fp16's subnormals (absolute resolution 2^-24, e.g. ~13 bits for a value of 5e-4 -- nerfstudio
+// initialises its tables at 1e-3); above, cvt_pkrtz saturates.  Scaling by a power of two is exact, so sn_finalize_weights moves
+// every layer into the upper part of the range once, on the host, at no run-time cost:
+//   features   f' = t0 f        t0 = 2^floor(log2(2^10 / max|table|)); the de-hashed copies / paired tables store t0 * row (levels read
+//                               from the uploaded table are multiplied in the kernel), the first layer's weights carry 1 / t0
+//   layer l    z_l' = s_l z_l   s_l = 2^floor(log2(2^14 / B_l)), B_l = interval bound of |z_l| over all inputs with |f| <= max|table|;
+//                               W_l' = W_l s_l / s_(l-1), b_l' = b_l s_l; ReLU commutes with s_l > 0; the last consumer divides it out
+// B_l is a true bound, so no activation can saturate; the largest weights of a layer land in [2^-1, 2^4] by construction.  The only
+// failure left is a scaled weight outside the fp16 range (a unit whose inputs are bounded ~0 next to ordinary ones): the handle then
+// renders precision-1 requests with the exact fp32 MFMA path (sn_effective_precision reports it).
+float pow2_floor(double x) {
+    if (!(x > 0.0) || !std::isfinite(x)) return 1.0f;
+    return (float)std::ldexp(1.0, (int)std::floor(std::log2(x)));
+}
+
+struct MainSplitPlan {
+    float t0 = 1.0f, s1 = 1.0f, s2 = 1.0f, s3 = 1.0f, s4 = 1.0f;
+    bool ok = true;
+    std::string why;
+    double max_bound = 0.0;  // largest interval bound of an (unscaled) activation
+};
+
+MainSplitPlan plan_split_scales(const SnFieldDesc& d, float table_absmax, bool scale_features, const float* W1, const float* b1, const float* W2,
+                                const float* b2, const float* Wc1, const float* bc1, const float* Wc2, const float* bc2, const float* app) {
+    MainSplitPlan pl;
+    const int geo = d.geo_feat_dim, sh = d.sh_levels * d.sh_levels, cin = sh + geo + d.appearance_embed_dim;
+    if (!std::isfinite(table_absmax)) {
+        pl.ok = false;
+        pl.why = "the hash table holds non-finite values";
+        return pl;
+    }
+    const double M0 = table_absmax;
+    pl.t0 = scale_features && M0 > 0.0 ? pow2_floor(1024.0 / M0) : 1.0f;
+    std::vector<double> B1(64), B2(16), Bc1(64), Bc2(64);
+    double m1 = 0, m2 = 0, m3 = 0, m4 = 0;
+    for (int n = 0; n < 64; ++n) {
+        double a = std::fabs(b1[n]);
+        for (int k = 0; k < 32; ++k) a += std::fabs(W1[n * 32 + k]) * M0;
+        B1[n] = a;
+        m1 = std::max(m1, a);
+    }
+    for (int r = 0; r < 16; ++r) {
+        double a = std::fabs(b2[r]);
+        for (int n = 0; n < 64; ++n) a += std::fabs(W2[r * 64 + n]) * B1[n];
+        B2[r] = a;
+        m2 = std::max(m2, a);
+    }
+    for (int n = 0; n < 64; ++n) {
+        double a = std::fabs(bc1[n]);
+        for (int e = 0; e < d.appearance_embed_dim; ++e) a += std::fabs(Wc1[n * cin + sh + geo + e] * app[e]);
+        for (int c = 0; c < sh; ++c) a += std::fabs(Wc1[n * cin + c]) * 3.0;  // |SH component| < 3 for degree 4 on [-1, 1]^3
+        for (int j = 0; j < geo; ++j) a += std::fabs(Wc1[n * cin + sh + j]) * B2[1 + j];
+        Bc1[n] = a;
+        m3 = std::max(m3, a);
+    }
+    for (int n = 0; n < 64; ++n) {
+        double a = std::fabs(bc2[n]);
+        for (int k = 0; k < 64; ++k) a += std::fabs(Wc2[n * 64 + k]) * Bc1[k];
+        Bc2[n] = a;
+        m4 = std::max(m4, a);
+    }
+    if (!std::isfinite(m1) || !std::isfinite(m2) || !std::isfinite(m3) || !std::isfinite(m4)) {
+        pl.ok = false;
+        pl.why = "non-finite MLP parameters";
+        return pl;
+    }
+    pl.max_bound = std::max(std::max(m1, m2), std::max(m3, m4));
+    pl.s1 = m1 > 0 ? pow2_floor(16384.0 / m1) : 1.0f;
+    pl.s2 = m2 > 0 ? pow2_floor(16384.0 / m2) : 1.0f;
+    pl.s3 = m3 > 0 ? pow2_floor(16384.0 / m3) : 1.0f;
+    pl.s4 = m4 > 0 ? pow2_floor(16384.0 / m4) : 1.0f;
+    return pl;
+}
+
+// true if every element of a scaled operand fits fp16 (|x| <= 65504) -- the split saturates beyond
+bool fits_half(const std::vector<float>& v) {
+    for (float x : v)
+        if (!(std::fabs(x) <= 65504.0f)) return false;
+    return true;
+}
+
 const std::vector<float>* find(SnHandle h, const std::string& name, size_t count) {
     auto it = h->host.find(name);
     if (it == h->host.end() || it->second.size() != count) return nullptr;
@@ -392,7 +481,7 @@ const std::vector<float>* find(SnHandle h, const std::string& name, size_t count
 }
 
 // Builds the x-paired copy of one hash table (sn_device.h): per level l, (bitlen(scale_l) + 1) tables of T 16-byte entries.
-int build_pairs(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, DevBuf& pairs, SnPairInfo& info, hipStream_t st) {
+int build_pairs(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, DevBuf& pairs, SnPairInfo& info, hipStream_t st, float scale = 1.0f) {
     const uint32_t T = 1u << d.log2_hashmap_size;
     uint64_t entries = 0;
     int n_t[SN_MAX_LEVELS];
@@ -419,7 +508,7 @@ int build_pairs(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, DevBuf&
         const uint64_t n = (uint64_t)n_t[l] * T;
         if (n == 0) continue;
         hipLaunchKernelGGL(sn_build_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)table.ptr,
-                           (float*)pairs.ptr, l, d.log2_hashmap_size, info.base[l], n_t[l]);
+                           (float*)pairs.ptr, l, d.log2_hashmap_size, info.base[l], n_t[l], scale);
     }
     SN_HIP(h, hipGetLastError());
     return SN_OK;
@@ -609,14 +698,63 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         app = find(h, "field.embedding_appearance.mean", (size_t)d.appearance_embed_dim);
         if (!app) return fail(h, SN_ERR_STATE, "missing field.embedding_appearance.mean");
     }
-    std::vector<float> img = build_main_image(d, t[0]->data(), t[1]->data(), t[2]->data(), t[3]->data(), t[4]->data(), t[5]->data(),
+    // max |row| of every hash table (device reduction): the input bound of the range conditioning below
+    float absmax_main = 0.0f, absmax_prop[SN_MAX_PROPOSALS] = {0.0f, 0.0f};
+    {
+        uint32_t* d_m = nullptr;
+        SN_HIP(h, hipMalloc((void**)&d_m, 4 * (1 + SN_MAX_PROPOSALS)));
+        SN_HIP(h, hipMemsetAsync(d_m, 0, 4 * (1 + SN_MAX_PROPOSALS), st));
+        hipLaunchKernelGGL(sn_absmax_kernel, dim3(1024), dim3(256), 0, st, (const float*)h->table_main.ptr, h->table_main.bytes / 4, d_m);
+        for (int i = 0; i < d.num_proposals; ++i)
+            if (h->table_prop[i].ptr)
+                hipLaunchKernelGGL(sn_absmax_kernel, dim3(256), dim3(256), 0, st, (const float*)h->table_prop[i].ptr, h->table_prop[i].bytes / 4, d_m + 1 + i);
+        uint32_t bits[1 + SN_MAX_PROPOSALS];
+        hipError_t e = hipMemcpyAsync(bits, d_m, sizeof(bits), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d_m);
+        if (e != hipSuccess) return fail(h, SN_ERR_HIP, std::string("sn_finalize_weights: table scan: ") + hipGetErrorString(e));
+        memcpy(&absmax_main, &bits[0], 4);
+        for (int i = 0; i < SN_MAX_PROPOSALS; ++i) memcpy(&absmax_prop[i], &bits[1 + i], 4);
+    }
+    const bool torch_main = d.main_field.grid_mode == 0;
+    const MainSplitPlan pl = plan_split_scales(d, absmax_main, torch_main, t[0]->data(), t[1]->data(), t[2]->data(), t[3]->data(), t[4]->data(),
+                                               t[5]->data(), t[6]->data(), t[7]->data(), app->data());
+    h->feat_scale_main = pl.t0;
+    h->split_ok = pl.ok;
+    h->split_why = pl.why;
+    h->normals_split_ok = pl.ok && absmax_main >= 0.125f && pl.max_bound <= 65504.0;
+    auto scaled = [](const std::vector<float>& v, double f) {
+        std::vector<float> o(v.size());
+        for (size_t i = 0; i < v.size(); ++i) o[i] = (float)((double)v[i] * f);  // f is a power of two: exact (barring under / overflow)
+        return o;
+    };
+    // exact-fp32 image: only the feature scale (the de-hashed copies carry it), W1 / t0 -- bit-identical results
+    const std::vector<float> W1f = scaled(*t[0], 1.0 / pl.t0);
+    std::vector<float> img = build_main_image(d, W1f.data(), t[1]->data(), t[2]->data(), t[3]->data(), t[4]->data(), t[5]->data(),
                                               t[6]->data(), t[7]->data(), t[8]->data(), t[9]->data(), app->data());
     if (!h->wimg_main.ptr) {
         SN_HIP(h, hipMalloc(&h->wimg_main.ptr, img.size() * 4));
         h->wimg_main.bytes = img.size() * 4;
     }
     SN_HIP(h, hipMemcpyAsync(h->wimg_main.ptr, img.data(), img.size() * 4, hipMemcpyHostToDevice, st));
-    std::vector<float> imgh = build_main_image_h(d, t[0]->data(), t[2]->data(), t[4]->data(), t[6]->data(), img);
+    // split-precision image: every layer in its conditioned range (plan_split_scales)
+    const int sh_n = d.sh_levels * d.sh_levels;
+    const std::vector<float> W1s = scaled(*t[0], (double)pl.s1 / pl.t0), b1s = scaled(*t[1], pl.s1);
+    const std::vector<float> W2s = scaled(*t[2], (double)pl.s2 / pl.s1), b2s = scaled(*t[3], pl.s2);
+    std::vector<float> Wc1s = scaled(*t[4], pl.s3);  // SH and appearance columns; the geo columns take s3 / s2
+    for (int n = 0; n < 64; ++n)
+        for (int j = 0; j < d.geo_feat_dim; ++j) Wc1s[(size_t)n * cin + sh_n + j] = (float)((double)(*t[4])[(size_t)n * cin + sh_n + j] * ((double)pl.s3 / pl.s2));
+    const std::vector<float> bc1s = scaled(*t[5], pl.s3);
+    const std::vector<float> Wc2s = scaled(*t[6], (double)pl.s4 / pl.s3), bc2s = scaled(*t[7], pl.s4);
+    const std::vector<float> Wc3s = scaled(*t[8], 1.0 / pl.s4);
+    if (h->split_ok && !(fits_half(W1s) && fits_half(W2s) && fits_half(Wc1s) && fits_half(Wc2s))) {
+        h->split_ok = false;
+        h->split_why = "a range-conditioned MLP weight leaves the fp16 range";
+    }
+    std::vector<float> img_s = build_main_image(d, W1s.data(), b1s.data(), W2s.data(), b2s.data(), Wc1s.data(), bc1s.data(), Wc2s.data(),
+                                                bc2s.data(), Wc3s.data(), t[9]->data(), app->data());
+    img_s[SnMainImg::B3 + 3] = 1.0f / pl.s2;
+    std::vector<float> imgh = build_main_image_h(d, W1s.data(), W2s.data(), Wc1s.data(), Wc2s.data(), img_s);
     if (!h->wimg_main_h.ptr) {
         SN_HIP(h, hipMalloc(&h->wimg_main_h.ptr, imgh.size() * 4));
         h->wimg_main_h.bytes = imgh.size() * 4;
@@ -703,10 +841,31 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         const std::vector<float>* w1 = find(h, pre + "mlp.layers.1.weight", 16);
         const std::vector<float>* b1 = find(h, pre + "mlp.layers.1.bias", 1);
         if (!w0 || !b0 || !w1 || !b1) return fail(h, SN_ERR_STATE, "missing or mis-sized MLP parameter under " + pre);
+        // range conditioning of the net's one matrix-core layer (see plan_split_scales): features carry t0p (stored in the net's
+        // de-hashed copies and paired tables), the hidden layer s1p; both are divided out by the weights around them
+        double t0p = 1.0, s1p = 1.0;
+        if (d.proposals[i].grid_mode == 0 && std::isfinite(absmax_prop[i]) && absmax_prop[i] > 0.0f) {
+            const double M = absmax_prop[i];
+            t0p = pow2_floor(1024.0 / M);
+            double m1 = 0.0;
+            for (int n = 0; n < 16; ++n) {
+                double a = std::fabs((*b0)[n]);
+                for (int k = 0; k < 10; ++k) a += std::fabs((*w0)[n * 10 + k]) * M;
+                m1 = std::max(m1, a);
+            }
+            if (std::isfinite(m1) && m1 > 0.0) s1p = pow2_floor(16384.0 / m1);
+            bool fits = true;
+            for (int n = 0; n < 16; ++n) {
+                fits = fits && std::fabs((*b0)[n] * s1p) <= 65504.0;
+                for (int k = 0; k < 10; ++k) fits = fits && std::fabs((*w0)[n * 10 + k] * s1p / t0p) <= 65504.0;
+            }
+            if (!fits) t0p = s1p = 1.0;  // leave this net unconditioned (it only places samples)
+        }
+        h->feat_scale_prop[i] = (float)t0p;
         std::vector<float> pack(SN_PROP_PACK_FLOATS, 0.0f);
         // W0 is stored k-major ([k][n]) so that two neighbouring hidden units share a register pair (v_pk_fma_f32)
         for (int n = 0; n < 16; ++n)
-            for (int k = 0; k < 10; ++k) pack[SN_PROP_W0 + k * 16 + n] = (*w0)[n * 10 + k];
+            for (int k = 0; k < 10; ++k) pack[SN_PROP_W0 + k * 16 + n] = (float)((*w0)[n * 10 + k] / t0p);
         memcpy(pack.data() + SN_PROP_B0, b0->data(), 16 * 4);
         memcpy(pack.data() + SN_PROP_W1, w1->data(), 16 * 4);
         pack[SN_PROP_B1] = (*b1)[0];
@@ -719,13 +878,13 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
                 for (int e = 0; e < 8; ++e) {
                     const int row = lane & 31, k = 8 * (lane >> 5) + e;
                     float x = 0.0f;
-                    if (row < 16) x = k < 10 ? (*w0)[row * 10 + k] : (k == 10 ? (*b0)[row] : 0.0f);
+                    if (row < 16) x = k < 10 ? (float)((*w0)[row * 10 + k] * s1p / t0p) : (k == 10 ? (float)((*b0)[row] * s1p) : 0.0f);
                     const uint16_t hi = f32_to_f16_rne(x);
                     ahi[lane * 8 + e] = hi;
                     alo[lane * 8 + e] = f32_to_f16_rne(x - f16_to_f32(hi));
                 }
             for (int hh = 0; hh < 2; ++hh)
-                for (int r = 0; r < 8; ++r) pack[SN_PROP_MW1 + hh * 8 + r] = (*w1)[(r & 3) + 8 * (r >> 2) + 4 * hh];
+                for (int r = 0; r < 8; ++r) pack[SN_PROP_MW1 + hh * 8 + r] = (float)((*w1)[(r & 3) + 8 * (r >> 2) + 4 * hh] / s1p);
         }
         if (!h->wpack_prop[i].ptr) {
             SN_HIP(h, hipMalloc(&h->wpack_prop[i].ptr, pack.size() * 4));
@@ -741,17 +900,18 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         const uint64_t cap_main = cap_env ? (uint64_t)std::max(1, atoi(cap_env)) : 600;
         const char* pe = getenv("SN_DENSE_ORIENT");  // 0: only the x-fast set of copies
         const int sets = (pe && atoi(pe) == 0) ? 1 : 3;
-        if (int rc = build_dense_copies(h, d.main_field, h->table_main, want, cap_main, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st, sets))
+        if (int rc = build_dense_copies(h, d.main_field, h->table_main, want, cap_main, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st, sets,
+                                        h->feat_scale_main))
             return rc;
         for (int i = 0; i < d.num_proposals; ++i)
             if (int rc = build_dense_copies(h, d.proposals[i], h->table_prop[i], want, 100, h->dense_prop[i], h->dense_info_prop[i],
-                                            h->dense_res_prop[i], h->nd_prop[i], st))
+                                            h->dense_res_prop[i], h->nd_prop[i], st, 1, h->feat_scale_prop[i]))
                 return rc;
     }
     bool wrap_ok = write_wrap_rows(d.main_field, h->table_main, st);
     for (int i = 0; i < d.num_proposals; ++i) {
         wrap_ok = write_wrap_rows(d.proposals[i], h->table_prop[i], st) && wrap_ok;
-        if (int rc = build_pairs(h, d.proposals[i], h->table_prop[i], h->pairs_prop[i], h->pinfo_prop[i], st)) return rc;
+        if (int rc = build_pairs(h, d.proposals[i], h->table_prop[i], h->pairs_prop[i], h->pinfo_prop[i], st, h->feat_scale_prop[i])) return rc;
     }
     h->dense_pairs_ok = wrap_ok;
     SN_HIP(h, hipGetLastError());
@@ -947,7 +1107,9 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     p.sbins = d_sbins;
     p.ebins = d_ebins;
     p.table = (const float*)h->table_main.ptr;
-    p.wimg = (const float*)(opts->precision == 0 ? h->wimg_main.ptr : h->wimg_main_h.ptr);
+    const bool split = opts->precision == 1 && h->split_ok;  // (a handle whose weights cannot be range-conditioned renders in exact fp32)
+    p.wimg = (const float*)(split ? h->wimg_main_h.ptr : h->wimg_main.ptr);
+    p.feat_scale = h->feat_scale_main;
     p.rgb = rgb;
     p.depth = depth;
     p.acc = accumulation;
@@ -993,7 +1155,6 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     }
     const char* abl_env = getenv("SN_ABLATE");  // profiling only: non-zero gives WRONG images (see sn_main.h)
     const int ablate = abl_env ? atoi(abl_env) : 0;
-    const bool split = opts->precision == 1;
     const bool tcnn = d.main_field.grid_mode == 1;
     const int nd = tcnn && h->dense_pairs_ok ? leading_dense(d.main_field) : -1;  // compile-time variants read dense levels as x-pairs
 #define SN_LAUNCH_MAIN_TORCH(MODE, PREC)                          \
@@ -1062,6 +1223,13 @@ int sn_render_rays_debug(SnHandle h, const float* origins, const float* directio
                             prop_depth_1, dump, stream);
 }
 
+int sn_effective_precision(SnHandle h, int32_t requested, int32_t kernel) {
+    if (!h || (requested != 0 && requested != 1) || (kernel != 0 && kernel != 1)) return -1;
+    if (!h->finalized) return -1;
+    if (requested == 0) return 0;
+    return (kernel == 0 ? h->split_ok : h->normals_split_ok) ? 1 : 0;
+}
+
 int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out) {
     if (!h || !out) return fail(h, SN_ERR_INVALID, "sn_debug_layout: null argument");
     if (which < -1 || which >= h->desc.num_proposals) return fail(h, SN_ERR_INVALID, "sn_debug_layout: bad field selector");
@@ -1075,6 +1243,7 @@ int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out) {
     }
     out->dense_set_stride = dc.perm_stride;
     out->dense_bytes = which < 0 ? h->dense_main.bytes : h->dense_prop[which].bytes;
+    out->feature_scale = which < 0 ? h->feat_scale_main : h->feat_scale_prop[which];
     if (which >= 0) {
         for (int l = 0; l < SN_MAX_LEVELS; ++l) out->pair_base[l] = h->pinfo_prop[which].base[l];
         out->pair_bytes = h->pairs_prop[which].bytes;
@@ -1155,7 +1324,7 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
     p.sbins = opts->initial_spacing_bins;
     p.ebins = d_ebins;
     p.table = (const float*)h->table_main.ptr;
-    const bool split = opts->precision == 1;
+    const bool split = opts->precision == 1 && h->normals_split_ok;
     p.wimg = (const float*)(split ? h->wimg_normals_h.ptr : h->wimg_normals.ptr);
     p.normals = normals;
     p.pred_normals = pred_normals;
@@ -1216,6 +1385,7 @@ int sn_hash_encode(SnHandle h, int32_t which, const float* q, int64_t n, float* 
     if (which >= 0) p.pinfo = h->pinfo_prop[which];
     else memset(&p.pinfo, 0, sizeof(p.pinfo));
     p.pairs_bytes = which >= 0 ? (uint32_t)h->pairs_prop[which].bytes : 0u;
+    p.inv_pair_scale = which >= 0 ? 1.0f / h->feat_scale_prop[which] : 1.0f;
     hipLaunchKernelGGL(sn_hash_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     SN_HIP(h, hipGetLastError());
     return SN_OK;
@@ -1236,7 +1406,9 @@ int sn_field_forward(SnHandle h, int32_t which, const float* positions, const fl
         p.directions = directions;
         p.n = n;
         p.table = (const float*)h->table_main.ptr;
+        if (precision == 1 && !h->split_ok) precision = 0;
         p.wimg = (const float*)(precision == 0 ? h->wimg_main.ptr : h->wimg_main_h.ptr);
+        p.feat_scale = h->feat_scale_main;
         for (int l = 0; l < 16; ++l) p.scal[l] = h->desc.main_field.scalings[l];
         p.log2_t = h->desc.main_field.log2_hashmap_size;
         p.avg_density = h->desc.average_init_density;

@@ -394,8 +394,10 @@ SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t leve
 
 // builds D_l for one level: one thread per entry
 // perm: 0 = entry i holds grid point (x, y, z) = (i % R, i / R % R, i / R^2); 1 = the roles of x and y swapped; 2 = x and z swapped
+// scale: an exact power of two applied to the copied values (the "feature scale" of the split-precision MLPs, sn_api.hip
+// plan_split_scales: the consuming layer's weights carry its inverse)
 __global__ void sn_build_dense_copy_kernel(const float* __restrict__ table, float* __restrict__ dense, int level, int log2_t, uint32_t R,
-                                           int perm) {
+                                           int perm, float scale) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R * R * R) return;
     const uint32_t c0 = i % R, c1 = (i / R) % R, c2 = i / (R * R);
@@ -403,7 +405,18 @@ __global__ void sn_build_dense_copy_kernel(const float* __restrict__ table, floa
     const uint32_t mask = (1u << log2_t) - 1u;
     const uint32_t row = (x ^ (y * 2654435761u) ^ (z * 805459861u)) & mask;
     const f32x2* lv = (const f32x2*)table + ((uint64_t)level << log2_t);
-    ((f32x2*)dense)[i] = lv[row];
+    const f32x2 v = lv[row];
+    ((f32x2*)dense)[i] = f32x2{v.x * scale, v.y * scale};
+}
+
+// max |x| over a buffer (bit pattern of the non-negative float, which orders like the value; NaN sorts above inf and so shows)
+__global__ void sn_absmax_kernel(const float* __restrict__ x, size_t n, uint32_t* out) {
+    uint32_t m = 0u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, sft));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
 // ARITH: 0 = the literal torch-path arithmetic, 1 = its fused-kernel form (sn_hash_corners_fast), 2 = tiny-cuda-nn grid
@@ -417,7 +430,7 @@ __global__ void sn_build_dense_copy_kernel(const float* __restrict__ table, floa
 template <int L, int GROUP = 0, int ARITH = 0, int ND = -1, bool DUMP = false>
 SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], float* feat,
                            const SnGridLevels* grid = nullptr, const SnDenseCopy* dense = nullptr, const float* qdense = nullptr,
-                           uint32_t dense_set_off = 0u, uint32_t* rec = nullptr) {
+                           uint32_t dense_set_off = 0u, uint32_t* rec = nullptr, float plain_scale = 1.0f) {
     constexpr bool FAST = ARITH != 0;
     const uint32_t mask = (1u << log2_t) - 1u;
 #pragma unroll
@@ -460,8 +473,10 @@ SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int l
             for (int k = 0; k < 8; ++k) rec[8 * l + k] = hl.boff[k];
         }
         f32x2 e = FAST ? sn_hash_blend_fast(v, hl.off) : sn_hash_blend(v, hl.off);
-        feat[2 * l] = e.x;
-        feat[2 * l + 1] = e.y;
+        // ARITH 1 (fused torch-grid kernels): the levels read from the uploaded table itself get the feature scale that the de-hashed
+        // copies already carry (an exact power of two; 1.0 everywhere else)
+        feat[2 * l] = ARITH == 1 ? e.x * plain_scale : e.x;
+        feat[2 * l + 1] = ARITH == 1 ? e.y * plain_scale : e.y;
     }
 }
 
@@ -564,7 +579,7 @@ SN_DEV void sn_hash_encode_pairs(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo&
 
 // builds P[l][t][r] for one table; grid over (entry r, slot = level-local table index), launched per level
 __global__ void sn_build_pairs_kernel(const float* __restrict__ table, float* __restrict__ pairs, int level, int log2_t, uint32_t base,
-                                      int n_t) {
+                                      int n_t, float scale) {
     const uint32_t T = 1u << log2_t;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)T * n_t) return;
@@ -572,7 +587,7 @@ __global__ void sn_build_pairs_kernel(const float* __restrict__ table, float* __
     const uint32_t m = ((2u << t) - 1u) & (T - 1u);
     const f32x2* lv = (const f32x2*)table + ((uint64_t)level << log2_t);
     const f32x2 a = lv[r], b = lv[r ^ m];
-    ((f32x4*)pairs)[(uint64_t)base + i] = f32x4{a.x, a.y, b.x, b.y};
+    ((f32x4*)pairs)[(uint64_t)base + i] = f32x4{a.x * scale, a.y * scale, b.x * scale, b.y * scale};
 }
 
 // ------------------------------------------------------------------------------------------

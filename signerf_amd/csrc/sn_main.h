@@ -33,7 +33,7 @@ struct SnMainImg {
     static constexpr int BC1 = 10336;   // [2][2][16]
     static constexpr int BC2 = 10400;   // [2][2][16]
     static constexpr int W3 = 10464;    // [n=3][h=2][32]
-    static constexpr int B3 = 10656;    // [4]
+    static constexpr int B3 = 10656;    // [4]: the 3 biases; [3] = 1 / (output scale of layer 2) of the split-precision image (h0 = row 0 * that)
     static constexpr int TOTAL = 10660; // floats (multiple of 4)
 };
 
@@ -320,7 +320,9 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
     // ---- layer 2 ----
     f32x16 g0[1], g1[1];
     sn_mlp_layer_h<1, 4>(ldsb + SnMainImgH::W2, tail + SnMainImgH::B2, op0, op1, g0, g1, lane);
-    h0 = upper ? g1[0][8] : g0[0][0];
+    // the layers run on power-of-two scaled activations (sn_api.hip plan_split_scales); the density row is scaled back here, the geo
+    // rows carry their scale into colour layer 1, whose weights hold the inverse
+    h0 = (upper ? g1[0][8] : g0[0][0]) * tail[SnMainImgH::B3 + 3];
     __builtin_amdgcn_sched_barrier(0);
     // ---- colour layer 1: k-step 0 <- layer-2 regs 0..7 (rows rho(e)+4h), k-step 1 <- SH ----
     {
@@ -419,6 +421,7 @@ struct SnMainParams {
     float near_plane, far_plane, avg_density;
     int sh_remap;
     int chunk_rays;
+    float feat_scale;   // torch grid: power-of-two scale of the hash features (carried by the de-hashed copies; applied here to the other levels)
     SnGridLevels grid;  // GRID 1: dense-level resolutions of the tiny-cuda-nn grid; GRID 0, ND > 0: R of the de-hashed coarse copies
     SnDenseCopy dense;  // GRID 0, ND > 0
     // test instrumentation (DUMP = 1 instantiations only; sn_render_rays_debug)
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
                 }
             }
             sn_hash_encode<16, SN_HASH_GROUP, (GRID ? 2 : (SN_FAST_HASH ? 1 : 0)), ND, DUMP>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, qd,
-                                                                                            dense_set_off, rec);
+                                                                                            dense_set_off, rec, p.feat_scale);
         }
         __builtin_amdgcn_sched_barrier(0);
         float h0, rgb[3];

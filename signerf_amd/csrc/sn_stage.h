@@ -165,6 +165,7 @@ struct SnHashStageParams {
     uint32_t pairs_bytes;
     int grid_mode;       // 1: tiny-cuda-nn grid semantics (level table in `grid`)
     SnGridLevels grid;
+    float inv_pair_scale;  // the paired tables hold the rows times a power of two (feature scale); this undoes it exactly
 };
 
 __global__ void sn_hash_encode_kernel(SnHashStageParams p) {
@@ -195,7 +196,7 @@ __global__ void sn_hash_encode_kernel(SnHashStageParams p) {
         float feat[32];
         if (p.num_levels == 16) sn_hash_encode_pairs<16>(prsrc, p.pinfo, p.scal, p.log2_t, q, feat);
         else sn_hash_encode_pairs<5>(prsrc, p.pinfo, p.scal, p.log2_t, q, feat);
-        for (int k = 0; k < 2 * p.num_levels; ++k) p.features[i * 2 * p.num_levels + k] = feat[k];
+        for (int k = 0; k < 2 * p.num_levels; ++k) p.features[i * 2 * p.num_levels + k] = feat[k] * p.inv_pair_scale;
     }
 }
 
@@ -216,6 +217,7 @@ struct SnFieldStageParams {
     float* rgb;      // [n,3] or null
     int grid_mode;   // 1: tiny-cuda-nn grid semantics
     SnGridLevels grid;
+    float feat_scale;  // power-of-two feature scale whose inverse the first layer's weights carry (both images)
 };
 
 template <int PREC>
@@ -244,6 +246,8 @@ __global__ __launch_bounds__(256, 2) void sn_main_field_stage_kernel(SnFieldStag
     float feat[32];
     if (p.grid_mode) sn_hash_encode<16, 0, 2>(rsrc, p.scal, p.log2_t, q, feat, &p.grid);
     else sn_hash_encode<16>(rsrc, p.scal, p.log2_t, q, feat);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) feat[k] *= p.feat_scale;
     float h0, rgb[3];
     if (PREC == 0) sn_main_field_f32(lds, feat, sh, lane, h0, rgb);
     else sn_main_field_h((const char*)lds, feat, shh, lane, h0, rgb);

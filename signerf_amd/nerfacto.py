@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import threading
+import warnings
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -214,6 +215,7 @@ class NerfactoModel(nn.Module):
         self._weights_dirty = True
         self._weights_lock = threading.Lock()
         self._grid_cache: Dict = {}
+        self._fallback_warned = False
         self.populate_modules()
 
     # -- module set-up (names = nerfstudio's; signerf.py:32-39 overrides this and calls super) -------------
@@ -287,6 +289,15 @@ class NerfactoModel(nn.Module):
         d.histogram_padding = 0.01
         return d
 
+    @property
+    def effective_precision(self) -> str:
+        """What ``config.precision`` resolves to for the uploaded parameters ("fp16x2" falls back to "fp32" for a handle whose split-
+        precision MLPs cannot be range-conditioned; sn_effective_precision)."""
+        if not self._handle or self._weights_dirty:
+            return self.config.precision
+        eff = _lib.load().sn_effective_precision(self._handle, PRECISIONS[self.config.precision], 0)
+        return {0: "fp32", 1: "fp16x2"}.get(eff, self.config.precision)
+
     def _ensure_engine(self):
         lib = _lib.load()
         if self.device.type != "cuda":
@@ -299,6 +310,10 @@ class NerfactoModel(nn.Module):
             if self._weights_dirty:
                 self._upload(lib)
                 self._weights_dirty = False
+        if not self._fallback_warned and self.effective_precision != self.config.precision:
+            self._fallback_warned = True
+            warnings.warn(f"signerf_amd: precision={self.config.precision!r} cannot hold fp32 grade for these parameters; "
+                          f"rendering with {self.effective_precision!r}", RuntimeWarning, stacklevel=3)
         return lib
 
     def _upload(self, lib):
@@ -323,6 +338,9 @@ class NerfactoModel(nn.Module):
                     app = torch.zeros(self.config.appearance_embed_dim, device=self.device)
                 up("field.embedding_appearance.mean", app)
             _lib.check(lib.sn_finalize_weights(self._handle, stream), self._handle, "sn_finalize_weights")
+            # "fp16x2" is a request: the library conditions the split-precision MLPs into fp16's range from the uploaded parameters and
+            # falls back to the exact-fp32 MFMA path for a handle it cannot condition (include/signerf_hip.h, sn_effective_precision)
+            self._fallback_warned = False
 
     def __del__(self):
         try:

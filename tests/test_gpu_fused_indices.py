@@ -154,6 +154,8 @@ def test_dehashed_copies_hold_the_tables_rows(full_model, gpu, which):
     sc = onf.hash_scalings(hc.num_levels, hc.base_res, hc.max_res)
     buf = ops.debug_read(model, which, 0)
     assert lay["n_dense"] == (11 if which < 0 else (5, 4)[which])
+    fs = lay["feature_scale"]
+    assert fs > 0 and float(np.log2(fs)).is_integer() and 512.0 <= fs * float(table.abs().max()) <= 1024.0
     n_sets = 3 if lay["dense_set_stride"] else 1
     assert (which < 0) == (n_sets == 3)
     checked = 0
@@ -164,12 +166,12 @@ def test_dehashed_copies_hold_the_tables_rows(full_model, gpu, which):
         c0, c1, c2 = e % R, (e // R) % R, e // (R * R)
         for st in range(n_sets):
             x, y, z = (c0, c1, c2) if st == 0 else ((c1, c0, c2) if st == 1 else (c2, c1, c0))
-            want = table[l][_hash(x, y, z, hc.log2_hashmap_size)]
+            want = table[l][_hash(x, y, z, hc.log2_hashmap_size)] * lay["feature_scale"]   # an exact power of two (range conditioning)
             base = (st * lay["dense_set_stride"] + lay["dense_off"][l]) // 4
             got = buf[base: base + 2 * R * R * R].view(-1, 2)
             assert torch.equal(got, want), f"field {which} level {l} set {st}"
             checked += R * R * R
-    print(f"field {which}: {checked} copied entries identical to table[hash(x, y, z)]")
+    print(f"field {which}: {checked} copied entries identical to table[hash(x, y, z)] x {lay['feature_scale']:g}")
 
 
 @pytest.mark.parametrize("which", [0, 1])
@@ -187,7 +189,8 @@ def test_paired_tables_hold_the_tables_rows(full_model, gpu, which):
         for t in range(n_t):
             m = ((2 << t) - 1) & (T - 1)
             got = pairs[lay["pair_base"][l] + t * T: lay["pair_base"][l] + (t + 1) * T]
-            assert torch.equal(got[:, 0:2], table[l]) and torch.equal(got[:, 2:4], table[l][r ^ m]), f"net {which} level {l} t {t}"
+            fs = lay["feature_scale"]
+            assert torch.equal(got[:, 0:2], table[l] * fs) and torch.equal(got[:, 2:4], table[l][r ^ m] * fs), f"net {which} level {l} t {t}"
 
 
 # ---- B-D on the BASELINE configurations -----------------------------------------------------------------------------------------
