@@ -22,7 +22,19 @@
  *   - a handle is re-entrant: render calls keep no state in the handle; scratch memory is
  *     caller-provided (SnRenderOpts.workspace), sized by sn_workspace_bytes().  Concurrent
  *     render calls on one handle (GUI thread + viewer thread, interface.py:83-116,
- *     viewer.py:334-336) are therefore safe as long as weights are not being re-uploaded.
+ *     viewer.py:334-336) run unordered and may overlap on the GPU.  Weight uploads ARE ordered
+ *     against them on the device: sn_upload_weights / sn_finalize_weights wait (stream-side)
+ *     for the handle's renders in flight, later renders wait for the upload.  The host-side
+ *     sequence "upload ..., finalize" itself must not be interleaved with render CALLS of other
+ *     threads (the Python shim holds a lock around it).
+ *   - SN_RENDER_CHAIN=1 in the environment (diagnostics) additionally makes every render of the
+ *     process wait for the previous one on its device.  Off by default.
+ *   - sn_last_error returns a per-thread copy of the text: valid until the calling thread's next
+ *     sn_last_error call.
+ *   - architecture limits (sn_create returns SN_ERR_INVALID otherwise -- the kernels are written
+ *     for nerfacto's shapes): main field 16 levels x 2 features, hidden 64, out 16, 2 layers,
+ *     log2_hashmap_size in [4, 21]; colour head 15 geo features + SH degree 4 (+ <= 256
+ *     appearance dims) -> 64 -> 64 -> 3; proposal nets 5 levels x 2 features, hidden 16, out 1.
  */
 #ifndef SIGNERF_HIP_H
 #define SIGNERF_HIP_H
@@ -144,8 +156,8 @@ size_t sn_workspace_bytes(SnHandle h, int32_t height, int32_t width, const SnRen
 /* origins/directions: [H,W,3]; nears/fars: [H,W,1] or NULL (collider).  Outputs (any may be NULL):
  * rgb [H,W,3], depth [H,W,1] (median), accumulation [H,W,1], expected_depth [H,W,1],
  * prop_depth_i [H,W,1].  Row-major ray order, identical to the reference's chunk loop.
- * Concurrency: calls may come from several host threads and HIP streams, on one handle or several; the library orders the
- * renders of a process on the device (each waits for the previous render's completion event), see DESIGN.md §5. */
+ * Concurrency: calls may come from several host threads and HIP streams, on one handle or several; they are not ordered against
+ * each other (see "Conventions"; DESIGN.md §5 has the history of the r01 hazard that once made a chain necessary). */
 int sn_render_rays(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars,
                    int32_t height, int32_t width, const SnRenderOpts* opts,
                    float* rgb, float* depth, float* accumulation, float* expected_depth,

@@ -92,7 +92,7 @@ def _as_column(x: Union[float, int, Tensor], batch: int, dtype) -> Tensor:
 class Cameras:
     """Pin-hole cameras (no distortion parameters -- the SIGNeRF constructor passes none)."""
 
-    def __init__(self, camera_to_worlds: Tensor, fx, fy, cx, cy, width=None, height=None):
+    def __init__(self, camera_to_worlds: Tensor, fx, fy, cx, cy, width=None, height=None, _host: Optional[Tensor] = None):
         c2w = torch.as_tensor(camera_to_worlds, dtype=torch.float32)
         self._zero_dim = c2w.ndim == 2
         if self._zero_dim:
@@ -110,9 +110,14 @@ class Cameras:
             height = (self._cy * 2).to(torch.int64)
         self._width = _as_column(width, b, torch.int64).to(c2w.device)
         self._height = _as_column(height, b, torch.int64).to(c2w.device)
-        # host mirror [B,18] = c2w(12), fx, fy, cx, cy, width, height: lets generate_rays launch without a device sync
-        self._host = torch.cat([self.camera_to_worlds_batched.reshape(b, 12), self._fx, self._fy, self._cx, self._cy,
-                                self._width.to(torch.float32), self._height.to(torch.float32)], dim=1).detach().cpu()
+        # host mirror [B,18] = c2w(12), fx, fy, cx, cy, width, height: lets generate_rays launch without a device sync.  Built once
+        # from the constructor's arguments; indexing and .to() hand their slice of it on (`_host`) instead of reading device
+        # tensors back -- cameras[i] in the sheet loops must not block the stream the previous camera renders on.
+        if _host is not None:
+            self._host = _host
+        else:
+            self._host = torch.cat([self.camera_to_worlds_batched.reshape(b, 12), self._fx, self._fy, self._cx, self._cy,
+                                    self._width.to(torch.float32), self._height.to(torch.float32)], dim=1).detach().cpu()
 
     # -- nerfstudio-shaped accessors: a 0-dim camera exposes [1] tensors, a batch [B,1] -----------------
     def _view(self, t: Tensor) -> Tensor:
@@ -146,18 +151,20 @@ class Cameras:
         if isinstance(idx, int):
             sl = slice(idx, idx + 1) if idx != -1 else slice(idx, None)
             cam = Cameras(self.camera_to_worlds_batched[sl], self._fx[sl], self._fy[sl], self._cx[sl], self._cy[sl],
-                          self._width[sl], self._height[sl])
+                          self._width[sl], self._height[sl], _host=self._host[sl])
             cam._zero_dim = True
             return cam
+        hidx = idx.cpu() if isinstance(idx, Tensor) else idx
         return Cameras(self.camera_to_worlds_batched[idx], self._fx[idx], self._fy[idx], self._cx[idx], self._cy[idx],
-                       self._width[idx], self._height[idx])
+                       self._width[idx], self._height[idx], _host=self._host[hidx])
 
     def __iter__(self):
         for i in range(len(self)):
             yield self[i]
 
     def to(self, device) -> "Cameras":
-        cam = Cameras(self.camera_to_worlds_batched.to(device), self._fx, self._fy, self._cx, self._cy, self._width, self._height)
+        cam = Cameras(self.camera_to_worlds_batched.to(device), self._fx, self._fy, self._cx, self._cy, self._width, self._height,
+                      _host=self._host)
         cam._zero_dim = self._zero_dim
         return cam
 

@@ -51,6 +51,9 @@ class NerfactoModelConfig(InstantiateConfig):
     proposal_initial_sampler: str = "piecewise"
     use_average_appearance_embedding: bool = True
     appearance_embed_dim: int = 32
+    camera_optimizer_mode: str = "SO3xR3"
+    """nerfstudio's ``camera_optimizer.mode`` [NS]: "off" leaves the model without the ``camera_opt`` param group.  Training-time
+    only -- the eval render never applies pose adjustments."""
     predict_normals: bool = False
     compute_normals: str = "lazy"
     """When ``predict_normals`` is set, the outputs hold "normals" and "pred_normals" (row a16).  "lazy" (default): they are

@@ -69,6 +69,13 @@ struct SnContext {
     std::string split_why;
     bool normals_split_ok = true;  // the normals kernel splits UNconditioned operands: allowed only while table and bounds sit in range
     bool finalized = false;
+    // ordering of weight uploads against renders in flight (RenderGuard below)
+    static constexpr int kRenderEvents = 8;
+    std::mutex ev_mu;
+    hipEvent_t render_ev[kRenderEvents] = {};
+    int render_ev_next = 0;
+    hipEvent_t weights_ev = nullptr;
+    bool weights_ev_recorded = false;
 };
 
 #ifndef SN_DENSE_LEVELS_DEFAULT
@@ -77,12 +84,13 @@ struct SnContext {
 
 namespace {
 
-// Render calls of one process are chained on the device, whatever host threads / HIP streams they come from: each call makes its
-// stream wait for the previous render's completion event and records its own when it has enqueued its kernels.  Host threads
-// stay asynchronous; only the kernels are ordered (a render fills the chip anyway).  History (r01, tools/concurrency_probe.py):
-// two renders in flight on two hardware queues corrupted lanes 48-63 of a few tiles per frame; the cause turned out to be an
-// instruction hazard in the proposal MLP that only the mixed-kernel issue pattern exposes (sn_proposal.h, sn_prop_h0) and is
-// fixed there.  The chain stays as a cheap second line of defence; SN_NO_RENDER_CHAIN=1 disables it (the tests run both ways).
+// Renders are NOT ordered against each other: a handle is re-entrant (no state of a render lives in it, scratch is the caller's),
+// so renders issued from several host threads / HIP streams overlap on the GPU.  History (r01, tools/concurrency_probe.py): two
+// renders in flight on two hardware queues corrupted lanes 48-63 of a few tiles per frame; the cause was an instruction hazard in
+// the proposal MLP that only the mixed-kernel issue pattern exposes (sn_proposal.h, sn_prop_h0), fixed there; r02 removed the packed-
+// fp32 instructions of that hazard family from the fused kernels altogether.  The device-side render chain that r01 kept "as a second
+// line of defence" is now an OPT-IN diagnostic: SN_RENDER_CHAIN=1 makes every render of the process wait for the previous one's
+// completion event on its device (the tests run both ways).
 struct RenderChain {
     std::mutex mu;
     hipEvent_t ev[16] = {};
@@ -90,20 +98,56 @@ struct RenderChain {
 };
 RenderChain g_chain;
 
-struct RenderChainGuard {
+// What IS ordered, per handle: weight uploads against the renders that read the buffers they overwrite.
+//   * every render makes its stream wait for the handle's last upload / finalize (weights_ev) and, when its kernels are enqueued,
+//     records one of the handle's render events (a small ring: the N most recent renders, whichever streams they ran on);
+//   * sn_upload_weights / sn_finalize_weights make their stream wait for all of those before touching a buffer.
+struct RenderGuard {
+    SnHandle h;
     hipStream_t st;
     int dev;
-    std::unique_lock<std::mutex> lk;
-    RenderChainGuard(hipStream_t s, int d) : st(s), dev(d & 15), lk(g_chain.mu) {
-        // SN_NO_RENDER_CHAIN=1 (diagnostics only, tools/concurrency_probe.py): leave concurrent renders unordered
-        const bool off = getenv("SN_NO_RENDER_CHAIN") != nullptr;
-        if (g_chain.recorded[dev] && !off) (void)hipStreamWaitEvent(st, g_chain.ev[dev], 0);
+    bool chain;
+    RenderGuard(SnHandle h_, hipStream_t s) : h(h_), st(s), dev(h_->device & 15) {
+        const char* e = getenv("SN_RENDER_CHAIN");
+        chain = e && atoi(e) != 0;
+        {
+            std::lock_guard<std::mutex> g(h->ev_mu);
+            if (h->weights_ev_recorded) (void)hipStreamWaitEvent(st, h->weights_ev, 0);
+        }
+        if (chain) {
+            std::lock_guard<std::mutex> g(g_chain.mu);
+            if (g_chain.recorded[dev]) (void)hipStreamWaitEvent(st, g_chain.ev[dev], 0);
+        }
     }
-    ~RenderChainGuard() {
-        if (!g_chain.ev[dev] && hipEventCreateWithFlags(&g_chain.ev[dev], hipEventDisableTiming) != hipSuccess) return;
-        if (hipEventRecord(g_chain.ev[dev], st) == hipSuccess) g_chain.recorded[dev] = true;
+    ~RenderGuard() {
+        {
+            std::lock_guard<std::mutex> g(h->ev_mu);
+            hipEvent_t& ev = h->render_ev[h->render_ev_next];
+            if (ev || hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+                if (hipEventRecord(ev, st) == hipSuccess) h->render_ev_next = (h->render_ev_next + 1) % SnContext::kRenderEvents;
+            }
+        }
+        if (chain) {
+            std::lock_guard<std::mutex> g(g_chain.mu);
+            if (!g_chain.ev[dev] && hipEventCreateWithFlags(&g_chain.ev[dev], hipEventDisableTiming) != hipSuccess) return;
+            if (hipEventRecord(g_chain.ev[dev], st) == hipSuccess) g_chain.recorded[dev] = true;
+        }
     }
 };
+
+// upload / finalize side of the per-handle ordering
+void wait_for_renders(SnHandle h, hipStream_t st) {
+    std::lock_guard<std::mutex> g(h->ev_mu);
+    for (hipEvent_t ev : h->render_ev)
+        if (ev) (void)hipStreamWaitEvent(st, ev, 0);
+}
+void mark_weights_written(SnHandle h, hipStream_t st) {
+    std::lock_guard<std::mutex> g(h->ev_mu);
+    if (!h->weights_ev && hipEventCreateWithFlags(&h->weights_ev, hipEventDisableTiming) != hipSuccess) return;
+    if (hipEventRecord(h->weights_ev, st) == hipSuccess) h->weights_ev_recorded = true;
+}
+
+thread_local std::string g_error_copy;  // sn_last_error hands out a per-thread copy: another thread may rewrite the handle's text
 
 int fail(SnHandle h, int code, const std::string& msg) {
     if (h) {
@@ -610,6 +654,12 @@ int sn_create(const SnFieldDesc* desc, SnHandle* out) {
 
 int sn_destroy(SnHandle h) {
     if (!h) return SN_OK;
+    for (hipEvent_t ev : h->render_ev)
+        if (ev) {
+            (void)hipEventSynchronize(ev);  // a render may still be reading the buffers released below
+            (void)hipEventDestroy(ev);
+        }
+    if (h->weights_ev) (void)hipEventDestroy(h->weights_ev);
     h->table_main.release();
     h->dense_main.release();
     h->wimg_main.release();
@@ -629,13 +679,15 @@ int sn_destroy(SnHandle h) {
 const char* sn_last_error(SnHandle h) {
     if (!h) return g_create_error.c_str();
     std::lock_guard<std::mutex> g(h->mu);
-    return h->error.c_str();
+    g_error_copy = h->error;  // valid until this THREAD's next sn_last_error call, whatever other threads do to the handle
+    return g_error_copy.c_str();
 }
 
 int sn_upload_weights(SnHandle h, const char* name, const void* data, size_t bytes, SnStream stream) {
     if (!h || !name || !data) return fail(h, SN_ERR_INVALID, "sn_upload_weights: null argument");
     hipStream_t st = (hipStream_t)stream;
     const std::string n(name);
+    wait_for_renders(h, st);  // renders in flight on other streams still read the buffers this call overwrites (or frees)
     auto upload_table = [&](DevBuf& buf, const SnHashMlpDesc& d) -> int {
         const size_t want = ((size_t)d.num_levels << d.log2_hashmap_size) * 2 * sizeof(float);
         if (bytes != want) return fail(h, SN_ERR_INVALID, n + ": expected " + std::to_string(want) + " bytes, got " + std::to_string(bytes));
@@ -646,6 +698,7 @@ int sn_upload_weights(SnHandle h, const char* name, const void* data, size_t byt
         }
         SN_HIP(h, hipMemcpyAsync(buf.ptr, data, want, hipMemcpyDefault, st));
         SN_HIP(h, hipStreamSynchronize(st));
+        mark_weights_written(h, st);
         {
             std::lock_guard<std::mutex> g(h->mu);
             h->finalized = false;  // the paired copies must be rebuilt
@@ -673,6 +726,7 @@ int sn_upload_weights(SnHandle h, const char* name, const void* data, size_t byt
 int sn_finalize_weights(SnHandle h, SnStream stream) {
     if (!h) return SN_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
+    wait_for_renders(h, st);
     const SnFieldDesc& d = h->desc;
     if (!h->table_main.ptr) return fail(h, SN_ERR_STATE, "missing field.mlp_base.encoder.hash_table");
     const int cin = d.sh_levels * d.sh_levels + d.geo_feat_dim + d.appearance_embed_dim;
@@ -916,6 +970,7 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
     h->dense_pairs_ok = wrap_ok;
     SN_HIP(h, hipGetLastError());
     SN_HIP(h, hipStreamSynchronize(st));
+    mark_weights_written(h, st);
     {
         std::lock_guard<std::mutex> g(h->mu);
         h->finalized = true;
@@ -1076,7 +1131,7 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     if (!opts->workspace || opts->workspace_bytes < wp.total)
         return fail(h, SN_ERR_WORKSPACE, "sn_render_rays: workspace too small, need " + std::to_string(wp.total) + " bytes");
     hipStream_t st = (hipStream_t)stream;
-    RenderChainGuard chain(st, h->device);  // orders this render after the previous one of the process, on the device
+    RenderGuard guard(h, st);  // waits for the handle's last weight upload; records this render for later uploads (opt-in: process-wide chain)
     char* ws = (char*)opts->workspace;
     const SnFieldDesc& d = h->desc;
     const TileGeom g = tile_geometry(height, width);
@@ -1306,7 +1361,7 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
     if (!opts->workspace || opts->workspace_bytes < wp.total)
         return fail(h, SN_ERR_WORKSPACE, "sn_render_normals: workspace too small, need " + std::to_string(wp.total) + " bytes");
     hipStream_t st = (hipStream_t)stream;
-    RenderChainGuard chain(st, h->device);
+    RenderGuard guard(h, st);
     char* ws = (char*)opts->workspace;
     const SnFieldDesc& d = h->desc;
     const TileGeom g = tile_geometry(height, width);

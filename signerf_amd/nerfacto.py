@@ -98,6 +98,25 @@ class PredNormalsFieldHead(nn.Module):
         self.net = nn.Linear(in_dim, 3)
 
 
+class CameraOptimizer(nn.Module):
+    """Parameters of nerfstudio's ``CameraOptimizer`` [NS]: ``pose_adjustment`` [num_cameras, 6] (so3 + translation), zeros at
+    init.  It adjusts TRAINING rays only (``apply_to_raybundle`` is a no-op in eval mode), so the render path never reads it; it
+    exists so that the "camera_opt" param group of signerf_config.py:56-59 and the ``camera_optimizer.*`` state-dict keys
+    (deleted by signerf_pipeline.py:110-131 before loading, kept by plain nerfacto checkpoints) have their counterpart."""
+
+    def __init__(self, num_cameras: int, mode: str = "SO3xR3"):
+        super().__init__()
+        self.mode = mode
+        if mode != "off":
+            self.pose_adjustment = nn.Parameter(torch.zeros((num_cameras, 6)))
+
+    def get_param_groups(self, param_groups: dict) -> None:
+        params = list(self.parameters())
+        if self.mode != "off":
+            assert len(params) > 0
+            param_groups["camera_opt"] = params
+
+
 class NerfactoField(nn.Module):
     """Parameters of nerfstudio's NerfactoField (A6-A9, A13-A15)."""
 
@@ -212,6 +231,7 @@ class NerfactoModel(nn.Module):
         self.kwargs = kwargs
         self.device_indicator_param = nn.Parameter(torch.empty(0))
         self._handle = C.c_void_p(None)
+        self._handle_device = None
         self._weights_dirty = True
         self._weights_lock = threading.Lock()
         self._grid_cache: Dict = {}
@@ -233,6 +253,7 @@ class NerfactoModel(nn.Module):
         for i in range(cfg.num_proposal_iterations):
             args = cfg.proposal_net_args_list[min(i, len(cfg.proposal_net_args_list) - 1)]
             self.proposal_networks.append(HashMLPDensityField(**args, implementation=cfg.implementation))
+        self.camera_optimizer = CameraOptimizer(self.num_train_data, cfg.camera_optimizer_mode)
 
     @property
     def device(self):
@@ -246,7 +267,10 @@ class NerfactoModel(nn.Module):
 
     # -- plugin surface the pipeline / trainer expect ---------------------------------------------------------
     def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
-        return {"proposal_networks": list(self.proposal_networks.parameters()), "fields": list(self.field.parameters())}
+        """nerfstudio's NerfactoModel.get_param_groups [NS]: the three groups signerf_config.py:47-60 attaches optimizers to."""
+        groups = {"proposal_networks": list(self.proposal_networks.parameters()), "fields": list(self.field.parameters())}
+        self.camera_optimizer.get_param_groups(param_groups=groups)
+        return groups
 
     def get_training_callbacks(self, training_callback_attributes=None) -> List:
         return []
@@ -303,10 +327,17 @@ class NerfactoModel(nn.Module):
         if self.device.type != "cuda":
             raise _lib.SignerfHipError("NerfactoModel renders on the GPU only: move it with .to('cuda') (no CPU fallback)")
         with self._weights_lock:
+            if self._handle and self._handle_device != self.device:
+                # model.to("cuda:N") after the first render: the handle and all its buffers live on the old GPU -- start over there
+                lib.sn_destroy(self._handle)
+                self._handle = C.c_void_p(None)
+                self._weights_dirty = True
+                self._grid_cache.clear()
             if not self._handle:
                 desc = self._field_desc()
                 with torch.cuda.device(self.device):
                     _lib.check(lib.sn_create(C.byref(desc), C.byref(self._handle)), None, "sn_create")
+                self._handle_device = self.device
             if self._weights_dirty:
                 self._upload(lib)
                 self._weights_dirty = False
@@ -364,7 +395,7 @@ class NerfactoModel(nn.Module):
             self._grid_cache[key] = (bins0.to(self.device), us)
         return self._grid_cache[key]
 
-    def _opts(self, H: int, W: int, lib):
+    def _opts(self, H: int, W: int, lib, single_chunk: bool = False):
         cfg = self.config
         n_levels = cfg.num_proposal_iterations
         o = _lib.SnRenderOpts()
@@ -374,7 +405,9 @@ class NerfactoModel(nn.Module):
         o.num_nerf_samples = cfg.num_nerf_samples_per_ray
         o.near_plane = cfg.near_plane if self.training else 0.0  # NearFarCollider: eval near = 0 (A3)
         o.far_plane = cfg.far_plane
-        o.chunk_rays = cfg.eval_num_rays_per_chunk
+        # the chunk size only shapes the expected-depth clip bounds (A17): per eval_num_rays_per_chunk rays for a camera bundle
+        # (Model.get_outputs_for_camera_ray_bundle's loop), over the whole bundle for Model.get_outputs / forward
+        o.chunk_rays = max(H * W, 1) if single_chunk else cfg.eval_num_rays_per_chunk
         o.precision = PRECISIONS[cfg.precision]
         bins0, us = self._grids(n_levels)
         o.initial_spacing_bins = bins0.data_ptr()
@@ -407,13 +440,13 @@ class NerfactoModel(nn.Module):
     def get_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
         """Flat bundle [R,...] -> dict of [R,C]."""
         R = len(ray_bundle)
-        return self._with_normals(ray_bundle.flatten(), 1, R, (R,))
+        return self._with_normals(ray_bundle.flatten(), 1, R, (R,), single_chunk=True)
 
     def forward(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
         return self.get_outputs(ray_bundle)
 
-    def _with_normals(self, b: RayBundle, H: int, W: int, shape) -> Dict[str, Tensor]:
-        out = {k: v.view(*shape, v.shape[-1]) for k, v in self._render(b, H, W).items()}
+    def _with_normals(self, b: RayBundle, H: int, W: int, shape, single_chunk: bool = False) -> Dict[str, Tensor]:
+        out = {k: v.view(*shape, v.shape[-1]) for k, v in self._render(b, H, W, single_chunk).items()}
         mode = self.config.compute_normals if self.config.predict_normals else "never"
         if mode == "never":
             return out
@@ -448,7 +481,7 @@ class NerfactoModel(nn.Module):
             del keep
         return {"normals": normals, "pred_normals": pred} if pred is not None else {"normals": normals}
 
-    def _render(self, b: RayBundle, H: int, W: int) -> Dict[str, Tensor]:
+    def _render(self, b: RayBundle, H: int, W: int, single_chunk: bool = False) -> Dict[str, Tensor]:
         lib = self._ensure_engine()
         if H * W == 0:  # an empty bundle renders to empty outputs, as the reference's chunk loop does
             z = lambda c: torch.empty((0, c), dtype=torch.float32, device=self.device)  # noqa: E731
@@ -460,7 +493,7 @@ class NerfactoModel(nn.Module):
         origins, directions, nears, fars = f32(b.origins), f32(b.directions), f32(b.nears), f32(b.fars)
         n = H * W
         with torch.cuda.device(dev):
-            o, keep = self._opts(H, W, lib)
+            o, keep = self._opts(H, W, lib, single_chunk)
             new = lambda c: torch.empty((n, c), dtype=torch.float32, device=dev)  # noqa: E731
             rgb, depth, acc, exp = new(3), new(1), new(1), new(1)
             props = [new(1) for _ in range(self.config.num_proposal_iterations)]

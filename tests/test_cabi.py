@@ -147,3 +147,24 @@ def test_unbuilt_config_values_are_rejected_at_model_set_up():
         with pytest.raises(NotImplementedError):
             SIGNeRFModelConfig(**kw).setup()
     SIGNeRFModelConfig(log2_hashmap_size=12).setup()   # the defaults build (CPU-side module set-up only)
+
+
+def test_method_registration_entry_point():
+    """The plugin registration of /root/reference/pyproject.toml:44-46 + signerf_config.py:16-62: the entry-point group exists, resolves
+    to a MethodSpecification-shaped object, its model config carries the reference's overrides and its optimizer groups are exactly
+    the groups the model hands out."""
+    import importlib
+
+    import tomli
+
+    with open(os.path.join(ROOT, "pyproject.toml"), "rb") as f:
+        eps = tomli.load(f)["project"]["entry-points"]["nerfstudio.method_configs"]
+    assert eps, "no entry point in group nerfstudio.method_configs"
+    mod, attr = next(iter(eps.values())).split(":")
+    spec = getattr(importlib.import_module(mod), attr)
+    assert spec.config.method_name == "signerf" and "SIGNeRF" in spec.description
+    m = spec.config.pipeline.model
+    assert (m.eval_num_rays_per_chunk, m.predict_normals, m.use_lpips, m.average_init_density) == (1 << 15, True, True, 0.01)
+    model = type(m)(log2_hashmap_size=12).setup()          # CPU-side module set-up only
+    assert set(spec.config.optimizers) == set(model.get_param_groups()) == {"proposal_networks", "fields", "camera_opt"}
+    assert spec.config.optimizers["camera_opt"]["optimizer"].lr == 1e-15

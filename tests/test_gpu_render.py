@@ -168,21 +168,23 @@ def test_state_dict_boundary(gpu):
     c = model.get_outputs_for_camera_ray_bundle(b)["rgb"]
     assert not torch.equal(a, c)
     groups = model.get_param_groups()
-    assert set(groups) == {"proposal_networks", "fields"} and model.get_training_callbacks(None) == []
+    # the three groups signerf_config.py:47-60 attaches optimizers to
+    assert set(groups) == {"proposal_networks", "fields", "camera_opt"} and model.get_training_callbacks(None) == []
+    assert len(groups["fields"]) > 0 and groups["camera_opt"][0].shape == (cfg.num_train_data, 6)   # (no proposal nets in this config)
 
 
 @pytest.mark.parametrize("two_models,chain", [(False, True), (True, True), (False, False), (True, False)])
 def test_concurrent_renders_from_two_threads(gpu, monkeypatch, two_models, chain):
     """The reference renders from two host threads (GUI callback + viewer, interface.py:83-116, viewer.py:334-336).  Two
-    threads on two streams, one model (or two): every frame equals its sequential render -- with the library's device-side render
-    chain and, more importantly, WITHOUT it (SN_NO_RENDER_CHAIN): kernels of the two renders then overlap on the GPU, which is
+    threads on two streams, one model (or two): every frame equals its sequential render -- by default (no ordering: kernels of the two
+    renders overlap on the GPU) and with the opt-in device-side render chain (SN_RENDER_CHAIN=1).  The overlap is
     what exposed the packed-FMA operand hazard of the proposal MLP (sn_proposal.h; ~100 000 wrong values per run before the fix)."""
     import threading
 
     if chain:
-        monkeypatch.delenv("SN_NO_RENDER_CHAIN", raising=False)
+        monkeypatch.setenv("SN_RENDER_CHAIN", "1")     # opt-in diagnostic: renders of the process serialised on the device
     else:
-        monkeypatch.setenv("SN_NO_RENDER_CHAIN", "1")
+        monkeypatch.delenv("SN_RENDER_CHAIN", raising=False)   # the default: the two threads' kernels overlap on the GPU
 
     cfg = small_config(num_proposal_samples_per_ray=(48, 24), num_nerf_samples_per_ray=16)
     model, _ = make_model(cfg, gpu)
@@ -368,3 +370,108 @@ def test_unsupported_options_fail_loudly(gpu):
         cfg2.setup().get_outputs_for_camera_ray_bundle(b)        # a model left on the CPU: no CPU path
     with pytest.raises(_lib.SignerfHipError):
         small_config(hidden_dim=32).setup().to(gpu).get_outputs_for_camera_ray_bundle(b)   # an MLP width the kernels are not built for
+
+
+def test_reference_style_subclass_renders(gpu):
+    """The subclass contract of /root/reference/signerf/signerf.py:27-82: ``populate_modules`` calls ``super()`` and then adds
+    training-only members, ``get_loss_dict`` is overridden.  Such a subclass must still build, load and render; its loss runs on the
+    rendered outputs."""
+    from signerf_amd import SIGNeRFModelConfig
+    from signerf_amd.nerfacto import SIGNeRFModel
+
+    class L1Loss(torch.nn.Module):
+        def forward(self, a, b):
+            return (a - b).abs().mean()
+
+    class MySIGNeRF(SIGNeRFModel):
+        def populate_modules(self):
+            super().populate_modules()
+            self.rgb_loss = L1Loss() if self.config.use_l1 else torch.nn.MSELoss()
+            self.lpips = torch.nn.Identity()       # stands in for LearnedPerceptualImagePatchSimilarity (torchmetrics is not installed)
+
+        def get_loss_dict(self, outputs, batch, metrics_dict=None) -> dict:
+            image = batch["image"].to(self.device)
+            return {"rgb_loss": self.rgb_loss(image, outputs["rgb"])}
+
+    cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=16)
+    cfg._target = MySIGNeRF
+    assert isinstance(cfg, SIGNeRFModelConfig)
+    model = cfg.setup(scene_box=None, num_train_data=cfg.num_train_data)
+    assert isinstance(model, MySIGNeRF) and isinstance(model.rgb_loss, L1Loss)
+    sd = scene.synthetic_state_dict(cfg, seed=0)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(gpu)
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 20.0, 20.0, 8.0, 8.0, 16, 16).to(gpu)
+    model.eval()
+    out = model.get_outputs_for_camera_ray_bundle(cams[0].generate_rays(camera_indices=0, aabb_box=model.render_aabb))
+    model.train()
+    ref = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg), *(t.cpu() for t in (cams[0].generate_rays(0).origins, cams[0].generate_rays(0).directions)))
+    assert rmse(out["rgb"], ref["rgb"]) <= 1e-3      # note: the base model was loaded with its own appearance table -> same mean as sd's
+    loss = model.get_loss_dict(out, {"image": torch.zeros(16, 16, 3)})
+    assert set(loss) == {"rgb_loss"} and float(loss["rgb_loss"]) == pytest.approx(float(out["rgb"].abs().mean()), rel=1e-6)
+    assert set(model.get_param_groups()) == {"proposal_networks", "fields", "camera_opt"}
+    assert "rgb_loss" not in " ".join(model.state_dict().keys())   # parameter-free extras do not disturb the checkpoint keys
+
+
+def test_flat_bundle_expected_depth_is_clipped_over_the_whole_bundle(gpu):
+    """Model.get_outputs clips `expected_depth` with the min / max sample mid-point of the bundle it is given [NS]; only
+    get_outputs_for_camera_ray_bundle's chunk loop clips per eval_num_rays_per_chunk rays."""
+    cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=24, eval_num_rays_per_chunk=64)
+    model, sd = make_model(cfg, gpu)
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 30.0, 30.0, 12.0, 12.0, 24, 24).to(gpu)
+    box = SceneBox(aabb=torch.tensor([[-0.2, -0.2, -0.2], [0.2, 0.2, 0.2]]))   # per-ray nears / fars: chunks get different ranges
+    b = cams[2].generate_rays(camera_indices=0, aabb_box=box)
+    flat = model.get_outputs(b.flatten())                                           # 576 rays = 9 chunks of 64 if it were chunked
+    nears, fars = b.nears.cpu().reshape(-1, 1), b.fars.cpu().reshape(-1, 1)
+    ref = onf.get_outputs(sd, oracle_config(cfg), b.origins.cpu().reshape(-1, 3), b.directions.cpu().reshape(-1, 3), nears, fars)
+    hit = (ref["depth"] < 1e6).reshape(-1)
+    assert int(hit.sum()) > 50
+    assert rmse(flat["expected_depth"].cpu()[hit], ref["expected_depth"][hit]) <= 5e-3
+    img = model.get_outputs_for_camera_ray_bundle(b)                                # the camera path keeps the per-chunk clip
+    ref_img = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg), b.origins.cpu(), b.directions.cpu(), b.nears.cpu(), b.fars.cpu())
+    hit2 = (ref_img["depth"] < 1e6)
+    assert rmse(img["expected_depth"].cpu()[hit2], ref_img["expected_depth"][hit2]) <= 5e-3
+
+
+def test_weight_reupload_while_another_thread_renders(gpu):
+    """`load_state_dict` / `mark_weights_dirty` re-uploads tables and weight images while a viewer thread keeps rendering
+    on the shared model from its own stream.  The library orders the upload against the renders in flight (and later renders against
+    the upload), so every frame the viewer sees is the render of ONE consistent set of weights -- never a mixture, never freed memory."""
+    import threading
+
+    cfg = small_config(num_proposal_samples_per_ray=(32, 16), num_nerf_samples_per_ray=16)
+    model, sd_a = make_model(cfg, gpu, seed=0)
+    sd_b = scene.synthetic_state_dict(cfg, seed=9)
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 200.0, 200.0, 96.0, 64.0, 192, 128).to(gpu)
+    b = cams[1].generate_rays(0)
+    expect = {}
+    for name, sd in (("a", sd_a), ("b", sd_b)):
+        model.load_state_dict(sd, strict=False)
+        expect[name] = model.get_outputs_for_camera_ray_bundle(b)["rgb"].clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(expect["a"], expect["b"])
+    stop, seen, errors = threading.Event(), {"a": 0, "b": 0, "other": 0}, []
+
+    def viewer():
+        try:
+            stream = torch.cuda.Stream(device=gpu)
+            with torch.cuda.stream(stream):
+                while not stop.is_set():
+                    rgb = model.get_outputs_for_camera_ray_bundle(b)["rgb"]
+                    stream.synchronize()
+                    key = "a" if torch.equal(rgb, expect["a"]) else ("b" if torch.equal(rgb, expect["b"]) else "other")
+                    seen[key] += 1
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    t = threading.Thread(target=viewer)
+    t.start()
+    for i in range(20):
+        model.load_state_dict(sd_a if i % 2 else sd_b, strict=False)
+        model.get_outputs_for_camera_ray_bundle(b)          # triggers the re-upload on this thread's stream
+        torch.cuda.synchronize()
+    stop.set()
+    t.join()
+    assert not errors, errors
+    print(f"viewer frames: {seen}")
+    assert seen["other"] == 0 and seen["a"] + seen["b"] > 20

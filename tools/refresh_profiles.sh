@@ -22,8 +22,8 @@ cp profiles/traffic.json "$OUT/traffic.json"
 bash tools/pmc_passes_k2.sh "$OUT/pmc_k2" > "$OUT/pmc_k2.log" 2>&1
 python tools/pmc_summary.py "$OUT/pmc_k2" sn_proposal_kernel > "$OUT/pmc_k2_summary.txt" 2>&1
 for m in shared two-models vs-uniform; do
-  echo "== concurrency_probe --mode $m (SN_NO_RENDER_CHAIN=1)" >> "$OUT/probes.txt"
-  SN_NO_RENDER_CHAIN=1 timeout 300 python tools/concurrency_probe.py --mode $m 2>&1 | tail -3 >> "$OUT/probes.txt"
+  echo "== concurrency_probe --mode $m (renders unordered: the default)" >> "$OUT/probes.txt"
+  timeout 300 python tools/concurrency_probe.py --mode $m 2>&1 | tail -3 >> "$OUT/probes.txt"
 done
 echo "== determinism_probe" >> "$OUT/probes.txt"
 timeout 300 python tools/determinism_probe.py 2>&1 | tail -3 >> "$OUT/probes.txt"
