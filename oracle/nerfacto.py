@@ -493,7 +493,13 @@ def field_pred_normals(params: Dict[str, Tensor], cfg: NerfactoConfig, positions
     -> MLP 27->64->64->64 (ReLU, linear output) -> PredNormalsFieldHead (Linear 64->3, tanh, L2-normalise)."""
     R, N = mlp_out.shape[:2]
     geo = mlp_out[..., 1 : 1 + cfg.geo_feat_dim]
-    x = torch.cat([nerf_encoding(positions.reshape(-1, 3)), geo.reshape(R * N, -1)], dim=-1)
+    if cfg.main.grid == "tcnn":  # implementation="tcnn": NeRFEncoding delegates to the library's Frequency encoding (UNPINNED)
+        from . import tcnn_layout
+
+        enc = tcnn_layout.frequency_encoding(positions.reshape(-1, 3), 2)
+    else:
+        enc = nerf_encoding(positions.reshape(-1, 3))
+    x = torch.cat([enc, geo.reshape(R * N, -1)], dim=-1)
     x = mlp_forward(x, params, "field.mlp_pred_normals", 3)
     x = torch.nn.functional.linear(x, params["field.field_head_pred_normals.net.weight"], params["field.field_head_pred_normals.net.bias"])
     return torch.nn.functional.normalize(torch.tanh(x), dim=-1).view(R, N, 3)

@@ -34,6 +34,10 @@ ASSUMPTIONS = (
     "n_hidden_layers = num_layers - 1 (nerfstudio's tcnn network config), so a 2-layer MLP is [W x in], [out_pad x W]",
     "hash primes (1, 2654435761, 805459861), uint32 arithmetic, index % level size",
     "state-dict key of every tcnn module ends in '.tcnn_encoding.params'",
+    "Frequency encoding: output j of n_frequencies F is sin(pi 2^((j / 2) % F) x_(j / 2F) + (j % 2) pi / 2) -- dimension-major, then "
+    "frequency, then (sin, cos); nerfstudio's NeRFEncoding(implementation='tcnn') returns it as is",
+    "field.mlp_pred_normals of a tcnn nerfacto = plain Network 27 -> 64 -> 64 -> 64 (inputs padded to 32 with ones), followed by the "
+    "torch PredNormalsFieldHead Linear(64, 3)",
 )
 
 HASH_PRIMES = (1, 2654435761, 805459861)
@@ -154,3 +158,15 @@ def mlp_unpack(flat: Tensor, in_dim: int, width: int, num_layers: int, out_dim: 
             out[f"layers.{i}.bias"] = torch.zeros(rows, dtype=flat.dtype)
     assert o == mlp_n_params(in_dim, width, num_layers, out_dim)
     return out
+
+
+def frequency_encoding(x: Tensor, n_frequencies: int) -> Tensor:
+    """tiny-cuda-nn's Frequency encoding (encodings/frequency.h): x [P, D] -> [P, D * 2F]; output j reads input dimension j // 2F at
+    frequency pi * 2^((j // 2) % F), even j = sin, odd j = the same shifted by pi / 2."""
+    P, D = x.shape
+    outs = []
+    for i in range(D):
+        for f in range(n_frequencies):
+            arg = x[:, i].double() * (2.0**f) * np.pi
+            outs += [torch.sin(arg), torch.sin(arg + np.pi / 2.0)]
+    return torch.stack(outs, dim=-1).to(torch.float32)

@@ -1396,6 +1396,7 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
     p.far_plane = opts->far_plane;
     p.avg_density = d.average_init_density;
     p.grid = grid_levels(d.main_field);
+    p.pe_rev_scale = d.main_field.grid_mode == 1 ? 0.5f : 1.0f;  // tiny-cuda-nn's Frequency encoding runs at pi 2^k
     const int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
     const size_t lds_bytes = split ? (size_t)SnNormImgH::TOTAL_BYTES : (size_t)SnNormImg::TOTAL * 4;
     const dim3 grid((unsigned)(gbx * gby)), block(256);

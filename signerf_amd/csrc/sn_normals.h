@@ -50,17 +50,20 @@ struct SnNormalsParams {
     int log2_t;
     float near_plane, far_plane, avg_density;
     SnGridLevels grid;
+    float pe_rev_scale;  // position encoding: 1 = nerfstudio's torch NeRFEncoding, sin(2 pi x 2^k); 0.5 = tiny-cuda-nn's Frequency, sin(pi x 2^k)
 };
 
 // NeRFEncoding(in_dim 3, 2 frequencies 2^0, 2^1): [sin(2 pi x_a 2^k)] for (a, k) a-major, then the same with a pi/2 phase.
 // v_sin_f32 takes its argument in revolutions, so sin(2 pi x 2^k) = v_sin(fract(x 2^k)): the power-of-two scaling and the
 // range reduction are exact (libm sinf's reduction path costs ~200 spilled registers here).
-SN_DEV void sn_position_encoding(const float p[3], float pe[12]) {
+// rev_scale = 0.5 gives tiny-cuda-nn's Frequency encoding, sin(pi x 2^k) and cos = the same a quarter revolution on (the scaling
+// stays a power of two, hence exact); the slot ORDER is this one in both cases -- tcnn_import permutes the first layer's columns.
+SN_DEV void sn_position_encoding(const float p[3], float pe[12], float rev_scale) {
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const float rev = p[a] * (float)(1 << k);
+            const float rev = p[a] * ((float)(1 << k) * rev_scale);
             pe[a * 2 + k] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev));
             pe[6 + a * 2 + k] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev + 0.25f));
         }
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormals
         {
             const float tm = (t0 + t1) * 0.5f;
             const float pw[3] = {fmaf(d[0], tm, o[0]), fmaf(d[1], tm, o[1]), fmaf(d[2], tm, o[2])};
-            sn_position_encoding(pw, pe);
+            sn_position_encoding(pw, pe, p.pe_rev_scale);
         }
         __builtin_amdgcn_sched_barrier(0);
         float h0, gfeat[32], x[3];

@@ -261,9 +261,9 @@ class NerfactoModel(nn.Module):
 
     @property
     def _has_pred_normals(self) -> bool:
-        """The pred-normal MLP is rendered for torch-path models only: a tiny-cuda-nn checkpoint keeps it as a flat vector behind
-        tcnn's own frequency encoding, which tcnn_import does not convert (its analytic normals are rendered)."""
-        return self.config.predict_normals and self.config.implementation == "torch"
+        """``predict_normals=True`` (signerf_config.py:33) gives the field its pred-normal MLP, in both implementations (a tiny-cuda-nn
+        checkpoint's flat vector is unpacked by tcnn_import)."""
+        return self.config.predict_normals
 
     # -- plugin surface the pipeline / trainer expect ---------------------------------------------------------
     def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:

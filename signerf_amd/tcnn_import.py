@@ -10,8 +10,8 @@ evaluate the grid with tiny-cuda-nn's indexing (csrc/sn_device.h, sn_hash_corner
 real library.  The layout facts are restated independently in oracle/tcnn_layout.py (ASSUMPTIONS there); the tests check this
 importer + the kernels against that restatement on synthetic parameter vectors.  What a real checkpoint would have to confirm:
 parameter order (network, then grid), row-major (out, in) matrices, the padding values (0 after a grid, 1 for a plain network),
-`n_hidden_layers = num_layers - 1`, and the state-dict key names (any key ending in ``.params`` is accepted, matched by module
-prefix).  The library computes in fp16 (parameters cast to half, fp16 blends and fp16-accumulated MMA); this path evaluates the
+`n_hidden_layers = num_layers - 1`, the state-dict key names (any key ending in ``.params`` is accepted, matched by module
+prefix), and for the pred-normal MLP the output order and frequencies of the library's Frequency encoding.  The library computes in fp16 (parameters cast to half, fp16 blends and fp16-accumulated MMA); this path evaluates the
 same parameters in fp32-grade arithmetic, so renders agree to fp16 noise, not bit for bit.  ``quantize_fp16=True`` rounds the
 parameters through fp16 the way the library's inference copy is.
 """
@@ -102,6 +102,11 @@ def convert_tcnn_state_dict(sd: Dict[str, Tensor], config, quantize_fp16: bool =
     out: Dict[str, Tensor] = {k: v for k, v in sd.items() if not k.endswith(".params")}
 
     def stack(prefix: str, levels: int, base: int, mx: int, log2_t: int, feats: int, width: int, out_dim: int):
+        # Partial checkpoints are normal: the reference strips every `proposal*` key before `load_state_dict(strict=False)` when it
+        # retrains (signerf_pipeline.py:126-131,141-144).  A module whose vectors are absent is simply not converted -- its keys
+        # then show up as missing keys (or raise under strict=True), exactly as for a torch-path checkpoint.
+        if not (_hits(sd, prefix) or _hits(sd, f"{prefix}.mlp") or _hits(sd, f"{prefix}.encoder")):
+            return
         if _hits(sd, prefix):  # one fused NetworkWithInputEncoding vector: network first, then the grid
             flat = _find(sd, prefix)
             n_net = _unpack_mlp(flat, f"{prefix}.mlp", levels * feats, width, 2, out_dim, 0.0, out)
@@ -116,11 +121,25 @@ def convert_tcnn_state_dict(sd: Dict[str, Tensor], config, quantize_fp16: bool =
 
     stack("field.mlp_base", config.num_levels, config.base_res, config.max_res, config.log2_hashmap_size, config.features_per_level,
           config.hidden_dim, 16)
-    head = _find(sd, "field.mlp_head")
-    in_dim = 16 + 15 + config.appearance_embed_dim
-    used = _unpack_mlp(head, "field.mlp_head", in_dim, config.hidden_dim_color, 3, 3, 1.0, out)
-    if used != head.numel():
-        raise ValueError(f"colour head vector has {head.numel()} values, expected {used}")
+    if _hits(sd, "field.mlp_head"):
+        head = _find(sd, "field.mlp_head")
+        in_dim = 16 + 15 + config.appearance_embed_dim
+        used = _unpack_mlp(head, "field.mlp_head", in_dim, config.hidden_dim_color, 3, 3, 1.0, out)
+        if used != head.numel():
+            raise ValueError(f"colour head vector has {head.numel()} values, expected {used}")
+    if _hits(sd, "field.mlp_pred_normals"):
+        # predict_normals=True (signerf_config.py:33): MLP [Frequency encoding of the position (12) | geo features (15)] -> 64 -> 64 ->
+        # 64, a plain tiny-cuda-nn Network (inputs padded to 32 with ones).  The library's Frequency encoding orders its outputs
+        # dimension-major -- (x: sin f0, cos f0, sin f1, cos f1), (y: ...), (z: ...) -- while this package (and nerfstudio's torch
+        # NeRFEncoding) orders them [sin(a, k) a-major | cos(a, k) a-major]; the first layer's columns are permuted accordingly.
+        # (Its frequencies are pi 2^k, not 2 pi 2^k: the kernel handles that, SnNormalsParams::pe_rev_scale.)
+        pn = _find(sd, "field.mlp_pred_normals")
+        used = _unpack_mlp(pn, "field.mlp_pred_normals", 12 + 15, 64, 3, 64, 1.0, out)
+        if used != pn.numel():
+            raise ValueError(f"pred-normal MLP vector has {pn.numel()} values, expected {used}")
+        w0 = out["field.mlp_pred_normals.layers.0.weight"]
+        perm = [a * 4 + k * 2 + 0 for a in range(3) for k in range(2)] + [a * 4 + k * 2 + 1 for a in range(3) for k in range(2)]
+        out["field.mlp_pred_normals.layers.0.weight"] = torch.cat([w0[:, perm], w0[:, 12:]], dim=1).contiguous()
     for i in range(config.num_proposal_iterations):
         a = config.proposal_net_args_list[min(i, len(config.proposal_net_args_list) - 1)]
         stack(f"proposal_networks.{i}.mlp_base", a.get("num_levels", 5), a.get("base_res", 16), a.get("max_res", 128),

@@ -91,6 +91,10 @@ def synthetic_tcnn_checkpoint(cfg, seed=0, base_gain=2.0, head_gain=3.0, num_ima
         sd[f"proposal_networks.{i}.mlp_base.tcnn_encoding.params"] = torch.cat(
             [net(2 * a["num_levels"], a["hidden_dim"], 2, 1, base_gain), grid(a["num_levels"], a.get("base_res", 16), a["max_res"], a["log2_hashmap_size"])])
     sd["field.embedding_appearance.embedding.weight"] = torch.randn(num_images, cfg.appearance_embed_dim, generator=g)
+    if cfg.predict_normals:  # plain Network 27 -> 64 -> 64 -> 64 + the (torch) PredNormalsFieldHead
+        sd["field.mlp_pred_normals.tcnn_encoding.params"] = net(12 + 15, 64, 3, 64, head_gain)
+        sd["field.field_head_pred_normals.net.weight"] = torch.randn(3, 64, generator=g) * (head_gain / 8.0)
+        sd["field.field_head_pred_normals.net.bias"] = torch.randn(3, generator=g) * 0.1
     return sd
 
 
@@ -115,4 +119,11 @@ def oracle_params_from_tcnn(sd, cfg):
     for i in range(cfg.num_proposal_iterations):
         a = cfg.proposal_net_args_list[min(i, len(cfg.proposal_net_args_list) - 1)]
         stack(f"proposal_networks.{i}.mlp_base", a["num_levels"], a.get("base_res", 16), a["max_res"], a["log2_hashmap_size"], a["hidden_dim"], 1)
+    if "field.mlp_pred_normals.tcnn_encoding.params" in sd:
+        # the oracle keeps the library's own input order (oracle/tcnn_layout.frequency_encoding), the importer permutes to this
+        # package's: two independent routes to the same function
+        for k, v in tl.mlp_unpack(sd["field.mlp_pred_normals.tcnn_encoding.params"], 12 + 15, 64, 3, 64, pad_value=1.0).items():
+            out[f"field.mlp_pred_normals.{k}"] = v
+        out["field.field_head_pred_normals.net.weight"] = sd["field.field_head_pred_normals.net.weight"]
+        out["field.field_head_pred_normals.net.bias"] = sd["field.field_head_pred_normals.net.bias"]
     return out

@@ -92,8 +92,8 @@ def test_tcnn_render_matches_oracle(gpu, props, precision):
 
 @pytest.mark.parametrize("props", [0, 2])
 def test_tcnn_analytic_normals_match_oracle(gpu, props):
-    """Row a16 on the tiny-cuda-nn grid: floor + 1 corners everywhere (no zero-slope grid points), dense and hashed levels.  The
-    pred-normal MLP of a tcnn checkpoint is not imported, so only "normals" is offered."""
+    """Row a16 on the tiny-cuda-nn grid: floor + 1 corners everywhere (no zero-slope grid points), dense and hashed levels; and the
+    checkpoint's pred-normal MLP (a plain tcnn Network behind the library's Frequency encoding) through tcnn_import."""
     import dataclasses
 
     cfg, sd, model = _tcnn_model(gpu, num_proposal_iterations=props, num_proposal_samples_per_ray=(48, 24) if props else (),
@@ -102,12 +102,15 @@ def test_tcnn_analytic_normals_match_oracle(gpu, props):
     H, W = 40, 56
     b = Cameras(scene.benchmark_cameras(8)[:, :3], 60.0, 60.0, W / 2, H / 2, W, H).to(gpu)[2].generate_rays(0)
     out = model.get_outputs_for_camera_ray_bundle(b)
-    assert "normals" in out and set(out) == {"rgb", "accumulation", "depth", "expected_depth", "normals"} | {f"prop_depth_{i}" for i in range(props)}
+    assert "normals" in out and set(out) == {"rgb", "accumulation", "depth", "expected_depth", "normals", "pred_normals"} | {f"prop_depth_{i}" for i in range(props)}
     ocfg = dataclasses.replace(oracle_config(cfg), predict_normals=True)
     ref = onf.get_outputs_for_camera_ray_bundle(params, ocfg, b.origins.cpu(), b.directions.cpu())
     d = (out["normals"].cpu() - ref["normals"]).abs().max(dim=-1).values
     print(f"tcnn normals props={props}: rmse {rmse(out['normals'], ref['normals']):.2e}, pixels off by > 1e-3: {int((d > 1e-3).sum())}/{d.numel()}")
     assert float(ref["normals"].std()) > 0.05
+    e_pred = rmse(out["pred_normals"], ref["pred_normals"])
+    print(f"tcnn pred_normals props={props}: rmse {e_pred:.2e} (std {float(ref['pred_normals'].std()):.3f})")
+    assert float(ref["pred_normals"].std()) > 0.05 and e_pred <= 1e-3    # continuous in the sample position: the plain gate holds
     if props == 0:
         assert rmse(out["normals"], ref["normals"]) <= 1e-3
     else:

@@ -52,7 +52,7 @@ def test_importer_agrees_with_the_oracle_unpacking():
     conv = convert_tcnn_state_dict(sd, cfg)
     ref = oracle_params_from_tcnn(sd, cfg)
     for k, v in ref.items():
-        if k.endswith("tcnn_grid"):
+        if k.endswith("tcnn_grid") or k == "field.mlp_pred_normals.layers.0.weight":   # (columns permuted: checked in its own test below)
             continue
         assert torch.equal(conv[k], v), k
     assert float(conv["field.mlp_head.layers.0.bias"].abs().max()) > 0       # the ones-padded input column became a bias
@@ -89,3 +89,49 @@ def test_importer_accepts_separate_encoding_and_network_vectors():
     assert set(split) == set(fused)
     for k in fused:
         assert torch.equal(split[k], fused[k]), k  # 32 grid features need no input padding, so the two forms coincide
+
+
+def test_pred_normal_mlp_is_imported_with_permuted_encoding_columns():
+    """predict_normals=True checkpoints: the flat 27 -> 64 -> 64 -> 64 Network is unpacked, its first-layer columns re-ordered from the
+    library's Frequency-encoding order (dimension-major: sin f0, cos f0, sin f1, cos f1) to this package's [sines | cosines]."""
+    cfg = small_config(implementation="tcnn")
+    assert cfg.predict_normals
+    sd = synthetic_tcnn_checkpoint(cfg, seed=2)
+    conv = convert_tcnn_state_dict(sd, cfg)
+    ref = oracle_params_from_tcnn(sd, cfg)
+    w_lib, w_pkg = ref["field.mlp_pred_normals.layers.0.weight"], conv["field.mlp_pred_normals.layers.0.weight"]
+    assert w_pkg.shape == (64, 27) and torch.equal(w_pkg[:, 12:], w_lib[:, 12:])
+    for a in range(3):
+        for k in range(2):
+            assert torch.equal(w_pkg[:, a * 2 + k], w_lib[:, a * 4 + k * 2])           # sin(axis a, frequency k)
+            assert torch.equal(w_pkg[:, 6 + a * 2 + k], w_lib[:, a * 4 + k * 2 + 1])   # cos
+    for k in ("layers.0.bias", "layers.1.weight", "layers.2.weight"):
+        assert torch.equal(conv[f"field.mlp_pred_normals.{k}"], ref[f"field.mlp_pred_normals.{k}"])
+    # the encoding itself: library order, frequencies pi 2^k
+    x = torch.tensor([[0.25, 0.5, 0.125]])
+    e = tl.frequency_encoding(x, 2)[0]
+    assert e.shape == (12,) and torch.allclose(e[:4], torch.tensor([2**-0.5, 2**-0.5, 1.0, 0.0]), atol=1e-6)   # sin, cos of pi/4; of pi/2
+
+
+def test_partial_checkpoint_without_proposal_vectors_loads():
+    """the reference strips every `proposal*` key before load_state_dict(strict=False) when it retrains
+    (signerf_pipeline.py:126-131,141-144) -- for a tiny-cuda-nn checkpoint that is the normal case and must not raise."""
+    cfg = small_config(implementation="tcnn")
+    sd = synthetic_tcnn_checkpoint(cfg, seed=1)
+    stripped = {k: v for k, v in sd.items() if "proposal" not in k}
+    assert len(stripped) < len(sd)
+    model = cfg.setup()
+    before = model.proposal_networks[0].mlp_base.encoder.hash_table.detach().clone()
+    res = model.load_state_dict(stripped, strict=False)
+    assert not res.unexpected_keys
+    assert any(k.startswith("proposal_networks.0.") for k in res.missing_keys) and any(k.startswith("proposal_networks.1.") for k in res.missing_keys)
+    assert not any(k.startswith("field.mlp_base") or k.startswith("field.mlp_head") for k in res.missing_keys)
+    assert torch.equal(model.proposal_networks[0].mlp_base.encoder.hash_table, before)        # untouched
+    full = convert_tcnn_state_dict(sd, cfg)
+    assert torch.equal(model.field.mlp_base.encoder.hash_table, full["field.mlp_base.encoder.hash_table"])
+    with pytest.raises(RuntimeError):                                                          # strict=True reports them as missing
+        cfg.setup().load_state_dict(stripped, strict=True)
+    # the same for a checkpoint that lacks only the colour head
+    no_head = {k: v for k, v in sd.items() if "mlp_head" not in k}
+    res = cfg.setup().load_state_dict(no_head, strict=False)
+    assert any(k.startswith("field.mlp_head") for k in res.missing_keys)

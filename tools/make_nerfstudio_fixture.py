@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Emit golden fixtures from the REAL nerfstudio 1.0.2 -- to be run wherever `pip install nerfstudio==1.0.2` works (it does not in
+the build container and never on the GPU box).  It pins what is unpinned today:
+
+  tests/golden/nerfstudio_nerfacto_torch.npz   the eval-mode render of nerfstudio's torch fallback (implementation="torch", CPU) on a
+                                               small seeded scene: pins oracle/nerfacto.py (rows a5-a17), including the three
+                                               conventions SURVEY Appendix A grades low/medium (SH on (d+1)/2, the aabb near/far
+                                               sentinel, the chunk-global expected-depth clip)
+  tests/golden/nerfstudio_nerfacto_tcnn.npz    (needs CUDA + tinycudann) a tiny `implementation="tcnn"` model's flat parameter
+                                               vectors and its render: pins oracle/tcnn_layout.py::ASSUMPTIONS and tcnn_import
+
+    python tools/make_nerfstudio_fixture.py [--tcnn]
+
+tests/test_oracle_vs_nerfstudio_fixture.py picks the files up when they exist (and is skipped when they do not).  The parameters are
+this repository's synthetic scene (signerf_amd/scene.py) loaded into the nerfstudio model under the same state-dict keys, so the
+fixture and the oracle evaluate the same field.  Only inputs and outputs are stored -- no nerfstudio source.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _small_nerfstudio_config(implementation):
+    from nerfstudio.models.nerfacto import NerfactoModelConfig
+
+    return NerfactoModelConfig(
+        implementation=implementation, eval_num_rays_per_chunk=1 << 10, predict_normals=True, average_init_density=0.01,
+        log2_hashmap_size=14,
+        proposal_net_args_list=[
+            {"hidden_dim": 16, "log2_hashmap_size": 12, "num_levels": 5, "max_res": 128, "use_linear": False},
+            {"hidden_dim": 16, "log2_hashmap_size": 12, "num_levels": 5, "max_res": 256, "use_linear": False}])
+
+
+def _render(model, c2w, W, H, focal, device, aabb=None):
+    from nerfstudio.cameras.cameras import Cameras, CameraType
+    from nerfstudio.data.scene_box import SceneBox
+
+    cams = Cameras(camera_to_worlds=c2w[None, :3, :4], fx=focal, fy=focal, cx=W / 2, cy=H / 2, width=W, height=H,
+                   camera_type=CameraType.PERSPECTIVE).to(device)
+    box = None if aabb is None else SceneBox(aabb=torch.tensor(aabb, dtype=torch.float32).view(2, 3))
+    bundle = cams.generate_rays(camera_indices=0, keep_shape=True, aabb_box=box)
+    model.eval()
+    with torch.no_grad():
+        out = model.get_outputs_for_camera_ray_bundle(bundle)
+    keep = {k: v.detach().cpu().numpy() for k, v in out.items() if isinstance(v, torch.Tensor)}
+    keep["origins"] = bundle.origins.detach().cpu().numpy()
+    keep["directions"] = bundle.directions.detach().cpu().numpy()
+    keep["pixel_area"] = bundle.pixel_area.detach().cpu().numpy()
+    if bundle.nears is not None:
+        keep["nears"], keep["fars"] = bundle.nears.detach().cpu().numpy(), bundle.fars.detach().cpu().numpy()
+    return keep
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tcnn", action="store_true", help="also emit the tiny-cuda-nn fixture (needs CUDA + tinycudann)")
+    args = ap.parse_args()
+    from nerfstudio.data.scene_box import SceneBox
+
+    from helpers import small_config
+    from signerf_amd import scene
+
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    box = SceneBox(aabb=torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]))
+    c2w = scene.benchmark_cameras(8)
+    W, H, focal = 40, 32, 48.0
+
+    # ---- torch fallback on the CPU: the parity target of the render path ----
+    torch.manual_seed(0)
+    ns_model = _small_nerfstudio_config("torch").setup(scene_box=box, num_train_data=50, metadata={}, device="cpu", grad_scaler=None)
+    cfg = small_config()                                  # the same architecture on this side
+    sd = scene.synthetic_state_dict(cfg, seed=0)
+    res = ns_model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys   # every key of the synthetic scene exists under the same name in nerfstudio
+    fx = {}
+    for cam, aabb in ((0, None), (3, None), (2, [-0.15, -0.12, -0.1, 0.12, 0.15, 0.1])):
+        r = _render(ns_model, c2w[cam], W, H, focal, "cpu", aabb)
+        for k, v in r.items():
+            fx[f"cam{cam}{'_aabb' if aabb else ''}.{k}"] = v
+    for k, v in sd.items():
+        fx["param." + k] = v.numpy()
+    np.savez_compressed(os.path.join(out_dir, "nerfstudio_nerfacto_torch.npz"), **fx)
+    print("wrote nerfstudio_nerfacto_torch.npz:", sorted(k for k in fx if not k.startswith("param."))[:12], "...")
+
+    # ---- tiny-cuda-nn (optional) ----
+    if args.tcnn:
+        assert torch.cuda.is_available(), "--tcnn needs CUDA + tinycudann"
+        torch.manual_seed(1)
+        t_model = _small_nerfstudio_config("tcnn").setup(scene_box=box, num_train_data=50, metadata={}, device="cuda", grad_scaler=None).cuda()
+        with torch.no_grad():  # make the field non-trivial: tcnn initialises grids at ~1e-4
+            for n, p in t_model.named_parameters():
+                if n.endswith(".params"):
+                    p.mul_(30.0)
+        fx = {"state." + k: v.detach().float().cpu().numpy() for k, v in t_model.state_dict().items()}
+        r = _render(t_model, c2w[1], W, H, focal, "cuda")
+        for k, v in r.items():
+            fx["cam1." + k] = v
+        np.savez_compressed(os.path.join(out_dir, "nerfstudio_nerfacto_tcnn.npz"), **fx)
+        print("wrote nerfstudio_nerfacto_tcnn.npz with state keys:", [k for k in fx if k.startswith("state.")])
+
+
+if __name__ == "__main__":
+    main()
