@@ -952,8 +952,11 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         const int want = std::max(0, std::min(e ? atoi(e) : SN_DENSE_LEVELS_DEFAULT, 12));
         const char* cap_env = getenv("SN_DENSE_CAP_MB");  // per-level size cap of the main grid's copies (experiments)
         const uint64_t cap_main = cap_env ? (uint64_t)std::max(1, atoi(cap_env)) : 600;
-        const char* pe = getenv("SN_DENSE_ORIENT");  // 0: only the x-fast set of copies
-        const int sets = (pe && atoi(pe) == 0) ? 1 : 3;
+        // Orientation sets (x-, y-, z-fast copies, the wave reading the one whose fast axis follows its pixel rows): measured r02 over the
+        // 8 sheet cameras (tools/dense_sweep.py, profiles/r02_dense_sweep.txt) 3 sets buy 0.4 % over 1 set at 3x the footprint
+        // (2.63 GB vs 0.88 GB) -- off by default, SN_DENSE_ORIENT=1 builds them.
+        const char* pe = getenv("SN_DENSE_ORIENT");
+        const int sets = (pe && atoi(pe) != 0) ? 3 : 1;
         if (int rc = build_dense_copies(h, d.main_field, h->table_main, want, cap_main, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st, sets,
                                         h->feat_scale_main))
             return rc;
@@ -1297,7 +1300,7 @@ int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out) {
         out->dense_off[l] = dc.off[l];
     }
     out->dense_set_stride = dc.perm_stride;
-    out->dense_bytes = which < 0 ? h->dense_main.bytes : h->dense_prop[which].bytes;
+    out->dense_bytes = out->n_dense > 0 ? (which < 0 ? h->dense_main.bytes : h->dense_prop[which].bytes) : 0;
     out->feature_scale = which < 0 ? h->feat_scale_main : h->feat_scale_prop[which];
     if (which >= 0) {
         for (int l = 0; l < SN_MAX_LEVELS; ++l) out->pair_base[l] = h->pinfo_prop[which].base[l];

@@ -156,8 +156,7 @@ def test_dehashed_copies_hold_the_tables_rows(full_model, gpu, which):
     assert lay["n_dense"] == (11 if which < 0 else (5, 4)[which])
     fs = lay["feature_scale"]
     assert fs > 0 and float(np.log2(fs)).is_integer() and 512.0 <= fs * float(table.abs().max()) <= 1024.0
-    n_sets = 3 if lay["dense_set_stride"] else 1
-    assert (which < 0) == (n_sets == 3)
+    n_sets = 3 if lay["dense_set_stride"] else 1   # (three orientation sets of the main grid only with SN_DENSE_ORIENT=1)
     checked = 0
     for l in range(lay["n_dense"]):
         R = lay["dense_res"][l]
@@ -244,6 +243,26 @@ def test_config2_fused_indices_full_size_crop(bench_model, gpu, cam, y0, x0):
     cfg, model, sd = bench_model
     cams = Cameras(scene.benchmark_cameras(8)[:, :3], 800.0, 800.0, 400.0, 400.0, 800, 800).to(gpu)
     _run_uniform(cfg, model, sd, gpu, _bundle_crop(cams[cam], y0, x0, 40, 40), f"config 2 (40x40 crop of camera {cam}'s 800x800 frame)")
+
+
+def test_config2_fused_indices_with_orientation_sets(gpu, monkeypatch):
+    """SN_DENSE_ORIENT=1: the y- / z-fast copies and the per-wave choice among them (camera 2's pixel rows run along another grid axis
+    than camera 0's)."""
+    monkeypatch.setenv("SN_DENSE_ORIENT", "1")
+    cfg = scene.benchmark_config(64)
+    model, sd = make_model(cfg, gpu)
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 800.0, 800.0, 400.0, 400.0, 800, 800).to(gpu)
+    for cam in (0, 2):
+        bundle = _bundle_crop(cams[cam], 384, 384, 32, 32)
+        _run_uniform(cfg, model, sd, gpu, bundle, f"config 2, 3 orientation sets (32x32 crop of camera {cam})")
+    lay = ops.debug_layout(model, -1)
+    assert lay["dense_set_stride"] > 0
+    _, dump = ops.render_rays_debug(model, _bundle_crop(cams[2], 384, 384, 32, 32), want=("main_fetch",))
+    sets = set((dump["main_fetch"][:, :, 0, 4] & 0xF).unique().tolist()) | set((dump["main_fetch"][:, :, 5, 4] & 0xF).unique().tolist())
+    _, dump0 = ops.render_rays_debug(model, _bundle_crop(cams[0], 384, 384, 32, 32), want=("main_fetch",))
+    sets |= set((dump0["main_fetch"][:, :, 0, 4] & 0xF).unique().tolist())
+    print("orientation sets read:", sorted(sets))
+    assert len(sets) >= 2                        # the two cameras do read different sets
 
 
 def test_config4_fused_indices_proposal_path(full_model, gpu):

@@ -306,11 +306,12 @@ def test_viewer_crop_box_bounds_the_rays(gpu):
 
 
 def test_orientation_sets_of_the_dehashed_copies_agree(gpu, monkeypatch):
-    """K1 reads the coarse levels from de-hashed copies kept in three orientations (x-, y-, z-fast) and picks one per wave from the
-    direction its pixel row moves in.  Cameras whose pixel rows run along grid x, y and z must render what the single-set build
-    (SN_DENSE_ORIENT=0) renders -- the entries are the same, only the order of the three lerps differs (<= 1 ulp per level)."""
+    """With SN_DENSE_ORIENT=1 K1 keeps the de-hashed copies in three orientations (x-, y-, z-fast) and picks one per wave from the
+    direction its pixel row moves in (off by default since r02: +0.4 % for 3x the footprint).  Cameras whose pixel rows run along
+    grid x, y and z must render what the default single-set build renders -- the entries are the same, only the order of the three
+    lerps differs (<= 1 ulp per level)."""
     cfg = scene.benchmark_config(32)
-    monkeypatch.setenv("SN_DENSE_ORIENT", "0")
+    monkeypatch.delenv("SN_DENSE_ORIENT", raising=False)
     one, _ = make_model(cfg, gpu)
     H = W = 64
     c2w = scene.benchmark_cameras(8)[:, :3].clone()
@@ -320,8 +321,11 @@ def test_orientation_sets_of_the_dehashed_copies_agree(gpu, monkeypatch):
     bundles = [cams[i].generate_rays(0) for i in (0, 2, 8)]
     base = [one.get_outputs_for_camera_ray_bundle(b) for b in bundles]
     base = [{k: o[k].clone() for k in ("rgb", "depth", "accumulation")} for o in base]
-    monkeypatch.delenv("SN_DENSE_ORIENT")
+    monkeypatch.setenv("SN_DENSE_ORIENT", "1")
     three, _ = make_model(cfg, gpu)
+    from signerf_amd import ops
+    three.get_outputs_for_camera_ray_bundle(bundles[0])
+    assert ops.debug_layout(three, -1)["dense_set_stride"] > 0 and ops.debug_layout(one, -1)["dense_set_stride"] == 0
     for b, ref in zip(bundles, base):
         out = three.get_outputs_for_camera_ray_bundle(b)
         assert rmse(out["rgb"], ref["rgb"]) <= 1e-6 and rmse(out["accumulation"], ref["accumulation"]) <= 1e-6
