@@ -14,7 +14,8 @@ SN_MAX_LEVELS = 16
 SN_MAX_PROPOSALS = 2
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libsignerf_hip.so")
+# SIGNERF_HIP_LIB: load another build of the library (A/B experiments with tools/ab_lib.py); the default is the in-tree build
+LIB_PATH = os.environ.get("SIGNERF_HIP_LIB") or os.path.join(_PKG_DIR, "libsignerf_hip.so")
 
 
 class SnHashMlpDesc(C.Structure):

@@ -41,16 +41,19 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = True, extra_flags=(), out_path: str = None) -> str:
+    """out_path: build a VARIANT (extra_flags, e.g. ("-DSN_MFMA_PRIO=1",)) next to the product library, for A/B runs
+    (SIGNERF_HIP_LIB=<out_path> selects it at load time)."""
+    if out_path is None and not force and not _stale():
         return LIB_PATH
+    target = out_path or LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tl = _torch_lib_dir()
     cmd = [hipcc, f"--offload-arch={ARCH}", *CODEGEN_FLAGS, "-fPIC", "-shared", "-no-hip-rt",
            "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Rpass-analysis=kernel-resource-usage",
            *extra_flags,
            *[os.path.join(CSRC, s) for s in SOURCES],
-           "-o", LIB_PATH, f"-L{tl}", "-lamdhip64", f"-Wl,-rpath,{tl}", "-Wl,-rpath,/opt/rocm/lib"]
+           "-o", target, f"-L{tl}", "-lamdhip64", f"-Wl,-rpath,{tl}", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
@@ -70,7 +73,7 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
         print("\n".join(other), file=sys.stderr)
     if r.returncode != 0:
         raise subprocess.CalledProcessError(r.returncode, cmd)
-    return LIB_PATH
+    return target
 
 
 if __name__ == "__main__":

@@ -211,6 +211,13 @@ struct SnOpH {  // one B operand (8 k-slots of one 32-sample tile), hi and lo pa
     }
 };
 
+// Wave priority around the MFMA cluster of every k-step (cdna_hip_programming.md T5): with three waves per SIMD in different phases the
+// arbiter otherwise serves the oldest wave's VALU first and the matrix pipe idles between a wave's clusters.  Measured r02, interleaved
+// A/B on one box (tools/ab_lib.sh): 3.084 -> 2.980 ms (-3.4 %), the same for priority 1, 2 or 3; raising the priority of the whole MLP
+// phase or of the hash phase instead: no effect; 2 waves/SIMD: -2.7 % alone, worse together with the priority.  0 disables.
+#ifndef SN_MFMA_PRIO
+#define SN_MFMA_PRIO 1
+#endif
 #ifndef SN_MFMA_H  // (tools/probes/mlp_probe.hip overrides it to time the VALU part of the MLP alone)
 #define SN_MFMA_H(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, ACC, 0, 0, 0)
 #endif
@@ -239,7 +246,7 @@ SN_DEV void sn_mlp_layer_h(const char* __restrict__ wimg, const float* __restric
         const f16x8 bh0 = __builtin_bit_cast(f16x8, op0[s].hi), bl0 = __builtin_bit_cast(f16x8, op0[s].lo);
         const f16x8 bh1 = __builtin_bit_cast(f16x8, op1[s].hi), bl1 = __builtin_bit_cast(f16x8, op1[s].lo);
         // small terms first, then hi.hi; independent accumulators interleaved
-#ifdef SN_MFMA_PRIO  // experiment (tools/probes/mlp_probe.hip): raise the wave's priority around its MFMA cluster
+#if SN_MFMA_PRIO
         __builtin_amdgcn_s_setprio(SN_MFMA_PRIO);
 #endif
 #pragma unroll
@@ -257,7 +264,7 @@ SN_DEV void sn_mlp_layer_h(const char* __restrict__ wimg, const float* __restric
             SN_MFMA_H(acc0[rt], ah[rt], bh0);
             SN_MFMA_H(acc1[rt], ah[rt], bh1);
         }
-#ifdef SN_MFMA_PRIO
+#if SN_MFMA_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
     }
@@ -545,6 +552,9 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
             // plain table: the x-paired layout (sn_device.h) measured no gain here (r01: 4.11 vs 4.18 ms) -- splitting a level
             // into per-t tables loses the x-locality of the plain layout (16 consecutive x share a 128-B line)
             const float qd[3] = {dsel == 1 ? q[1] : (dsel == 2 ? q[2] : q[0]), dsel == 1 ? q[0] : q[1], dsel == 2 ? q[0] : q[2]};
+#if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 3  // experiment: the hash phase (gather issue) at raised priority
+            __builtin_amdgcn_s_setprio(1);
+#endif
             uint32_t* rec = nullptr;
             if (DUMP && valid) {
                 const size_t smp = (size_t)ray * (size_t)S + (size_t)i;
@@ -557,8 +567,14 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
             }
             sn_hash_encode<16, SN_HASH_GROUP, (GRID ? 2 : (SN_FAST_HASH ? 1 : 0)), ND, DUMP>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, qd,
                                                                                             dense_set_off, rec, p.feat_scale);
+#if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 3
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
+#if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 2  // experiment: the whole MLP phase at raised priority
+        __builtin_amdgcn_s_setprio(1);
+#endif
         float h0, rgb[3];
         if (ABLATE & 2) {
             float a = 0.f, bsum = 0.f;
@@ -577,6 +593,9 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
             sn_main_field_h((const char*)lds, feat, shh, lane, h0, rgb);
         }
         __builtin_amdgcn_sched_barrier(0);
+#if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
         float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
         r = rgb[0];
         g = rgb[1];

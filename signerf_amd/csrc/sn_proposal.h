@@ -91,12 +91,18 @@ SN_DEV float sn_prop_mlp_mfma(const float* __restrict__ w, const float* feat, in
     const f16x8 b0h = __builtin_bit_cast(f16x8, xh), b0l = __builtin_bit_cast(f16x8, xl);
     const f16x8 b1h = __builtin_bit_cast(f16x8, yh), b1l = __builtin_bit_cast(f16x8, yl);
     f32x16 c0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#if defined(SN_PROP_PRIO) && SN_PROP_PRIO  // experiment (tools/ab_lib.sh): priority around the layer's six MFMAs
+    __builtin_amdgcn_s_setprio(SN_PROP_PRIO);
+#endif
     SN_MFMA_H(c0, al, b0h);
     SN_MFMA_H(c1, al, b1h);
     SN_MFMA_H(c0, ah, b0l);
     SN_MFMA_H(c1, ah, b1l);
     SN_MFMA_H(c0, ah, b0h);
     SN_MFMA_H(c1, ah, b1h);
+#if defined(SN_PROP_PRIO) && SN_PROP_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // layer 2: this lane holds hidden units (r & 3) + 8 (r >> 2) + 4 h, r = 0..7, of its column in both tiles
     const f32x4* w1 = (const f32x4*)(w + SN_PROP_MW1 + (lane >> 5) * 8);
     const f32x4 wa = w1[0], wb = w1[1];
