@@ -54,7 +54,7 @@ def main():
             cur = {}
         rd = 32 * a.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * a.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * a.get("TCC_EA0_RDREQ_128B_sum", 0)
         wr = a.get("WRITE_SIZE", 0) * 1024
-        cur[prec] = {"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+        cur[prec] = {"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "commit": os.environ.get("SN_COMMIT", "unknown"),
                      "source": "tools/pmc_passes.sh: TCC_EA0_RDREQ_{32,64,128}B_sum x size + WRITE_SIZE KiB, kernel " + pat}
         json.dump(cur, open(path, "w"), indent=1)
         print("updated", path)

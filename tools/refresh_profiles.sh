@@ -9,11 +9,13 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 timeout 600 python bench.py > "$OUT/bench_sheet64.json" 2> "$OUT/bench_sheet64.err"
-timeout 600 python bench.py --workload nerfacto1080 --steps 10 --warmup 2 > "$OUT/bench_nerfacto1080.json" 2> "$OUT/bench_nerfacto1080.err"
+timeout 600 python bench.py --workload nerfacto1080 --steps 60 --warmup 5 > "$OUT/bench_nerfacto1080.json" 2> "$OUT/bench_nerfacto1080.err"
+timeout 300 python tools/kernel_counts.py > "$OUT/kernel_counts.txt" 2>&1
+timeout 300 python tools/kernel_counts.py sn_render_main_kernelILi1ELi1ELi0ELi0ELi11ELb0E >> "$OUT/kernel_counts.txt" 2>&1
 timeout 300 python tools/normals_bench.py > "$OUT/normals_bench.txt" 2>&1
 timeout 300 python tools/normals_bench.py --workload nerfacto1080 >> "$OUT/normals_bench.txt" 2>&1
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_sheet64" -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/prof_sheet64.log" 2>&1)
-(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_nerfacto1080" -- python "$ROOT/bench.py" --workload nerfacto1080 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/prof_nerfacto1080.log" 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_nerfacto1080" -- python "$ROOT/bench.py" --workload nerfacto1080 --steps 30 --warmup 3 --no-cpu-baseline > "$OUT/prof_nerfacto1080.log" 2>&1)
 python tools/rocprof_summary.py "$OUT/prof_sheet64" > "$OUT/kernel_stats_sheet64.txt" 2>&1
 python tools/rocprof_summary.py "$OUT/prof_nerfacto1080" > "$OUT/kernel_stats_nerfacto1080.txt" 2>&1
 bash tools/pmc_passes.sh "$OUT/pmc_k1" > "$OUT/pmc_k1.log" 2>&1
