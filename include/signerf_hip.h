@@ -215,9 +215,10 @@ int sn_pdf_sample(const float* spacing_bins, const float* weights, int64_t n_ray
  *                                            nerfstudio corner order 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf
  *                                            (x y z; the kernels take the "c" corner as floor + 1: it differs from ceil only where the
  *                                            coordinate is an integer, i.e. where that corner's blend weight is exactly 0);
- *   level read from its de-hashed copy       words 0..3 = byte offset, within the buffer of copies, of the four 16-byte fetches
- *                                            (y1 z1), (y0 z1), (y0 z0), (y1 z0), each holding the x0 and x0 + 1 entries;
- *                                            word 4 = 0xD0000000 | orientation set (0 x-fast, 1 y-fast, 2 z-fast);
+ *   level read from its de-hashed copy,      words 0..3 = byte offset, within the buffer of copies, of the four 16-byte fetches
+ *     plain-row form                         (y1 z1), (y0 z1), (y0 z0), (y1 z0), each holding the x0 and x0 + 1 rows; word 4 = 0xD0000000;
+ *     bilinear-coefficient form              words 0, 1 = byte offset of the 32-byte entries of grid points (x0, y0, z0) and (x0, y0, z0 + 1);
+ *                                            word 4 = 0xB0000000;
  *   level read from the x-paired tables      words 0..3 = 16-byte entry number of the four fetches (same order), each holding row r
  *                                            and row r ^ (2^(t+1) - 1); word 4 = 0xA0000000 | t.
  * sn_debug_layout / sn_debug_read expose the layout and the contents of those derived buffers so that a test can map every record
@@ -236,9 +237,11 @@ int sn_render_rays_debug(SnHandle h, const float* origins, const float* directio
                          float* prop_depth_0, float* prop_depth_1, const SnDebugDump* dump, SnStream stream);
 typedef struct SnDebugLayout {
     int32_t n_dense;                   /* leading levels that are read from de-hashed copies */
-    uint32_t dense_res[12];            /* R of level l: entry (c0, c1, c2) sits at c0 + R c1 + R^2 c2 */
-    uint32_t dense_off[12];            /* byte offset of level l's copy within one orientation set */
-    uint32_t dense_set_stride;         /* bytes between orientation sets (0: only the x-fast set exists) */
+    int32_t n_bc;                      /* of those, the leading levels stored in bilinear-coefficient form: 32 bytes per grid point (x, y, z) =
+                                        * {A, B | C, D} x 2 features, A = v(x,y,z), B = v(x+1,y,z) - A, C = v(x,y+1,z) - A,
+                                        * D = (v(x+1,y+1,z) - v(x+1,y,z)) - C; the other copied levels hold plain rows (8 bytes per grid point) */
+    uint32_t dense_res[12];            /* R of level l: grid point (x, y, z) sits at entry x + R y + R^2 z */
+    uint32_t dense_off[12];            /* byte offset of level l's copy within the buffer */
     uint64_t dense_bytes;              /* size of the buffer of copies */
     uint32_t pair_base[SN_MAX_LEVELS]; /* which >= 0: first 16-byte entry of level l's t = 0 paired table (table t follows at t << log2_T) */
     uint64_t pair_bytes;

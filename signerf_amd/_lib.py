@@ -88,9 +88,9 @@ class SnDebugDump(C.Structure):
 class SnDebugLayout(C.Structure):
     _fields_ = [
         ("n_dense", C.c_int32),
+        ("n_bc", C.c_int32),
         ("dense_res", C.c_uint32 * 12),
         ("dense_off", C.c_uint32 * 12),
-        ("dense_set_stride", C.c_uint32),
         ("dense_bytes", C.c_uint64),
         ("pair_base", C.c_uint32 * SN_MAX_LEVELS),
         ("pair_bytes", C.c_uint64),

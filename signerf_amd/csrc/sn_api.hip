@@ -197,7 +197,7 @@ SnGridLevels grid_levels(const SnHashMlpDesc& d) {
 // 3.33 / 3.30 / 3.26 ms for 0 / 8 / 9 / 10 / 11 copied levels), the proposal nets (352 samples per ray over the coarse levels)
 // lose with the 137 MB copy of the second net's finest level (frame 18.8 vs 17.5 ms) -- hence the two caps.
 int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, int want, uint64_t cap_mb, DevBuf& buf, SnDenseCopy& info,
-                       SnGridLevels& res, int& nd_out, hipStream_t st, int n_sets = 1, float scale = 1.0f) {
+                       SnGridLevels& res, int& nd_out, hipStream_t st, int bc_levels, float scale = 1.0f) {
     nd_out = 0;
     memset(&info, 0, sizeof(info));
     memset(&res, 0, sizeof(res));
@@ -207,35 +207,35 @@ int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, 
     int nd = 0;
     for (int l = 0; l < want && l < d.num_levels && l < 12; ++l) {
         const uint64_t r = (uint64_t)d.scalings[l] + 2;
-        if (r > 1400 || r * r * r * 8 > cap_mb * 1000 * 1000) break;  // 8 R^2 must fit 24 bits
+        if (r > 700 || r * r * r * 8 > cap_mb * 1000 * 1000) break;  // 32 R^2 (bilinear-coefficient entries) must fit 24 bits
         R[l] = (uint32_t)r;
         info.off[l] = (uint32_t)bytes;
-        bytes += (r * r * r + 1) * 8;  // one spare row: the last entry's 16-byte read stays inside the buffer
+        // bilinear-coefficient levels: 32 bytes per grid point; plain-row levels: 8, plus one spare row (the last entry's 16-byte read)
+        bytes += l < bc_levels ? r * r * r * 32 : (r * r * r + 1) * 8;
         bytes = (bytes + 255) & ~255ull;
         ++nd;
     }
     if (nd == 0) return SN_OK;
-    // orientation sets (y-fast, z-fast) behind the x-fast one, as long as 32-bit buffer offsets reach them
-    const uint64_t set_bytes = bytes;
-    if (n_sets > 1 && set_bytes * (uint64_t)n_sets >= 0xf0000000ull) n_sets = 1;
-    bytes = set_bytes * (uint64_t)n_sets;
+    if (bytes >= 0xf0000000ull) return fail(h, SN_ERR_INVALID, "de-hashed copies exceed the 32-bit buffer-offset range");
     if (buf.bytes != bytes) {
         buf.release();
         SN_HIP(h, hipMalloc(&buf.ptr, bytes));
         buf.bytes = bytes;
     }
     SN_HIP(h, hipMemsetAsync(buf.ptr, 0, bytes, st));
-    for (int set = 0; set < n_sets; ++set)
-        for (int l = 0; l < nd; ++l) {
-            const uint32_t n = R[l] * R[l] * R[l];
-            hipLaunchKernelGGL(sn_build_dense_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)table.ptr,
-                               (float*)((char*)buf.ptr + (uint64_t)set * set_bytes + info.off[l]), l, d.log2_hashmap_size, R[l], set, scale);
-            info.res[l] = R[l];
-        }
+    for (int l = 0; l < nd; ++l) {
+        const uint32_t n = R[l] * R[l] * R[l];
+        float* dst = (float*)((char*)buf.ptr + info.off[l]);
+        if (l < bc_levels)
+            hipLaunchKernelGGL(sn_build_bc_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)table.ptr, dst, l, d.log2_hashmap_size, R[l], scale);
+        else
+            hipLaunchKernelGGL(sn_build_dense_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)table.ptr, dst, l, d.log2_hashmap_size, R[l], scale);
+        info.res[l] = R[l];
+    }
     SN_HIP(h, hipGetLastError());
     info.base = (const float*)buf.ptr;
     info.bytes = (uint32_t)bytes;
-    info.perm_stride = n_sets > 1 ? (uint32_t)set_bytes : 0u;
+    info.n_bc = (uint32_t)std::min(nd, std::max(bc_levels, 0));
     nd_out = nd;
     return SN_OK;
 }
@@ -952,17 +952,12 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         const int want = std::max(0, std::min(e ? atoi(e) : SN_DENSE_LEVELS_DEFAULT, 12));
         const char* cap_env = getenv("SN_DENSE_CAP_MB");  // per-level size cap of the main grid's copies (experiments)
         const uint64_t cap_main = cap_env ? (uint64_t)std::max(1, atoi(cap_env)) : 600;
-        // Orientation sets (x-, y-, z-fast copies, the wave reading the one whose fast axis follows its pixel rows): measured r02 over the
-        // 8 sheet cameras (tools/dense_sweep.py, profiles/r02_dense_sweep.txt) 3 sets buy 0.4 % over 1 set at 3x the footprint
-        // (2.63 GB vs 0.88 GB) -- off by default, SN_DENSE_ORIENT=1 builds them.
-        const char* pe = getenv("SN_DENSE_ORIENT");
-        const int sets = (pe && atoi(pe) != 0) ? 3 : 1;
-        if (int rc = build_dense_copies(h, d.main_field, h->table_main, want, cap_main, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st, sets,
-                                        h->feat_scale_main))
+        if (int rc = build_dense_copies(h, d.main_field, h->table_main, want, cap_main, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st,
+                                        SN_BC_MAIN, h->feat_scale_main))
             return rc;
         for (int i = 0; i < d.num_proposals; ++i)
             if (int rc = build_dense_copies(h, d.proposals[i], h->table_prop[i], want, 100, h->dense_prop[i], h->dense_info_prop[i],
-                                            h->dense_res_prop[i], h->nd_prop[i], st, 1, h->feat_scale_prop[i]))
+                                            h->dense_res_prop[i], h->nd_prop[i], st, SN_BC_PROP, h->feat_scale_prop[i]))
                 return rc;
     }
     bool wrap_ok = write_wrap_rows(d.main_field, h->table_main, st);
@@ -1301,7 +1296,7 @@ int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out) {
         out->dense_res[l] = dc.res[l];
         out->dense_off[l] = dc.off[l];
     }
-    out->dense_set_stride = dc.perm_stride;
+    out->n_bc = (int32_t)dc.n_bc;
     out->dense_bytes = out->n_dense > 0 ? (which < 0 ? h->dense_main.bytes : h->dense_prop[which].bytes) : 0;
     out->feature_scale = which < 0 ? h->feat_scale_main : h->feat_scale_prop[which];
     if (which >= 0) {

@@ -345,10 +345,13 @@ struct SnDenseCopy {
     uint32_t bytes;
     uint32_t off[12];      // byte offset of level l's copy (l < number of copied levels <= 12)
     uint32_t res[12];      // R of level l
-    // Orientation copies (main grid): the same levels again with the y (k = 1) or z (k = 2) axis as the fast one, at byte offset
-    // k * perm_stride; 0 = only the x-fast set exists.  A wave picks the set whose fast axis is the grid axis along which its
-    // pixel row moves (sn_render_main_kernel): the 8 lanes of a tile row then read neighbouring entries instead of 8 far rows.
-    uint32_t perm_stride;
+    // Levels [0, n_bc) are stored in BILINEAR-COEFFICIENT form, 32 bytes per grid point (x, y, z):
+    //     A = v(x,y,z)   B = v(x+1,y,z) - A   C = v(x,y+1,z) - A   D = (v(x+1,y+1,z) - v(x+1,y,z)) - C          (2 features each)
+    // so that the blend inside one z slice is A + ox B + oy (C + ox D): 3 FMAs per feature instead of 3 lerps of 2 instructions, and a
+    // level costs 16 VALU of blend instead of 28 -- the fused kernels are VALU-issue bound (r02).  Same four 16-byte gathers per level
+    // (two adjacent ones per slice).  The remaining copied levels keep plain rows (8 bytes, x + 1 = next row).  Orientation sets
+    // (r01: y- / z-fast duplicates, +0.4 % for 3x the bytes, profiles/r02_dense_sweep.txt) are gone.
+    uint32_t n_bc;
 };
 
 // rec (test instrumentation, sn_render_rays_debug): where non-null, receives the byte offsets of the four 16-byte fetches
@@ -392,16 +395,69 @@ SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t leve
     return sn_hash_blend_fast(v, off);
 }
 
-// builds D_l for one level: one thread per entry
-// perm: 0 = entry i holds grid point (x, y, z) = (i % R, i / R % R, i / R^2); 1 = the roles of x and y swapped; 2 = x and z swapped
+// One level in bilinear-coefficient form (SnDenseCopy::n_bc): per feature  f_z(ox, oy) = A + ox B + oy (C + ox D), then the z lerp.
+// Algebraically the trilinear blend; rounding differs from the lerp form by a few ulp of the table magnitude (the blend was never
+// bit-exact with the reference's association -- DESIGN.md "Numerics").
+SN_DEV f32x2 sn_hash_level_dense_bc(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_off_bytes, const float q[3], float scale, uint32_t R,
+                                    uint32_t* rec = nullptr) {
+    uint32_t f[3];
+    float off[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = q[a] * scale;
+        off[a] = __builtin_amdgcn_fractf(x);
+        f[a] = (uint32_t)(int)x;
+    }
+    // 32-byte entries; R <= 255 keeps 32 R^2 and every product inside 24 bits
+    const uint32_t R32 = R << 5, R2_32 = (R * R) << 5;
+    const uint32_t b = (f[0] << 5) + __umul24(f[1], R32) + __umul24(f[2], R2_32);
+    const uint32_t o_z1 = level_off_bytes + R2_32;  // the z + 1 slice: a wave-uniform stride, carried by the scalar offset
+    if (rec) {
+        rec[0] = b + level_off_bytes;
+        rec[1] = b + o_z1;
+    }
+    const f32x4 ab0 = sn_table_load_pair(rsrc, b, level_off_bytes), cd0 = sn_table_load_pair(rsrc, b + 16u, level_off_bytes);
+    const f32x4 ab1 = sn_table_load_pair(rsrc, b, o_z1), cd1 = sn_table_load_pair(rsrc, b + 16u, o_z1);
+    const float ox = off[0], oy = off[1], oz = off[2];
+    f32x2 out;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float z0 = fmaf(ox, ab0[2 + c], fmaf(oy, fmaf(ox, cd0[2 + c], cd0[c]), ab0[c]));
+        const float z1 = fmaf(ox, ab1[2 + c], fmaf(oy, fmaf(ox, cd1[2 + c], cd1[c]), ab1[c]));
+        out[c] = fmaf(z1 - z0, oz, z0);
+    }
+    return out;
+}
+
+// builds one level in bilinear-coefficient form: one thread per grid point, entry i <-> (x, y, z) = (i % R, i / R % R, i / R^2)
+__global__ void sn_build_bc_copy_kernel(const float* __restrict__ table, float* __restrict__ dense, int level, int log2_t, uint32_t R, float scale) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * R * R) return;
+    const uint32_t x = i % R, y = (i / R) % R, z = i / (R * R);
+    const uint32_t mask = (1u << log2_t) - 1u;
+    const f32x2* lv = (const f32x2*)table + ((uint64_t)level << log2_t);
+    auto row = [&](uint32_t xx, uint32_t yy) {
+        const f32x2 v = lv[(xx ^ (yy * 2654435761u) ^ (z * 805459861u)) & mask];
+        return f32x2{v.x * scale, v.y * scale};
+    };
+    const f32x2 v00 = row(x, y), v10 = row(x + 1u, y), v01 = row(x, y + 1u), v11 = row(x + 1u, y + 1u);
+    f32x4* e = (f32x4*)dense + (uint64_t)i * 2u;
+    {
+#pragma clang fp contract(off)
+        const f32x2 B = v10 - v00, Cc = v01 - v00, D = (v11 - v10) - Cc;  // plain IEEE subtractions (the tests rebuild them with torch)
+        e[0] = f32x4{v00.x, v00.y, B.x, B.y};
+        e[1] = f32x4{Cc.x, Cc.y, D.x, D.y};
+    }
+}
+
+// builds D_l for one level in plain-row form: one thread per entry, entry i holds grid point (x, y, z) = (i % R, i / R % R, i / R^2)
 // scale: an exact power of two applied to the copied values (the "feature scale" of the split-precision MLPs, sn_api.hip
 // plan_split_scales: the consuming layer's weights carry its inverse)
 __global__ void sn_build_dense_copy_kernel(const float* __restrict__ table, float* __restrict__ dense, int level, int log2_t, uint32_t R,
-                                           int perm, float scale) {
+                                           float scale) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R * R * R) return;
-    const uint32_t c0 = i % R, c1 = (i / R) % R, c2 = i / (R * R);
-    const uint32_t x = perm == 1 ? c1 : (perm == 2 ? c2 : c0), y = perm == 1 ? c0 : c1, z = perm == 2 ? c0 : c2;
+    const uint32_t x = i % R, y = (i / R) % R, z = i / (R * R);
     const uint32_t mask = (1u << log2_t) - 1u;
     const uint32_t row = (x ^ (y * 2654435761u) ^ (z * 805459861u)) & mask;
     const f32x2* lv = (const f32x2*)table + ((uint64_t)level << log2_t);
@@ -425,12 +481,14 @@ __global__ void sn_absmax_kernel(const float* __restrict__ x, size_t n, uint32_t
 // With ND >= 0 the dense levels use the paired 16-byte gathers of sn_hash_level_dense_pairs.
 // DUMP / rec (test instrumentation behind sn_render_rays_debug; include/signerf_hip.h "SnDebugDump"): where `rec` is non-null the
 // lane records, per level, the 8 words that identify what it fetched: a hashed level -> the byte offsets of its 8 rows within the
-// level, nerfstudio corner order; a de-hashed level -> words 0..3 = byte offsets of the four 16-byte fetches within the buffer of
-// copies, word 4 = 0xD0000000 | orientation set.  Taken from the very registers that feed the loads.
-template <int L, int GROUP = 0, int ARITH = 0, int ND = -1, bool DUMP = false>
+// level, nerfstudio corner order; a de-hashed level in plain-row form -> words 0..3 = byte offsets of the four 16-byte fetches within
+// the buffer of copies, word 4 = 0xD0000000; in bilinear-coefficient form -> words 0, 1 = byte offsets of the z and z + 1 entries
+// (32 bytes each), word 4 = 0xB0000000.  Taken from the very registers that feed the loads.
+// NBC (ARITH 1, ND > 0): levels [0, NBC) of the de-hashed copies are in bilinear-coefficient form (SnDenseCopy::n_bc).
+template <int L, int GROUP = 0, int ARITH = 0, int ND = -1, bool DUMP = false, int NBC = 0>
 SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], float* feat,
-                           const SnGridLevels* grid = nullptr, const SnDenseCopy* dense = nullptr, const float* qdense = nullptr,
-                           uint32_t dense_set_off = 0u, uint32_t* rec = nullptr, float plain_scale = 1.0f) {
+                           const SnGridLevels* grid = nullptr, const SnDenseCopy* dense = nullptr, uint32_t* rec = nullptr,
+                           float plain_scale = 1.0f) {
     constexpr bool FAST = ARITH != 0;
     const uint32_t mask = (1u << log2_t) - 1u;
 #pragma unroll
@@ -445,11 +503,13 @@ SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int l
         if (ARITH == 1 && ND > 0 && l < ND && l < 12) {  // torch grid: de-hashed copy of a coarse level
             uint32_t R = dense->res[l];
             asm volatile("" : "+s"(R));  // keep the per-level strides out of the loop-invariant set (SGPR pressure, see sn_grid_dense_res)
-            // qdense / dense_set_off: the position with its axes in the order of the orientation set this wave reads (or q, set 0)
-            const f32x2 e = sn_hash_level_dense_copy(sn_table_rsrc(dense->base, dense->bytes), dense->off[l] + dense_set_off, qdense ? qdense : q, scal[l], R,
-                                                     DUMP && rec ? rec + 8 * l : nullptr);
+            const __amdgpu_buffer_rsrc_t drsrc = sn_table_rsrc(dense->base, dense->bytes);
+            uint32_t* lrec = DUMP && rec ? rec + 8 * l : nullptr;
+            const f32x2 e = l < NBC ? sn_hash_level_dense_bc(drsrc, dense->off[l], q, scal[l], R, lrec)
+                                    : sn_hash_level_dense_copy(drsrc, dense->off[l], q, scal[l], R, lrec);
             if (DUMP && rec) {
-                rec[8 * l + 4] = 0xD0000000u | (dense->perm_stride ? dense_set_off / dense->perm_stride : 0u);
+                if (l < NBC) rec[8 * l + 2] = rec[8 * l + 3] = 0u;
+                rec[8 * l + 4] = l < NBC ? 0xB0000000u : 0xD0000000u;
                 rec[8 * l + 5] = rec[8 * l + 6] = rec[8 * l + 7] = 0u;
             }
             feat[2 * l] = e.x;

@@ -404,6 +404,14 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
 #ifndef SN_MAIN_WAVES_PER_SIMD
 #define SN_MAIN_WAVES_PER_SIMD 3
 #endif
+// how many of the leading de-hashed levels are kept in bilinear-coefficient form (sn_device.h SnDenseCopy::n_bc; 32 bytes per grid
+// point: levels 0-8 of the main grid are 0.51 GB, level 9 alone would add 0.82 GB) -- host and kernels read the same constants
+#ifndef SN_BC_MAIN
+#define SN_BC_MAIN 9
+#endif
+#ifndef SN_BC_PROP
+#define SN_BC_PROP 5
+#endif
 
 struct SnMainParams {
     const float* origins;     // [H*W,3]
@@ -500,17 +508,6 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
     else shh.build(d, p.sh_remap);
 
     const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table, (16u << p.log2_t) * 8u);
-    // Orientation of the de-hashed copies for this wave: the grid axis along which the pixel row moves (direction of lane 1 minus
-    // lane 0) becomes the fast axis, so the 8 lanes of a tile row gather neighbouring entries.  Wave-uniform.
-    int dsel = 0;
-    if (GRID == 0 && ND > 0 && p.dense.perm_stride != 0u) {
-        const float ax = fabsf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(d[0]), 1)) - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d[0]), 0)));
-        const float ay = fabsf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(d[1]), 1)) - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d[1]), 0)));
-        const float az = fabsf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(d[2]), 1)) - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d[2]), 0)));
-        dsel = (ay > ax && ay >= az) ? 1 : ((az > ax && az > ay) ? 2 : 0);
-        dsel = __builtin_amdgcn_readfirstlane(dsel);
-    }
-    const uint32_t dense_set_off = (uint32_t)dsel * p.dense.perm_stride;
     const int S = p.n_samples;
     const float* eb = nullptr;
     if (MODE == 1) eb = p.ebins + ((int64_t)(ty * p.tiles_x + tx) * (S + 1)) * 64 + lane;
@@ -551,7 +548,6 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
         } else {
             // plain table: the x-paired layout (sn_device.h) measured no gain here (r01: 4.11 vs 4.18 ms) -- splitting a level
             // into per-t tables loses the x-locality of the plain layout (16 consecutive x share a 128-B line)
-            const float qd[3] = {dsel == 1 ? q[1] : (dsel == 2 ? q[2] : q[0]), dsel == 1 ? q[0] : q[1], dsel == 2 ? q[0] : q[2]};
 #if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 3  // experiment: the hash phase (gather issue) at raised priority
             __builtin_amdgcn_s_setprio(1);
 #endif
@@ -565,8 +561,8 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
                     p.dump_q[smp * 3 + 2] = q[2];
                 }
             }
-            sn_hash_encode<16, SN_HASH_GROUP, (GRID ? 2 : (SN_FAST_HASH ? 1 : 0)), ND, DUMP>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, qd,
-                                                                                            dense_set_off, rec, p.feat_scale);
+            sn_hash_encode<16, SN_HASH_GROUP, (GRID ? 2 : (SN_FAST_HASH ? 1 : 0)), ND, DUMP, (ND > SN_BC_MAIN ? SN_BC_MAIN : (ND > 0 ? ND : 0))>(
+                rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
 #if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 3
             __builtin_amdgcn_s_setprio(0);
 #endif

@@ -139,7 +139,7 @@ SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, cons
         sn_hash_encode<5, 0, 2, -1>(plain, scal.v, log2_t, q, feat, grid);
     } else if (ND > 0) {
         // torch grid: levels [0, ND) from their de-hashed copies (4 gathers, 6 index instructions), the rest from the x-paired tables
-        sn_hash_encode<(ND > 0 ? ND : 1), 0, 1, ND, DUMP>(plain, scal.v, log2_t, q, feat, grid, dense, nullptr, 0u, rec);
+        sn_hash_encode<(ND > 0 ? ND : 1), 0, 1, ND, DUMP, (ND > SN_BC_PROP ? SN_BC_PROP : ND)>(plain, scal.v, log2_t, q, feat, grid, dense, rec);
         if (ND < 5) sn_hash_encode_pairs<5, 0, true, (ND > 0 && ND < 5 ? ND : 0), false, DUMP>(prsrc, pi, scal.v, log2_t, q, feat, rec);
     } else {
         sn_hash_encode_pairs<5, 0, true, 0, false, DUMP>(prsrc, pi, scal.v, log2_t, q, feat, rec);

@@ -31,6 +31,40 @@ from .config import NerfactoModelConfig, SIGNeRFModelConfig
 PRECISIONS = {"fp32": 0, "fp16x2": 1}
 
 
+class _RWLock:
+    """Many render calls, or one weight upload.  The C ABI orders uploads against renders ON THE DEVICE, but the host-side sequence
+    sn_upload_weights ... sn_finalize_weights leaves the handle un-finalized in between, so a render CALL of another thread (the viewer
+    rendering on the shared model while the generator thread reloads weights) must not start inside it."""
+
+    def __init__(self):
+        self._cond = threading.Condition()
+        self._readers = 0
+        self._writer = False
+
+    def acquire_read(self):
+        with self._cond:
+            while self._writer:
+                self._cond.wait()
+            self._readers += 1
+
+    def release_read(self):
+        with self._cond:
+            self._readers -= 1
+            if self._readers == 0:
+                self._cond.notify_all()
+
+    def acquire_write(self):
+        with self._cond:
+            while self._writer or self._readers:
+                self._cond.wait()
+            self._writer = True
+
+    def release_write(self):
+        with self._cond:
+            self._writer = False
+            self._cond.notify_all()
+
+
 # ------------------------------------------------------------------------------------------------------
 # parameter containers (state-dict layout of nerfstudio's "torch" implementation)
 # ------------------------------------------------------------------------------------------------------
@@ -234,6 +268,7 @@ class NerfactoModel(nn.Module):
         self._handle_device = None
         self._weights_dirty = True
         self._weights_lock = threading.Lock()
+        self._engine_rw = _RWLock()
         self._grid_cache: Dict = {}
         self._fallback_warned = False
         self.populate_modules()
@@ -339,8 +374,12 @@ class NerfactoModel(nn.Module):
                     _lib.check(lib.sn_create(C.byref(desc), C.byref(self._handle)), None, "sn_create")
                 self._handle_device = self.device
             if self._weights_dirty:
-                self._upload(lib)
-                self._weights_dirty = False
+                self._engine_rw.acquire_write()   # no render call of another thread between the first upload and finalize
+                try:
+                    self._upload(lib)
+                    self._weights_dirty = False
+                finally:
+                    self._engine_rw.release_write()
         if not self._fallback_warned and self.effective_precision != self.config.precision:
             self._fallback_warned = True
             warnings.warn(f"signerf_amd: precision={self.config.precision!r} cannot hold fp32 grade for these parameters; "
@@ -475,9 +514,13 @@ class NerfactoModel(nn.Module):
             o, keep = self._opts(H, W, lib)
             normals = torch.empty((H * W, 3), dtype=torch.float32, device=dev)
             pred = torch.empty((H * W, 3), dtype=torch.float32, device=dev) if self._has_pred_normals else None
-            st = lib.sn_render_normals(self._handle, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(nears), _lib.ptr(fars), H, W,
-                                       C.byref(o), _lib.ptr(normals), _lib.ptr(pred), _lib.current_stream())
-            _lib.check(st, self._handle, "sn_render_normals")
+            self._engine_rw.acquire_read()
+            try:
+                st = lib.sn_render_normals(self._handle, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(nears), _lib.ptr(fars), H, W,
+                                           C.byref(o), _lib.ptr(normals), _lib.ptr(pred), _lib.current_stream())
+                _lib.check(st, self._handle, "sn_render_normals")
+            finally:
+                self._engine_rw.release_read()
             del keep
         return {"normals": normals, "pred_normals": pred} if pred is not None else {"normals": normals}
 
@@ -498,10 +541,14 @@ class NerfactoModel(nn.Module):
             rgb, depth, acc, exp = new(3), new(1), new(1), new(1)
             props = [new(1) for _ in range(self.config.num_proposal_iterations)]
             pp = [_lib.ptr(p) for p in props] + [None] * (2 - len(props))
-            st = lib.sn_render_rays(self._handle, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(nears), _lib.ptr(fars), H, W,
-                                    C.byref(o), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc), _lib.ptr(exp), pp[0], pp[1],
-                                    _lib.current_stream())
-            _lib.check(st, self._handle, "sn_render_rays")
+            self._engine_rw.acquire_read()
+            try:
+                st = lib.sn_render_rays(self._handle, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(nears), _lib.ptr(fars), H, W,
+                                        C.byref(o), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc), _lib.ptr(exp), pp[0], pp[1],
+                                        _lib.current_stream())
+                _lib.check(st, self._handle, "sn_render_rays")
+            finally:
+                self._engine_rw.release_read()
             # the workspace and grids are consumed by work already enqueued on this stream; the caching allocator
             # is stream-ordered, so dropping `keep` here is safe.
             del keep

@@ -8,7 +8,8 @@ and read most levels from derived buffers (de-hashed copies, x-paired tables).  
 with their DUMP flag (sn_render_rays_debug), record what every ray-sample fetched, and the records are mapped back to rows of the
 uploaded hash tables:
 
-  A. the derived buffers hold exactly the table's rows (every entry of every copy / pair table);
+  A. the derived buffers hold exactly what they claim, computed from the table's rows (every entry of every copy / pair table:
+     plain rows, or the bilinear coefficients {v00, v10 - v00, v01 - v00, (v11 - v10) - (v01 - v00)} of the coarsest levels);
   B. GIVEN the position a kernel hashed (also dumped), the rows it fetched are the oracle's rows, bit for bit -- every level, every
      corner, every sample (the "c" corner is floor + 1: it differs from the oracle's ceil only where that corner's weight is exactly 0);
   C. the positions differ from the oracle's strict-IEEE positions by a few ulp; the voxel-boundary flips that causes are COUNTED and
@@ -52,26 +53,28 @@ def _decode(rec, lay, log2_t):
     for l in range(L):
         r = rec[:, l]
         t = tag[:, l]
-        if bool((t == 0xD).all()):  # de-hashed copy
-            assert l < lay["n_dense"]
+        if bool((t == 0xB).all()):  # de-hashed copy, bilinear-coefficient form: 32-byte entries of (x0, y0, z0) and (x0, y0, z0 + 1)
+            assert l < lay["n_bc"]
             R = lay["dense_res"][l]
-            st = r[:, 4] & 0xF
-            assert int(st.max()) <= 2 and (lay["dense_set_stride"] > 0 or int(st.max()) == 0)
-            ent = (r[:, 0:4] - (st * lay["dense_set_stride"])[:, None] - lay["dense_off"][l])
+            ent = r[:, 0:2] - lay["dense_off"][l]
+            assert bool((ent % 32 == 0).all()) and bool((ent >= 0).all())
+            ent = ent // 32
+            x, y, z = ent % R, (ent // R) % R, ent // (R * R)
+            assert bool((x[:, 1] == x[:, 0]).all() and (y[:, 1] == y[:, 0]).all() and (z[:, 1] == z[:, 0] + 1).all())
+            assert int(x.max()) + 1 < R and int(y.max()) + 1 < R and int(z.max()) < R     # every row an entry stands for is a grid point of the copy
+            rows[:, l] = _rows_from_floor(torch.stack([x[:, 0], y[:, 0], z[:, 0]], dim=-1), log2_t)
+        elif bool((t == 0xD).all()):  # de-hashed copy, plain rows: four 16-byte fetches (y1 z1), (y0 z1), (y0 z0), (y1 z0), each x0 and x0 + 1
+            assert lay["n_bc"] <= l < lay["n_dense"]
+            R = lay["dense_res"][l]
+            ent = r[:, 0:4] - lay["dense_off"][l]
             assert bool((ent % 8 == 0).all()) and bool((ent >= 0).all())
             ent = ent // 8
             c0, c1, c2 = ent % R, (ent // R) % R, ent // (R * R)
-            # fetch order: (y1 z1), (y0 z1), (y0 z0), (y1 z0) in the copy's own axes; all four share c0
             assert bool((c0 == c0[:, 2:3]).all())
             assert bool((c1[:, 0] == c1[:, 2] + 1).all() and (c1[:, 1] == c1[:, 2]).all() and (c1[:, 3] == c1[:, 2] + 1).all())
             assert bool((c2[:, 0] == c2[:, 2] + 1).all() and (c2[:, 1] == c2[:, 2] + 1).all() and (c2[:, 3] == c2[:, 2]).all())
             assert int(c0.max()) + 1 < R and int(c1.max()) < R and int(c2.max()) < R   # the x0 + 1 entry stays inside the level
-            f0, f1, f2 = c0[:, 2], c1[:, 2], c2[:, 2]
-            # orientation set: 0 (c0,c1,c2) = (x,y,z); 1 = (y,x,z); 2 = (z,y,x)
-            x = torch.where(st == 1, f1, torch.where(st == 2, f2, f0))
-            y = torch.where(st == 1, f0, f1)
-            z = torch.where(st == 2, f0, f2)
-            rows[:, l] = _rows_from_floor(torch.stack([x, y, z], dim=-1), log2_t)
+            rows[:, l] = _rows_from_floor(torch.stack([c0[:, 2], c1[:, 2], c2[:, 2]], dim=-1), log2_t)
         elif bool((t == 0xA).all()):  # x-paired tables
             tt = r[:, 4] & 0xFF
             rel = r[:, 0:4] - lay["pair_base"][l]
@@ -153,23 +156,27 @@ def test_dehashed_copies_hold_the_tables_rows(full_model, gpu, which):
     table = sd[f"{prefix}.encoder.hash_table"].to(gpu).view(hc.num_levels, 1 << hc.log2_hashmap_size, 2)
     sc = onf.hash_scalings(hc.num_levels, hc.base_res, hc.max_res)
     buf = ops.debug_read(model, which, 0)
-    assert lay["n_dense"] == (11 if which < 0 else (5, 4)[which])
+    assert lay["n_dense"] == (11 if which < 0 else (5, 4)[which]) and lay["n_bc"] == (9 if which < 0 else (5, 4)[which])
     fs = lay["feature_scale"]
     assert fs > 0 and float(np.log2(fs)).is_integer() and 512.0 <= fs * float(table.abs().max()) <= 1024.0
-    n_sets = 3 if lay["dense_set_stride"] else 1   # (three orientation sets of the main grid only with SN_DENSE_ORIENT=1)
     checked = 0
     for l in range(lay["n_dense"]):
         R = lay["dense_res"][l]
         assert R == int(sc[l]) + 2
         e = torch.arange(R * R * R, device=gpu, dtype=torch.int64)
-        c0, c1, c2 = e % R, (e // R) % R, e // (R * R)
-        for st in range(n_sets):
-            x, y, z = (c0, c1, c2) if st == 0 else ((c1, c0, c2) if st == 1 else (c2, c1, c0))
-            want = table[l][_hash(x, y, z, hc.log2_hashmap_size)] * lay["feature_scale"]   # an exact power of two (range conditioning)
-            base = (st * lay["dense_set_stride"] + lay["dense_off"][l]) // 4
+        x, y, z = e % R, (e // R) % R, e // (R * R)
+        v = lambda dx, dy: table[l][_hash(x + dx, y + dy, z, hc.log2_hashmap_size)] * fs   # noqa: E731  (fs: an exact power of two)
+        base = lay["dense_off"][l] // 4
+        if l < lay["n_bc"]:   # {A, B | C, D}: the kernel's own plain fp32 subtractions, rebuilt here with torch
+            v00, v10, v01, v11 = v(0, 0), v(1, 0), v(0, 1), v(1, 1)
+            c = v01 - v00
+            want = torch.cat([v00, v10 - v00, c, (v11 - v10) - c], dim=1)
+            got = buf[base: base + 8 * R * R * R].view(-1, 8)
+        else:
+            want = v(0, 0)
             got = buf[base: base + 2 * R * R * R].view(-1, 2)
-            assert torch.equal(got, want), f"field {which} level {l} set {st}"
-            checked += R * R * R
+        assert torch.equal(got, want), f"field {which} level {l}"
+        checked += R * R * R
     print(f"field {which}: {checked} copied entries identical to table[hash(x, y, z)] x {lay['feature_scale']:g}")
 
 
@@ -243,26 +250,6 @@ def test_config2_fused_indices_full_size_crop(bench_model, gpu, cam, y0, x0):
     cfg, model, sd = bench_model
     cams = Cameras(scene.benchmark_cameras(8)[:, :3], 800.0, 800.0, 400.0, 400.0, 800, 800).to(gpu)
     _run_uniform(cfg, model, sd, gpu, _bundle_crop(cams[cam], y0, x0, 40, 40), f"config 2 (40x40 crop of camera {cam}'s 800x800 frame)")
-
-
-def test_config2_fused_indices_with_orientation_sets(gpu, monkeypatch):
-    """SN_DENSE_ORIENT=1: the y- / z-fast copies and the per-wave choice among them (camera 2's pixel rows run along another grid axis
-    than camera 0's)."""
-    monkeypatch.setenv("SN_DENSE_ORIENT", "1")
-    cfg = scene.benchmark_config(64)
-    model, sd = make_model(cfg, gpu)
-    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 800.0, 800.0, 400.0, 400.0, 800, 800).to(gpu)
-    for cam in (0, 2):
-        bundle = _bundle_crop(cams[cam], 384, 384, 32, 32)
-        _run_uniform(cfg, model, sd, gpu, bundle, f"config 2, 3 orientation sets (32x32 crop of camera {cam})")
-    lay = ops.debug_layout(model, -1)
-    assert lay["dense_set_stride"] > 0
-    _, dump = ops.render_rays_debug(model, _bundle_crop(cams[2], 384, 384, 32, 32), want=("main_fetch",))
-    sets = set((dump["main_fetch"][:, :, 0, 4] & 0xF).unique().tolist()) | set((dump["main_fetch"][:, :, 5, 4] & 0xF).unique().tolist())
-    _, dump0 = ops.render_rays_debug(model, _bundle_crop(cams[0], 384, 384, 32, 32), want=("main_fetch",))
-    sets |= set((dump0["main_fetch"][:, :, 0, 4] & 0xF).unique().tolist())
-    print("orientation sets read:", sorted(sets))
-    assert len(sets) >= 2                        # the two cameras do read different sets
 
 
 def test_config4_fused_indices_proposal_path(full_model, gpu):
