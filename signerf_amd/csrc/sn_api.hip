@@ -449,7 +449,9 @@ std::vector<float> build_main_image_h(const SnFieldDesc& d, const float* W1, con
 // renders precision-1 requests with the exact fp32 MFMA path (sn_effective_precision reports it).
 float pow2_floor(double x) {
     if (!(x > 0.0) || !std::isfinite(x)) return 1.0f;
-    return (float)std::ldexp(1.0, (int)std::floor(std::log2(x)));
+    // exponent clamped to +-80: scales stay finite fp32 numbers with finite products and reciprocals whatever the parameters are
+    // (a table whose largest entry is below 2^-70 is a zero field for every practical purpose)
+    return (float)std::ldexp(1.0, std::max(-80, std::min(80, (int)std::floor(std::log2(x)))));
 }
 
 struct MainSplitPlan {

@@ -158,3 +158,26 @@ def test_proposal_nets_with_small_tables(gpu):
     e_rgb, e_depth = rmse(out["rgb"], ref["rgb"]), rmse(out["depth"], ref["depth"])
     print(f"proposal path, all tables x1e-3: rgb RMSE {e_rgb:.2e}, depth RMSE {e_depth:.2e}")
     assert e_rgb <= 1e-3 and e_depth <= 1e-3 and float(ref["rgb"].std()) > 0.05
+
+
+@pytest.mark.parametrize("table_scale", [0.0, 1e-30, float("nan")])
+def test_degenerate_tables_do_not_break_the_conditioning(gpu, table_scale):
+    """All-zero, vanishing and non-finite tables: the scales stay finite (exponents are clamped), a NaN table falls back to exact fp32 and
+    both precisions render the same thing (NaN pixels included)."""
+    cfg, model, sd = _scene(gpu, table_scale=table_scale, compensate=False)
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 32.0, 32.0, 16.0, 16.0, 32, 32).to(gpu)
+    b = cams[0].generate_rays(camera_indices=0)
+    outs = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        for prec in ("fp32", "fp16x2"):
+            model.config.precision = prec
+            outs[prec] = {k: v.clone() for k, v in model.get_outputs_for_camera_ray_bundle(b).items() if k in ("rgb", "depth", "accumulation")}
+    if table_scale != table_scale:
+        assert model.effective_precision == "fp32"
+        assert all(torch.equal(torch.nan_to_num(outs["fp32"][k], nan=-7.0), torch.nan_to_num(outs["fp16x2"][k], nan=-7.0)) for k in outs["fp32"])
+    else:
+        assert model.effective_precision == "fp16x2"
+        assert bool(torch.isfinite(outs["fp16x2"]["rgb"]).all()) and rmse(outs["fp16x2"]["rgb"], outs["fp32"]["rgb"]) <= 5e-6
+        ref = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg), b.origins.cpu(), b.directions.cpu())
+        assert rmse(outs["fp16x2"]["rgb"], ref["rgb"]) <= 1e-3
