@@ -40,6 +40,7 @@ VALU_ISSUE_CYCLES = 4.0         # one VALU / MFMA issue slot per SIMD every 4 cy
 GATHER_MIN_CYCLES = 16.0        # a 64-lane gather costs the CU's L1/TA >= 16 cycles (4 lanes per clock), DESIGN.md "What the L1 charges"
 MFMA_F16_CYCLES = 32.0          # v_mfma_f32_32x32x16_f16 pipe time per SIMD
 MFMA_F32_CYCLES = 64.0          # v_mfma_f32_32x32x2_f32
+MFMA_PORT_CYCLES = 14.0         # vector-issue-port time an f16 32x32x16 MFMA takes in the probes (12.4-16.9; its operand traffic), for the empirical model
 
 
 def measured_traffic(precision):
@@ -358,12 +359,20 @@ def main():
                     r["frac"] = r["achieved"] / r["peak"]
                     r["roof_ms"] = r["per_wave_step"] * wave_steps * r["cycles_each"] / (r["units"] * clock * 1e9) * 1e3
                 bound = max(roofs, key=lambda k: roofs[k]["frac"])
+                # Empirical issue model (NOT a roof): in the probes an f16 32x32x16 MFMA keeps the SIMD's vector issue port for ~12-17 cycles
+                # (its 24 source + 16 destination registers), not for one 4-cycle slot -- profiles/r02_overlap2_probe.txt, r02_mlp_probe.txt
+                model_cycles = cnt["valu"] * VALU_ISSUE_CYCLES + cnt["mfma"] * (MFMA_PORT_CYCLES if args.precision != "fp32" else MFMA_F32_CYCLES)
+                model_ms = model_cycles * wave_steps / (N_SIMDS * clock * 1e9) * 1e3
                 line["roofline"] = {
                     "bound": bound, "achieved": roofs[bound]["achieved"], "peak": roofs[bound]["peak"], "unit": "G wave-instructions/s",
                     "frac": roofs[bound]["frac"], "traffic": traffic, "traffic_profiled_at": traffic_commit,
                     "kernel": cnt["kernel"], "kernel_ms": k_med, "sustained_clock_ghz": clock,
                     "instructions_per_wave_step": {k: cnt[k] for k in ("valu", "mfma", "vmem_load", "lds", "packed_f32") if k in cnt} | {"gather": n_gather},
                     "roofs": roofs,
+                    "empirical_issue_model": {"ms": model_ms, "frac": model_ms / k_med,
+                                              "what": "VALU x 4 cycles + MFMA x %g cycles of vector-issue-port time per wave-step at the sustained clock "
+                                                      "(measured port cost of an MFMA; the f32-input MFMA holds the port for its whole 64 cycles)"
+                                                      % (MFMA_PORT_CYCLES if args.precision != "fp32" else MFMA_F32_CYCLES)},
                     "note": "bound = the hardware resource with the largest busy fraction at the clock the chip sustains under this kernel "
                             "(power-limited, well below the 2.4 GHz peak).  The matrix pipe hides plain VALU issued beside it only in part "
                             "(profiles/r02_overlap2_probe.txt, r02_mlp_probe.txt), so the simd-issue and matrix-pipe fractions sum to more "
