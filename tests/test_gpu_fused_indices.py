@@ -177,7 +177,8 @@ def test_dehashed_copies_hold_the_tables_rows(full_model, gpu, which):
             got = buf[base: base + 2 * R * R * R].view(-1, 2)
         assert torch.equal(got, want), f"field {which} level {l}"
         checked += R * R * R
-    print(f"field {which}: {checked} copied entries identical to table[hash(x, y, z)] x {lay['feature_scale']:g}")
+    print(f"field {which}: {checked} grid points of the copies rebuilt from table[hash(x, y, z)] x {lay['feature_scale']:g}: identical "
+          f"({lay['n_bc']} levels as bilinear coefficients, {lay['n_dense'] - lay['n_bc']} as rows)")
 
 
 @pytest.mark.parametrize("which", [0, 1])

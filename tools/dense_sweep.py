@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Value per byte of the de-hashed copies of the main grid: K1 time over the 8 reference-sheet cameras and the
-HBM footprint of the copies for 0 / 8 / 9 / 10 / 11 copied levels x 1 / 3 orientation sets, interleaved in one process.
+HBM footprint of the copies for 0 / 8 / 9 / 10 / 11 copied levels, interleaved in one process.
 
     python tools/dense_sweep.py [--reps 3] [--frames 6]
 """
