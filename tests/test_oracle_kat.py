@@ -238,3 +238,33 @@ def test_normals_outputs_are_unit_vectors_and_follow_finite_differences():
     for k in ("normals", "pred_normals"):
         v = out[k] * 2 - 1
         assert out[k].shape == (4, 3) and torch.allclose(v.norm(dim=-1), torch.ones(4), atol=1e-4), k
+
+
+def test_sh_basis_against_scipy_on_unit_directions():
+    """The 16 real-SH polynomials of `sh_components` against an independent implementation (scipy's complex spherical harmonics,
+    recombined into the real basis): component (l, m) at index l^2 + l + m must equal the real SH of that degree and order up to the
+    sign convention (nerfstudio's table follows the graphics convention without the Condon-Shortley phase) -- guards the 16
+    coefficients and monomials against transcription errors.  (On unit vectors only: nerfstudio's torch path feeds (d + 1) / 2, on
+    which the same polynomials are evaluated.)"""
+    import warnings
+
+    import numpy as np
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from scipy.special import sph_harm
+
+    g = torch.Generator().manual_seed(3)
+    d = torch.nn.functional.normalize(torch.randn(500, 3, generator=g, dtype=torch.float64), dim=-1)
+    comp = onf.sh_components(d, 4).numpy()
+    x, y, z = d[:, 0].numpy(), d[:, 1].numpy(), d[:, 2].numpy()
+    theta = np.arctan2(y, x)                 # azimuth
+    phi = np.arccos(np.clip(z, -1.0, 1.0))   # polar angle
+    for l in range(4):
+        for m in range(-l, l + 1):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")      # (scipy deprecates sph_harm in favour of sph_harm_y; either is fine here)
+                Y = sph_harm(abs(m), l, theta, phi)
+            real = Y.real if m == 0 else (np.sqrt(2.0) * (Y.imag if m < 0 else Y.real))
+            got = comp[:, l * l + l + m]
+            err = min(np.abs(got - real).max(), np.abs(got + real).max())   # equal up to the sign convention
+            assert err <= 1e-12, (l, m, err)
