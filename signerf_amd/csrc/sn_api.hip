@@ -442,7 +442,7 @@ std::vector<float> build_main_image_h(const SnFieldDesc& d, const float* W1, con
 // every layer into the upper part of the range once, on the host, at no run-time cost:
 //   features   f' = t0 f        t0 = 2^floor(log2(2^10 / max|table|)); the de-hashed copies / paired tables store t0 * row (levels read
 //                               from the uploaded table are multiplied in the kernel), the first layer's weights carry 1 / t0
-//   layer l    z_l' = s_l z_l   s_l = 2^floor(log2(2^14 / B_l)), B_l = interval bound of |z_l| over all inputs with |f| <= max|table|;
+//   layer l    z_l' = s_l z_l   s_l = 2^floor(log2(2^10 / B_l)), B_l = interval bound of |z_l| over all inputs with |f| <= max|table|;
 //                               W_l' = W_l s_l / s_(l-1), b_l' = b_l s_l; ReLU commutes with s_l > 0; the last consumer divides it out
 // B_l is a true bound, so no activation can saturate; the largest weights of a layer land in [2^-1, 2^4] by construction.  The only
 // failure left is a scaled weight outside the fp16 range (a unit whose inputs are bounded ~0 next to ordinary ones): the handle then
@@ -506,10 +506,13 @@ MainSplitPlan plan_split_scales(const SnFieldDesc& d, float table_absmax, bool s
         return pl;
     }
     pl.max_bound = std::max(std::max(m1, m2), std::max(m3, m4));
-    pl.s1 = m1 > 0 ? pow2_floor(16384.0 / m1) : 1.0f;
-    pl.s2 = m2 > 0 ? pow2_floor(16384.0 / m2) : 1.0f;
-    pl.s3 = m3 > 0 ? pow2_floor(16384.0 / m3) : 1.0f;
-    pl.s4 = m4 > 0 ? pow2_floor(16384.0 / m4) : 1.0f;
+    // target: every scaled pre-activation below 2^10 -- far inside fp16's range, and below 2048, which the ReLU folded into the operand
+    // split needs (sn_main.h sn_split2_relu: the low part a - RTZ16(a) must stay below 1 for its clamp to be a plain max(., 0))
+    const double target = SN_RELU_FOLD ? 1024.0 : 16384.0;
+    pl.s1 = m1 > 0 ? pow2_floor(target / m1) : 1.0f;
+    pl.s2 = m2 > 0 ? pow2_floor(target / m2) : 1.0f;
+    pl.s3 = m3 > 0 ? pow2_floor(target / m3) : 1.0f;
+    pl.s4 = m4 > 0 ? pow2_floor(target / m4) : 1.0f;
     return pl;
 }
 

@@ -198,8 +198,37 @@ SN_DEV void sn_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
     lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(la, lb));
 }
 
+// ReLU folded into the split (K1 only: needs the range conditioning of sn_finalize_weights, which keeps every pre-activation below 2^10):
+//   hi = max(RTZ16(a), 0) as ONE packed-f16 max for the pair;   lo = RTZ16(clamp(a - RTZ16(a), 0, 1)).
+// RTZ rounds toward zero, so a - RTZ16(a) has the sign of a: for a < 0 both parts become 0, for a >= 0 the residual is in [0, ulp16(a)) and
+// stays below 1 because |a| < 2048 -- the clamp of v_fma_mix_f32 is then exactly max(., 0).  5 instructions per pair instead of 6
+// (two v_max_i32 + the plain split): -128 VALU per wave-step.  (r01 had tried the same fold without the range guarantee and dropped it:
+// activations >= 2048 lose their low part.)
+#ifndef SN_RELU_FOLD
+#define SN_RELU_FOLD 1
+#endif
+SN_DEV void sn_split2_relu(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const uint32_t hr = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+    float la, lb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0] clamp" : "=v"(la) : "v"(hr), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(lb) : "v"(hr), "v"(b));
+    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(la, lb));
+    typedef _Float16 sn_h2 __attribute__((ext_vector_type(2)));
+    const sn_h2 zero = {(_Float16)0.0f, (_Float16)0.0f};
+    hi = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(sn_h2, hr), zero));  // v_pk_max_f16
+}
+
 struct SnOpH {  // one B operand (8 k-slots of one 32-sample tile), hi and lo parts
     u32x4 hi, lo;
+    SN_DEV void set_relu(const float v[8]) {  // operands = relu(v), see sn_split2_relu
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint32_t h, l;
+            sn_split2_relu(v[2 * e], v[2 * e + 1], h, l);
+            hi[e] = h;
+            lo[e] = l;
+        }
+    }
     SN_DEV void set(const float v[8]) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -289,9 +318,18 @@ struct SnShOpsH {
     }
 };
 
-// ReLU + split of one 32-row accumulator tile into its two B operands (k-steps 2rt, 2rt+1)
+// ReLU + split of one 32-row accumulator tile into its two B operands (k-steps 2rt, 2rt+1).
+// FOLD: the conditioned kernels fold the ReLU into the split (sn_split2_relu); the normals kernel, which splits unconditioned operands, does not.
+template <bool FOLD = false>
 SN_DEV void sn_acc_to_ops(const f32x16& acc, bool relu, SnOpH& s0, SnOpH& s1) {
     float v[16];
+    if (FOLD && relu) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[r];
+        s0.set_relu(v);
+        s1.set_relu(v + 8);
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = relu ? sn_relu(acc[r]) : acc[r];
     s0.set(v);
@@ -321,8 +359,8 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-        sn_acc_to_ops(a0[rt], true, op0[2 * rt], op0[2 * rt + 1]);
-        sn_acc_to_ops(a1[rt], true, op1[2 * rt], op1[2 * rt + 1]);
+        sn_acc_to_ops<SN_RELU_FOLD != 0>(a0[rt], true, op0[2 * rt], op0[2 * rt + 1]);
+        sn_acc_to_ops<SN_RELU_FOLD != 0>(a1[rt], true, op1[2 * rt], op1[2 * rt + 1]);
     }
     // ---- layer 2 ----
     f32x16 g0[1], g1[1];
@@ -348,8 +386,8 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-        sn_acc_to_ops(a0[rt], true, op0[2 * rt], op0[2 * rt + 1]);
-        sn_acc_to_ops(a1[rt], true, op1[2 * rt], op1[2 * rt + 1]);
+        sn_acc_to_ops<SN_RELU_FOLD != 0>(a0[rt], true, op0[2 * rt], op0[2 * rt + 1]);
+        sn_acc_to_ops<SN_RELU_FOLD != 0>(a1[rt], true, op1[2 * rt], op1[2 * rt + 1]);
     }
     // ---- colour layer 2 (two 32-row passes: halves the live accumulators, same MFMAs) + colour layer 3 on the VALU ----
     const int h = lane >> 5;
