@@ -53,6 +53,8 @@ struct SnContext {
     DevBuf wimg_normals;                // SnNormImg (sn_normals.h); built when the weights are finalized
     DevBuf wimg_normals_h;              // SnNormImgH: its fp16 hi+lo form
     bool has_pred_normals = false;      // field.mlp_pred_normals.* / field.field_head_pred_normals.* were uploaded
+    DevBuf pairs_main;            // x-paired copies of the main grid's levels that have no de-hashed copy (SN_MAIN_PAIRS, sn_main.h)
+    SnPairInfo pinfo_main{};
     DevBuf dense_main;            // de-hashed copies of the coarse levels of a torch-path main grid (sn_device.h SnDenseCopy)
     SnDenseCopy dense_info{};
     SnGridLevels dense_res{};     // their resolutions R = scale + 2, packed like a tcnn level table
@@ -530,7 +532,8 @@ const std::vector<float>* find(SnHandle h, const std::string& name, size_t count
 }
 
 // Builds the x-paired copy of one hash table (sn_device.h): per level l, (bitlen(scale_l) + 1) tables of T 16-byte entries.
-int build_pairs(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, DevBuf& pairs, SnPairInfo& info, hipStream_t st, float scale = 1.0f) {
+int build_pairs(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, DevBuf& pairs, SnPairInfo& info, hipStream_t st, float scale = 1.0f,
+                int first_level = 0) {
     const uint32_t T = 1u << d.log2_hashmap_size;
     uint64_t entries = 0;
     int n_t[SN_MAX_LEVELS];
@@ -541,6 +544,7 @@ int build_pairs(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, DevBuf&
         for (uint32_t s = (uint32_t)ceilf(d.scalings[l]) + 1u; s; s >>= 1) ++bits;
         n_t[l] = bits + 1;
         if (((gl.packed[l >> 2] >> ((l & 3) * 8)) & 0xffu) != 0u) n_t[l] = 0;  // dense tcnn level: read from the plain table
+        if (l < first_level) n_t[l] = 0;                                        // levels that are read from de-hashed copies
         info.base[l] = (uint32_t)entries;
         entries += (uint64_t)n_t[l] * T;
     }
@@ -667,6 +671,7 @@ int sn_destroy(SnHandle h) {
     if (h->weights_ev) (void)hipEventDestroy(h->weights_ev);
     h->table_main.release();
     h->dense_main.release();
+    h->pairs_main.release();
     h->wimg_main.release();
     h->wimg_main_h.release();
     h->wimg_normals.release();
@@ -965,6 +970,14 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
                                             h->dense_res_prop[i], h->nd_prop[i], st, SN_BC_PROP, h->feat_scale_prop[i]))
                 return rc;
     }
+#if SN_MAIN_PAIRS
+    // main grid, torch semantics: the levels beyond the de-hashed ones from x-paired tables (4 gathers per level instead of 8)
+    if (d.main_field.grid_mode == 0 && h->nd_torch > 0 && d.num_proposals > 0) {  // read by the bins-mode kernel only (sn_main.h)
+        if (int rc = build_pairs(h, d.main_field, h->table_main, h->pairs_main, h->pinfo_main, st, h->feat_scale_main, h->nd_torch)) return rc;
+    } else {
+        h->pairs_main.release();
+    }
+#endif
     bool wrap_ok = write_wrap_rows(d.main_field, h->table_main, st);
     for (int i = 0; i < d.num_proposals; ++i) {
         wrap_ok = write_wrap_rows(d.proposals[i], h->table_prop[i], st) && wrap_ok;
@@ -1170,6 +1183,9 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     const bool split = opts->precision == 1 && h->split_ok;  // (a handle whose weights cannot be range-conditioned renders in exact fp32)
     p.wimg = (const float*)(split ? h->wimg_main_h.ptr : h->wimg_main.ptr);
     p.feat_scale = h->feat_scale_main;
+    p.pairs = (const float*)h->pairs_main.ptr;
+    p.pairs_bytes = (uint32_t)h->pairs_main.bytes;
+    p.pinfo = h->pinfo_main;
     p.rgb = rgb;
     p.depth = depth;
     p.acc = accumulation;
@@ -1304,10 +1320,9 @@ int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out) {
     out->n_bc = (int32_t)dc.n_bc;
     out->dense_bytes = out->n_dense > 0 ? (which < 0 ? h->dense_main.bytes : h->dense_prop[which].bytes) : 0;
     out->feature_scale = which < 0 ? h->feat_scale_main : h->feat_scale_prop[which];
-    if (which >= 0) {
-        for (int l = 0; l < SN_MAX_LEVELS; ++l) out->pair_base[l] = h->pinfo_prop[which].base[l];
-        out->pair_bytes = h->pairs_prop[which].bytes;
-    }
+    const SnPairInfo& pi = which < 0 ? h->pinfo_main : h->pinfo_prop[which];
+    for (int l = 0; l < SN_MAX_LEVELS; ++l) out->pair_base[l] = pi.base[l];
+    out->pair_bytes = which < 0 ? h->pairs_main.bytes : h->pairs_prop[which].bytes;  // (main field: only for models with proposal nets)
     return SN_OK;
 }
 
@@ -1317,7 +1332,7 @@ int sn_debug_read(SnHandle h, int32_t which, int32_t what, void* dst, size_t byt
     if (!h->finalized) return fail(h, SN_ERR_STATE, "sn_debug_read: weights not finalized");
     const DevBuf* src = nullptr;
     if (what == 0) src = which < 0 ? &h->dense_main : &h->dense_prop[which];
-    else if (what == 1 && which >= 0) src = &h->pairs_prop[which];
+    else if (what == 1) src = which < 0 ? &h->pairs_main : &h->pairs_prop[which];
     if (!src || !src->ptr) return fail(h, SN_ERR_INVALID, "sn_debug_read: no such buffer");
     if (bytes != src->bytes) return fail(h, SN_ERR_INVALID, "sn_debug_read: expected " + std::to_string(src->bytes) + " bytes");
     SN_HIP(h, hipMemcpyAsync(dst, src->ptr, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -450,6 +450,15 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
 #ifndef SN_BC_PROP
 #define SN_BC_PROP 5
 #endif
+// torch grid: the hashed levels of the main field (those without a de-hashed copy) from x-paired tables -- one 16-byte gather per
+// corner pair, 4 per level instead of 8 (sn_device.h "x-paired hash tables"); 0.47 GB for nerfacto's levels 11-15.  Re-measured r02 with the
+// gather path as a co-bottleneck (same-box A/B): uniform sampler (the 800x800x64 bench) 2.88 vs 2.87-2.90 ms -- the 20 gathers saved are
+// paid back by a lower sustained clock (1.69 vs 1.75 GHz: wider fetches, more fabric traffic), as r01 had found; behind the proposal
+// sampler (samples concentrated near surfaces) the 1080p frame drops 15.82 -> 15.39 ms.  So: bins mode only, built only for models with
+// proposal nets.
+#ifndef SN_MAIN_PAIRS
+#define SN_MAIN_PAIRS 1
+#endif
 
 struct SnMainParams {
     const float* origins;     // [H*W,3]
@@ -475,6 +484,9 @@ struct SnMainParams {
     int sh_remap;
     int chunk_rays;
     float feat_scale;   // torch grid: power-of-two scale of the hash features (carried by the de-hashed copies; applied here to the other levels)
+    const float* pairs;  // SN_MAIN_PAIRS: x-paired tables of the levels >= ND (pre-scaled by feat_scale), or null
+    uint32_t pairs_bytes;
+    SnPairInfo pinfo;
     SnGridLevels grid;  // GRID 1: dense-level resolutions of the tiny-cuda-nn grid; GRID 0, ND > 0: R of the de-hashed coarse copies
     SnDenseCopy dense;  // GRID 0, ND > 0
     // test instrumentation (DUMP = 1 instantiations only; sn_render_rays_debug)
@@ -599,8 +611,17 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
                     p.dump_q[smp * 3 + 2] = q[2];
                 }
             }
-            sn_hash_encode<16, SN_HASH_GROUP, (GRID ? 2 : (SN_FAST_HASH ? 1 : 0)), ND, DUMP, (ND > SN_BC_MAIN ? SN_BC_MAIN : (ND > 0 ? ND : 0))>(
-                rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
+            if (SN_MAIN_PAIRS && MODE == 1 && GRID == 0 && ND > 0 && ND < 16) {
+                // de-hashed levels [0, ND), then the hashed levels [ND, 16) from the x-paired tables
+                sn_hash_encode<(ND > 0 ? ND : 1), SN_HASH_GROUP, 1, ND, DUMP, (ND > SN_BC_MAIN ? SN_BC_MAIN : (ND > 0 ? ND : 0))>(
+                    rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
+                __builtin_amdgcn_sched_barrier(0);
+                sn_hash_encode_pairs<16, SN_HASH_GROUP, true, (ND > 0 && ND < 16 ? ND : 0), false, DUMP>(sn_table_rsrc(p.pairs, p.pairs_bytes), p.pinfo, p.scal,
+                                                                                                       p.log2_t, q, feat, rec);
+            } else {
+                sn_hash_encode<16, SN_HASH_GROUP, (GRID ? 2 : (SN_FAST_HASH ? 1 : 0)), ND, DUMP, (ND > SN_BC_MAIN ? SN_BC_MAIN : (ND > 0 ? ND : 0))>(
+                    rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
+            }
 #if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 3
             __builtin_amdgcn_s_setprio(0);
 #endif

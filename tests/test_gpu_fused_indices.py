@@ -181,17 +181,20 @@ def test_dehashed_copies_hold_the_tables_rows(full_model, gpu, which):
           f"({lay['n_bc']} levels as bilinear coefficients, {lay['n_dense'] - lay['n_bc']} as rows)")
 
 
-@pytest.mark.parametrize("which", [0, 1])
+@pytest.mark.parametrize("which", [-1, 0, 1])
 def test_paired_tables_hold_the_tables_rows(full_model, gpu, which):
+    """The x-paired tables: every level of a proposal net; for the main field the levels that have no de-hashed copy (read by K1 behind
+    the proposal sampler)."""
     cfg, model, sd = full_model
     lay = ops.debug_layout(model, which)
-    hc = oracle_config(cfg).proposals[which]
+    hc = oracle_config(cfg).main if which < 0 else oracle_config(cfg).proposals[which]
+    prefix = "field.mlp_base" if which < 0 else f"proposal_networks.{which}.mlp_base"
     T = 1 << hc.log2_hashmap_size
-    table = sd[f"proposal_networks.{which}.mlp_base.encoder.hash_table"].to(gpu).view(hc.num_levels, T, 2)
+    table = sd[f"{prefix}.encoder.hash_table"].to(gpu).view(hc.num_levels, T, 2)
     sc = onf.hash_scalings(hc.num_levels, hc.base_res, hc.max_res)
     pairs = ops.debug_read(model, which, 1).view(-1, 4)
     r = torch.arange(T, device=gpu, dtype=torch.int64)
-    for l in range(hc.num_levels):
+    for l in range(lay["n_dense"] if which < 0 else 0, hc.num_levels):
         n_t = (int(np.ceil(float(sc[l]))) + 1).bit_length() + 1
         for t in range(n_t):
             m = ((2 << t) - 1) & (T - 1)
