@@ -459,6 +459,9 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
 #ifndef SN_MAIN_PAIRS
 #define SN_MAIN_PAIRS 1
 #endif
+#ifndef SN_STRIP_W
+#define SN_STRIP_W 8  // r02 same-box A/B over widths 0 / 4 / 8 / 12 / 16: 2.826 / 2.803 / 2.805 / 2.817 / 2.823 ms (camera 0)
+#endif
 
 struct SnMainParams {
     const float* origins;     // [H*W,3]
@@ -533,8 +536,26 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
     // workgroup = 2x2 tiles
     const int gbx = (p.tiles_x + 1) >> 1, gby = (p.tiles_y + 1) >> 1;
     const int blk = sn_xcd_remap(blockIdx.x, gbx * gby);
-    const int tx = (blk % gbx) * 2 + (wave & 1);
-    const int ty = (blk / gbx) * 2 + (wave >> 1);
+    // linear index -> workgroup coordinates.  SN_STRIP_W > 0: column strips SN_STRIP_W workgroups wide, each walked row by row, so that the
+    // ~96 workgroups an XCD runs at a time cover a squarer patch of the image (more voxels shared in its L2) than two full-width rows
+    int bx, by;
+    if (SN_STRIP_W > 0) {
+        const int full = (gbx / SN_STRIP_W) * SN_STRIP_W * gby;  // workgroups inside complete strips
+        if (blk < full) {
+            const int strip = blk / (SN_STRIP_W * gby), r = blk % (SN_STRIP_W * gby);
+            bx = strip * SN_STRIP_W + r % SN_STRIP_W;
+            by = r / SN_STRIP_W;
+        } else {
+            const int w = gbx - (gbx / SN_STRIP_W) * SN_STRIP_W, r = blk - full;  // the narrower last strip
+            bx = (gbx / SN_STRIP_W) * SN_STRIP_W + r % w;
+            by = r / w;
+        }
+    } else {
+        bx = blk % gbx;
+        by = blk / gbx;
+    }
+    const int tx = bx * 2 + (wave & 1);
+    const int ty = by * 2 + (wave >> 1);
     if (tx >= p.tiles_x || ty >= p.tiles_y) return;  // wave-uniform
     const int tw = 1 << p.tile_w_log2;
     const int px = (tx << p.tile_w_log2) + (lane & (tw - 1));
