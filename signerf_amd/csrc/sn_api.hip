@@ -63,7 +63,6 @@ struct SnContext {
     SnDenseCopy dense_info_prop[SN_MAX_PROPOSALS]{};
     SnGridLevels dense_res_prop[SN_MAX_PROPOSALS]{};
     int nd_prop[SN_MAX_PROPOSALS] = {0, 0};
-    bool dense_pairs_ok = true;  // tcnn grids: every dense level is shorter than its slot (room for the wrap row, sn_finalize_weights)
     // Range conditioning of the split-precision (fp16 hi + lo) MLPs, decided by sn_finalize_weights (plan_split_scales):
     float feat_scale_main = 1.0f;                      // power of two carried by the main grid's de-hashed copies (1 for tcnn grids)
     float feat_scale_prop[SN_MAX_PROPOSALS] = {1.0f, 1.0f};  // ... by a proposal net's de-hashed copies and paired tables
@@ -203,12 +202,14 @@ int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, 
     nd_out = 0;
     memset(&info, 0, sizeof(info));
     memset(&res, 0, sizeof(res));
-    if (d.grid_mode != 0 || want <= 0 || !table.ptr) return SN_OK;
+    if (want <= 0 || !table.ptr) return SN_OK;
+    const SnGridLevels tcnn_dense = grid_levels(d);  // tiny-cuda-nn: resolution of the levels it indexes densely (all 0 for torch grids)
     uint64_t bytes = 0;
     uint32_t R[12];
     int nd = 0;
     for (int l = 0; l < want && l < d.num_levels && l < 12; ++l) {
-        const uint64_t r = (uint64_t)d.scalings[l] + 2;
+        // grid points per axis a sample can touch: torch x = q scale in [0, scale) -> floor + 1 <= scale + 1; tcnn x = scale q + 0.5
+        const uint64_t r = d.grid_mode == 0 ? (uint64_t)d.scalings[l] + 2 : (uint64_t)floorf(d.scalings[l] + 0.5f) + 2;
         if (r > 700 || r * r * r * 8 > cap_mb * 1000 * 1000) break;  // 32 R^2 (bilinear-coefficient entries) must fit 24 bits
         R[l] = (uint32_t)r;
         info.off[l] = (uint32_t)bytes;
@@ -228,10 +229,11 @@ int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, 
     for (int l = 0; l < nd; ++l) {
         const uint32_t n = R[l] * R[l] * R[l];
         float* dst = (float*)((char*)buf.ptr + info.off[l]);
+        const uint32_t dres = (tcnn_dense.packed[l >> 2] >> ((l & 3) * 8)) & 0xffu;
         if (l < bc_levels)
-            hipLaunchKernelGGL(sn_build_bc_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)table.ptr, dst, l, d.log2_hashmap_size, R[l], scale);
+            hipLaunchKernelGGL(sn_build_bc_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)table.ptr, dst, l, d.log2_hashmap_size, R[l], scale, dres);
         else
-            hipLaunchKernelGGL(sn_build_dense_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)table.ptr, dst, l, d.log2_hashmap_size, R[l], scale);
+            hipLaunchKernelGGL(sn_build_dense_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)table.ptr, dst, l, d.log2_hashmap_size, R[l], scale, dres);
         info.res[l] = R[l];
     }
     SN_HIP(h, hipGetLastError());
@@ -240,27 +242,6 @@ int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, 
     info.n_bc = (uint32_t)std::min(nd, std::max(bc_levels, 0));
     nd_out = nd;
     return SN_OK;
-}
-
-// tiny-cuda-nn dense levels: copy row 0 of the level behind its last row, so that a 16-byte read at the last row returns the
-// wrapped x + 1 corner (sn_hash_level_dense_pairs).  Returns false if some dense level fills its whole slot (no room).
-bool write_wrap_rows(const SnHashMlpDesc& d, const DevBuf& table, hipStream_t st) {
-    if (d.grid_mode != 1) return true;
-    const SnGridLevels g = grid_levels(d);
-    const uint64_t T = 1ull << d.log2_hashmap_size;
-    bool ok = true;
-    for (int l = 0; l < d.num_levels; ++l) {
-        const uint64_t r = (g.packed[l >> 2] >> ((l & 3) * 8)) & 0xffu;
-        if (!r) continue;
-        const uint64_t size = ((r * r * r + 7) / 8) * 8;
-        if (size >= T) {
-            ok = false;
-            continue;
-        }
-        char* lvl = (char*)table.ptr + ((uint64_t)l * T) * 8;
-        (void)hipMemcpyAsync(lvl + size * 8, lvl, 8, hipMemcpyDeviceToDevice, st);
-    }
-    return ok;
 }
 
 // number of leading dense levels if the dense levels form a prefix of the level list, else -1
@@ -780,8 +761,7 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         memcpy(&absmax_main, &bits[0], 4);
         for (int i = 0; i < SN_MAX_PROPOSALS; ++i) memcpy(&absmax_prop[i], &bits[1 + i], 4);
     }
-    const bool torch_main = d.main_field.grid_mode == 0;
-    const MainSplitPlan pl = plan_split_scales(d, absmax_main, torch_main, t[0]->data(), t[1]->data(), t[2]->data(), t[3]->data(), t[4]->data(),
+    const MainSplitPlan pl = plan_split_scales(d, absmax_main, true, t[0]->data(), t[1]->data(), t[2]->data(), t[3]->data(), t[4]->data(),
                                                t[5]->data(), t[6]->data(), t[7]->data(), app->data());
     h->feat_scale_main = pl.t0;
     h->split_ok = pl.ok;
@@ -908,7 +888,7 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         // range conditioning of the net's one matrix-core layer (see plan_split_scales): features carry t0p (stored in the net's
         // de-hashed copies and paired tables), the hidden layer s1p; both are divided out by the weights around them
         double t0p = 1.0, s1p = 1.0;
-        if (d.proposals[i].grid_mode == 0 && std::isfinite(absmax_prop[i]) && absmax_prop[i] > 0.0f) {
+        if (std::isfinite(absmax_prop[i]) && absmax_prop[i] > 0.0f) {
             const double M = absmax_prop[i];
             t0p = pow2_floor(1024.0 / M);
             double m1 = 0.0;
@@ -972,18 +952,14 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
     }
 #if SN_MAIN_PAIRS
     // main grid, torch semantics: the levels beyond the de-hashed ones from x-paired tables (4 gathers per level instead of 8)
-    if (d.main_field.grid_mode == 0 && h->nd_torch > 0 && d.num_proposals > 0) {  // read by the bins-mode kernel only (sn_main.h)
+    if (h->nd_torch > 0 && d.num_proposals > 0) {  // read by the bins-mode kernel only (sn_main.h)
         if (int rc = build_pairs(h, d.main_field, h->table_main, h->pairs_main, h->pinfo_main, st, h->feat_scale_main, h->nd_torch)) return rc;
     } else {
         h->pairs_main.release();
     }
 #endif
-    bool wrap_ok = write_wrap_rows(d.main_field, h->table_main, st);
-    for (int i = 0; i < d.num_proposals; ++i) {
-        wrap_ok = write_wrap_rows(d.proposals[i], h->table_prop[i], st) && wrap_ok;
+    for (int i = 0; i < d.num_proposals; ++i)
         if (int rc = build_pairs(h, d.proposals[i], h->table_prop[i], h->pairs_prop[i], h->pinfo_prop[i], st, h->feat_scale_prop[i])) return rc;
-    }
-    h->dense_pairs_ok = wrap_ok;
     SN_HIP(h, hipGetLastError());
     SN_HIP(h, hipStreamSynchronize(st));
     mark_weights_written(h, st);
@@ -1092,10 +1068,8 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
         pp.tables[i] = (const float*)h->table_prop[i].ptr;
         pp.table_bytes[i] = (uint32_t)h->table_prop[i].bytes;
         pp.grid[i] = grid_levels(d.proposals[i]);
-        if (d.proposals[i].grid_mode == 0 && h->nd_prop[i] > 0) {
-            pp.grid[i] = h->dense_res_prop[i];
-            pp.dense[i] = h->dense_info_prop[i];
-        }
+        pp.feat_scale[i] = h->feat_scale_prop[i];
+        pp.dense[i] = h->dense_info_prop[i];
         pp.log2_t[i] = d.proposals[i].log2_hashmap_size;
         for (int l = 0; l < 5; ++l) pp.scal[i][l] = d.proposals[i].scalings[l];
         pp.n_samples[i] = opts->num_proposal_samples[i];
@@ -1115,16 +1089,22 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
             pp.dump_pdf[i] = dump->pdf_index[i];
             pp.dump_q[i] = dump->prop_q[i];
         }
+        for (int i = 0; i < nprop; ++i) pp.grid[i] = h->dense_res_prop[i];
         hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4, true>), pgrid, pblock, 0, st, pp);
     } else
     if (d.proposals[0].grid_mode == 1) {
-        // nerfacto's proposal nets (max_res 128 / 256, T = 2^17) have 3 and 2 leading dense levels; other shapes take the
-        // run-time form
-        const int nd0 = leading_dense(d.proposals[0]), nd1 = nprop > 1 ? leading_dense(d.proposals[1]) : 2;
-        if (nd0 == 3 && nd1 == 2 && h->dense_pairs_ok) hipLaunchKernelGGL((sn_proposal_kernel<1, 3, 2>), pgrid, pblock, 0, st, pp);
-        else hipLaunchKernelGGL((sn_proposal_kernel<1, -1, -1>), pgrid, pblock, 0, st, pp);
+        // nerfacto's proposal nets (max_res 128 / 256): 5 and 4 levels have de-hashed copies, which must cover every level tiny-cuda-nn
+        // indexes densely (3 and 2 at T = 2^17); other shapes read the uploaded tables with the per-level run-time decision
+        const int td0 = leading_dense(d.proposals[0]), td1 = nprop > 1 ? leading_dense(d.proposals[1]) : 0;
+        if (nprop == 2 && h->nd_prop[0] == 5 && h->nd_prop[1] == 4 && td0 >= 0 && td0 <= 5 && td1 >= 0 && td1 <= 4) {
+            for (int i = 0; i < nprop; ++i) pp.grid[i] = h->dense_res_prop[i];
+            hipLaunchKernelGGL((sn_proposal_kernel<1, 5, 4>), pgrid, pblock, 0, st, pp);
+        } else {
+            hipLaunchKernelGGL((sn_proposal_kernel<1, -1, -1>), pgrid, pblock, 0, st, pp);
+        }
     } else if (nprop == 2 && h->nd_prop[0] == 5 && h->nd_prop[1] == 4) {
         // nerfacto's nets (max_res 128 / 256): every level but the finest of the second net has a de-hashed copy
+        for (int i = 0; i < nprop; ++i) pp.grid[i] = h->dense_res_prop[i];
         const char* fast = getenv("SN_PDF_FAST");  // A/B knob (sn_pdf_lane): reciprocal multiplications instead of IEEE divisions, -0.8 %
         if (fast && atoi(fast)) hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4, false, true>), pgrid, pblock, 0, st, pp);
         else hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4>), pgrid, pblock, 0, st, pp);
@@ -1206,8 +1186,13 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     p.avg_density = d.average_init_density;
     p.sh_remap = d.sh_remap;
     p.chunk_rays = opts->chunk_rays;
+    const bool tcnn = d.main_field.grid_mode == 1;
+    // de-hashed copies are used when they cover every level tiny-cuda-nn indexes densely (always true for torch grids and for nerfacto's
+    // tcnn shapes); otherwise the run-time variant (ND = -1) reads the uploaded table
+    const int td = tcnn ? leading_dense(d.main_field) : 0;
+    const bool use_copies = h->nd_torch > 0 && (!tcnn || (td >= 0 && td <= h->nd_torch));
     p.grid = grid_levels(d.main_field);
-    if (d.main_field.grid_mode == 0 && h->nd_torch > 0) {
+    if (use_copies) {
         p.grid = h->dense_res;
         p.dense = h->dense_info;
     }
@@ -1217,34 +1202,23 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     const dim3 grid((unsigned)(gbx * gby)), block(256);
 #define SN_LAUNCH_MAIN(MODE, PREC, ABL, GRID, ND) \
     hipLaunchKernelGGL((sn_render_main_kernel<MODE, PREC, ABL, GRID, ND>), grid, block, lds_bytes, st, p)
-#define SN_LAUNCH_MAIN_TCNN(MODE, PREC)                           \
-    switch (nd) {                                                 \
-        case 0: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 0); break;       \
-        case 1: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 1); break;       \
-        case 2: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 2); break;       \
-        case 3: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 3); break;       \
-        case 4: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 4); break;       \
-        case 5: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 5); break;       \
-        case 6: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 6); break;       \
-        case 7: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, 7); break;       \
-        default: SN_LAUNCH_MAIN(MODE, PREC, 0, 1, -1); break;     \
-    }
     const char* abl_env = getenv("SN_ABLATE");  // profiling only: non-zero gives WRONG images (see sn_main.h)
     const int ablate = abl_env ? atoi(abl_env) : 0;
-    const bool tcnn = d.main_field.grid_mode == 1;
-    const int nd = tcnn && h->dense_pairs_ok ? leading_dense(d.main_field) : -1;  // compile-time variants read dense levels as x-pairs
-#define SN_LAUNCH_MAIN_TORCH(MODE, PREC)                          \
-    switch (h->nd_torch) {                                        \
-        case 5: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 5); break;       \
-        case 6: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 6); break;       \
-        case 7: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 7); break;       \
-        case 8: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 8); break;       \
-        case 9: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 9); break;       \
-        case 10: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 10); break;     \
-        case 11: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 11); break;     \
-        case 12: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, 12); break;     \
-        default: SN_LAUNCH_MAIN(MODE, PREC, 0, 0, -1); break;     \
+    const int nd_launch = use_copies ? h->nd_torch : -1;
+#define SN_LAUNCH_MAIN_ND(MODE, PREC, GRID)                          \
+    switch (nd_launch) {                                             \
+        case 5: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 5); break;       \
+        case 6: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 6); break;       \
+        case 7: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 7); break;       \
+        case 8: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 8); break;       \
+        case 9: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 9); break;       \
+        case 10: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 10); break;     \
+        case 11: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 11); break;     \
+        case 12: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 12); break;     \
+        default: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, -1); break;     \
     }
+#define SN_LAUNCH_MAIN_TORCH(MODE, PREC) SN_LAUNCH_MAIN_ND(MODE, PREC, 0)
+#define SN_LAUNCH_MAIN_TCNN(MODE, PREC) SN_LAUNCH_MAIN_ND(MODE, PREC, 1)
     if (dump) {
         // instrumented instantiations: the production variant (torch grid, 11 de-hashed levels), both samplers, both precisions
         if (tcnn || h->nd_torch != 11)
@@ -1274,6 +1248,7 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     }
 #undef SN_LAUNCH_MAIN_TCNN
 #undef SN_LAUNCH_MAIN_TORCH
+#undef SN_LAUNCH_MAIN_ND
 #undef SN_LAUNCH_MAIN
     SN_HIP(h, hipGetLastError());
     if (expected_depth) {
@@ -1513,6 +1488,7 @@ int sn_field_forward(SnHandle h, int32_t which, const float* positions, const fl
         p.table_bytes = (uint32_t)h->table_prop[which].bytes;
         p.grid_mode = h->desc.proposals[which].grid_mode;
         p.grid = grid_levels(h->desc.proposals[which]);
+        p.feat_scale = h->feat_scale_prop[which];
         hipLaunchKernelGGL(sn_prop_field_stage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
     }
     SN_HIP(h, hipGetLastError());

@@ -294,49 +294,18 @@ SN_DEV f32x2 sn_table_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, uint3
 // Encode one point over L levels -> feat[2L], level-major.  `scal` must be wave-uniform.
 // GROUP > 0 fences the instruction scheduler every GROUP levels: at most GROUP*8 gathers (GROUP*16 VGPRs) are in flight,
 // which keeps the fused kernels inside their register budget (the scheduler otherwise hoists all L*8 loads).
-// One DENSE tiny-cuda-nn level with four 16-byte gathers instead of eight 8-byte ones: in a dense level the x + 1 corner is
-// the next row, so one dwordx4 at row i returns both x corners.  The wrap of the library (index % size) is kept: the base
-// row wraps with min(i, i - size), and the row after the level's last one holds a COPY of row 0 (written by
-// sn_finalize_weights; the host only selects this path when every dense level is shorter than its slot).
+// one 16-byte gather (two adjacent rows, or half a bilinear-coefficient entry)
 SN_DEV f32x4 sn_table_load_pair(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, uint32_t level_off_bytes) {
     typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
     u32x4_ r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, (int)level_off_bytes, 0);
     return f32x4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
 }
 
-SN_DEV f32x2 sn_hash_level_dense_pairs(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_off_bytes, const float q[3], float scale, uint32_t r) {
-    uint32_t f[3];
-    float off[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float x = fmaf(scale, q[a], 0.5f);
-        off[a] = __builtin_amdgcn_fractf(x);
-        f[a] = (uint32_t)(int)x;
-    }
-    // r <= 255 and the coordinates are <= r, so every product fits 24 bits: full-rate v_mul_u32_u24 / v_mad_u32_u24 (v_mul_lo_u32
-    // is quarter rate)
-    const uint32_t r2 = r * r, size = (r2 * r + 7u) & ~7u;
-    const uint32_t i_ff = f[0] + __umul24(f[1], r) + __umul24(f[2], r2);  // (x0, y0, z0)
-    const uint32_t i_cf = i_ff + r, i_fc = i_ff + r2, i_cc = i_ff + r + r2;  // (y1,z0), (y0,z1), (y1,z1)
-    auto wrap8 = [&](uint32_t i) { return min(i, i - size) << 3; };
-    const f32x4 p_cc = sn_table_load_pair(rsrc, wrap8(i_cc), level_off_bytes);
-    const f32x4 p_fc = sn_table_load_pair(rsrc, wrap8(i_fc), level_off_bytes);
-    const f32x4 p_ff = sn_table_load_pair(rsrc, wrap8(i_ff), level_off_bytes);
-    const f32x4 p_cf = sn_table_load_pair(rsrc, wrap8(i_cf), level_off_bytes);
-    f32x2 v[8];
-    v[3] = f32x2{p_cc.x, p_cc.y};
-    v[0] = f32x2{p_cc.z, p_cc.w};
-    v[2] = f32x2{p_fc.x, p_fc.y};
-    v[1] = f32x2{p_fc.z, p_fc.w};
-    v[6] = f32x2{p_ff.x, p_ff.y};
-    v[5] = f32x2{p_ff.z, p_ff.w};
-    v[7] = f32x2{p_cf.x, p_cf.y};
-    v[4] = f32x2{p_cf.z, p_cf.w};
-    return sn_hash_blend_fast(v, off);
-}
-
-// De-hashed copies of the COARSE levels of a torch-path grid (an MI355X data layout, not a change of arithmetic):
-//     D_l[x + R y + R^2 z] = table[l][hash(x, y, z)],   R = scale_l + 2,   0 <= x, y, z <= scale_l + 1
+// De-hashed copies of the COARSE levels of a grid (an MI355X data layout, not a change of arithmetic):
+//     D_l[x + R y + R^2 z] = table[l][index_l(x, y, z)],   0 <= x, y, z < R
+// index_l = the grid's own row function: nerfstudio's torch HashEncoding hashes every level (R = scale_l + 2); tiny-cuda-nn indexes a level
+// whose whole grid fits the table densely, x + y res + z res^2 modulo the level size, and hashes the others (R = floor(scale_l + 0.5) + 2;
+// its positions are scale q + 0.5, TCNN below).
 // built once by sn_finalize_weights.  In D_l the x + 1 corner is the next row, so a level costs four 16-byte gathers instead
 // of eight 8-byte ones and neighbouring voxels share cache lines.  Values are the table's own, so results are bit-identical
 // to the hashed reads.  Which levels are copied is the host's choice (sn_api.hip, build_dense_copies).
@@ -356,13 +325,14 @@ struct SnDenseCopy {
 
 // rec (test instrumentation, sn_render_rays_debug): where non-null, receives the byte offsets of the four 16-byte fetches
 // (order: y1 z1, y0 z1, y0 z0, y1 z0 -- each returns the x0 and x0 + 1 entries) within the buffer of copies.
+template <bool TCNN = false>
 SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_off_bytes, const float q[3], float scale, uint32_t R,
                                       uint32_t* rec = nullptr) {
     uint32_t f[3];
     float off[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float x = q[a] * scale;
+        const float x = TCNN ? fmaf(scale, q[a], 0.5f) : q[a] * scale;
         off[a] = __builtin_amdgcn_fractf(x);
         f[a] = (uint32_t)(int)x;
     }
@@ -398,13 +368,14 @@ SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t leve
 // One level in bilinear-coefficient form (SnDenseCopy::n_bc): per feature  f_z(ox, oy) = A + ox B + oy (C + ox D), then the z lerp.
 // Algebraically the trilinear blend; rounding differs from the lerp form by a few ulp of the table magnitude (the blend was never
 // bit-exact with the reference's association -- DESIGN.md "Numerics").
+template <bool TCNN = false>
 SN_DEV f32x2 sn_hash_level_dense_bc(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_off_bytes, const float q[3], float scale, uint32_t R,
                                     uint32_t* rec = nullptr) {
     uint32_t f[3];
     float off[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float x = q[a] * scale;
+        const float x = TCNN ? fmaf(scale, q[a], 0.5f) : q[a] * scale;
         off[a] = __builtin_amdgcn_fractf(x);
         f[a] = (uint32_t)(int)x;
     }
@@ -429,15 +400,26 @@ SN_DEV f32x2 sn_hash_level_dense_bc(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_
     return out;
 }
 
+// row of grid point (x, y, z) inside level slot `lv`: dense_res = 0 -> the xor hash (torch grids: every level; tcnn: the hashed levels),
+// else tiny-cuda-nn's dense index x + y res + z res^2 modulo the level size next_multiple(res^3, 8)
+SN_DEV uint32_t sn_grid_row(uint32_t x, uint32_t y, uint32_t z, uint32_t mask, uint32_t dense_res) {
+    if (dense_res) {
+        const uint32_t r2 = dense_res * dense_res, size = (r2 * dense_res + 7u) & ~7u;
+        return (x + y * dense_res + z * r2) % size;
+    }
+    return (x ^ (y * 2654435761u) ^ (z * 805459861u)) & mask;
+}
+
 // builds one level in bilinear-coefficient form: one thread per grid point, entry i <-> (x, y, z) = (i % R, i / R % R, i / R^2)
-__global__ void sn_build_bc_copy_kernel(const float* __restrict__ table, float* __restrict__ dense, int level, int log2_t, uint32_t R, float scale) {
+__global__ void sn_build_bc_copy_kernel(const float* __restrict__ table, float* __restrict__ dense, int level, int log2_t, uint32_t R, float scale,
+                                        uint32_t dense_res) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R * R * R) return;
     const uint32_t x = i % R, y = (i / R) % R, z = i / (R * R);
     const uint32_t mask = (1u << log2_t) - 1u;
     const f32x2* lv = (const f32x2*)table + ((uint64_t)level << log2_t);
     auto row = [&](uint32_t xx, uint32_t yy) {
-        const f32x2 v = lv[(xx ^ (yy * 2654435761u) ^ (z * 805459861u)) & mask];
+        const f32x2 v = lv[sn_grid_row(xx, yy, z, mask, dense_res)];
         return f32x2{v.x * scale, v.y * scale};
     };
     const f32x2 v00 = row(x, y), v10 = row(x + 1u, y), v01 = row(x, y + 1u), v11 = row(x + 1u, y + 1u);
@@ -454,12 +436,12 @@ __global__ void sn_build_bc_copy_kernel(const float* __restrict__ table, float* 
 // scale: an exact power of two applied to the copied values (the "feature scale" of the split-precision MLPs, sn_api.hip
 // plan_split_scales: the consuming layer's weights carry its inverse)
 __global__ void sn_build_dense_copy_kernel(const float* __restrict__ table, float* __restrict__ dense, int level, int log2_t, uint32_t R,
-                                           float scale) {
+                                           float scale, uint32_t dense_res) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R * R * R) return;
     const uint32_t x = i % R, y = (i / R) % R, z = i / (R * R);
     const uint32_t mask = (1u << log2_t) - 1u;
-    const uint32_t row = (x ^ (y * 2654435761u) ^ (z * 805459861u)) & mask;
+    const uint32_t row = sn_grid_row(x, y, z, mask, dense_res);
     const f32x2* lv = (const f32x2*)table + ((uint64_t)level << log2_t);
     const f32x2 v = lv[row];
     ((f32x2*)dense)[i] = f32x2{v.x * scale, v.y * scale};
@@ -476,9 +458,9 @@ __global__ void sn_absmax_kernel(const float* __restrict__ x, size_t n, uint32_t
 }
 
 // ARITH: 0 = the literal torch-path arithmetic, 1 = its fused-kernel form (sn_hash_corners_fast), 2 = tiny-cuda-nn grid
-// semantics (sn_hash_corners_tcnn; `grid` must then point at the level table).
-// ND (ARITH 2 only): levels [0, ND) are dense and the rest hashed, fixed at compile time; -1 = per-level run-time decision.
-// With ND >= 0 the dense levels use the paired 16-byte gathers of sn_hash_level_dense_pairs.
+// semantics read from the uploaded table (sn_hash_corners_tcnn, dense / hashed decided per level at run time; `grid` must point at the
+// level table), 3 = tiny-cuda-nn semantics in the fused kernels: levels [0, ND) from their de-hashed copies, the rest hashed.
+// ND (ARITH 1 / 3): number of leading levels read from de-hashed copies (`dense`).
 // DUMP / rec (test instrumentation behind sn_render_rays_debug; include/signerf_hip.h "SnDebugDump"): where `rec` is non-null the
 // lane records, per level, the 8 words that identify what it fetched: a hashed level -> the byte offsets of its 8 rows within the
 // level, nerfstudio corner order; a de-hashed level in plain-row form -> words 0..3 = byte offsets of the four 16-byte fetches within
@@ -494,19 +476,13 @@ SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int l
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         if (GROUP > 0 && l > 0 && (l % GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
-        if (ARITH == 2 && ND >= 0 && l < ND) {
-            const f32x2 e = sn_hash_level_dense_pairs(rsrc, ((uint32_t)l << log2_t) * 8u, q, scal[l], sn_grid_dense_res(*grid, l));
-            feat[2 * l] = e.x;
-            feat[2 * l + 1] = e.y;
-            continue;
-        }
-        if (ARITH == 1 && ND > 0 && l < ND && l < 12) {  // torch grid: de-hashed copy of a coarse level
+        if ((ARITH == 1 || ARITH == 3) && ND > 0 && l < ND && l < 12) {  // de-hashed copy of a coarse level
             uint32_t R = dense->res[l];
             asm volatile("" : "+s"(R));  // keep the per-level strides out of the loop-invariant set (SGPR pressure, see sn_grid_dense_res)
             const __amdgpu_buffer_rsrc_t drsrc = sn_table_rsrc(dense->base, dense->bytes);
             uint32_t* lrec = DUMP && rec ? rec + 8 * l : nullptr;
-            const f32x2 e = l < NBC ? sn_hash_level_dense_bc(drsrc, dense->off[l], q, scal[l], R, lrec)
-                                    : sn_hash_level_dense_copy(drsrc, dense->off[l], q, scal[l], R, lrec);
+            const f32x2 e = l < NBC ? sn_hash_level_dense_bc<ARITH == 3>(drsrc, dense->off[l], q, scal[l], R, lrec)
+                                    : sn_hash_level_dense_copy<ARITH == 3>(drsrc, dense->off[l], q, scal[l], R, lrec);
             if (DUMP && rec) {
                 if (l < NBC) rec[8 * l + 2] = rec[8 * l + 3] = 0u;
                 rec[8 * l + 4] = l < NBC ? 0xB0000000u : 0xD0000000u;
@@ -517,11 +493,8 @@ SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int l
             continue;
         }
         SnHashLevel hl;
-        if (ARITH == 2) {
-            if (ND < 0) sn_hash_corners_tcnn<-1>(q, scal[l], mask, sn_grid_dense_res(*grid, l), hl);
-            else if (l < ND) sn_hash_corners_tcnn<1>(q, scal[l], mask, sn_grid_dense_res(*grid, l), hl);
-            else sn_hash_corners_tcnn<0>(q, scal[l], mask, 0u, hl);
-        }
+        if (ARITH == 3) sn_hash_corners_tcnn<0>(q, scal[l], mask, 0u, hl);  // beyond the copies every level is hashed (the host checks)
+        else if (ARITH == 2) sn_hash_corners_tcnn<-1>(q, scal[l], mask, sn_grid_dense_res(*grid, l), hl);
         else if (ARITH == 1) sn_hash_corners_fast(q, scal[l], mask, hl);
         else sn_hash_corners(q, scal[l], mask, hl);
         const uint32_t lvl = ((uint32_t)l << log2_t) * 8u;
@@ -533,10 +506,10 @@ SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int l
             for (int k = 0; k < 8; ++k) rec[8 * l + k] = hl.boff[k];
         }
         f32x2 e = FAST ? sn_hash_blend_fast(v, hl.off) : sn_hash_blend(v, hl.off);
-        // ARITH 1 (fused torch-grid kernels): the levels read from the uploaded table itself get the feature scale that the de-hashed
-        // copies already carry (an exact power of two; 1.0 everywhere else)
-        feat[2 * l] = ARITH == 1 ? e.x * plain_scale : e.x;
-        feat[2 * l + 1] = ARITH == 1 ? e.y * plain_scale : e.y;
+        // fused kernels: the levels read from the uploaded table itself get the feature scale that the de-hashed copies already carry
+        // (an exact power of two; the default 1.0 folds away everywhere else)
+        feat[2 * l] = ARITH != 0 ? e.x * plain_scale : e.x;
+        feat[2 * l + 1] = ARITH != 0 ? e.y * plain_scale : e.y;
     }
 }
 

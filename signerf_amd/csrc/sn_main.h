@@ -490,8 +490,8 @@ struct SnMainParams {
     const float* pairs;  // SN_MAIN_PAIRS: x-paired tables of the levels >= ND (pre-scaled by feat_scale), or null
     uint32_t pairs_bytes;
     SnPairInfo pinfo;
-    SnGridLevels grid;  // GRID 1: dense-level resolutions of the tiny-cuda-nn grid; GRID 0, ND > 0: R of the de-hashed coarse copies
-    SnDenseCopy dense;  // GRID 0, ND > 0
+    SnGridLevels grid;  // ND > 0: R of the de-hashed coarse copies; GRID 1, ND = -1: dense-level resolutions of the tiny-cuda-nn grid
+    SnDenseCopy dense;  // ND > 0
     // test instrumentation (DUMP = 1 instantiations only; sn_render_rays_debug)
     uint32_t* dump_fetch;  // [H*W][S][16][8] fetch records (sn_hash_encode) or null
     float* dump_q;         // [H*W][S][3] normalised positions that were hashed, or null
@@ -632,16 +632,18 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
                     p.dump_q[smp * 3 + 2] = q[2];
                 }
             }
-            if (SN_MAIN_PAIRS && MODE == 1 && GRID == 0 && ND > 0 && ND < 16) {
+            // grid arithmetic: 1 = nerfstudio torch grid (fused form), 3 = tiny-cuda-nn grid with de-hashed copies, 2 = tiny-cuda-nn grid read
+            // from the uploaded table with the dense / hashed decision per level at run time (ND = -1: shapes the copies do not cover)
+            constexpr int AR = GRID ? (ND > 0 ? 3 : 2) : (SN_FAST_HASH ? 1 : 0);
+            constexpr int NBC = ND > SN_BC_MAIN ? SN_BC_MAIN : (ND > 0 ? ND : 0);
+            if (SN_MAIN_PAIRS && MODE == 1 && ND > 0 && ND < 16) {
                 // de-hashed levels [0, ND), then the hashed levels [ND, 16) from the x-paired tables
-                sn_hash_encode<(ND > 0 ? ND : 1), SN_HASH_GROUP, 1, ND, DUMP, (ND > SN_BC_MAIN ? SN_BC_MAIN : (ND > 0 ? ND : 0))>(
-                    rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
+                sn_hash_encode<(ND > 0 ? ND : 1), SN_HASH_GROUP, AR, ND, DUMP, NBC>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
                 __builtin_amdgcn_sched_barrier(0);
-                sn_hash_encode_pairs<16, SN_HASH_GROUP, true, (ND > 0 && ND < 16 ? ND : 0), false, DUMP>(sn_table_rsrc(p.pairs, p.pairs_bytes), p.pinfo, p.scal,
-                                                                                                       p.log2_t, q, feat, rec);
+                sn_hash_encode_pairs<16, SN_HASH_GROUP, true, (ND > 0 && ND < 16 ? ND : 0), GRID == 1, DUMP>(sn_table_rsrc(p.pairs, p.pairs_bytes), p.pinfo,
+                                                                                                           p.scal, p.log2_t, q, feat, rec);
             } else {
-                sn_hash_encode<16, SN_HASH_GROUP, (GRID ? 2 : (SN_FAST_HASH ? 1 : 0)), ND, DUMP, (ND > SN_BC_MAIN ? SN_BC_MAIN : (ND > 0 ? ND : 0))>(
-                    rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
+                sn_hash_encode<16, SN_HASH_GROUP, AR, ND, DUMP, NBC>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
             }
 #if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 3
             __builtin_amdgcn_s_setprio(0);

@@ -120,27 +120,24 @@ SN_DEV float sn_prop_mlp_mfma(const float* __restrict__ w, const float* feat, in
 // pre-activation density of one proposal net at normalised position q.
 // The MLP (10 -> 16 -> 1) runs on the matrix cores in split precision (sn_prop_mlp_mfma above; SN_PROP_MFMA=0 keeps the VALU form:
 // weights broadcast from LDS, two hidden units per v_pk_fma_f32).  History (r01): an exact-fp32 version (v_mfma_f32_32x32x2_f32,
-// 11 MFMAs x 64 cycles) was 9 % SLOWER than the VALU form -- on gfx950 a SIMD's matrix pipe and VALU do not run concurrently
-// (tools/probes/overlap_probe.hip), so MFMA cycles simply replace VALU cycles; the fp16 hi+lo form needs 6 MFMAs x 32 cycles for
-// the whole layer (K = 16 in one k-step) and measured 4 % faster on the 1080p nerfacto frame (17.5 -> 16.8 ms, same box).
-// GRID = 1 (tiny-cuda-nn grid semantics): `plain` is the plain table of the net and `grid` its level table.  With the number of
-// leading dense levels ND known at compile time the dense levels read x-corner pairs straight from the plain table and the
-// hashed levels use the x-paired tables `prsrc` (built for those levels only); ND = -1 reads everything from the plain table.
+// 11 MFMAs x 64 cycles) was 9 % SLOWER than the VALU form -- the f32-input MFMA runs at the vector rate and does not overlap with VALU
+// work at all (re-measured r02, tools/probes/overlap2_probe.hip), so its cycles simply replace VALU cycles; the fp16 hi+lo form needs
+// 6 MFMAs x 32 cycles for the whole layer (K = 16 in one k-step), which plain VALU instructions do overlap with, and measured 4 %
+// faster on the 1080p nerfacto frame (17.5 -> 16.8 ms, same box).
+// GRID = 1: tiny-cuda-nn grid semantics (positions scale q + 0.5; `grid` = the level table).  ND > 0 (both grids): levels [0, ND) from
+// their de-hashed copies (`dense`), the rest from the x-paired tables `prsrc`; ND = -1: torch grid -> everything from the paired
+// tables, tcnn grid -> everything from the uploaded table `plain` with the dense / hashed decision per level at run time (its values
+// then take the feature scale here: `plain_scale`).
 template <int GRID = 0, int ND = -1, bool DUMP = false>
 SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, const SnScal5& scal, int log2_t, const float* __restrict__ w,
                         const float q[3], const SnGridLevels* grid = nullptr, __amdgpu_buffer_rsrc_t plain = __amdgpu_buffer_rsrc_t(),
-                        const SnDenseCopy* dense = nullptr, uint32_t* rec = nullptr) {
+                        const SnDenseCopy* dense = nullptr, uint32_t* rec = nullptr, float plain_scale = 1.0f) {
     float feat[10];
-    if (GRID == 1 && ND >= 0) {
-        // dense levels: paired 16-byte gathers from the plain table; hashed levels: the x-paired tables
-        if (ND > 0) sn_hash_encode<(ND > 0 ? ND : 1), 0, 2, ND>(plain, scal.v, log2_t, q, feat, grid);
-        sn_hash_encode_pairs<5, 0, true, ND, true>(prsrc, pi, scal.v, log2_t, q, feat);
+    if (ND > 0) {
+        sn_hash_encode<(ND > 0 ? ND : 1), 0, (GRID ? 3 : 1), ND, DUMP, (ND > SN_BC_PROP ? SN_BC_PROP : ND)>(plain, scal.v, log2_t, q, feat, grid, dense, rec);
+        if (ND < 5) sn_hash_encode_pairs<5, 0, true, (ND > 0 && ND < 5 ? ND : 0), GRID == 1, DUMP>(prsrc, pi, scal.v, log2_t, q, feat, rec);
     } else if (GRID == 1) {
-        sn_hash_encode<5, 0, 2, -1>(plain, scal.v, log2_t, q, feat, grid);
-    } else if (ND > 0) {
-        // torch grid: levels [0, ND) from their de-hashed copies (4 gathers, 6 index instructions), the rest from the x-paired tables
-        sn_hash_encode<(ND > 0 ? ND : 1), 0, 1, ND, DUMP, (ND > SN_BC_PROP ? SN_BC_PROP : ND)>(plain, scal.v, log2_t, q, feat, grid, dense, rec);
-        if (ND < 5) sn_hash_encode_pairs<5, 0, true, (ND > 0 && ND < 5 ? ND : 0), false, DUMP>(prsrc, pi, scal.v, log2_t, q, feat, rec);
+        sn_hash_encode<5, 0, 2, -1>(plain, scal.v, log2_t, q, feat, grid, nullptr, nullptr, plain_scale);
     } else {
         sn_hash_encode_pairs<5, 0, true, 0, false, DUMP>(prsrc, pi, scal.v, log2_t, q, feat, rec);
     }
@@ -254,6 +251,7 @@ struct SnPropParams {
     float* ebins_out;                     // [tile][n_final+1][64]
     float* prop_depth[SN_MAX_PROPOSALS];  // [H*W] or null
     // test instrumentation (DUMP = 1 instantiations only; sn_render_rays_debug)
+    float feat_scale[SN_MAX_PROPOSALS];      // power-of-two feature scale of net k (carried by its copies / paired tables; applied to plain reads)
     uint32_t* dump_fetch[SN_MAX_PROPOSALS];  // [H*W][n_samples[k]][5][8] fetch records of net k, or null
     float* dump_q[SN_MAX_PROPOSALS];         // [H*W][n_samples[k]][3] hashed positions of net k, or null
     int32_t* dump_pdf[SN_MAX_PROPOSALS];     // [H*W][m_k + 1] searchsorted index of every u of resampling step k, or null
@@ -328,7 +326,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
                 p.dump_q[LV][smp * 3 + 2] = q[2];
             }
         }
-        const float h0 = sn_prop_h0<GRID, ND, DUMP>(rsrc, pi, scal, log2_t, wp, q, &p.grid[LV], plain, &p.dense[LV], rec);
+        const float h0 = sn_prop_h0<GRID, ND, DUMP>(rsrc, pi, scal, log2_t, wp, q, &p.grid[LV], plain, &p.dense[LV], rec, p.feat_scale[LV]);
         const float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
         float wt;
         {
@@ -456,6 +454,7 @@ struct SnPropStageParams {
     uint32_t table_bytes;
     int grid_mode;
     SnGridLevels grid;
+    float feat_scale;  // tcnn grid mode: the pack's first layer carries 1 / this; the plain table's rows are multiplied by it here
 };
 
 __global__ void sn_prop_field_stage_kernel(SnPropStageParams p) {
@@ -468,7 +467,8 @@ __global__ void sn_prop_field_stage_kernel(SnPropStageParams p) {
 #pragma unroll
     for (int l = 0; l < 5; ++l) scal.v[l] = p.scal[l];
     float h0;
-    if (p.grid_mode) h0 = sn_prop_h0<1, -1>(sn_table_rsrc(p.pairs, p.pairs_bytes), p.pinfo, scal, p.log2_t, p.wpack, q, &p.grid, sn_table_rsrc(p.table, p.table_bytes));
+    if (p.grid_mode) h0 = sn_prop_h0<1, -1>(sn_table_rsrc(p.pairs, p.pairs_bytes), p.pinfo, scal, p.log2_t, p.wpack, q, &p.grid, sn_table_rsrc(p.table, p.table_bytes),
+                                            nullptr, nullptr, p.feat_scale);
     else h0 = sn_prop_h0<0, -1>(sn_table_rsrc(p.pairs, p.pairs_bytes), p.pinfo, scal, p.log2_t, p.wpack, q);
     if (i < p.n) p.density[i] = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
 }

@@ -165,9 +165,9 @@ def test_tcnn_all_levels_dense_runtime_path(gpu):
     assert float(ref["rgb"].std()) > 0.02
 
 
-def test_tcnn_dense_levels_as_x_pairs_with_room(gpu):
-    """Main grid T = 2^14 (2 leading dense levels, both shorter than their slot) and no proposal nets: the compile-time variant
-    that reads dense levels as 16-byte x-pairs, including the wrap row behind each dense level."""
+def test_tcnn_dense_levels_through_the_dehashed_copies(gpu):
+    """Main grid T = 2^14 (2 leading dense levels) and no proposal nets: the de-hashed copies are built with tiny-cuda-nn's own row
+    function -- dense index (with its wrap modulo the level size at the far faces) for those two levels, the xor hash for the rest."""
     cfg, sd, model = _tcnn_model(gpu, seed=5, num_proposal_iterations=0, num_nerf_samples_per_ray=32)
     m = tl.grid_meta(cfg.num_levels, cfg.base_res, cfg.max_res, cfg.log2_hashmap_size)
     assert m.dense[:3] == [True, True, False] and all(m.offsets[i + 1] - m.offsets[i] < (1 << cfg.log2_hashmap_size) for i in range(2))
