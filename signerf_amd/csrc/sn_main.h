@@ -186,6 +186,9 @@ struct SnMainImgH {
 // reads the fp16 half straight out of the packed register (fma(hi16, -1.0, a) in fp32, exact) -- 4 instructions per pair
 // instead of mask, mask, convert, packed subtract, convert.  hipcc does not select fma_mix for this pattern, hence the asm
 // (a plain VALU instruction: no hazard class of its own; checked on hardware by tools/probes/mix_probe).
+// Tried r02: forming the low pair with v_fma_mixlo_f16 / v_fma_mixhi_f16 (fp16 results written straight into the halves of the packed
+// register, 3 instructions per pair, 1444 -> 1356 VALU per wave-step) is SLOWER, 2.85 -> 2.98 ms: those two opcodes issue at half rate on
+// gfx950 (8.5 cycles per wave64 against 4.7 for v_fma_mix_f32 / v_cvt_pkrtz / v_pk_max_f16; tools/probes/overlap2_probe.hip).
 SN_DEV void sn_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
 #ifdef SN_PROBE_NOSPLIT  // tools/probes/mlp_probe.hip: the MFMA part of the MLP alone (no instruction, dependencies kept)
     asm volatile("" : "=v"(hi), "=v"(lo) : "v"(a), "v"(b));

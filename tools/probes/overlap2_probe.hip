@@ -18,9 +18,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define DEV __device__ __forceinline__
 
-enum { F_FMA = 0, F_PKFMA, F_XAD, F_CVTPK, F_MUL24, F_EXP, F_PKADD, F_XOR, F_FMAMIX, F_MAXI, F_FRACT, F_MOV, F_NKIND };
+enum { F_FMA = 0, F_PKFMA, F_XAD, F_CVTPK, F_MUL24, F_EXP, F_PKADD, F_XOR, F_FMAMIX, F_MAXI, F_FRACT, F_MOV, F_MIXLO, F_MIXHI, F_PKMAXH, F_MIXCLAMP, F_NKIND };
 static const char* kind_name[F_NKIND] = {"v_fma_f32", "v_pk_fma_f32", "v_xad_u32", "v_cvt_pkrtz", "v_mul_u32_u24", "v_exp_f32",
-                                         "v_pk_add_f32", "v_xor_b32", "v_fma_mix_f32", "v_max_i32", "v_fract_f32", "v_mov_b32"};
+                                         "v_pk_add_f32", "v_xor_b32", "v_fma_mix_f32", "v_max_i32", "v_fract_f32", "v_mov_b32",
+                                         "v_fma_mixlo_f16", "v_fma_mixhi_f16", "v_pk_max_f16", "fma_mix clamp"};
 
 template <int K>
 DEV void filler(float& x, f32x2& xp, float c1, float c2, f32x2 cp) {
@@ -36,6 +37,11 @@ DEV void filler(float& x, f32x2& xp, float c1, float c2, f32x2 cp) {
     if (K == F_MAXI) asm volatile("v_max_i32 %0, %0, %1" : "+v"(x) : "v"(c1));
     if (K == F_FRACT) asm volatile("v_fract_f32 %0, %0" : "+v"(x));
     if (K == F_MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(c1));
+    // 16-bit results written into one half of the destination (r02: tried for the low part of the operand split, slower in K1)
+    if (K == F_MIXLO) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "+v"(x) : "v"(c1), "v"(c2));
+    if (K == F_MIXHI) asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x) : "v"(c1), "v"(c2));
+    if (K == F_PKMAXH) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(x) : "v"(c1));
+    if (K == F_MIXCLAMP) asm volatile("v_fma_mix_f32 %0, %0, -1.0, %1 op_sel_hi:[1,0,0] clamp" : "+v"(x) : "v"(c2));
 }
 
 template <int MK>
@@ -304,6 +310,13 @@ int main() {
     sweep_same<1, F_MAXI>(n, cyc, out);
     sweep_same<1, F_FRACT>(n, cyc, out);
     sweep_same<1, F_MOV>(n, cyc, out);
+    sweep_same<0, F_MIXLO>(n, cyc, out);
+    sweep_same<1, F_MIXLO>(n, cyc, out);
+    sweep_same<0, F_MIXHI>(n, cyc, out);
+    sweep_same<1, F_MIXHI>(n, cyc, out);
+    sweep_same<0, F_PKMAXH>(n, cyc, out);
+    sweep_same<1, F_PKMAXH>(n, cyc, out);
+    sweep_same<1, F_MIXCLAMP>(n, cyc, out);
     // B: different waves of one SIMD
     run_two<1, F_FMA>(40000, 10000, 0, 0, cyc, ids, out);
     run_two<1, F_FMA>(40000, 10000, 1, 0, cyc, ids, out);
@@ -313,6 +326,9 @@ int main() {
     run_two<1, F_XAD>(40000, 10000, 0, 0, cyc, ids, out);
     run_two<1, F_PKFMA>(40000, 10000, 0, 0, cyc, ids, out);
     run_two<1, F_CVTPK>(40000, 10000, 0, 0, cyc, ids, out);
+    run_two<1, F_MIXLO>(40000, 10000, 0, 0, cyc, ids, out);
+    run_two<1, F_PKMAXH>(40000, 10000, 0, 0, cyc, ids, out);
+    run_two<1, F_FMAMIX>(40000, 10000, 0, 0, cyc, ids, out);
     // C: K1-shaped phases: ~510 VALU then 120 MFMA with 7 VALU each
     run_phases<F_FMA, 512, 120, 0, 12>(1000, cyc, out);
     run_phases<F_FMA, 512, 120, 7, 12>(1000, cyc, out);
