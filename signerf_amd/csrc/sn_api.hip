@@ -913,19 +913,28 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         memcpy(pack.data() + SN_PROP_B0, b0->data(), 16 * 4);
         memcpy(pack.data() + SN_PROP_W1, w1->data(), 16 * 4);
         pack[SN_PROP_B1] = (*b1)[0];
-        // matrix-core form (sn_prop_mlp_mfma): A[i = lane & 31][k = 8 (lane >> 5) + e], fp16 hi / lo (lo = RNE(x - hi)); k < 10:
-        // W0[i][k], k = 10: b0[i]; rows >= 16 and k > 10 are zero
+        // matrix-core form (sn_prop_mlp_mfma): two A operands [lane][e], A[row = lane & 31][k = 8 (lane >> 5) + e], fp16 hi / lo
+        // (lo = RNE(x - hi)).  Rows 0..15 are the hidden units for the rays of lanes 0..31 (k = 0..7), rows 16..31 the same units for
+        // the rays of lanes 32..63 (k = 8..15); the other half of every row is zero.  Operand 1: e <-> W0[unit][e]; operand 2:
+        // e = 0, 1 <-> W0[unit][8], W0[unit][9], e = 2 <-> b0[unit].
         {
-            uint16_t* ahi = (uint16_t*)(pack.data() + SN_PROP_MA_HI);
-            uint16_t* alo = (uint16_t*)(pack.data() + SN_PROP_MA_LO);
+            uint16_t* a1hi = (uint16_t*)(pack.data() + SN_PROP_MA1_HI);
+            uint16_t* a1lo = (uint16_t*)(pack.data() + SN_PROP_MA1_LO);
+            uint16_t* a2hi = (uint16_t*)(pack.data() + SN_PROP_MA2_HI);
+            uint16_t* a2lo = (uint16_t*)(pack.data() + SN_PROP_MA2_LO);
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e) {
-                    const int row = lane & 31, k = 8 * (lane >> 5) + e;
-                    float x = 0.0f;
-                    if (row < 16) x = k < 10 ? (float)((*w0)[row * 10 + k] * s1p / t0p) : (k == 10 ? (float)((*b0)[row] * s1p) : 0.0f);
-                    const uint16_t hi = f32_to_f16_rne(x);
-                    ahi[lane * 8 + e] = hi;
-                    alo[lane * 8 + e] = f32_to_f16_rne(x - f16_to_f32(hi));
+                    const int row = lane & 31, half = lane >> 5, unit = row & 15;
+                    float x1 = 0.0f, x2 = 0.0f;
+                    if ((row >> 4) == half) {
+                        x1 = (float)((*w0)[unit * 10 + e] * s1p / t0p);
+                        x2 = e < 2 ? (float)((*w0)[unit * 10 + 8 + e] * s1p / t0p) : (e == 2 ? (float)((*b0)[unit] * s1p) : 0.0f);
+                    }
+                    const uint16_t h1 = f32_to_f16_rne(x1), h2 = f32_to_f16_rne(x2);
+                    a1hi[lane * 8 + e] = h1;
+                    a1lo[lane * 8 + e] = f32_to_f16_rne(x1 - f16_to_f32(h1));
+                    a2hi[lane * 8 + e] = h2;
+                    a2lo[lane * 8 + e] = f32_to_f16_rne(x2 - f16_to_f32(h2));
                 }
             for (int hh = 0; hh < 2; ++hh)
                 for (int r = 0; r < 8; ++r) pack[SN_PROP_MW1 + hh * 8 + r] = (float)((*w1)[(r & 3) + 8 * (r >> 2) + 4 * hh] / s1p);

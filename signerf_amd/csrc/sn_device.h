@@ -35,6 +35,12 @@ SN_DEV float sn_spacing_inv(float x) {
     return x < 0.5f ? 2.0f * x : 1.0f / (2.0f - 2.0f * x);
 }
 
+// mid-point of a bin, un-fused (the reference's (start + end) / 2)
+SN_DEV float sn_mid(float a, float b) {
+#pragma clang fp contract(off)
+    return (a + b) / 2.0f;
+}
+
 // spacing bin -> euclidean distance along the ray: s^-1(b * s_far + (1 - b) * s_near)
 SN_DEV float sn_euclid(float b, float s_near, float s_far) {
 #pragma clang fp contract(off)
@@ -76,8 +82,11 @@ SN_DEV bool sn_sample_q_fast(const float o[3], const float d[3], float start, fl
 #pragma unroll
     for (int c = 0; c < 3; ++c) p[c] = fmaf(d[c], t, o[c]);
     const float mag = fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2]));
-    if (!(mag < 1.0f)) {
-        const float r = __builtin_amdgcn_rcpf(mag);
+    // No selects: r = min(1 / mag, 1) makes k = (2 - r) r exactly 1 inside the unit box, where the contraction is the identity (NaN
+    // positions stay NaN: min returns 1, NaN * 1).  v_cndmask_b32 in its VCC form issues ~5x slower than other VALU instructions on gfx950
+    // (tools/probes/overlap2_probe.hip, r02), so the fused kernels avoid per-step selects.
+    {
+        const float r = fminf(__builtin_amdgcn_rcpf(mag), 1.0f);
         const float k = (2.0f - r) * r;
 #pragma unroll
         for (int c = 0; c < 3; ++c) p[c] = k * p[c];
@@ -387,8 +396,19 @@ SN_DEV f32x2 sn_hash_level_dense_bc(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_
         rec[0] = b + level_off_bytes;
         rec[1] = b + o_z1;
     }
+#if defined(SN_EXP_ONE_LOAD)  // experiment (wrong images): one of the four fetches only -- how much of the kernel is the gather path?
+    const f32x4 ab0 = sn_table_load_pair(rsrc, b, level_off_bytes), cd0 = ab0, ab1 = ab0, cd1 = ab0;
+#elif defined(SN_EXP_TWO_LOAD)  // experiment (wrong images): two fetches and 8 extra VALU instructions -- the cost shape of a pair-cooperative fetch
+    const f32x4 ab0 = sn_table_load_pair(rsrc, b, level_off_bytes), cd0 = sn_table_load_pair(rsrc, b + 16u, level_off_bytes);
+    f32x4 ab1 = ab0, cd1 = cd0;
+    asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5"
+                 : "+v"(ab1.x), "+v"(ab1.y), "+v"(ab1.z), "+v"(ab1.w) : "v"(off[0]), "v"(off[1]));
+    asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5"
+                 : "+v"(cd1.x), "+v"(cd1.y), "+v"(cd1.z), "+v"(cd1.w) : "v"(off[0]), "v"(off[1]));
+#else
     const f32x4 ab0 = sn_table_load_pair(rsrc, b, level_off_bytes), cd0 = sn_table_load_pair(rsrc, b + 16u, level_off_bytes);
     const f32x4 ab1 = sn_table_load_pair(rsrc, b, o_z1), cd1 = sn_table_load_pair(rsrc, b + 16u, o_z1);
+#endif
     const float ox = off[0], oy = off[1], oz = off[2];
     f32x2 out;
 #pragma unroll
@@ -687,6 +707,7 @@ struct SnComposite {
         median = 0.f;
         median_idx = 0;
         found = false;
+        below = 0.f;
     }
 
     // One sample.  Returns the weight.
@@ -720,6 +741,44 @@ struct SnComposite {
         c[1] += w * g;
         c[2] += w * b;
         return w;
+    }
+
+    // The main kernel's form of step<true>: the same sums without per-step selects (see sn_sample_q_fast).  Requires what that kernel
+    // guarantees: delta, density >= 0 or NaN, so w >= 0 or NaN and max(w, 0) IS nan_to_num(w); colours in [0, 1] or NaN, likewise.
+    // The median is not tracked but COUNTED: cumsum(w) is non-decreasing, so the first index with cum_w >= 0.5 equals the number of
+    // steps with cum_w < 0.5; `below` accumulates clamp(2^100 (0.5 - cum_w), 0, 1), which is exactly 1 or 0 (|0.5 - cum_w| is 0 or
+    // >= 2^-25).  The caller turns the count into the index and re-reads that bin (median_index(), sn_main.h).
+    float below;
+    SN_DEV void step_fused(float start, float end, float density, float r, float g, float b) {
+        float w, mid;
+        {
+#pragma clang fp contract(off)
+            const float delta = end - start;
+            const float tau = delta * density;
+            const float alpha = 1.0f - sn_exp<true>(-tau);
+            const float trans = sn_exp<true>(-(float)cum_tau);
+            w = fmaxf(alpha * trans, 0.0f);
+            cum_tau += (double)tau;
+            mid = (start + end) / 2.0f;
+            cum_w += (double)w;
+        }
+        below += __builtin_amdgcn_fmed3f(fmaf((float)cum_w, -0x1p100f, 0x1p99f), 0.0f, 1.0f);
+        r = fmaxf(r, 0.0f);
+        g = fmaxf(g, 0.0f);
+        b = fmaxf(b, 0.0f);
+        sum_w += w;
+        sum_wd += w * mid;
+        c[0] += w * r;
+        c[1] += w * g;
+        c[2] += w * b;
+    }
+    SN_DEV int median_index(int n) const { return min((int)below, n - 1); }
+    // finish() for step_fused: the caller supplies the median sample's mid-point
+    SN_DEV void finish_fused(int n, float median_mid, float r, float g, float b, float out_rgb[3], float& depth, float& acc, float& exp_raw) {
+        found = true;
+        median = median_mid;
+        median_idx = median_index(n);
+        finish(n, median_mid, r, g, b, out_rgb, depth, acc, exp_raw);
     }
 
     // After the last sample (index n-1, mid-point last_mid, colour r,g,b = 'last_sample' background).

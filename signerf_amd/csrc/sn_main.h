@@ -678,25 +678,28 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
         __builtin_amdgcn_s_setprio(0);
 #endif
         float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
-        r = rgb[0];
-        g = rgb[1];
-        b = rgb[2];
         // A NaN position (e.g. the 1e10 sentinel of a ray that misses render_aabb overflows to inf/inf) is NaN all the
-        // way through the reference's field; v_max-based ReLU would launder it, so restore it here.
-        if ((q[0] != q[0]) | (q[1] != q[1]) | (q[2] != q[2])) {
-            density = __builtin_nanf("");
-            r = g = b = density;
-        }
-        comp.step<true>(i, t0, t1, density, r, g, b);
-        {
-#pragma clang fp contract(off)
-            last_mid = (t0 + t1) / 2.0f;
-        }
-        if (i == 0) first_mid = last_mid;
+        // way through the reference's field; v_max-based ReLU would launder it, so restore it here -- by arithmetic, not selects
+        // (sn_sample_q_fast): q * 0 is +-0 for a finite q and NaN for a NaN one, and x + +-0 == x.
+        const float nan_term = fmaf(q[2], 0.0f, fmaf(q[1], 0.0f, q[0] * 0.0f));
+        density += nan_term;
+        r = rgb[0] + nan_term;
+        g = rgb[1] + nan_term;
+        b = rgb[2] + nan_term;
+        comp.step_fused(t0, t1, density, r, g, b);
         t0 = t1;
     }
     float out_rgb[3], depth, acc, exp_raw;
-    comp.finish(S, last_mid, r, g, b, out_rgb, depth, acc, exp_raw);
+    {
+        // the mid-points the outputs need -- first, last, median sample -- from the same bins with the loop's own arithmetic, once per ray
+        auto bin = [&](int k) -> float {
+            return MODE == 0 ? (shared_bins ? etab[k] : sn_euclid(p.sbins ? p.sbins[k] : (float)k / (float)S, s_near, s_far)) : eb[(int64_t)k * 64];
+        };
+        const int mi = comp.median_index(S);
+        first_mid = sn_mid(bin(0), bin(1));
+        last_mid = sn_mid(bin(S - 1), bin(S));
+        comp.finish_fused(S, sn_mid(bin(mi), bin(mi + 1)), r, g, b, out_rgb, depth, acc, exp_raw);
+    }
     if (valid) {
         const int64_t pix = (int64_t)py * p.width + px;
         if (p.rgb) {

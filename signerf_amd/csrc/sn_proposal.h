@@ -31,13 +31,15 @@
 #define SN_PROP_B0 160
 #define SN_PROP_W1 176
 #define SN_PROP_B1 192
-// ... followed by the matrix-core form of the same weights (SN_PROP_MFMA): the A operand of v_mfma_f32_32x32x16_f16 as fp16
-// hi / lo parts, [lane][8 halves] each -- A[i = lane & 31][k = 8 (lane >> 5) + e] = W0[i][k] (k < 10), b0[i] (k = 10), 0 --
-// and the layer-2 weights in accumulator order, [h][r] = W1[(r & 3) + 8 (r >> 2) + 4 h], r = 0..7
-#define SN_PROP_MA_HI 196
-#define SN_PROP_MA_LO 452
-#define SN_PROP_MW1 708
-#define SN_PROP_PACK_FLOATS 724
+// ... followed by the matrix-core form of the same weights (SN_PROP_MFMA): two A operands of v_mfma_f32_32x32x16_f16 as fp16 hi / lo
+// parts, [lane][8 halves] each (sn_prop_mlp_mfma below: rows 0..15 serve the rays of lanes 0..31 through k = 0..7, rows 16..31 the rays
+// of lanes 32..63 through k = 8..15), and the layer-2 weights in accumulator order, [h][r] = W1[(r & 3) + 8 (r >> 2) + 4 h], r = 0..7
+#define SN_PROP_MA1_HI 196
+#define SN_PROP_MA1_LO 452
+#define SN_PROP_MA2_HI 708
+#define SN_PROP_MA2_LO 964
+#define SN_PROP_MW1 1220
+#define SN_PROP_PACK_FLOATS 1236
 #ifndef SN_PROP_MFMA
 #define SN_PROP_MFMA 1
 #endif
@@ -53,14 +55,19 @@ SN_DEV void sn_swap_halves_u(uint32_t& a, uint32_t& b) {
     b = r[1];
 }
 
-// The 10 -> 16 -> 1 MLP of the wave's 64 samples on the matrix cores, split precision (sn_main.h): features as fp16 hi + lo,
-// three v_mfma_f32_32x32x16_f16 per 32-sample tile (hi.hi + hi.lo + lo.hi, fp32 accumulate) -- K = 16 holds the 10 features
-// and the bias slot in ONE k-step.  B operand of tile 0 (rays 0..31): lanes 0..31 carry k = 0..7 = their own features 0..7,
-// lanes 32..63 carry k = 8..15 = (feature 8, feature 9, 1.0, 0 ...) of ray lane - 32; tile 1 the other way round: one
-// permlane32_swap of (X, Y) per packed register gives both.  Layer 2 is 8 FMAs per lane and tile plus one swap.
-// 6 MFMAs (32 cycles each) + ~65 VALU instead of 187 VALU + 48 LDS reads.
+// The 10 -> 16 -> 1 MLP of the wave's 64 samples on the matrix cores, split precision (sn_main.h): features as fp16 hi + lo, products
+// hi.hi + hi.lo + lo.hi with fp32 accumulation.
+// The layer has 16 hidden units and a 32x32x16 tile has 32 rows, so ONE tile serves all 64 rays with every lane feeding its OWN
+// features -- no cross-lane traffic in front of the MFMAs (r02; r01 built two 32-ray tiles with 8 v_permlane32_swap, a half-rate
+// instruction that also needs wait states in front, sn_swap_halves):
+//     B[k = 8 h + e][column j] = the e-th operand of the ray in lane j + 32 h        (h = lane >> 5: just what the lane holds)
+//     A[row i][k]              = W[i][k] for i < 16, k < 8;   W[i - 16][k - 8] for i >= 16, k >= 8;   0 elsewhere
+//     => D[i][j] = hidden unit i of ray j (i < 16), hidden unit i - 16 of ray j + 32 (i >= 16).
+// Two such k-steps: operands (feature 0..7), then (feature 8, feature 9, 1.0 for the bias, 0 ...).  6 MFMAs as before, one
+// accumulator tile instead of two.  Layer 2: a lane holds 8 hidden units of ray j (accumulator registers 0..7) and 8 of ray j + 32
+// (registers 8..15); one swap of the two partial sums completes both rays.
 SN_DEV float sn_prop_mlp_mfma(const float* __restrict__ w, const float* feat, int lane) {
-    u32x4 xh, xl, yh = {0u, 0x00003c00u /* (1.0h, 0) -> the bias slot k = 10 */, 0u, 0u}, yl = {0u, 0u, 0u, 0u};
+    u32x4 xh, xl, yh = {0u, 0x00003c00u /* (1.0h, 0) -> the bias slot e = 2 */, 0u, 0u}, yl = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         uint32_t h, l;
@@ -74,46 +81,37 @@ SN_DEV float sn_prop_mlp_mfma(const float* __restrict__ w, const float* feat, in
         yh[0] = h;
         yl[0] = l;
     }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        uint32_t a = xh[m], b = yh[m];
-        sn_swap_halves_u(a, b);
-        xh[m] = a;  // tile 0
-        yh[m] = b;  // tile 1
-        a = xl[m];
-        b = yl[m];
-        sn_swap_halves_u(a, b);
-        xl[m] = a;
-        yl[m] = b;
-    }
-    const f16x8 ah = __builtin_bit_cast(f16x8, *(const u32x4*)(w + SN_PROP_MA_HI + lane * 4));
-    const f16x8 al = __builtin_bit_cast(f16x8, *(const u32x4*)(w + SN_PROP_MA_LO + lane * 4));
-    const f16x8 b0h = __builtin_bit_cast(f16x8, xh), b0l = __builtin_bit_cast(f16x8, xl);
-    const f16x8 b1h = __builtin_bit_cast(f16x8, yh), b1l = __builtin_bit_cast(f16x8, yl);
-    f32x16 c0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, c1 = c0;
+    const f16x8 a1h = __builtin_bit_cast(f16x8, *(const u32x4*)(w + SN_PROP_MA1_HI + lane * 4));
+    const f16x8 a1l = __builtin_bit_cast(f16x8, *(const u32x4*)(w + SN_PROP_MA1_LO + lane * 4));
+    const f16x8 a2h = __builtin_bit_cast(f16x8, *(const u32x4*)(w + SN_PROP_MA2_HI + lane * 4));
+    const f16x8 a2l = __builtin_bit_cast(f16x8, *(const u32x4*)(w + SN_PROP_MA2_LO + lane * 4));
+    const f16x8 b1h = __builtin_bit_cast(f16x8, xh), b1l = __builtin_bit_cast(f16x8, xl);
+    const f16x8 b2h = __builtin_bit_cast(f16x8, yh), b2l = __builtin_bit_cast(f16x8, yl);
+    f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #if defined(SN_PROP_PRIO) && SN_PROP_PRIO  // experiment (tools/ab_lib.sh): priority around the layer's six MFMAs
     __builtin_amdgcn_s_setprio(SN_PROP_PRIO);
 #endif
-    SN_MFMA_H(c0, al, b0h);
-    SN_MFMA_H(c1, al, b1h);
-    SN_MFMA_H(c0, ah, b0l);
-    SN_MFMA_H(c1, ah, b1l);
-    SN_MFMA_H(c0, ah, b0h);
-    SN_MFMA_H(c1, ah, b1h);
+    // small terms first
+    SN_MFMA_H(c, a1l, b1h);
+    SN_MFMA_H(c, a2l, b2h);
+    SN_MFMA_H(c, a1h, b1l);
+    SN_MFMA_H(c, a2h, b2l);
+    SN_MFMA_H(c, a1h, b1h);
+    SN_MFMA_H(c, a2h, b2h);
 #if defined(SN_PROP_PRIO) && SN_PROP_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
-    // layer 2: this lane holds hidden units (r & 3) + 8 (r >> 2) + 4 h, r = 0..7, of its column in both tiles
+    // layer 2: accumulator register r holds hidden unit (r & 3) + 8 ((r & 7) >> 2) + 4 h of ray j (r < 8) / ray j + 32 (r >= 8)
     const f32x4* w1 = (const f32x4*)(w + SN_PROP_MW1 + (lane >> 5) * 8);
     const f32x4 wa = w1[0], wb = w1[1];
     float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const float wv = r < 4 ? wa[r] : wb[r - 4];
-        p0 = fmaf(wv, sn_relu(c0[r]), p0);
-        p1 = fmaf(wv, sn_relu(c1[r]), p1);
+        p0 = fmaf(wv, sn_relu(c[r]), p0);
+        p1 = fmaf(wv, sn_relu(c[8 + r]), p1);
     }
-    sn_swap_halves(p0, p1);  // lower lane j: both halves of tile 0, column j; upper lane: tile 1
+    sn_swap_halves(p0, p1);  // lower lane: its own half of ray j + the upper lane's; upper lane: both halves of ray j + 32
     return p0 + p1 + w[SN_PROP_B1];
 }
 
@@ -171,9 +169,9 @@ SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, cons
     }
     float out = o2.x + o2.y;
 #endif
-    // v_max-based ReLU launders NaN; the reference's field is NaN all the way for a NaN position
-    if ((q[0] != q[0]) | (q[1] != q[1]) | (q[2] != q[2])) out = __builtin_nanf("");
-    return out;
+    // v_max-based ReLU launders NaN; the reference's field is NaN all the way for a NaN position.  Restored by arithmetic (q * 0 is +-0
+    // or NaN), not by a select -- sn_sample_q_fast explains why.
+    return out + fmaf(q[2], 0.0f, fmaf(q[1], 0.0f, q[0] * 0.0f));
 }
 
 // ---- PDFSampler, eval mode (A11), one ray per lane --------------------------------------------------------------------
@@ -306,8 +304,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
 #pragma unroll
     for (int l = 0; l < 5; ++l) pi.base[l] = p.pinfo[LV].base[l];
     double cum_tau = 0.0, cum_w = 0.0, swp = 0.0;
-    bool found = false;
-    float median = 0.0f, mid = 0.0f;
+    float below = 0.0f;  // number of steps with cumsum(w) < 0.5 = index of the median sample (SnComposite::step_fused)
     float e0 = eb_shared ? eb_shared[0] : sn_euclid(sb(0), s_near, s_far);
 #pragma unroll 1
     for (int i = 0; i < N; ++i) {
@@ -332,22 +329,22 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
         {
 #pragma clang fp contract(off)
             const float tau = (e1 - e0) * density;
-            wt = (1.0f - sn_exp<true>(-tau)) * sn_exp<true>(-(float)cum_tau);
-            if (wt != wt) wt = 0.0f;
+            wt = fmaxf((1.0f - sn_exp<true>(-tau)) * sn_exp<true>(-(float)cum_tau), 0.0f);  // nan_to_num: tau >= 0 or NaN, so wt >= 0 or NaN
             cum_tau += (double)tau;
-            mid = (e0 + e1) / 2.0f;
             cum_w += (double)wt;
             swp += (double)(wt + p.hist_pad);
         }
-        if (!found && (float)cum_w >= 0.5f) {
-            found = true;
-            median = mid;
-        }
+        below += __builtin_amdgcn_fmed3f(fmaf((float)cum_w, -0x1p100f, 0x1p99f), 0.0f, 1.0f);
         w[(int64_t)i * 64] = wt;
         e0 = e1;
     }
     sum_wp = swp;
-    median_out = found ? median : mid;
+    {
+        const int mi = min((int)below, N - 1);
+        const float ea = eb_shared ? eb_shared[mi] : sn_euclid(sb(mi), s_near, s_far);
+        const float ec = eb_shared ? eb_shared[mi + 1] : sn_euclid(sb(mi + 1), s_near, s_far);
+        median_out = sn_mid(ea, ec);
+    }
 }
 
 // GRID 1: ND0 / ND1 = leading dense levels of the two nets (-1: run-time decision per level)

@@ -18,10 +18,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define DEV __device__ __forceinline__
 
-enum { F_FMA = 0, F_PKFMA, F_XAD, F_CVTPK, F_MUL24, F_EXP, F_PKADD, F_XOR, F_FMAMIX, F_MAXI, F_FRACT, F_MOV, F_MIXLO, F_MIXHI, F_PKMAXH, F_MIXCLAMP, F_NKIND };
+enum { F_FMA = 0, F_PKFMA, F_XAD, F_CVTPK, F_MUL24, F_EXP, F_PKADD, F_XOR, F_FMAMIX, F_MAXI, F_FRACT, F_MOV, F_MIXLO, F_MIXHI, F_PKMAXH, F_MIXCLAMP, F_CVTI, F_BITOP3, F_FMAC, F_SUB, F_ADD3, F_MAD24, F_LSHL, F_CNDMASK, F_ADDF64, F_CVTF64, F_SWAP, F_FLOOR, F_RCP, F_CVTU, F_CNDMASK64, F_BFI, F_CMP, F_CNDMASKC, F_NKIND };
 static const char* kind_name[F_NKIND] = {"v_fma_f32", "v_pk_fma_f32", "v_xad_u32", "v_cvt_pkrtz", "v_mul_u32_u24", "v_exp_f32",
                                          "v_pk_add_f32", "v_xor_b32", "v_fma_mix_f32", "v_max_i32", "v_fract_f32", "v_mov_b32",
-                                         "v_fma_mixlo_f16", "v_fma_mixhi_f16", "v_pk_max_f16", "fma_mix clamp"};
+                                         "v_fma_mixlo_f16", "v_fma_mixhi_f16", "v_pk_max_f16", "fma_mix clamp",
+                                         "v_cvt_i32_f32", "v_bitop3_b32", "v_fmac_f32", "v_sub_f32", "v_add3_u32", "v_mad_u32_u24", "v_lshlrev_b32",
+                                         "v_cndmask_b32", "v_add_f64", "v_cvt_f64_f32", "v_permlane32_swap", "v_floor_f32", "v_rcp_f32", "v_cvt_f32_u32",
+                                         "v_cndmask_b32_e64(sgpr)", "v_bfi_b32", "v_cmp_lt_f32", "v_cndmask const"};
 
 template <int K>
 DEV void filler(float& x, f32x2& xp, float c1, float c2, f32x2 cp) {
@@ -41,6 +44,28 @@ DEV void filler(float& x, f32x2& xp, float c1, float c2, f32x2 cp) {
     if (K == F_MIXLO) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "+v"(x) : "v"(c1), "v"(c2));
     if (K == F_MIXHI) asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x) : "v"(c1), "v"(c2));
     if (K == F_PKMAXH) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(x) : "v"(c1));
+    // the rest of K1's opcode mix (r02: which of them are not full rate?)
+    if (K == F_CVTI) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(x));
+    if (K == F_BITOP3) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x28" : "+v"(x) : "v"(c1), "v"(c2));
+    if (K == F_FMAC) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x) : "v"(c1), "v"(c2));
+    if (K == F_SUB) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x) : "v"(c2));
+    if (K == F_ADD3) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(c1), "v"(c2));
+    if (K == F_MAD24) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x) : "v"(c1), "v"(c2));
+    if (K == F_LSHL) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(x));
+    if (K == F_CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(c1));
+    if (K == F_ADDF64) asm volatile("v_add_f64 %0, %0, %1" : "+v"(xp) : "v"(cp));
+    if (K == F_CVTF64) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(xp) : "v"(c1));
+    if (K == F_SWAP) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(xp.x));
+    if (K == F_FLOOR) asm volatile("v_floor_f32 %0, %0" : "+v"(x));
+    if (K == F_RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(x));
+    if (K == F_CVTU) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(x));
+    if (K == F_CNDMASK64) {
+        uint64_t m = 0x5555555555555555ull;
+        asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(c1), "s"(m));
+    }
+    if (K == F_BFI) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(x) : "v"(c1), "v"(c2));
+    if (K == F_CMP) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x), "v"(c1) : "vcc");
+    if (K == F_CNDMASKC) asm volatile("v_cndmask_b32 %0, 0, %1, vcc" : "=v"(x) : "v"(c1));
     if (K == F_MIXCLAMP) asm volatile("v_fma_mix_f32 %0, %0, -1.0, %1 op_sel_hi:[1,0,0] clamp" : "+v"(x) : "v"(c2));
 }
 
@@ -317,6 +342,27 @@ int main() {
     sweep_same<0, F_PKMAXH>(n, cyc, out);
     sweep_same<1, F_PKMAXH>(n, cyc, out);
     sweep_same<1, F_MIXCLAMP>(n, cyc, out);
+    sweep_same<0, F_CVTI>(n, cyc, out);
+    sweep_same<0, F_BITOP3>(n, cyc, out);
+    sweep_same<0, F_FMAC>(n, cyc, out);
+    sweep_same<0, F_SUB>(n, cyc, out);
+    sweep_same<0, F_ADD3>(n, cyc, out);
+    sweep_same<0, F_MAD24>(n, cyc, out);
+    sweep_same<0, F_LSHL>(n, cyc, out);
+    sweep_same<0, F_CNDMASK>(n, cyc, out);
+    sweep_same<0, F_ADDF64>(n, cyc, out);
+    sweep_same<0, F_CVTF64>(n, cyc, out);
+    sweep_same<0, F_SWAP>(n, cyc, out);
+    sweep_same<0, F_FLOOR>(n, cyc, out);
+    sweep_same<0, F_RCP>(n, cyc, out);
+    sweep_same<0, F_CVTU>(n, cyc, out);
+    sweep_same<0, F_MOV>(n, cyc, out);
+    sweep_same<0, F_FRACT>(n, cyc, out);
+    sweep_same<0, F_MUL24>(n, cyc, out);
+    sweep_same<0, F_MAXI>(n, cyc, out);
+    sweep_same<1, F_CVTI>(n, cyc, out);
+    sweep_same<1, F_BITOP3>(n, cyc, out);
+    sweep_same<1, F_SWAP>(n, cyc, out);
     // B: different waves of one SIMD
     run_two<1, F_FMA>(40000, 10000, 0, 0, cyc, ids, out);
     run_two<1, F_FMA>(40000, 10000, 1, 0, cyc, ids, out);
@@ -337,5 +383,27 @@ int main() {
     run_phases<F_FMA, 512, 120, 7, 8>(1000, cyc, out);
     run_phases<F_FMA, 512, 120, 7, 4>(1000, cyc, out);
     run_phases<F_XAD, 512, 120, 7, 12>(1000, cyc, out);
+    // throughput of single opcodes with 3 waves per SIMD (column A: 512 fillers per iteration): which opcodes are slower than full rate
+    // when other waves could fill their issue gaps?
+    run_phases<F_FMA, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_CNDMASK, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_SWAP, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_MIXLO, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_EXP, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_MOV, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_CVTF64, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_FMAMIX, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_CVTPK, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_PKMAXH, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_FMAC, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_BITOP3, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_CNDMASK64, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_BFI, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_CMP, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_CNDMASKC, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_MAXI, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_CVTI, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_ADDF64, 512, 1, 0, 12>(1000, cyc, out);
+    run_phases<F_RCP, 512, 1, 0, 12>(1000, cyc, out);
     return 0;
 }
