@@ -23,7 +23,14 @@
 #define SN_PROP_MAX_SAMPLES 256
 #define SN_PROP_WAVES 4
 #ifndef SN_PROP_WG_PER_CU
-#define SN_PROP_WG_PER_CU 5  // = waves per SIMD the kernel is compiled for (<= 96 VGPRs)
+#define SN_PROP_WG_PER_CU 3  // = waves per SIMD the kernel is compiled for (<= 168 VGPRs)
+#endif
+// leading levels of a proposal net whose bilinear coefficients are kept in registers across the steps of the marching loop
+// (sn_device.h SnBcCache; 16 VGPRs per level).  Same-box A/B on the 1080p nerfacto frame (r02, tools/ab_lib.sh, 4 rounds of 40 frames;
+// K2 is ~57 % of the frame): no cache at 5 waves/SIMD (the previous configuration) 15.13 ms, no cache at 3 waves 15.38; 2 levels at
+// 4 waves 14.75; 3 / 4 / 5 levels at 3 waves 14.53 / 14.52 / 14.54 (5 levels spill).
+#ifndef SN_PROP_CACHE
+#define SN_PROP_CACHE 4
 #endif
 
 // proposal-net MLP pack (floats): W0 [k=10][n=16] (k-major), b0 [16], W1 [16], b1
@@ -126,13 +133,15 @@ SN_DEV float sn_prop_mlp_mfma(const float* __restrict__ w, const float* feat, in
 // their de-hashed copies (`dense`), the rest from the x-paired tables `prsrc`; ND = -1: torch grid -> everything from the paired
 // tables, tcnn grid -> everything from the uploaded table `plain` with the dense / hashed decision per level at run time (its values
 // then take the feature scale here: `plain_scale`).
-template <int GRID = 0, int ND = -1, bool DUMP = false>
+template <int GRID = 0, int ND = -1, bool DUMP = false, int NCACHE = 0>
 SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, const SnScal5& scal, int log2_t, const float* __restrict__ w,
                         const float q[3], const SnGridLevels* grid = nullptr, __amdgpu_buffer_rsrc_t plain = __amdgpu_buffer_rsrc_t(),
-                        const SnDenseCopy* dense = nullptr, uint32_t* rec = nullptr, float plain_scale = 1.0f) {
+                        const SnDenseCopy* dense = nullptr, uint32_t* rec = nullptr, float plain_scale = 1.0f, SnBcCache* cache = nullptr) {
     float feat[10];
     if (ND > 0) {
-        sn_hash_encode<(ND > 0 ? ND : 1), 0, (GRID ? 3 : 1), ND, DUMP, (ND > SN_BC_PROP ? SN_BC_PROP : ND)>(plain, scal.v, log2_t, q, feat, grid, dense, rec);
+        constexpr int NBCP = ND > SN_BC_PROP ? SN_BC_PROP : ND;
+        sn_hash_encode<(ND > 0 ? ND : 1), 0, (GRID ? 3 : 1), ND, DUMP, NBCP, (NCACHE < NBCP ? NCACHE : NBCP)>(plain, scal.v, log2_t, q, feat, grid, dense, rec,
+                                                                                                            1.0f, cache);
         if (ND < 5) sn_hash_encode_pairs<5, 0, true, (ND > 0 && ND < 5 ? ND : 0), GRID == 1, DUMP>(prsrc, pi, scal.v, log2_t, q, feat, rec);
     } else if (GRID == 1) {
         sn_hash_encode<5, 0, 2, -1>(plain, scal.v, log2_t, q, feat, grid, nullptr, nullptr, plain_scale);
@@ -305,6 +314,10 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
     for (int l = 0; l < 5; ++l) pi.base[l] = p.pinfo[LV].base[l];
     double cum_tau = 0.0, cum_w = 0.0, swp = 0.0;
     float below = 0.0f;  // number of steps with cumsum(w) < 0.5 = index of the median sample (SnComposite::step_fused)
+    constexpr int NCACHE = ND > 0 ? (SN_PROP_CACHE < ND ? SN_PROP_CACHE : ND) : 0;
+    SnBcCache cache[NCACHE > 0 ? NCACHE : 1];
+#pragma unroll
+    for (int l = 0; l < (NCACHE > 0 ? NCACHE : 1); ++l) cache[l].reset();
     float e0 = eb_shared ? eb_shared[0] : sn_euclid(sb(0), s_near, s_far);
 #pragma unroll 1
     for (int i = 0; i < N; ++i) {
@@ -323,7 +336,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
                 p.dump_q[LV][smp * 3 + 2] = q[2];
             }
         }
-        const float h0 = sn_prop_h0<GRID, ND, DUMP>(rsrc, pi, scal, log2_t, wp, q, &p.grid[LV], plain, &p.dense[LV], rec, p.feat_scale[LV]);
+        const float h0 = sn_prop_h0<GRID, ND, DUMP, NCACHE>(rsrc, pi, scal, log2_t, wp, q, &p.grid[LV], plain, &p.dense[LV], rec, p.feat_scale[LV], cache);
         const float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
         float wt;
         {

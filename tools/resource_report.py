@@ -3,7 +3,10 @@
 import os, re, subprocess, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
+sys.path.insert(0, root)
+from signerf_amd.build import CODEGEN_FLAGS  # noqa: E402  (the flags the library is built with)
+
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *CODEGEN_FLAGS, "-fPIC", "-c",
        os.path.join(root, "signerf_amd/csrc/sn_api.hip"), "-o", "/tmp/sn_rr.o",
        "-Rpass-analysis=kernel-resource-usage", *sys.argv[1:]]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
