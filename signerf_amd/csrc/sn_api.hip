@@ -1635,7 +1635,7 @@ int sn_aabb_mask_condition(const float* origins, const float* directions, const 
     if (e == hipSuccess) e = hipMemsetAsync(p.stats + 1, 0xff, 4, st);
     if (e == hipSuccess) e = hipMemsetAsync(p.stats + 2, 0, 4, st);
     if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_aabb_mask_condition memset: ") + hipGetErrorString(e));
-    hipLaunchKernelGGL(sn_mask_visible_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(sn_mask_visible_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, SN_MASK_VIS_BLOCKS)), dim3(256), 0, st, p);
     if (p.dilate) hipLaunchKernelGGL(sn_mask_prefix_kernel, dim3((unsigned)height), dim3(64), 0, st, p);
     hipLaunchKernelGGL(sn_mask_condition_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
     e = hipGetLastError();

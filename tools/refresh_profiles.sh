@@ -14,6 +14,8 @@ timeout 300 python tools/kernel_counts.py > "$OUT/kernel_counts.txt" 2>&1
 timeout 300 python tools/kernel_counts.py sn_render_main_kernelILi1ELi1ELi0ELi0ELi11ELb0E >> "$OUT/kernel_counts.txt" 2>&1
 timeout 300 python tools/normals_bench.py > "$OUT/normals_bench.txt" 2>&1
 timeout 300 python tools/normals_bench.py --workload nerfacto1080 >> "$OUT/normals_bench.txt" 2>&1
+timeout 300 python tools/views_bench.py --size 800 2>&1 | tail -1 > "$OUT/views_bench.txt"
+timeout 300 python tools/views_bench.py --size 512 2>&1 | tail -1 >> "$OUT/views_bench.txt"
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_sheet64" -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/prof_sheet64.log" 2>&1)
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_nerfacto1080" -- python "$ROOT/bench.py" --workload nerfacto1080 --steps 30 --warmup 3 --no-cpu-baseline > "$OUT/prof_nerfacto1080.log" 2>&1)
 python tools/rocprof_summary.py "$OUT/prof_sheet64" > "$OUT/kernel_stats_sheet64.txt" 2>&1
