@@ -286,6 +286,14 @@ SN_DEV void sn_hash_corners_tcnn(const float q[3], float scale, uint32_t mask, u
     }
 }
 
+// a * b + c on the full-rate 24-bit multiplier, b wave-uniform (an SGPR: the one constant-bus operand a VOP3 instruction may carry).
+// hipcc forms `v_mul_u32_u24; v_mul_u32_u24; v_lshlrev; v_add3` for x * 2^k + y * s1 + z * s2; two of these and the shift are 3.
+SN_DEV uint32_t sn_mad24(uint32_t a, uint32_t b_uniform, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+}
+
 // Buffer resource over a hash table (base must be wave-uniform: a kernel argument).
 SN_DEV __amdgpu_buffer_rsrc_t sn_table_rsrc(const float* table, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, (int)bytes, 0x00020000);
@@ -348,7 +356,7 @@ SN_DEV f32x2 sn_hash_level_dense_copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t leve
     // byte offsets directly: the x8 is folded into the (wave-uniform) strides; R <= 255, so 8 R^2 and every product fit 24 bits
     // (full-rate v_mul_u32_u24 / v_mad_u32_u24; v_mul_lo_u32 is quarter rate)
     const uint32_t R8 = R << 3, R28 = (R * R) << 3;
-    const uint32_t b_ff = (f[0] << 3) + __umul24(f[1], R8) + __umul24(f[2], R28);
+    const uint32_t b_ff = sn_mad24(f[2], R28, sn_mad24(f[1], R8, f[0] << 3));
     // the y + 1 / z + 1 strides are wave-uniform: they ride in the buffer instruction's SCALAR offset (3 s_add per level on the
     // scalar port) instead of three per-lane v_add
     const uint32_t o_cf = level_off_bytes + R8, o_fc = level_off_bytes + R28, o_cc = level_off_bytes + (R8 + R28);
@@ -390,7 +398,7 @@ SN_DEV f32x2 sn_hash_level_dense_bc(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_
     }
     // 32-byte entries; R <= 255 keeps 32 R^2 and every product inside 24 bits
     const uint32_t R32 = R << 5, R2_32 = (R * R) << 5;
-    const uint32_t b = (f[0] << 5) + __umul24(f[1], R32) + __umul24(f[2], R2_32);
+    const uint32_t b = sn_mad24(f[2], R2_32, sn_mad24(f[1], R32, f[0] << 5));  // shift + two v_mad_u32_u24
     const uint32_t o_z1 = level_off_bytes + R2_32;  // the z + 1 slice: a wave-uniform stride, carried by the scalar offset
     if (rec) {
         rec[0] = b + level_off_bytes;
@@ -442,7 +450,7 @@ SN_DEV f32x2 sn_hash_level_dense_bc_cached(__amdgpu_buffer_rsrc_t rsrc, uint32_t
         f[a] = (uint32_t)(int)x;
     }
     const uint32_t R32 = R << 5, R2_32 = (R * R) << 5;
-    const uint32_t b = (f[0] << 5) + __umul24(f[1], R32) + __umul24(f[2], R2_32);
+    const uint32_t b = sn_mad24(f[2], R2_32, sn_mad24(f[1], R32, f[0] << 5));  // shift + two v_mad_u32_u24
     const uint32_t o_z1 = level_off_bytes + R2_32;
     if (rec) {
         rec[0] = b + level_off_bytes;
