@@ -392,7 +392,36 @@ def main():
                                      "note": "issued MFMA flops (3-term fp16 split, 32-row tile padding) = matrix-pipe busy fraction at the 2.4 GHz "
                                              "peak clock; algorithmic = 22 784 FLOP per sample (SURVEY 8(d))"}
         else:
-            line["roofline"] = dict(line["roofline_hbm"])
+            # Proposal path: the vector issue port over the whole render call (K2's two marching loops + K1 in bins mode), static
+            # instruction counts of the loaded library x the steps each loop runs.  K2's resampling passes (~18 % of its VALU in the PMC
+            # profile) are not counted, so the fraction is a lower bound of the port's busy share.
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import kernel_counts
+
+                k2 = kernel_counts.mfma_loops("sn_proposal_kernelILi0ELi5ELi4ELb0ELb0E")
+                k1 = kernel_counts.loop_counts("sn_render_main_kernelILi1ELi%dELi0ELi0ELi11ELb0E" % (0 if args.precision == "fp32" else 1))
+                steps_k2 = list(cfg.num_proposal_samples_per_ray[:cfg.num_proposal_iterations])
+                if len(k2) != len(steps_k2):
+                    raise RuntimeError("expected one marching loop per proposal net, found %d" % len(k2))
+                clock = sustained_clock_ghz(6)
+                tiles = ((W + 7) // 8) * ((H + 7) // 8)
+                slots = sum(n * (c["valu"] + c["mfma"]) for n, c in zip(steps_k2, k2)) + S * (k1["valu"] + k1["mfma"])
+                achieved = slots * tiles / (k_med * 1e-3) / 1e9
+                peak = N_SIMDS * clock / VALU_ISSUE_CYCLES
+                line["roofline"] = {
+                    "bound": "simd-issue", "achieved": achieved, "peak": peak, "unit": "G wave-instructions/s", "frac": achieved / peak,
+                    "traffic": None, "kernel": "sn_proposal_kernel<0,5,4> + sn_render_main_kernel<1,*> (whole render call)", "kernel_ms": k_med,
+                    "sustained_clock_ghz": clock,
+                    "instructions_per_wave_step": {"K2 net %d (%d steps)" % (i, n): {k: c.get(k, 0) for k in ("valu", "mfma", "gather")}
+                                                   for i, (n, c) in enumerate(zip(steps_k2, k2))} |
+                                                  {"K1 bins mode (%d steps)" % S: {k: k1.get(k, 0) for k in ("valu", "mfma", "gather")}},
+                    "note": "VALU + MFMA instructions through the one vector issue port of a SIMD (4 cycles each) at the clock the chip "
+                            "sustains under this call; static counts (paths the workload does not take included, K2's resampling passes "
+                            "excluded).  rocprofv3 PMC of K2 alone: VALU port 0.94 busy (profiles/r02_K2_960x540_pmc_summary.txt)."}
+            except Exception as e:  # noqa: BLE001
+                line["roofline"] = {"bound": "simd-issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None,
+                                    "traffic": None, "error": repr(e)}
         if not args.no_alt_precision:
             other = "fp32" if args.precision == "fp16x2" else "fp16x2"
             ms = kernel_ms_of(other)

@@ -55,6 +55,56 @@ def classify(op: str) -> str:
     return "other"
 
 
+def _disassemble(kernel_substr: str, lib: str):
+    with tempfile.TemporaryDirectory() as wd:
+        co = _code_object(lib, wd)
+        syms = subprocess.run([OBJDUMP, "-t", co], capture_output=True, text=True, check=True).stdout
+        names = [ln.split()[-1] for ln in syms.splitlines() if kernel_substr in ln and " F " in ln and ".text" in ln]
+        names = [n for n in names if not n.endswith(".kd")]
+        if len(names) != 1:
+            raise RuntimeError(f"{kernel_substr!r} matches {len(names)} kernels: {names[:4]}")
+        dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f"--disassemble-symbols={names[0]}", co], capture_output=True, text=True,
+                             check=True).stdout
+    insts = []  # (address, opcode, text)
+    for ln in dis.splitlines():
+        m = re.match(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", ln)
+        if m:
+            insts.append((int(m.group(3), 16), m.group(1), ln))
+    return names[0], insts
+
+
+def mfma_loops(kernel_substr: str, lib: str = LIB) -> list:
+    """The innermost loops of a kernel that contain matrix-core instructions (the proposal kernel has two: the marching loops of its
+    two nets), each as {"valu", "mfma", "gather", ...}.  Static counts: every instruction between the loop head and its backward branch,
+    paths the workload does not take included."""
+    name, insts = _disassemble(kernel_substr, lib)
+    base = insts[0][0]
+    spans = []
+    for addr, op, ln in insts:
+        if op.startswith(("s_branch", "s_cbranch")):
+            m = re.search(r"\+0x([0-9a-fA-F]+)>", ln)
+            if m:
+                tgt = base + int(m.group(1), 16)
+                if tgt < addr and any(o.startswith("v_mfma") for a, o, _ in insts if tgt <= a <= addr):
+                    spans.append((tgt, addr))
+    spans.sort(key=lambda s: s[1] - s[0])
+    picked = []
+    for s in spans:
+        if not any(s[0] <= q[0] and q[1] <= s[1] for q in picked):
+            picked.append(s)
+    out = []
+    for lo, hi in sorted(picked):
+        c = {"kernel": name, "loop_bytes": hi - lo}
+        for addr, op, ln in insts:
+            if lo <= addr <= hi:
+                k = classify(op)
+                c[k] = c.get(k, 0) + 1
+                if op.startswith(("buffer_load_dwordx2", "buffer_load_dwordx4")):
+                    c["gather"] = c.get("gather", 0) + 1
+        out.append(c)
+    return out
+
+
 def loop_counts(kernel_substr: str, lib: str = LIB) -> dict:
     """{"kernel": mangled name, "valu", "mfma", "vmem_load", "lds", "salu", ..., "packed_f32": n, "loop_bytes": n}"""
     with tempfile.TemporaryDirectory() as wd:
