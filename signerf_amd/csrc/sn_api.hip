@@ -1060,6 +1060,10 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     for (int i = 0; i < SN_MAX_PROPOSALS; ++i) pp.pdf_u[i] = opts->pdf_u[i];
     pp.ebins_out = d_ebins;
     pp.scratch = (float*)(ws + wp.off_prop_scratch);
+    {
+        const char* e = getenv("SN_PROP_CACHE_OFF");  // test switch, see SnPropParams::cache_off
+        pp.cache_off = e && atoi(e) ? 1 : 0;
+    }
     pp.prop_depth[0] = prop_depth_0;
     pp.prop_depth[1] = prop_depth_1;
     pp.height = height;

@@ -436,7 +436,11 @@ SN_DEV f32x2 sn_hash_level_dense_bc(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_
 struct SnBcCache {
     uint32_t b;  // byte offset of the entry the held coefficients belong to (0xffffffff: nothing held)
     f32x4 ab0, cd0, ab1, cd1;
-    SN_DEV void reset() { b = 0xffffffffu; }
+    bool always;  // wave-uniform test switch (SN_PROP_CACHE_OFF=1): re-fetch on every step, i.e. the plain path
+    SN_DEV void reset(bool always_refetch = false) {
+        b = 0xffffffffu;
+        always = always_refetch;
+    }
 };
 template <bool TCNN = false>
 SN_DEV f32x2 sn_hash_level_dense_bc_cached(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_off_bytes, const float q[3], float scale, uint32_t R,
@@ -456,7 +460,7 @@ SN_DEV f32x2 sn_hash_level_dense_bc_cached(__amdgpu_buffer_rsrc_t rsrc, uint32_t
         rec[0] = b + level_off_bytes;
         rec[1] = b + o_z1;
     }
-    if (__builtin_amdgcn_ballot_w64(b != c.b) != 0ull) {
+    if (__builtin_amdgcn_ballot_w64(b != c.b) != 0ull || c.always) {
         c.b = b;
         c.ab0 = sn_table_load_pair(rsrc, b, level_off_bytes);
         c.cd0 = sn_table_load_pair(rsrc, b + 16u, level_off_bytes);

@@ -278,6 +278,7 @@ struct SnPropParams {
     int n_final;
     int height, width, tile_w_log2, tile_h_log2, tiles_x, tiles_y;
     float near_plane, far_plane, avg_density, hist_pad;
+    int cache_off;  // test switch: the coefficient cache re-fetches on every step (tests/test_gpu_render.py compares the two bit for bit)
 };
 
 // per-wave scratch: weights [256][64] + two spacing-bin arrays [257][64]
@@ -317,7 +318,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
     constexpr int NCACHE = ND > 0 ? (SN_PROP_CACHE < ND ? SN_PROP_CACHE : ND) : 0;
     SnBcCache cache[NCACHE > 0 ? NCACHE : 1];
 #pragma unroll
-    for (int l = 0; l < (NCACHE > 0 ? NCACHE : 1); ++l) cache[l].reset();
+    for (int l = 0; l < (NCACHE > 0 ? NCACHE : 1); ++l) cache[l].reset(p.cache_off != 0);
     float e0 = eb_shared ? eb_shared[0] : sn_euclid(sb(0), s_near, s_far);
 #pragma unroll 1
     for (int i = 0; i < N; ++i) {

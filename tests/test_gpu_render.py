@@ -328,6 +328,25 @@ def test_dehashed_and_plain_reads_agree(gpu, monkeypatch):
     assert lay["n_dense"] == 11 and lay["n_bc"] == 9
 
 
+def test_proposal_coefficient_cache_is_bit_identical(gpu, monkeypatch):
+    """K2 keeps the bilinear coefficients of its four coarsest levels in registers across the steps of the marching loop and re-fetches
+    them only when a lane of the wave leaves its voxel.  SN_PROP_CACHE_OFF=1 re-fetches on every step (the plain path): every output of
+    the proposal path must be bit-identical either way."""
+    cfg = scene.proposal_config()
+    model, _ = make_model(cfg, gpu)
+    H, W = 72, 104
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 1.2 * H, 1.2 * H, W / 2, H / 2, W, H).to(gpu)
+    keys = ("rgb", "depth", "accumulation", "expected_depth", "prop_depth_0", "prop_depth_1")
+    for i in (0, 3, 6):
+        b = cams[i].generate_rays(0)
+        out = {k: v.clone() for k, v in model.get_outputs_for_camera_ray_bundle(b).items() if k in keys}
+        monkeypatch.setenv("SN_PROP_CACHE_OFF", "1")
+        ref = model.get_outputs_for_camera_ray_bundle(b)
+        monkeypatch.delenv("SN_PROP_CACHE_OFF")
+        for k in keys:
+            assert torch.equal(out[k], ref[k]), k
+
+
 def test_empty_bundle_renders_to_empty_outputs(gpu):
     """A bundle with no rays (an empty row-major slice, as the reference's chunk loop can produce): every output is [0, C]."""
     cfg = small_config(num_proposal_samples_per_ray=(24, 12), num_nerf_samples_per_ray=8)
