@@ -1409,13 +1409,20 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
     const size_t lds_bytes = split ? (size_t)SnNormImgH::TOTAL_BYTES : (size_t)SnNormImg::TOTAL * 4;
     const dim3 grid((unsigned)(gbx * gby)), block(256);
     const bool tcnn = d.main_field.grid_mode == 1;
-#define SN_LAUNCH_NORMALS(MODE, GRID)                                                                        \
-    if (split) hipLaunchKernelGGL((sn_normals_kernel<MODE, GRID, 1>), grid, block, lds_bytes, st, p);        \
-    else hipLaunchKernelGGL((sn_normals_kernel<MODE, GRID, 0>), grid, block, lds_bytes, st, p)
+#define SN_LAUNCH_NORMALS(MODE, GRID, ND)                                                                      \
+    if (split) hipLaunchKernelGGL((sn_normals_kernel<MODE, GRID, 1, ND>), grid, block, lds_bytes, st, p);      \
+    else hipLaunchKernelGGL((sn_normals_kernel<MODE, GRID, 0, ND>), grid, block, lds_bytes, st, p)
+    // nerfacto's torch grid with its default 11 de-hashed levels reads them (168 gathers per step instead of 256); other shapes and the
+    // tiny-cuda-nn grid read the uploaded table
+    const bool copies = !tcnn && h->nd_torch == 11 && h->dense_main.ptr;
+    if (copies) {
+        p.dense = h->dense_info;
+        p.inv_feat_scale = 1.0f / h->feat_scale_main;
+    }
     if (nprop > 0) {
-        if (tcnn) { SN_LAUNCH_NORMALS(1, 1); } else { SN_LAUNCH_NORMALS(1, 0); }
+        if (tcnn) { SN_LAUNCH_NORMALS(1, 1, -1); } else if (copies) { SN_LAUNCH_NORMALS(1, 0, 11); } else { SN_LAUNCH_NORMALS(1, 0, -1); }
     } else {
-        if (tcnn) { SN_LAUNCH_NORMALS(0, 1); } else { SN_LAUNCH_NORMALS(0, 0); }
+        if (tcnn) { SN_LAUNCH_NORMALS(0, 1, -1); } else if (copies) { SN_LAUNCH_NORMALS(0, 0, 11); } else { SN_LAUNCH_NORMALS(0, 0, -1); }
     }
 #undef SN_LAUNCH_NORMALS
     SN_HIP(h, hipGetLastError());

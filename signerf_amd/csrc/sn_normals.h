@@ -50,6 +50,8 @@ struct SnNormalsParams {
     int log2_t;
     float near_plane, far_plane, avg_density;
     SnGridLevels grid;
+    SnDenseCopy dense;     // ND > 0: the main grid's de-hashed copies (r02: the normals kernel was gather-issue bound with 256 hashed gathers per step)
+    float inv_feat_scale;  // ND > 0: the copies carry the power-of-two feature scale of the split-precision render; this kernel's images do not
     float pe_rev_scale;  // position encoding: 1 = nerfstudio's torch NeRFEncoding, sin(2 pi x 2^k); 0.5 = tiny-cuda-nn's Frequency, sin(pi x 2^k)
 };
 
@@ -294,22 +296,98 @@ SN_DEV void sn_normals_field_h(const char* __restrict__ ldsb, const float* feat,
 #ifndef SN_GRAD_GROUP
 #define SN_GRAD_GROUP 4
 #endif
-template <int GRID>
+// ND > 0 (torch grid): levels [0, ND) come from the de-hashed copies, [0, NBC) of them in bilinear-coefficient form, where the slopes
+// are the coefficients themselves: per z slice d/d ox = B + oy D, d/d oy = C + ox D, and d/d oz = slice 1 - slice 0.  The copies hold
+// feature_scale x value; `inv_scale` (its exact inverse) rides in the per-level factor.
+template <int GRID, int ND = -1, int NBC = 0>
 SN_DEV void sn_hash_encode_grad(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], const float* gfeat,
-                                const SnGridLevels* grid, float g[3]) {
+                                const SnGridLevels* grid, float g[3], const SnDenseCopy* dense = nullptr, float inv_scale = 1.0f) {
     const uint32_t mask = (1u << log2_t) - 1u;
     g[0] = g[1] = g[2] = 0.0f;
 #pragma unroll
     for (int l = 0; l < 16; ++l) {
         if (l > 0 && (l % SN_GRAD_GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
-        SnHashLevel hl;
-        if (GRID) sn_hash_corners_tcnn<-1>(q, scal[l], mask, sn_grid_dense_res(*grid, l), hl);
-        else sn_hash_corners_fast(q, scal[l], mask, hl);
-        const uint32_t lvl = ((uint32_t)l << log2_t) * 8u;
-        f32x2 v[8];
+        if (ND > 0 && l < NBC && l < 12) {
+            uint32_t R = dense->res[l];
+            asm volatile("" : "+s"(R));
+            const __amdgpu_buffer_rsrc_t drsrc = sn_table_rsrc(dense->base, dense->bytes);
+            uint32_t f[3];
+            float off[3];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = sn_table_load(rsrc, hl.boff[k], lvl);
-        const float ox = hl.off[0], oy = hl.off[1], oz = hl.off[2];
+            for (int a = 0; a < 3; ++a) {
+                const float x = q[a] * scal[l];
+                off[a] = __builtin_amdgcn_fractf(x);
+                f[a] = (uint32_t)(int)x;
+            }
+            const uint32_t R32 = R << 5, R2_32 = (R * R) << 5;
+            const uint32_t b = sn_mad24(f[2], R2_32, sn_mad24(f[1], R32, f[0] << 5));
+            const uint32_t o0 = dense->off[l], o1 = o0 + R2_32;
+            const f32x4 ab0 = sn_table_load_pair(drsrc, b, o0), cd0 = sn_table_load_pair(drsrc, b + 16u, o0);
+            const f32x4 ab1 = sn_table_load_pair(drsrc, b, o1), cd1 = sn_table_load_pair(drsrc, b + 16u, o1);
+            const float ox = off[0], oy = off[1], oz = off[2];
+            float dx[2], dy[2], dz[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float e0 = fmaf(ox, cd0[2 + c], cd0[c]), e1 = fmaf(ox, cd1[2 + c], cd1[c]);   // d slice / d oy
+                const float z0 = fmaf(ox, ab0[2 + c], fmaf(oy, e0, ab0[c])), z1 = fmaf(ox, ab1[2 + c], fmaf(oy, e1, ab1[c]));
+                const float h0 = fmaf(oy, cd0[2 + c], ab0[2 + c]), h1 = fmaf(oy, cd1[2 + c], ab1[2 + c]);  // d slice / d ox
+                dx[c] = fmaf(h1 - h0, oz, h0);
+                dy[c] = fmaf(e1 - e0, oz, e0);
+                dz[c] = z1 - z0;
+                // an integer coordinate: torch's ceil == floor corner pair has no slope (see the hashed branch below)
+                if (ox == 0.0f) dx[c] = 0.0f;
+                if (oy == 0.0f) dy[c] = 0.0f;
+                if (oz == 0.0f) dz[c] = 0.0f;
+            }
+            const float sl = scal[l] * inv_scale;
+            const float ga = gfeat[2 * l] * sl, gb = gfeat[2 * l + 1] * sl;
+            g[0] = fmaf(ga, dx[0], fmaf(gb, dx[1], g[0]));
+            g[1] = fmaf(ga, dy[0], fmaf(gb, dy[1], g[1]));
+            g[2] = fmaf(ga, dz[0], fmaf(gb, dz[1], g[2]));
+            continue;
+        }
+        f32x2 v[8];
+        float ox, oy, oz, sl = scal[l];
+        if (ND > 0 && l < ND && l < 12) {  // de-hashed copy in plain-row form: four 16-byte fetches (sn_hash_level_dense_copy)
+            uint32_t R = dense->res[l];
+            asm volatile("" : "+s"(R));
+            const __amdgpu_buffer_rsrc_t drsrc = sn_table_rsrc(dense->base, dense->bytes);
+            uint32_t f[3];
+            float off[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float x = q[a] * scal[l];
+                off[a] = __builtin_amdgcn_fractf(x);
+                f[a] = (uint32_t)(int)x;
+            }
+            const uint32_t R8 = R << 3, R28 = (R * R) << 3;
+            const uint32_t b_ff = sn_mad24(f[2], R28, sn_mad24(f[1], R8, f[0] << 3));
+            const uint32_t o_ff = dense->off[l], o_cf = o_ff + R8, o_fc = o_ff + R28, o_cc = o_ff + (R8 + R28);
+            const f32x4 p_cc = sn_table_load_pair(drsrc, b_ff, o_cc), p_fc = sn_table_load_pair(drsrc, b_ff, o_fc);
+            const f32x4 p_ff = sn_table_load_pair(drsrc, b_ff, o_ff), p_cf = sn_table_load_pair(drsrc, b_ff, o_cf);
+            v[3] = f32x2{p_cc.x, p_cc.y};
+            v[0] = f32x2{p_cc.z, p_cc.w};
+            v[2] = f32x2{p_fc.x, p_fc.y};
+            v[1] = f32x2{p_fc.z, p_fc.w};
+            v[6] = f32x2{p_ff.x, p_ff.y};
+            v[5] = f32x2{p_ff.z, p_ff.w};
+            v[7] = f32x2{p_cf.x, p_cf.y};
+            v[4] = f32x2{p_cf.z, p_cf.w};
+            ox = off[0];
+            oy = off[1];
+            oz = off[2];
+            sl *= inv_scale;
+        } else {
+            SnHashLevel hl;
+            if (GRID) sn_hash_corners_tcnn<-1>(q, scal[l], mask, sn_grid_dense_res(*grid, l), hl);
+            else sn_hash_corners_fast(q, scal[l], mask, hl);
+            const uint32_t lvl = ((uint32_t)l << log2_t) * 8u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = sn_table_load(rsrc, hl.boff[k], lvl);
+            ox = hl.off[0];
+            oy = hl.off[1];
+            oz = hl.off[2];
+        }
         const float nx = 1.0f - ox, ny = 1.0f - oy, nz = 1.0f - oz;
         // corner order 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf; the "c" corner of an axis has weight off
         f32x2 dx = ((v[0] - v[3]) * oy + (v[1] - v[2]) * ny) * oz + ((v[4] - v[7]) * oy + (v[5] - v[6]) * ny) * nz;
@@ -325,7 +403,7 @@ SN_DEV void sn_hash_encode_grad(__amdgpu_buffer_rsrc_t rsrc, const float* scal, 
             if (oy == 0.0f) dy = f32x2{0.0f, 0.0f};
             if (oz == 0.0f) dz = f32x2{0.0f, 0.0f};
         }
-        const float ga = gfeat[2 * l] * scal[l], gb = gfeat[2 * l + 1] * scal[l];
+        const float ga = gfeat[2 * l] * sl, gb = gfeat[2 * l + 1] * sl;
         g[0] = fmaf(ga, dx.x, fmaf(gb, dx.y, g[0]));
         g[1] = fmaf(ga, dy.x, fmaf(gb, dy.y, g[1]));
         g[2] = fmaf(ga, dz.x, fmaf(gb, dz.y, g[2]));
@@ -333,7 +411,7 @@ SN_DEV void sn_hash_encode_grad(__amdgpu_buffer_rsrc_t rsrc, const float* scal, 
 }
 
 template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int GRID /*0 torch grid, 1 tiny-cuda-nn grid*/,
-          int PREC /*0 exact fp32 MFMA, 1 fp16 hi+lo split MFMA*/>
+          int PREC /*0 exact fp32 MFMA, 1 fp16 hi+lo split MFMA*/, int ND = -1 /*torch grid: leading levels read from the de-hashed copies*/>
 // (the run-time dense / hashed branch of the tiny-cuda-nn grid needs more registers than 2 waves per SIMD leave: 1 wave there)
 __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormalsParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -382,7 +460,15 @@ __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormals
         // one ulp off lands in the neighbouring voxel of a fine level about once per thousand samples
         const bool sel = sn_sample_q(o, d, t0, t1, q);
         float feat[32];
-        sn_hash_encode<16, 4, (GRID ? 2 : 1), -1>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, nullptr);
+        constexpr int NBC = ND > SN_BC_MAIN ? SN_BC_MAIN : (ND > 0 ? ND : 0);
+        if (ND > 0) {
+            // values of the copies are the table's own times the feature scale (an exact power of two), divided out again here
+            sn_hash_encode<16, 4, 1, ND, false, NBC>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense);
+#pragma unroll
+            for (int k = 0; k < 2 * (ND > 0 ? ND : 0); ++k) feat[k] *= p.inv_feat_scale;
+        } else {
+            sn_hash_encode<16, 4, (GRID ? 2 : 1), -1>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, nullptr);
+        }
         float pe[12];
         {
             const float tm = (t0 + t1) * 0.5f;
@@ -398,7 +484,7 @@ __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormals
         // opaque copies of q: otherwise the compiler keeps the first pass's 128 corner offsets alive across the MLPs to reuse
         // them here (~120 spilled registers) instead of recomputing them
         asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]));
-        sn_hash_encode_grad<GRID>(rsrc, p.scal, p.log2_t, q, gfeat, &p.grid, g);
+        sn_hash_encode_grad<GRID, ND, NBC>(rsrc, p.scal, p.log2_t, q, gfeat, &p.grid, g, &p.dense, p.inv_feat_scale);
         __builtin_amdgcn_sched_barrier(0);
         // Field.get_normals: -F.normalize(grad) = -grad / max(|grad|, 1e-12)
         const float gl = fmaxf(sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), 1e-12f);
