@@ -291,6 +291,10 @@ SN_DEV void sn_normals_field_h(const char* __restrict__ ldsb, const float* feat,
     }
 }
 
+// 1.0 for an in-voxel offset > 0, 0.0 for exactly 0: offsets are v_fract results in [0, 1), a positive one is >= 2^-24 x 2^-12, so
+// clamp(off * 2^127) is exactly 0 or 1 -- one multiply with the clamp modifier instead of a compare and a select
+SN_DEV float sn_nonzero01(float off) { return __builtin_amdgcn_fmed3f(off * 0x1p127f, 0.0f, 1.0f); }
+
 // g_q += sum over levels of scale_l * (g_feat[2l], g_feat[2l+1]) . d(feature pair)/d(offset): the gradient of the trilinear
 // blend (sn_hash_blend's association) w.r.t. the in-voxel offset; floor / ceil carry no gradient.
 #ifndef SN_GRAD_GROUP
@@ -334,16 +338,13 @@ SN_DEV void sn_hash_encode_grad(__amdgpu_buffer_rsrc_t rsrc, const float* scal, 
                 dx[c] = fmaf(h1 - h0, oz, h0);
                 dy[c] = fmaf(e1 - e0, oz, e0);
                 dz[c] = z1 - z0;
-                // an integer coordinate: torch's ceil == floor corner pair has no slope (see the hashed branch below)
-                if (ox == 0.0f) dx[c] = 0.0f;
-                if (oy == 0.0f) dy[c] = 0.0f;
-                if (oz == 0.0f) dz[c] = 0.0f;
             }
             const float sl = scal[l] * inv_scale;
             const float ga = gfeat[2 * l] * sl, gb = gfeat[2 * l + 1] * sl;
-            g[0] = fmaf(ga, dx[0], fmaf(gb, dx[1], g[0]));
-            g[1] = fmaf(ga, dy[0], fmaf(gb, dy[1], g[1]));
-            g[2] = fmaf(ga, dz[0], fmaf(gb, dz[1], g[2]));
+            // an integer coordinate: torch's ceil == floor corner pair has no slope along that axis (see the hashed branch below)
+            g[0] = fmaf(fmaf(ga, dx[0], gb * dx[1]), sn_nonzero01(ox), g[0]);
+            g[1] = fmaf(fmaf(ga, dy[0], gb * dy[1]), sn_nonzero01(oy), g[1]);
+            g[2] = fmaf(fmaf(ga, dz[0], gb * dz[1]), sn_nonzero01(oz), g[2]);
             continue;
         }
         f32x2 v[8];
@@ -388,25 +389,32 @@ SN_DEV void sn_hash_encode_grad(__amdgpu_buffer_rsrc_t rsrc, const float* scal, 
             oy = hl.off[1];
             oz = hl.off[2];
         }
-        const float nx = 1.0f - ox, ny = 1.0f - oy, nz = 1.0f - oz;
-        // corner order 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf; the "c" corner of an axis has weight off
-        f32x2 dx = ((v[0] - v[3]) * oy + (v[1] - v[2]) * ny) * oz + ((v[4] - v[7]) * oy + (v[5] - v[6]) * ny) * nz;
-        const f32x2 f03 = v[0] * ox + v[3] * nx, f12 = v[1] * ox + v[2] * nx;
-        const f32x2 f56 = v[5] * ox + v[6] * nx, f47 = v[4] * ox + v[7] * nx;
-        f32x2 dy = (f03 - f12) * oz + (f47 - f56) * nz;
-        f32x2 dz = (f03 * oy + f12 * ny) - (f47 * oy + f56 * ny);
+        // corner order 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf; the "c" corner of an axis has weight off.
+        // Plain fp32 instructions, lerps as a + w (b - a) (sn_hash_blend_fast explains both): the slopes are differences of lerps.
+        f32x2 dx, dy, dz;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float x03 = v[0][c] - v[3][c], x12 = v[1][c] - v[2][c], x47 = v[4][c] - v[7][c], x56 = v[5][c] - v[6][c];
+            const float xz1 = fmaf(x03 - x12, oy, x12), xz0 = fmaf(x47 - x56, oy, x56);   // d/d ox in the slices z + 1, z
+            dx[c] = fmaf(xz1 - xz0, oz, xz0);
+            const float f03 = fmaf(x03, ox, v[3][c]), f12 = fmaf(x12, ox, v[2][c]), f47 = fmaf(x47, ox, v[7][c]), f56 = fmaf(x56, ox, v[6][c]);
+            const float y1 = f03 - f12, y0 = f47 - f56;                                    // d/d oy in the slices z + 1, z
+            dy[c] = fmaf(y1 - y0, oz, y0);
+            dz[c] = fmaf(y1, oy, f12) - fmaf(y0, oy, f56);
+        }
+        const float ga = gfeat[2 * l] * sl, gb = gfeat[2 * l + 1] * sl;
         if (!GRID) {
             // torch path: where scale * q is an integer in fp32 (about 6e-4 of the samples: ulp(x) / 1 at the fine levels),
             // ceil(x) == floor(x), both corners of that axis are the SAME table row and autograd sees no slope along it; the
-            // kernels fetch floor + 1 (value-identical, weight 0), so the slope is dropped explicitly
-            if (ox == 0.0f) dx = f32x2{0.0f, 0.0f};
-            if (oy == 0.0f) dy = f32x2{0.0f, 0.0f};
-            if (oz == 0.0f) dz = f32x2{0.0f, 0.0f};
+            // kernels fetch floor + 1 (value-identical, weight 0), so the slope is dropped explicitly -- as a 0 / 1 factor, not a select
+            g[0] = fmaf(fmaf(ga, dx.x, gb * dx.y), sn_nonzero01(ox), g[0]);
+            g[1] = fmaf(fmaf(ga, dy.x, gb * dy.y), sn_nonzero01(oy), g[1]);
+            g[2] = fmaf(fmaf(ga, dz.x, gb * dz.y), sn_nonzero01(oz), g[2]);
+        } else {
+            g[0] = fmaf(ga, dx.x, fmaf(gb, dx.y, g[0]));
+            g[1] = fmaf(ga, dy.x, fmaf(gb, dy.y, g[1]));
+            g[2] = fmaf(ga, dz.x, fmaf(gb, dz.y, g[2]));
         }
-        const float ga = gfeat[2 * l] * sl, gb = gfeat[2 * l + 1] * sl;
-        g[0] = fmaf(ga, dx.x, fmaf(gb, dx.y, g[0]));
-        g[1] = fmaf(ga, dy.x, fmaf(gb, dy.y, g[1]));
-        g[2] = fmaf(ga, dz.x, fmaf(gb, dz.y, g[2]));
     }
 }
 
@@ -488,14 +496,15 @@ __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormals
         __builtin_amdgcn_sched_barrier(0);
         // Field.get_normals: -F.normalize(grad) = -grad / max(|grad|, 1e-12)
         const float gl = fmaxf(sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), 1e-12f);
-        const float an[3] = {-g[0] / gl, -g[1] / gl, -g[2] / gl};
+        const float igl = -__builtin_amdgcn_rcpf(gl);  // (1-ulp reciprocals: the per-sample normals are weighted, summed and renormalised)
+        const float an[3] = {g[0] * igl, g[1] * igl, g[2] * igl};
         // PredNormalsFieldHead: tanh, then F.normalize
         const float tx3[3] = {sn_tanh(x[0]), sn_tanh(x[1]), sn_tanh(x[2])};
-        const float tl = fmaxf(sqrtf(tx3[0] * tx3[0] + tx3[1] * tx3[1] + tx3[2] * tx3[2]), 1e-12f);
+        const float itl = __builtin_amdgcn_rcpf(fmaxf(sqrtf(tx3[0] * tx3[0] + tx3[1] * tx3[1] + tx3[2] * tx3[2]), 1e-12f));
         const float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
         const float w = comp.step<true>(i, t0, t1, density, an[0], an[1], an[2]);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) pn[c] = fmaf(w, tx3[c] / tl, pn[c]);
+        for (int c = 0; c < 3; ++c) pn[c] = fmaf(w * itl, tx3[c], pn[c]);
         t0 = t1;
     }
     if (valid) {
