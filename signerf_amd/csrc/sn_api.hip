@@ -936,8 +936,17 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
                     a2hi[lane * 8 + e] = h2;
                     a2lo[lane * 8 + e] = f32_to_f16_rne(x2 - f16_to_f32(h2));
                 }
+            // layer 2 as (w x + w |x|) / 2: MW1 holds w / 2 in accumulator order (per unit of the s1p-scaled accumulators), LIN the linear half
             for (int hh = 0; hh < 2; ++hh)
-                for (int r = 0; r < 8; ++r) pack[SN_PROP_MW1 + hh * 8 + r] = (float)((*w1)[(r & 3) + 8 * (r >> 2) + 4 * hh] / s1p);
+                for (int r = 0; r < 8; ++r) pack[SN_PROP_MW1 + hh * 8 + r] = (float)(0.5 * (*w1)[(r & 3) + 8 * (r >> 2) + 4 * hh] / s1p);
+            double cl = 0.0;
+            for (int n = 0; n < 16; ++n) cl += (double)(*w1)[n] * (double)(*b0)[n];
+            for (int k = 0; k < 10; ++k) {
+                double v = 0.0;
+                for (int n = 0; n < 16; ++n) v += (double)(*w1)[n] * (double)(*w0)[n * 10 + k];
+                pack[SN_PROP_LIN + k] = (float)(0.5 * v / t0p);
+            }
+            pack[SN_PROP_LIN + 10] = (float)(0.5 * cl + (double)(*b1)[0]);
         }
         if (!h->wpack_prop[i].ptr) {
             SN_HIP(h, hipMalloc(&h->wpack_prop[i].ptr, pack.size() * 4));

@@ -46,7 +46,10 @@
 #define SN_PROP_MA2_HI 708
 #define SN_PROP_MA2_LO 964
 #define SN_PROP_MW1 1220
-#define SN_PROP_PACK_FLOATS 1236
+// ... and the linear half of layer 2 (sn_prop_mlp_mfma): [k < 10] = sum_r W1[r] W0[r][k] / 2 (per unit of the SCALED features), [10] =
+// sum_r W1[r] b0[r] / 2 + b1
+#define SN_PROP_LIN 1236
+#define SN_PROP_PACK_FLOATS 1252
 #ifndef SN_PROP_MFMA
 #define SN_PROP_MFMA 1
 #endif
@@ -108,18 +111,26 @@ SN_DEV float sn_prop_mlp_mfma(const float* __restrict__ w, const float* feat, in
 #if defined(SN_PROP_PRIO) && SN_PROP_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
-    // layer 2: accumulator register r holds hidden unit (r & 3) + 8 ((r & 7) >> 2) + 4 h of ray j (r < 8) / ray j + 32 (r >= 8)
+    // layer 2: accumulator register r holds hidden unit (r & 3) + 8 ((r & 7) >> 2) + 4 h of ray j (r < 8) / ray j + 32 (r >= 8).
+    // w relu(x) = (w x + w |x|) / 2: the |x| half is ONE fma per unit (the absolute value is a source modifier) instead of a max and an
+    // fma; the linear half, sum_r w_r x_r, is a linear function of the ray's 10 features and is evaluated as such by the ray's own lane
+    // (10 fma, coefficients folded on the host): 26 VALU instead of 32.
     const f32x4* w1 = (const f32x4*)(w + SN_PROP_MW1 + (lane >> 5) * 8);
     const f32x4 wa = w1[0], wb = w1[1];
     float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const float wv = r < 4 ? wa[r] : wb[r - 4];
-        p0 = fmaf(wv, sn_relu(c[r]), p0);
-        p1 = fmaf(wv, sn_relu(c[8 + r]), p1);
+        p0 = fmaf(wv, __builtin_fabsf(c[r]), p0);
+        p1 = fmaf(wv, __builtin_fabsf(c[8 + r]), p1);
     }
+    const f32x4* lw = (const f32x4*)(w + SN_PROP_LIN);
+    const f32x4 l0 = lw[0], l1 = lw[1], l2 = lw[2];
+    float lin = l2[2];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) lin = fmaf(k < 4 ? l0[k] : (k < 8 ? l1[k - 4] : l2[k - 8]), feat[k], lin);
     sn_swap_halves(p0, p1);  // lower lane: its own half of ray j + the upper lane's; upper lane: both halves of ray j + 32
-    return p0 + p1 + w[SN_PROP_B1];
+    return (p0 + p1) + lin;
 }
 
 // pre-activation density of one proposal net at normalised position q.
