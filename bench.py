@@ -81,7 +81,7 @@ def physical_cores():
 
 def cpu_baseline(main_cfg, main_sd, width, height, samples):
     """The CPU oracle (kind "port": nerfstudio itself cannot be installed here) timed on bounded samples of the BASELINE
-    configurations: a centred crop of the headline frame (config 2), config 1 in full, a 240x135 crop of config 4.
+    configurations: a centred crop of the headline frame (config 2), config 1 in full, a 160x90 crop of config 4.
     Threads = physical cores, set explicitly."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_config, small_config
@@ -122,9 +122,9 @@ def cpu_baseline(main_cfg, main_sd, width, height, samples):
                           "ms_per_frame": dt1 * 1e3})
     c4 = scene.proposal_config()
     sd4 = scene.synthetic_state_dict(c4, seed=0)
-    dt4 = timed(c4, sd4, 1920, 1080, 1.2 * 1080, 240, 135, chunk=8192)  # chunked: bounds the oracle's memory (352 proposal samples per ray)
-    n4 = 240 * 135
-    out["others"].append({"config": "config 4: centred 240x135 crop of the 1920x1080 frame, proposal nets 256 + 96 + 48 main samples", "seconds": dt4,
+    dt4 = timed(c4, sd4, 1920, 1080, 1.2 * 1080, 160, 90, chunk=8192)  # chunked: bounds the oracle's memory (352 proposal samples per ray)
+    n4 = 160 * 90
+    out["others"].append({"config": "config 4: centred 160x90 crop of the 1920x1080 frame, proposal nets 256 + 96 + 48 main samples", "seconds": dt4,
                           "ray_samples_per_s": n4 * 48 / dt4, "field_evaluations_per_s": n4 * 400 / dt4,
                           "ms_per_frame_extrapolated": dt4 * 1e3 * (1920 * 1080) / n4})
     torch.set_num_threads(old_threads)
