@@ -11,7 +11,9 @@ Cameras.generate_rays -> Model.get_outputs_for_camera_ray_bundle, followed (N>1)
 Weak scaling: per-GPU work is fixed.  Inputs (weights, camera) are resident in HBM before the timed region.
 Prints ONE JSON line (see DESIGN.md "Measurement"):
   value            whole-job ray-samples/s over the K timed steps (wall clock between barriers + device syncs, max over ranks)
-  kernel_ms        HIP-event time of every timed render call on its launch stream: mean / median / min / max / p05 / p95
+                   Consecutive steps go to --frames-in-flight (default 2) alternating HIP streams: frames are independent, so the head of
+                   one fills the wave slots the tail of the previous leaves idle (800x800 = 3.26 rounds of waves; signerf_amd.sheet.FrameStreams)
+  kernel_ms        HIP-event time of a render call alone on the chip (one-stream leg after the timed region): mean / median / min / max / p05 / p95
   roofline         the hardware issue roof that binds the dominant kernel (K1 sn_render_main_kernel), as a fraction < 1: instruction
                    counts per wave-step come from the disassembly of the loaded library (tools/kernel_counts.py), the clock from
                    sn_clock_probe running beside the renders; `roofs` lists every roof considered
@@ -148,6 +150,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1: nccl = RCCL over xGMI (the real thing); gloo = host-staged gathers, for dry "
                          "runs of the N > 1 code on a box with fewer GPUs than ranks (ranks then share GPUs)")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="consecutive steps are issued on this many alternating HIP streams (signerf_amd.sheet.FrameStreams: frames of "
+                         "different cameras are independent, the head of one fills the wave slots the tail of the previous leaves idle); "
+                         "1 = one stream, every launch waits for the previous one to drain")
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the extra (untimed-region) run of the other precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -237,22 +243,29 @@ def main():
 
     pending = [None]  # the previous step's tile all-gather, still in flight
 
+    frames = sheet.FrameStreams(dev, max(1, args.frames_in_flight))
+    issued = [0]
+
     def step(timed: bool):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
-        bundle = cam.generate_rays(camera_indices=0, aabb_box=model.render_aabb)
-        e0.record()
-        out = model.get_outputs_for_camera_ray_bundle(bundle)
-        e1.record()
-        tile = torch.cat([out["rgb"], out["depth"]], dim=-1)[None]
+        handle = None
+        with frames.frame(issued[0]):  # this step's stream (one of --frames-in-flight, round robin)
+            bundle = cam.generate_rays(camera_indices=0, aabb_box=model.render_aabb)
+            e0.record()
+            out = model.get_outputs_for_camera_ray_bundle(bundle)
+            e1.record()
+            tile = frames.keep(torch.cat([out["rgb"], out["depth"]], dim=-1)[None])
+            if world > 1:
+                # depth-1 pipeline: this frame's all-gather (RCCL's own stream, ordered behind this step's stream) overlaps the next
+                # frames' renders; every gather is waited for inside the timed region (drain() below)
+                handle = sheet.gather_tiles_async(tile, world)
+        issued[0] += 1
         if timed:
             render_ms.append((e0, e1))
         if world == 1:
             return tile
-        # depth-1 pipeline: this frame's all-gather (RCCL's own stream) overlaps the next frame's render; every gather is
-        # waited for inside the timed region (drain() below)
-        handle = sheet.gather_tiles_async(tile, world)
-        done = pending[0].wait() if pending[0] is not None else None
+        done = pending[0].wait() if pending[0] is not None else None  # on the caller's stream, not on a render stream
         pending[0] = handle
         return done
 
@@ -274,6 +287,7 @@ def main():
     for _ in range(args.steps):
         tiles = step(True)
     tiles = drain() if world > 1 else tiles
+    frames.join()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -283,7 +297,24 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    per_step = sorted(a.elapsed_time(b) for a, b in render_ms)
+    latency = sorted(a.elapsed_time(b) for a, b in render_ms)  # with several frames in flight: the span of a call that shared the chip
+    # Per-launch time of the render call with nothing else on the chip: an untimed-region leg on ONE stream (what rocprofv3 reports for
+    # `bench.py --frames-in-flight 1`, profiles/); the roofline fractions below are per launch and use this.
+    if args.frames_in_flight > 1:
+        serial = []
+        for i in range(min(args.steps, 100) + 2):
+            bundle = cam.generate_rays(camera_indices=0, aabb_box=model.render_aabb)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            model.get_outputs_for_camera_ray_bundle(bundle)
+            b.record()
+            if i >= 2:
+                serial.append((a, b))
+        torch.cuda.synchronize()
+        per_step = sorted(a.elapsed_time(b) for a, b in serial)
+        render_ms[:] = serial  # (the clock probe sizes itself from these)
+    else:
+        per_step = latency
     kernel_ms = sum(per_step) / max(len(per_step), 1)
 
     if rank == 0:
@@ -311,8 +342,14 @@ def main():
                        "backend": (args.backend if world > 1 else None), "ranks_share_a_gpu": shared_gpu},
             "ms_per_frame": elapsed / args.steps * 1e3,
             "timed_region_s": elapsed,
+            "frames_in_flight": max(1, args.frames_in_flight),
             "kernel_ms": {"mean": kernel_ms, "median": k_med, "min": per_step[0], "max": per_step[-1], "p05": pct(0.05), "p95": pct(0.95), "n": n_steps,
-                          "what": "HIP-event time of each timed render call on its launch stream (K1 + two memsets + the clip kernel; + K2 with proposal nets)"},
+                          "what": "HIP-event time of a render call on its launch stream with nothing else in flight (K1 + two memsets + the clip "
+                                  "kernel; + K2 with proposal nets)" + ("; measured in a one-stream leg after the timed region -- the timed steps "
+                                  "overlap the tail of one frame with the head of the next, see frame_latency_ms" if args.frames_in_flight > 1 else "")},
+            "frame_latency_ms": {"median": statistics.median(latency), "p05": latency[int(0.05 * len(latency))], "p95": latency[int(0.95 * len(latency))],
+                                 "what": "HIP-event span of each TIMED render call on its own stream (with %d frames in flight a call shares the "
+                                         "chip with its neighbours: the span grows, the frame period ms_per_step shrinks)" % max(1, args.frames_in_flight)},
             "rays_per_sec": world * W * H * args.steps / elapsed,
             # SURVEY §8(d) metric (3): every field evaluation of a ray (proposal nets + main field)
             "field_evaluations_per_sec": world * W * H * (S + (sum(cfg.num_proposal_samples_per_ray[:cfg.num_proposal_iterations])
@@ -422,6 +459,9 @@ def main():
             except Exception as e:  # noqa: BLE001
                 line["roofline"] = {"bound": "simd-issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None,
                                     "traffic": None, "error": repr(e)}
+        if line["roofline"].get("frac") and args.frames_in_flight > 1 and world == 1:
+            # the same roof at the job's frame period (frames overlapped) instead of per launch
+            line["roofline"]["frac_at_frame_period"] = line["roofline"]["frac"] * k_med / (elapsed / args.steps * 1e3)
         if not args.no_alt_precision:
             other = "fp32" if args.precision == "fp16x2" else "fp16x2"
             ms = kernel_ms_of(other)

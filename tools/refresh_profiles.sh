@@ -16,8 +16,8 @@ timeout 300 python tools/normals_bench.py > "$OUT/normals_bench.txt" 2>&1
 timeout 300 python tools/normals_bench.py --workload nerfacto1080 >> "$OUT/normals_bench.txt" 2>&1
 timeout 300 python tools/views_bench.py --size 800 2>&1 | tail -1 > "$OUT/views_bench.txt"
 timeout 300 python tools/views_bench.py --size 512 2>&1 | tail -1 >> "$OUT/views_bench.txt"
-(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_sheet64" -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/prof_sheet64.log" 2>&1)
-(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_nerfacto1080" -- python "$ROOT/bench.py" --workload nerfacto1080 --steps 30 --warmup 3 --no-cpu-baseline > "$OUT/prof_nerfacto1080.log" 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_sheet64" -- python "$ROOT/bench.py" --frames-in-flight 1 --no-cpu-baseline > "$OUT/prof_sheet64.log" 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_nerfacto1080" -- python "$ROOT/bench.py" --frames-in-flight 1 --workload nerfacto1080 --steps 30 --warmup 3 --no-cpu-baseline > "$OUT/prof_nerfacto1080.log" 2>&1)
 python tools/rocprof_summary.py "$OUT/prof_sheet64" > "$OUT/kernel_stats_sheet64.txt" 2>&1
 python tools/rocprof_summary.py "$OUT/prof_nerfacto1080" > "$OUT/kernel_stats_nerfacto1080.txt" 2>&1
 bash tools/pmc_passes.sh "$OUT/pmc_k1" > "$OUT/pmc_k1.log" 2>&1
