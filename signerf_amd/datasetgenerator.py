@@ -162,7 +162,16 @@ def generate_reference_sheet(config: DatasetGeneratorConfig, graph, cameras, sca
     """``DatasetGenerator.generate_reference_sheet`` (:470-593).  cameras: the rows*cols-1 reference cameras (indexable);
     diffuse(image, image, mask, condition) -> edited sheet [SH,SW,3] stands for ``self.diffuser.diffuse`` (:559).
     -> (image_sheet, mask_sheet, condition_sheet, edited_sheet, references) as the reference returns them."""
-    views = [render_camera(config, graph, cameras[i]) for i in range(len(cameras))]
+    # the reference cameras are independent: consecutive ones go to alternating streams (sheet.FrameStreams: the head of one frame fills
+    # the wave slots the tail of the previous one leaves idle); the sheet is composed on the caller's stream after the join
+    from .sheet import FrameStreams
+
+    fs = FrameStreams(getattr(graph, "device", None))
+    views = []
+    for i in range(len(cameras)):
+        with fs.frame(i):
+            views.append(tuple(fs.keep(t) for t in render_camera(config, graph, cameras[i])))
+    fs.join()
     image_sheet, mask_sheet, condition_sheet, references = compose_reference_sheet(config, views, scaled_image_width, scaled_image_height)
     edited = diffuse(image_sheet, image_sheet, mask_sheet, condition_sheet)
     H, W = views[0][0].shape[0], views[0][0].shape[1]

@@ -347,6 +347,35 @@ def test_proposal_coefficient_cache_is_bit_identical(gpu, monkeypatch):
             assert torch.equal(out[k], ref[k]), k
 
 
+def test_frames_on_alternating_streams_are_bit_identical(gpu):
+    """sheet.FrameStreams issues consecutive cameras on two HIP streams (the head of one frame overlaps the tail of the previous one).
+    Renders of a handle are independent and re-entrant: the sheet must equal the one-stream sheet bit for bit, with and without
+    proposal nets, and the per-view generator path (render + mask + condition) likewise."""
+    from signerf_amd import sheet
+    from signerf_amd.datasetgenerator import DatasetGeneratorConfig
+
+    for cfg in (scene.benchmark_config(16), small_config(num_proposal_samples_per_ray=(24, 12), num_nerf_samples_per_ray=8)):
+        model, _ = make_model(cfg, gpu)
+        H, W = 56, 72
+        cams = Cameras(scene.benchmark_cameras(8)[:, :3], 1.1 * H, 1.1 * H, W / 2, H / 2, W, H).to(gpu)
+
+        def render_fn(i):
+            out = model.get_outputs_for_camera_ray_bundle(cams[i].generate_rays(camera_indices=0, aabb_box=model.render_aabb))
+            return out["rgb"], out["depth"]
+
+        one = sheet.render_cameras_sharded(render_fn, 8, device=gpu, frames_in_flight=1)
+        for _ in range(3):
+            two = sheet.render_cameras_sharded(render_fn, 8, device=gpu, frames_in_flight=2)
+            assert torch.equal(one, two)
+        assert torch.equal(sheet.render_reference_sheet(model, cams), one)
+        gen = DatasetGeneratorConfig(aabb_min=[-0.2, -0.2, -0.2], aabb_max=[0.2, 0.2, 0.2])
+        from signerf_amd.datasetgenerator import render_camera
+        views = sheet.render_views(model, cams, gen)
+        for i in (0, 5):
+            rgb, mask, cond = render_camera(gen, model, cams[i])
+            assert torch.equal(views[i, ..., :3], rgb) and torch.equal(views[i, ..., 3:4], mask.to(rgb.dtype)) and torch.equal(views[i, ..., 4:5], cond)
+
+
 def test_empty_bundle_renders_to_empty_outputs(gpu):
     """A bundle with no rays (an empty row-major slice, as the reference's chunk loop can produce): every output is [0, C]."""
     cfg = small_config(num_proposal_samples_per_ray=(24, 12), num_nerf_samples_per_ray=8)
