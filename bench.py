@@ -355,14 +355,14 @@ def main():
             "field_evaluations_per_sec": world * W * H * (S + (sum(cfg.num_proposal_samples_per_ray[:cfg.num_proposal_iterations])
                                                                if args.workload != "sheet64" else 0)) * args.steps / elapsed,
         }
-        achieved_gbps = (W * H * bytes_per_ray) / (kernel_ms * 1e-3) / 1e9
+        achieved_gbps = (W * H * bytes_per_ray) / (k_med * 1e-3) / 1e9
         traffic, traffic_commit = measured_traffic(args.precision) if args.workload == "sheet64" else (None, None)
         line["roofline_hbm"] = {
             "bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved_gbps / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_profiled_at": traffic_commit,
             "kernel": ("sn_render_main_kernel<0,%d>" % (0 if args.precision == "fp32" else 1)) if args.workload == "sheet64"
             else "sn_proposal_kernel + sn_render_main_kernel<1,*> (whole render call)",
-            "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": W * H * bytes_per_ray,
+            "kernel_ms": k_med, "algorithmic_bytes_per_launch": W * H * bytes_per_ray,
             "note": "SURVEY 8(d)'s definition (1024 algorithmic bytes per main-field sample).  frac > 1 is NOT a fraction of a binding "
                     "roof: the 64 MiB table never leaves L1/L2/Infinity Cache (`traffic` = fabric bytes per launch from the committed "
                     "rocprofv3 PMC passes, ~0.17x the algorithmic bytes).  The roofs that bind are in `roofline`."}
@@ -423,9 +423,9 @@ def main():
             # against the dense peak of that MFMA type (MI355X_MICROARCH.md: 2.5 PFLOP/s f16, 157.3 TFLOP/s f32-input).
             per_step, flop, peak = (120, 2 * 32 * 32 * 16, 2500.0) if args.precision == "fp16x2" else (320, 2 * 32 * 32 * 2, 157.3)
             issued = (W * H * S / 64) * per_step * flop
-            line["roofline_mfma"] = {"bound": "mfma", "achieved": issued / (kernel_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                                     "frac": issued / (kernel_ms * 1e-3) / 1e12 / peak,
-                                     "algorithmic_tflops": W * H * S * 22784 / (kernel_ms * 1e-3) / 1e12,
+            line["roofline_mfma"] = {"bound": "mfma", "achieved": issued / (k_med * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                     "frac": issued / (k_med * 1e-3) / 1e12 / peak,
+                                     "algorithmic_tflops": W * H * S * 22784 / (k_med * 1e-3) / 1e12,
                                      "note": "issued MFMA flops (3-term fp16 split, 32-row tile padding) = matrix-pipe busy fraction at the 2.4 GHz "
                                              "peak clock; algorithmic = 22 784 FLOP per sample (SURVEY 8(d))"}
         else:
