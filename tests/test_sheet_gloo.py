@@ -180,3 +180,21 @@ def test_overlapped_gathers_deliver_every_frame_in_order(tmp_path):
         for step, sheet_tiles in enumerate(got):
             want = torch.stack([torch.cat(_fake_render(100 * step + k), dim=-1) for k in range(world)])
             assert torch.equal(sheet_tiles, want), (r, step)
+
+
+def test_frame_streams_degrade_to_in_order_execution_on_cpu():
+    """sheet.FrameStreams without a GPU (these gloo tests, a CPU-only host): frames run in order on the caller's thread, keep() and join()
+    are no-ops."""
+    fs = sheet.FrameStreams(torch.device("cpu"))
+    order = []
+    for k in range(5):
+        with fs.frame(k):
+            order.append(k)
+            t = fs.keep(torch.full((2,), float(k)))
+            assert float(t.sum()) == 2.0 * k
+    fs.join()
+    assert order == list(range(5))
+    fs = sheet.FrameStreams(None)
+    with fs.frame(0):
+        pass
+    fs.join()
