@@ -185,6 +185,8 @@ def test_overlapped_gathers_deliver_every_frame_in_order(tmp_path):
 def test_frame_streams_degrade_to_in_order_execution_on_cpu():
     """sheet.FrameStreams without a GPU (these gloo tests, a CPU-only host): frames run in order on the caller's thread, keep() and join()
     are no-ops."""
+    from signerf_amd import sheet
+
     fs = sheet.FrameStreams(torch.device("cpu"))
     order = []
     for k in range(5):
