@@ -26,6 +26,21 @@ def run(nstreams, frames):
             outs.append(out["rgb"][0, 0, 0])
             if len(outs) > 8: outs.pop(0)
     torch.cuda.synchronize(); return (time.perf_counter() - t) / frames * 1e3
+def check(nstreams, frames):
+    """Every frame of a pipelined run against the one-stream frame, bit for bit (full size: the r01 hazards showed up as a few tiles per frame)."""
+    ref = model.get_outputs_for_camera_ray_bundle(cam.generate_rays(camera_indices=0, aabb_box=model.render_aabb))
+    ref = {k: ref[k].clone() for k in ("rgb", "depth", "accumulation", "expected_depth")}
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    for st in streams: st.wait_stream(torch.cuda.current_stream())
+    kept = []
+    for k in range(frames):
+        with torch.cuda.stream(streams[k % nstreams]):
+            out = model.get_outputs_for_camera_ray_bundle(cam.generate_rays(camera_indices=0, aabb_box=model.render_aabb))
+            kept.append({kk: out[kk] for kk in ref})
+    torch.cuda.synchronize()
+    bad = sum(0 if all(torch.equal(o[kk], ref[kk]) for kk in ref) else 1 for o in kept)
+    print(f"{a.workload} {W}x{H}: {frames} frames on {nstreams} streams, frames differing from the one-stream frame: {bad}")
 run(1, 10); run(2, 10)
+check(2, min(a.frames, 120))
 for rep in range(3):
     print(f"{a.workload} {W}x{H}: 1 stream {run(1, a.frames):.4f} ms/frame   2 streams {run(2, a.frames):.4f}   3 streams {run(3, a.frames):.4f}")
