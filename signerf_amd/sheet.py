@@ -38,6 +38,9 @@ class TileGather:
         if self._work is not None:
             self._work.wait()
             self._work = None
+            if self._gathered.is_cuda:
+                # the buffer may have been allocated on a frame's stream (FrameStreams) and is read from the waiting stream from here on
+                self._gathered.record_stream(torch.cuda.current_stream(self._gathered.device))
         if self._device is not None:  # staged through the host (gloo): back to the GPU the tiles came from
             self._gathered, self._device = self._gathered.to(self._device), None
         g = self._gathered
