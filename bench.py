@@ -343,6 +343,8 @@ def main():
             "ms_per_frame": elapsed / args.steps * 1e3,
             "timed_region_s": elapsed,
             "frames_in_flight": max(1, args.frames_in_flight),
+            # for comparison with one-launch-at-a-time figures (r01's lines, rocprofv3): samples of one frame over the per-launch time
+            "one_stream_ray_samples_per_s_per_gpu": W * H * S / (k_med * 1e-3),
             "kernel_ms": {"mean": kernel_ms, "median": k_med, "min": per_step[0], "max": per_step[-1], "p05": pct(0.05), "p95": pct(0.95), "n": n_steps,
                           "what": "HIP-event time of a render call on its launch stream with nothing else in flight (K1 + two memsets + the clip "
                                   "kernel; + K2 with proposal nets)" + ("; measured in a one-stream leg after the timed region -- the timed steps "
