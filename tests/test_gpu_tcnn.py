@@ -148,6 +148,15 @@ def test_tcnn_render_full_size_grids(gpu, precision):
     print("tcnn full-size render", {k: f"{v:.2e}" for k, v in e.items()})
     assert all(v <= 1e-3 for v in e.values()), e
     assert float(ref["rgb"].std()) > 0.05
+    # the proposal kernel's cross-step coefficient cache (tiny-cuda-nn instantiation): re-fetching on every step changes no bit
+    import os
+    os.environ["SN_PROP_CACHE_OFF"] = "1"
+    try:
+        plain = model.get_outputs_for_camera_ray_bundle(b)
+    finally:
+        del os.environ["SN_PROP_CACHE_OFF"]
+    for k in ("rgb", "depth", "accumulation", "expected_depth", "prop_depth_0", "prop_depth_1"):
+        assert torch.equal(out[k], plain[k]), k
 
 
 def test_tcnn_all_levels_dense_runtime_path(gpu):
