@@ -277,6 +277,11 @@ def main():
 
     model._ensure_engine()  # library load, weight upload and de-hashed copies are set-up, not a step (matters only for --warmup 0)
     torch.cuda.synchronize()
+    if args.warmup < args.frames_in_flight:
+        # every render stream allocates its output / workspace blocks on first use (hipMalloc): one priming frame per stream is set-up
+        # like the upload above (matters only for --warmup 0 / 1)
+        for _ in range(max(1, args.frames_in_flight)):
+            step(False)
     for _ in range(args.warmup):
         step(False)
     drain()
