@@ -160,7 +160,7 @@ def _default_device():
     return torch.device("cpu")
 
 
-def render_views(model, cameras, generator_config, group=None) -> Tensor:
+def render_views(model, cameras, generator_config, group=None, frames_in_flight: int = 2) -> Tensor:
     """BASELINE.json configs[4]: the per-view work of the dataset-generator loops
     (/root/reference/signerf/datasetgenerator/datasetgenerator.py:331-338 and :517-519): for every camera, render ->
     mask -> condition (``render_camera``, aabb mode), sharded round-robin over the ranks, tiles all-gathered.
@@ -172,7 +172,7 @@ def render_views(model, cameras, generator_config, group=None) -> Tensor:
         rgb, mask, cond = render_camera(generator_config, model, cameras[i])
         return rgb, torch.cat([mask.to(rgb.dtype), cond], dim=-1)
 
-    return render_cameras_sharded(render_fn, len(cameras), group, device=getattr(model, "device", None))
+    return render_cameras_sharded(render_fn, len(cameras), group, device=getattr(model, "device", None), frames_in_flight=frames_in_flight)
 
 
 def render_reference_sheet(model, cameras, group=None) -> Tensor:

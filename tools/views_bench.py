@@ -19,6 +19,7 @@ from signerf_amd.datasetgenerator import DatasetGeneratorConfig  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--frames-in-flight", type=int, default=2)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = scene.proposal_config()
@@ -31,14 +32,14 @@ c2w = torch.cat([scene.benchmark_cameras(8), random_sphere_poses(50, torch.devic
 S = a.size
 cams = Cameras(c2w[:, :3], 1.2 * S, 1.2 * S, S / 2, S / 2, S, S).to(dev)
 gen = DatasetGeneratorConfig(aabb_min=[-0.2, -0.2, -0.2], aabb_max=[0.2, 0.2, 0.2])
-sheet.render_views(model, cams, gen)
+sheet.render_views(model, cams, gen, frames_in_flight=a.frames_in_flight)
 torch.cuda.synchronize()
 best = 1e9
 for _ in range(a.reps):
     t = time.perf_counter()
-    tiles = sheet.render_views(model, cams, gen)
+    tiles = sheet.render_views(model, cams, gen, frames_in_flight=a.frames_in_flight)
     torch.cuda.synchronize()
     best = min(best, time.perf_counter() - t)
 n = len(cams)
-print(f"{n} views {S}x{S} (256+96+48 samples, aabb mask 50x50 dilation, condition): {best * 1e3:.1f} ms total, {best * 1e3 / n:.2f} ms per view, "
+print(f"{n} views {S}x{S}, {a.frames_in_flight} in flight (256+96+48 samples, aabb mask 50x50 dilation, condition): {best * 1e3:.1f} ms total, {best * 1e3 / n:.2f} ms per view, "
       f"{n * S * S * 400 / best / 1e9:.1f} G field evaluations/s; mask coverage {float(tiles[..., 3].mean()):.3f}")
