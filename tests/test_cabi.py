@@ -116,6 +116,20 @@ def test_isa_has_no_packed_result_into_swizzle_pairs():
     assert r.returncode == 0, r.stdout[-2000:]
 
 
+def test_static_instruction_counts_of_the_fused_kernels(built_lib):
+    """bench.py's issue roofs are built from static counts of the loaded library (tools/kernel_counts.py): the sample loop of K1 holds the
+    120 MFMAs of the split-precision MLPs, its gathers and no packed-fp32 VALU; the proposal kernel has one marching loop per net with
+    the 6 MFMAs of the one-tile layer."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_counts
+
+    k1 = kernel_counts.loop_counts("sn_render_main_kernelILi0ELi1ELi0ELi0ELi11ELb0E")
+    assert k1["mfma"] == 120 and k1["gather"] == 84 and k1["packed_f32"] == 0 and 1300 < k1["valu"] < 1500
+    k2 = kernel_counts.mfma_loops("sn_proposal_kernelILi0ELi5ELi4ELb0ELb0E")
+    assert [c["mfma"] for c in k2] == [6, 6] and all(c["gather"] == 20 and 250 < c["valu"] < 340 for c in k2)
+
+
 def test_lazy_outputs_dict_semantics():
     """signerf_amd.nerfacto.LazyOutputs: the normals entries are produced once, on first use, and only then."""
     from signerf_amd.nerfacto import LazyOutputs
