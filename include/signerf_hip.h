@@ -34,7 +34,8 @@
  *   - other environment switches, all off / at their defaults in normal use and none of them changes what a render means:
  *     SN_DENSE_LEVELS=n / SN_DENSE_CAP_MB=m (read by sn_finalize_weights: how many leading levels get de-hashed copies; 0 = none),
  *     SN_PROP_CACHE_OFF=1 (the proposal kernel re-fetches its cached level coefficients on every step; bit-identical results,
- *     tests/test_gpu_render.py), SN_PDF_FAST=1 (reciprocal instead of IEEE divisions in the fused resampler: A/B knob, changes low bits),
+ *     tests/test_gpu_render.py), SN_PDF_IEEE=1 (its resampler divides with plain IEEE divisions instead of the reciprocal + exact
+ *     residual form; bit-identical results, same test file), SN_PDF_FAST=1 (reciprocal instead of IEEE divisions in the fused resampler: A/B knob, changes low bits),
  *     SN_HASH_PLAIN=1 (sn_hash_encode ignores the copies), SN_ABLATE=k (profiling only: WRONG images).
  *   - architecture limits (sn_create returns SN_ERR_INVALID otherwise -- the kernels are written
  *     for nerfacto's shapes): main field 16 levels x 2 features, hidden 64, out 16, 2 layers,

@@ -1072,6 +1072,8 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     {
         const char* e = getenv("SN_PROP_CACHE_OFF");  // test switch, see SnPropParams::cache_off
         pp.cache_off = e && atoi(e) ? 1 : 0;
+        const char* e2 = getenv("SN_PDF_IEEE");  // test switch, see SnPropParams::pdf_ieee
+        pp.pdf_ieee = e2 && atoi(e2) ? 1 : 0;
     }
     pp.prop_depth[0] = prop_depth_0;
     pp.prop_depth[1] = prop_depth_1;

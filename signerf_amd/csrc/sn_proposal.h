@@ -214,20 +214,44 @@ struct SnPdfNorm {
 // multiplication by a reciprocal, each within 1-2 ulp of the true quotient.  Measured r02 on the 1080p nerfacto frame: 16.37 vs 16.50 ms
 // (-0.8 %); not worth giving up the literal arithmetic of the CDF search, so the fused kernel keeps the IEEE divisions like the stage
 // entry point sn_pdf_sample does.
-template <bool FAST = false, typename SB, typename EMIT>
+// RECIP (the fused kernel, r02): the per-weight division num / denom has a loop-invariant denominator, so the IEEE quotient is formed
+// from its correctly rounded reciprocal y = RN(1 / denom) (one IEEE division per ray) as  q0 = RN(num y);  e = num - q0 denom (exact,
+// one fma);  q = RN(q0 + e y)  -- Markstein's theorem: q == RN(num / denom) for every num, unless the significand of denom is all
+// ones (then y is not accurate enough).  Such a denominator (1 in 8 M), or one outside [2^-60, 2^60] (residual underflow; never the
+// case: 1e-5 <= denom <= ~260), sends the whole wave down the plain IEEE path.  3 instead of ~10 VALU per weight, bit-identical
+// (tests/test_gpu_render.py::test_resampler_reciprocal_division_is_bit_identical; SN_PDF_IEEE=1 forces the plain path).
+template <bool FAST = false, bool RECIP = false, typename SB, typename EMIT>
 SN_DEV void sn_pdf_lane(const float* __restrict__ w, int wstride, int N, int M, const float* u, float pad, const SnPdfNorm& nm, SB sb,
-                        EMIT emit) {
+                        EMIT emit, bool force_ieee = false) {
     int j = 0;
     double cum = 0.0;
     float c_prev = 0.0f, b_prev = sb(0);
     float uj = u[0];
-    const float inv_denom = FAST ? 1.0f / nm.denom : 0.0f;
+    float inv_denom = 0.0f;
+    bool recip = false;
+    {
+#pragma clang fp contract(off)
+        if (FAST || RECIP) inv_denom = 1.0f / nm.denom;
+    }
+    if (RECIP && !FAST) {
+        const uint32_t bits = __float_as_uint(nm.denom);
+        const bool unsafe = (bits & 0x7fffffu) == 0x7fffffu || !(nm.denom >= 0x1p-60f && nm.denom <= 0x1p60f);
+        recip = !force_ieee && !__any(unsafe);  // wave-uniform
+    }
     for (int i = 0; i < N; ++i) {
         float c_next, b_next = sb(i + 1);
         {
 #pragma clang fp contract(off)
             const float num = (w[(int64_t)i * wstride] + pad) + nm.padding;
-            const float pdf = FAST ? num * inv_denom : num / nm.denom;
+            float pdf;
+            if (FAST) {
+                pdf = num * inv_denom;
+            } else if (RECIP && recip) {
+                const float q0 = num * inv_denom;
+                pdf = __builtin_fmaf(__builtin_fmaf(-q0, nm.denom, num), inv_denom, q0);
+            } else {
+                pdf = num / nm.denom;
+            }
             cum += (double)pdf;
             c_next = fminf(1.0f, (float)cum);
         }
@@ -289,6 +313,7 @@ struct SnPropParams {
     int n_final;
     int height, width, tile_w_log2, tile_h_log2, tiles_x, tiles_y;
     float near_plane, far_plane, avg_density, hist_pad;
+    int pdf_ieee;   // test switch (SN_PDF_IEEE=1): the resampler divides with the plain IEEE sequence instead of sn_pdf_lane's RECIP form
     int cache_off;  // test switch: the coefficient cache re-fetches on every step (tests/test_gpu_render.py compares the two bit for bit)
 };
 
@@ -438,23 +463,23 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
             if (DUMP && dump_ray >= 0 && p.dump_pdf[k]) p.dump_pdf[k][(size_t)dump_ray * (size_t)(m + 1) + (size_t)j] = idx;
         };
         if (p.n_levels == 1) {
-            sn_pdf_lane<FASTPDF>(W, 64, n0, p.n_final, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; }, [&](int j, float v, int idx) {
+            sn_pdf_lane<FASTPDF, true>(W, 64, n0, p.n_final, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; }, [&](int j, float v, int idx) {
                 eb_tile[(int64_t)j * 64] = sn_euclid(v, s_near, s_far);
                 dump_idx(0, p.n_final, j, idx);
-            });
+            }, p.pdf_ieee != 0);
         } else {
             const int n1 = p.n_samples[1];
-            sn_pdf_lane<FASTPDF>(W, 64, n0, n1, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; }, [&](int j, float v, int idx) {
+            sn_pdf_lane<FASTPDF, true>(W, 64, n0, n1, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; }, [&](int j, float v, int idx) {
                 B0[(int64_t)j * 64] = v;
                 dump_idx(0, n1, j, idx);
-            });
+            }, p.pdf_ieee != 0);
             sn_prop_level<1, GRID, ND1, DUMP>(p, L.wpack[1], [&](int i) { return B0[(int64_t)i * 64]; }, W, n1, o, d, s_near, s_far, sum_wp, med, dump_ray);
             if (valid && p.prop_depth[1]) p.prop_depth[1][pix] = med;
             nm.set(sum_wp, n1);
-            sn_pdf_lane<FASTPDF>(W, 64, n1, p.n_final, L.u[1], p.hist_pad, nm, [&](int i) { return B0[(int64_t)i * 64]; }, [&](int j, float v, int idx) {
+            sn_pdf_lane<FASTPDF, true>(W, 64, n1, p.n_final, L.u[1], p.hist_pad, nm, [&](int i) { return B0[(int64_t)i * 64]; }, [&](int j, float v, int idx) {
                 eb_tile[(int64_t)j * 64] = sn_euclid(v, s_near, s_far);
                 dump_idx(1, p.n_final, j, idx);
-            });
+            }, p.pdf_ieee != 0);
         }
         (void)B1;
     }

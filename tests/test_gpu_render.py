@@ -347,6 +347,26 @@ def test_proposal_coefficient_cache_is_bit_identical(gpu, monkeypatch):
             assert torch.equal(out[k], ref[k]), k
 
 
+def test_resampler_reciprocal_division_is_bit_identical(gpu, monkeypatch):
+    """The fused resampler forms weight / sum from the correctly rounded reciprocal of the (loop-invariant) sum plus one exact residual
+    step (Markstein; csrc/sn_proposal.h sn_pdf_lane RECIP) instead of an IEEE division per weight.  The quotients are the IEEE
+    quotients: with SN_PDF_IEEE=1 (plain divisions) every output of the proposal path is bit-identical, on scenes of different weight
+    scales."""
+    keys = ("rgb", "depth", "accumulation", "expected_depth", "prop_depth_0", "prop_depth_1")
+    for cfg, kw in ((scene.proposal_config(), {}), (small_config(num_proposal_samples_per_ray=(40, 24), num_nerf_samples_per_ray=12), {})):
+        model, _ = make_model(cfg, gpu, **kw)
+        H, W = 64, 88
+        cams = Cameras(scene.benchmark_cameras(8)[:, :3], 1.2 * H, 1.2 * H, W / 2, H / 2, W, H).to(gpu)
+        for i in (1, 4, 7):
+            b = cams[i].generate_rays(0)
+            out = {k: v.clone() for k, v in model.get_outputs_for_camera_ray_bundle(b).items() if k in keys}
+            monkeypatch.setenv("SN_PDF_IEEE", "1")
+            ref = model.get_outputs_for_camera_ray_bundle(b)
+            monkeypatch.delenv("SN_PDF_IEEE")
+            for k in keys:
+                assert torch.equal(out[k], ref[k]), k
+
+
 def test_frames_on_alternating_streams_are_bit_identical(gpu):
     """sheet.FrameStreams issues consecutive cameras on two HIP streams (the head of one frame overlaps the tail of the previous one).
     Renders of a handle are independent and re-entrant: the sheet must equal the one-stream sheet bit for bit, with and without
