@@ -16,8 +16,8 @@ else:
     cfg = scene.proposal_config(); W, H = a.size or (1920, 1080); focal = 1.2 * H
 model = cfg.setup(); model.load_state_dict(scene.synthetic_state_dict(cfg, seed=0), strict=False); model = model.to(dev).eval()
 cam = Cameras(scene.benchmark_cameras(8)[:, :3], focal, focal, W / 2, H / 2, W, H).to(dev)[0]
-def run(nstreams, frames):
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+def run(nstreams, frames, prio=False):
+    streams = [torch.cuda.Stream(device=dev, priority=(-1 if (prio and k == 0) else 0)) for k in range(nstreams)]
     outs = []
     torch.cuda.synchronize(); t = time.perf_counter()
     for k in range(frames):
@@ -43,4 +43,5 @@ def check(nstreams, frames):
 run(1, 10); run(2, 10)
 check(2, min(a.frames, 120))
 for rep in range(3):
-    print(f"{a.workload} {W}x{H}: 1 stream {run(1, a.frames):.4f} ms/frame   2 streams {run(2, a.frames):.4f}   3 streams {run(3, a.frames):.4f}")
+    print(f"{a.workload} {W}x{H}: 1 stream {run(1, a.frames):.4f} ms/frame   2 streams {run(2, a.frames):.4f}   3 streams {run(3, a.frames):.4f}"
+          f"   2 streams, one at high priority {run(2, a.frames, True):.4f}")
