@@ -258,6 +258,10 @@ typedef struct SnDebugLayout {
 int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out);
 /* what: 0 = the buffer of de-hashed copies, 1 = the x-paired tables (proposal nets).  dst: device pointer, bytes must match. */
 int sn_debug_read(SnHandle h, int32_t which, int32_t what, void* dst, size_t bytes, SnStream stream);
+/* The diagnostic switches of the environment (SN_RENDER_CHAIN, SN_PROP_CACHE_OFF, SN_PDF_IEEE, SN_PDF_FAST, SN_ABLATE,
+ * SN_HASH_PLAIN) are read by sn_create and sn_finalize_weights, never by a render call; a test that flips one between two renders
+ * of the same handle calls this to have it re-read. */
+int sn_debug_reload_env(SnHandle h);
 
 /* ---- measurement aid (bench.py's issue roofs need the clock the chip actually sustains under the render) ------------------
  * Enqueues a ONE-WAVE kernel that idles for `seconds` (<= 1) of the device's constant-rate wall clock and reports how many shader

@@ -118,6 +118,7 @@ SIGNATURES = {
                                        _FP, _FP, _FP, _FP, _FP, _FP, C.POINTER(SnDebugDump), C.c_void_p]),
     "sn_debug_layout": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(SnDebugLayout)]),
     "sn_debug_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _FP, C.c_size_t, C.c_void_p]),
+    "sn_debug_reload_env": (C.c_int, [C.c_void_p]),
     "sn_clock_probe": (C.c_int, [_FP, C.c_double, C.c_void_p]),
     "sn_effective_precision": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "sn_render_normals": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.POINTER(SnRenderOpts), _FP, _FP, C.c_void_p]),

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -70,13 +71,19 @@ struct SnContext {
     std::string split_why;
     bool normals_split_ok = true;  // the normals kernel splits UNconditioned operands: allowed only while table and bounds sit in range
     bool finalized = false;
-    // ordering of weight uploads against renders in flight (RenderGuard below)
-    static constexpr int kRenderEvents = 8;
+    // ordering of weight uploads against renders in flight (RenderGuard below): the completion event of the LAST render of every
+    // stream that rendered with this handle (a stream is in-order, so its last render covers its earlier ones)
+    static constexpr size_t kMaxRenderStreams = 64;
     std::mutex ev_mu;
-    hipEvent_t render_ev[kRenderEvents] = {};
-    int render_ev_next = 0;
+    std::map<hipStream_t, hipEvent_t> render_ev;
+    std::vector<hipEvent_t> spare_ev;
     hipEvent_t weights_ev = nullptr;
     bool weights_ev_recorded = false;
+    // diagnostic / test switches of the environment, read when the handle is created, when its weights are finalized and by
+    // sn_debug_reload_env -- not by every render call (getenv on the render path of several threads)
+    struct Switches {
+        std::atomic<int> render_chain{0}, prop_cache_off{0}, pdf_ieee{0}, pdf_fast{0}, ablate{0}, hash_plain{0};
+    } sw;
 };
 
 #ifndef SN_DENSE_LEVELS_DEFAULT
@@ -103,14 +110,26 @@ RenderChain g_chain;
 //   * every render makes its stream wait for the handle's last upload / finalize (weights_ev) and, when its kernels are enqueued,
 //     records one of the handle's render events (a small ring: the N most recent renders, whichever streams they ran on);
 //   * sn_upload_weights / sn_finalize_weights make their stream wait for all of those before touching a buffer.
+int env_int(const char* name) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+void load_switches(SnHandle h) {
+    h->sw.render_chain = env_int("SN_RENDER_CHAIN") != 0;
+    h->sw.prop_cache_off = env_int("SN_PROP_CACHE_OFF") != 0;  // test switch, see SnPropParams::cache_off
+    h->sw.pdf_ieee = env_int("SN_PDF_IEEE") != 0;              // test switch, see SnPropParams::pdf_ieee
+    h->sw.pdf_fast = env_int("SN_PDF_FAST") != 0;              // A/B knob (sn_pdf_lane): reciprocal multiplications instead of IEEE divisions
+    h->sw.ablate = env_int("SN_ABLATE");                       // profiling only: non-zero gives WRONG images (see sn_main.h)
+    h->sw.hash_plain = env_int("SN_HASH_PLAIN") != 0;          // stage kernel: plain table instead of the x-paired one
+}
+
 struct RenderGuard {
     SnHandle h;
     hipStream_t st;
     int dev;
     bool chain;
     RenderGuard(SnHandle h_, hipStream_t s) : h(h_), st(s), dev(h_->device & 15) {
-        const char* e = getenv("SN_RENDER_CHAIN");
-        chain = e && atoi(e) != 0;
+        chain = h->sw.render_chain.load(std::memory_order_relaxed) != 0;
         {
             std::lock_guard<std::mutex> g(h->ev_mu);
             if (h->weights_ev_recorded) (void)hipStreamWaitEvent(st, h->weights_ev, 0);
@@ -123,9 +142,30 @@ struct RenderGuard {
     ~RenderGuard() {
         {
             std::lock_guard<std::mutex> g(h->ev_mu);
-            hipEvent_t& ev = h->render_ev[h->render_ev_next];
-            if (ev || hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
-                if (hipEventRecord(ev, st) == hipSuccess) h->render_ev_next = (h->render_ev_next + 1) % SnContext::kRenderEvents;
+            auto it = h->render_ev.find(st);
+            if (it == h->render_ev.end()) {
+                hipEvent_t ev = nullptr;
+                if (h->render_ev.size() >= SnContext::kMaxRenderStreams) {
+                    // too many distinct streams (streams created and dropped per call): retire another stream's entry WITHOUT losing
+                    // its render -- this stream first waits for it, so the event recorded below completes after both (ADVICE r02:
+                    // an evicted event must not be dropped silently)
+                    auto victim = h->render_ev.begin();
+                    (void)hipStreamWaitEvent(st, victim->second, 0);
+                    ev = victim->second;
+                    h->render_ev.erase(victim);
+                } else if (!h->spare_ev.empty()) {
+                    ev = h->spare_ev.back();
+                    h->spare_ev.pop_back();
+                } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+                    ev = nullptr;
+                }
+                if (ev) it = h->render_ev.emplace(st, ev).first;
+            }
+            if (it != h->render_ev.end() && hipEventRecord(it->second, st) != hipSuccess) {
+                // cannot track this render: fall back to the only safe thing
+                (void)hipStreamSynchronize(st);
+            } else if (it == h->render_ev.end()) {
+                (void)hipStreamSynchronize(st);
             }
         }
         if (chain) {
@@ -136,11 +176,10 @@ struct RenderGuard {
     }
 };
 
-// upload / finalize side of the per-handle ordering
+// upload / finalize side of the per-handle ordering: wait (stream-side) for the last render of EVERY stream
 void wait_for_renders(SnHandle h, hipStream_t st) {
     std::lock_guard<std::mutex> g(h->ev_mu);
-    for (hipEvent_t ev : h->render_ev)
-        if (ev) (void)hipStreamWaitEvent(st, ev, 0);
+    for (auto& kv : h->render_ev) (void)hipStreamWaitEvent(st, kv.second, 0);
 }
 void mark_weights_written(SnHandle h, hipStream_t st) {
     std::lock_guard<std::mutex> g(h->ev_mu);
@@ -638,17 +677,24 @@ int sn_create(const SnFieldDesc* desc, SnHandle* out) {
         delete c;
         return fail(nullptr, SN_ERR_HIP, "hipGetDevice failed (no HIP device?)");
     }
+    load_switches(c);
     *out = c;
+    return SN_OK;
+}
+
+int sn_debug_reload_env(SnHandle h) {
+    if (!h) return SN_ERR_INVALID;
+    load_switches(h);
     return SN_OK;
 }
 
 int sn_destroy(SnHandle h) {
     if (!h) return SN_OK;
-    for (hipEvent_t ev : h->render_ev)
-        if (ev) {
-            (void)hipEventSynchronize(ev);  // a render may still be reading the buffers released below
-            (void)hipEventDestroy(ev);
-        }
+    for (auto& kv : h->render_ev) {
+        (void)hipEventSynchronize(kv.second);  // a render may still be reading the buffers released below
+        (void)hipEventDestroy(kv.second);
+    }
+    for (hipEvent_t ev : h->spare_ev) (void)hipEventDestroy(ev);
     if (h->weights_ev) (void)hipEventDestroy(h->weights_ev);
     h->table_main.release();
     h->dense_main.release();
@@ -717,6 +763,7 @@ int sn_upload_weights(SnHandle h, const char* name, const void* data, size_t byt
 int sn_finalize_weights(SnHandle h, SnStream stream) {
     if (!h) return SN_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
+    load_switches(h);
     wait_for_renders(h, st);
     const SnFieldDesc& d = h->desc;
     if (!h->table_main.ptr) return fail(h, SN_ERR_STATE, "missing field.mlp_base.encoder.hash_table");
@@ -1069,12 +1116,8 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     for (int i = 0; i < SN_MAX_PROPOSALS; ++i) pp.pdf_u[i] = opts->pdf_u[i];
     pp.ebins_out = d_ebins;
     pp.scratch = (float*)(ws + wp.off_prop_scratch);
-    {
-        const char* e = getenv("SN_PROP_CACHE_OFF");  // test switch, see SnPropParams::cache_off
-        pp.cache_off = e && atoi(e) ? 1 : 0;
-        const char* e2 = getenv("SN_PDF_IEEE");  // test switch, see SnPropParams::pdf_ieee
-        pp.pdf_ieee = e2 && atoi(e2) ? 1 : 0;
-    }
+    pp.cache_off = h->sw.prop_cache_off.load(std::memory_order_relaxed);
+    pp.pdf_ieee = h->sw.pdf_ieee.load(std::memory_order_relaxed);
     pp.prop_depth[0] = prop_depth_0;
     pp.prop_depth[1] = prop_depth_1;
     pp.height = height;
@@ -1129,8 +1172,7 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     } else if (nprop == 2 && h->nd_prop[0] == 5 && h->nd_prop[1] == 4) {
         // nerfacto's nets (max_res 128 / 256): every level but the finest of the second net has a de-hashed copy
         for (int i = 0; i < nprop; ++i) pp.grid[i] = h->dense_res_prop[i];
-        const char* fast = getenv("SN_PDF_FAST");  // A/B knob (sn_pdf_lane): reciprocal multiplications instead of IEEE divisions, -0.8 %
-        if (fast && atoi(fast)) hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4, false, true>), pgrid, pblock, 0, st, pp);
+        if (h->sw.pdf_fast.load(std::memory_order_relaxed)) hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4, false, true>), pgrid, pblock, 0, st, pp);
         else hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4>), pgrid, pblock, 0, st, pp);
     } else {
         hipLaunchKernelGGL((sn_proposal_kernel<0, -1, -1>), pgrid, pblock, 0, st, pp);
@@ -1226,8 +1268,7 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     const dim3 grid((unsigned)(gbx * gby)), block(256);
 #define SN_LAUNCH_MAIN(MODE, PREC, ABL, GRID, ND) \
     hipLaunchKernelGGL((sn_render_main_kernel<MODE, PREC, ABL, GRID, ND>), grid, block, lds_bytes, st, p)
-    const char* abl_env = getenv("SN_ABLATE");  // profiling only: non-zero gives WRONG images (see sn_main.h)
-    const int ablate = abl_env ? atoi(abl_env) : 0;
+    const int ablate = h->sw.ablate.load(std::memory_order_relaxed);
     const int nd_launch = use_copies ? h->nd_torch : -1;
 #define SN_LAUNCH_MAIN_ND(MODE, PREC, GRID)                          \
     switch (nd_launch) {                                             \
@@ -1459,8 +1500,7 @@ int sn_hash_encode(SnHandle h, int32_t which, const float* q, int64_t n, float* 
     p.indices = indices;
     // Proposal nets: when the weights are finalized the features come from the x-paired tables (the production layout of K2);
     // SN_HASH_PLAIN=1 forces the plain table so that tests can check the two layouts against each other.
-    const char* plain = getenv("SN_HASH_PLAIN");
-    const bool use_pairs = which >= 0 && h->finalized && !(plain && atoi(plain)) && d.grid_mode == 0;
+    const bool use_pairs = which >= 0 && h->finalized && !h->sw.hash_plain.load(std::memory_order_relaxed) && d.grid_mode == 0;
     p.grid_mode = d.grid_mode;
     p.grid = grid_levels(d);
     p.pairs = use_pairs ? (const float*)h->pairs_prop[which].ptr : nullptr;

@@ -72,13 +72,23 @@ class GeneratedDataset:
 
     SUBDIRS = ("images", "masks", "conditions", "rendered", "originals")
 
-    def __init__(self, path: Union[str, Path], dataset_name: str, downscale_factor: int = 2):
+    def __init__(self, path: Union[str, Path], dataset_name: str, downscale_factor: int = 2, write_images: bool = True, save_workers: int = 0):
+        """write_images=False: directories and transforms.json only (the bench's "PNG writes off" leg).  save_workers > 0: PNG encoding
+        and the file writes run on that many host threads (zlib releases the GIL) while the caller goes on to the next view; the
+        bytes of a file do not depend on it.  ``flush()`` waits for them."""
         self.dataset_path = Path(path) / dataset_name
         self.downscale_factor = downscale_factor
+        self.write_images = write_images
         self.dirs: Dict[str, Path] = {}
+        self._pool = None
+        self._pending: List = []
+        if save_workers > 0:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._pool = ThreadPoolExecutor(max_workers=save_workers)
 
     def init_directory(self) -> None:
-        """datasetgenerator.py:146-175 (config.yml is the reference's yaml pickle of its own config class; not written here)."""
+        """datasetgenerator.py:146-175 (config.yml is written by DatasetGenerator.init_directory)."""
         self.dataset_path.mkdir(parents=True, exist_ok=True)
         for name in self.SUBDIRS:
             for key, d in ((name, self.dataset_path / name), (f"{name}_scaled", self.dataset_path / f"{name}_{self.downscale_factor}")):
@@ -87,6 +97,29 @@ class GeneratedDataset:
         self.dirs["references"] = self.dataset_path / "references"
         self.dirs["references"].mkdir(parents=True, exist_ok=True)
         self.transforms_path = self.dataset_path / "transforms.json"
+
+    def save_image(self, tensor: Tensor, path: Path) -> None:
+        """``tensor_to_image(tensor).save(path)``: the truncating uint8 cast on the GPU, one device-to-host copy of the bytes, PNG
+        encoding on the host (in the pool when there is one)."""
+        if not self.write_images:
+            return
+        from PIL import Image
+
+        assert len(tensor.shape) == 3 and tensor.shape[2] in (1, 3), "Tensor must be of shape (H, W, 1) or (H, W, 3)"
+        u8 = tensor_to_uint8(tensor).cpu().numpy()
+
+        def write():
+            (Image.fromarray(u8.squeeze(), "L") if u8.shape[2] == 1 else Image.fromarray(u8)).save(path)
+
+        if self._pool is None:
+            write()
+        else:
+            self._pending.append(self._pool.submit(write))
+
+    def flush(self) -> None:
+        pending, self._pending = self._pending, []
+        for f in pending:
+            f.result()
 
     @staticmethod
     def new_transforms(original_transform_matrix: Tensor, original_scale_factor: float, is_synthetic: bool = False,
@@ -102,7 +135,7 @@ class GeneratedDataset:
         """datasetgenerator.py:398-468: PNGs by key + one frame appended to the transforms."""
         def save(key: str, directory: str, stem: str):
             if key in images:
-                tensor_to_image(images[key]).save(self.dirs[directory] / f"{stem}_{idx}.png")
+                self.save_image(images[key], self.dirs[directory] / f"{stem}_{idx}.png")
 
         save("edited", "images", "image")
         save("render", "originals" if is_original else "rendered", "image")
@@ -124,5 +157,6 @@ class GeneratedDataset:
         return current_transforms
 
     def write_transforms(self, transforms: Dict[str, Any]) -> None:
+        self.flush()
         with open(self.transforms_path, "w", encoding="utf8") as f:
             json.dump(transforms, f, indent=4)

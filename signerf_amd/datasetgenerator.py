@@ -13,8 +13,11 @@ small kernels behind ``sn_aabb_mask_condition`` and nothing leaves the device.
 from __future__ import annotations
 
 import ctypes as C
+import datetime
+import time
 from dataclasses import dataclass, field
-from typing import List, Optional, Tuple
+from pathlib import Path
+from typing import Any, Callable, Dict, List, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -24,9 +27,16 @@ from . import _lib
 
 @dataclass
 class DatasetGeneratorConfig:
-    """The fields of the reference's DatasetGeneratorConfig (datasetgenerator.py:32-81) that shape render_camera."""
+    """The fields of the reference's DatasetGeneratorConfig (datasetgenerator.py:32-81) except the two sub-configs of components that are
+    out of scope (``renderer``: the OpenGL mesh rasteriser; ``diffuser``: the HTTP client -- ``DatasetGenerator`` takes a callable)."""
 
+    path: Path = field(default_factory=lambda: Path("./generations"))
+    dataset_name: str = field(default_factory=lambda: "experiment-" + datetime.datetime.now().strftime("%Y%m%d-%H%M%S"))
     downscale_factor: int = 2
+    fx: Optional[float] = None
+    fy: Optional[float] = None
+    cx: Optional[float] = None
+    cy: Optional[float] = None
     width: Optional[int] = None
     height: Optional[int] = None
     masking_mode: str = "aabb"
@@ -39,6 +49,7 @@ class DatasetGeneratorConfig:
     border_width_between_images: int = 0
     inverse_mask: bool = False
     manual_depth: Optional[Tuple[float, float]] = None
+    combine_shape_with_depth: bool = False   # shape mode only (mesh rasteriser, out of scope); carried for signature parity
 
 
 def aabb_mask_and_condition(depth: Tensor, rays_o: Tensor, rays_d: Tensor, aabb: Tensor, mask_dialation: Optional[Tuple[int, int]] = (50, 50),
@@ -126,10 +137,9 @@ def compose_reference_sheet(config: DatasetGeneratorConfig, views, scaled_image_
         raise ValueError(f"Camera count {len(views)} is not equal to (rows * cols) - 1 = {config.rows * config.cols - 1}")
     dev = views[0][0].device
     sh, sw = sheet_geometry(config, scaled_image_width, scaled_image_height)
-    with torch.cuda.device(dev):
-        image_sheet = torch.ones((sh, sw, 3), dtype=torch.float32, device=dev)
-        mask_sheet = torch.zeros((sh, sw, 1), dtype=torch.float32, device=dev)
-        condition_sheet = torch.zeros((sh, sw, 1), dtype=torch.float32, device=dev)
+    image_sheet = torch.ones((sh, sw, 3), dtype=torch.float32, device=dev)
+    mask_sheet = torch.zeros((sh, sw, 1), dtype=torch.float32, device=dev)
+    condition_sheet = torch.zeros((sh, sw, 1), dtype=torch.float32, device=dev)
     references = []
     for i, (render, mask, condition) in enumerate(views):
         r0, r1, c0, c1 = cell_window(config, i, scaled_image_width, scaled_image_height)
@@ -158,20 +168,24 @@ def split_reference_sheet(config: DatasetGeneratorConfig, edited_sheet: Tensor, 
     return edited_sheet
 
 
-def generate_reference_sheet(config: DatasetGeneratorConfig, graph, cameras, scaled_image_width: int, scaled_image_height: int, diffuse):
+def generate_reference_sheet(config: DatasetGeneratorConfig, graph, cameras, scaled_image_width: int, scaled_image_height: int, diffuse,
+                             render_camera_fn=None):
     """``DatasetGenerator.generate_reference_sheet`` (:470-593).  cameras: the rows*cols-1 reference cameras (indexable);
     diffuse(image, image, mask, condition) -> edited sheet [SH,SW,3] stands for ``self.diffuser.diffuse`` (:559).
-    -> (image_sheet, mask_sheet, condition_sheet, edited_sheet, references) as the reference returns them."""
+    -> (image_sheet, mask_sheet, condition_sheet, edited_sheet, references) as the reference returns them.
+    render_camera_fn(config, graph, camera) replaces ``render_camera`` (``DatasetGenerator`` hands out pre-computed views)."""
+    if len(cameras) != config.rows * config.cols - 1:
+        raise ValueError(f"Camera count {len(cameras)} is not equal to (rows * cols) - 1 = {config.rows * config.cols - 1}")
     # the reference cameras are independent: consecutive ones go to alternating streams (sheet.FrameStreams: the head of one frame fills
     # the wave slots the tail of the previous one leaves idle); the sheet is composed on the caller's stream after the join
     from .sheet import FrameStreams
 
-    fs = FrameStreams(getattr(graph, "device", None))
+    render = render_camera_fn or render_camera
     views = []
-    for i in range(len(cameras)):
-        with fs.frame(i):
-            views.append(tuple(fs.keep(t) for t in render_camera(config, graph, cameras[i])))
-    fs.join()
+    with FrameStreams(getattr(graph, "device", None)) as fs:
+        for i in range(len(cameras)):
+            with fs.frame(i):
+                views.append(tuple(fs.keep(t) for t in render(config, graph, cameras[i])))
     image_sheet, mask_sheet, condition_sheet, references = compose_reference_sheet(config, views, scaled_image_width, scaled_image_height)
     edited = diffuse(image_sheet, image_sheet, mask_sheet, condition_sheet)
     H, W = views[0][0].shape[0], views[0][0].shape[1]
@@ -181,14 +195,15 @@ def generate_reference_sheet(config: DatasetGeneratorConfig, graph, cameras, sca
 
 
 def generate_with_reference_sheet(config: DatasetGeneratorConfig, graph, camera, original: Optional[Tensor], scaled_image_width: int,
-                                  scaled_image_height: int, image_reference_sheet: Tensor, condition_reference_sheet: Tensor, diffuse):
+                                  scaled_image_height: int, image_reference_sheet: Tensor, condition_reference_sheet: Tensor, diffuse,
+                                  render_camera_fn=None):
     """``DatasetGenerator.generate_with_reference_sheet`` (:597-674): render one view, paste it into the LAST cell of the (edited)
     reference sheet, diffuse, cut the cell out, blend by the mask and up-scale.  `original`: the loaded original image
     [H,W,3] replacing the render (:628-630; file I/O stays with the caller), or None.  The two sheets are modified in place,
     as in the reference.  -> dict with the reference's keys."""
     from .ops import resize_bilinear
 
-    render, mask, condition = render_camera(config, graph, camera)
+    render, mask, condition = (render_camera_fn or render_camera)(config, graph, camera)
     if original is not None:
         render = original.to(render.device)
     last = config.rows * config.cols - 1
@@ -205,3 +220,258 @@ def generate_with_reference_sheet(config: DatasetGeneratorConfig, graph, camera,
     edited = resize_bilinear(edited_scaled, config.height or H, config.width or W)
     return {"render": render, "mask": mask, "condition": condition, "edited": edited, "render_scaled": render_scaled,
             "mask_scaled": mask_scaled, "condition_scaled": condition_scaled, "edited_scaled": edited_scaled}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The generator loop itself (BASELINE.json configs[4]; SURVEY §8(d) "Config 5", §8(e) "Ordering constraint"):
+# ``DatasetGenerator.generate_dataset`` of the reference (datasetgenerator.py:185-393).
+# ----------------------------------------------------------------------------------------------------------------------
+def identity_diffuse(original_image: Tensor, rendered_image: Tensor, mask_image: Tensor, condition_image: Tensor) -> Tensor:
+    """What ``Diffuser.diffuse`` returns when the Stable-Diffusion server cannot be reached
+    (/root/reference/signerf/diffuser/diffuser.py:182-185): its first argument -- the same tensor object, not a copy."""
+    return original_image
+
+
+def _camera_key(camera) -> bytes:
+    """Identity of a 0-dim camera (pose + intrinsics), read from the host mirror: no device sync."""
+    host = getattr(camera, "_host", None)
+    if host is None:
+        host = torch.cat([camera.camera_to_worlds.reshape(-1).float().cpu()] +
+                         [torch.as_tensor(getattr(camera, k)).reshape(-1).float().cpu() for k in ("fx", "fy", "cx", "cy", "width", "height")])
+    return host.contiguous().numpy().tobytes()
+
+
+class DatasetGenerator:
+    """``DatasetGenerator`` of the reference for ``masking_mode="aabb"``: same constructor arguments, attributes and methods
+    (``init_directory``, ``generate_dataset``, ``save_generated_images``, ``generate_reference_sheet``,
+    ``generate_with_reference_sheet``, ``render_camera``), the same files on disk.
+
+    What is different, and why (SURVEY §8(e) "Ordering constraint to preserve"): the reference interleaves NeRF renders with diffusion
+    calls in one sequential loop (:517-519, :331-338).  The renders depend only on the read-only field and their own camera, so
+    ``generate_dataset`` computes ALL of them first -- render + mask + condition of the reference views, the generated views and (when
+    merging) the original views, sharded camera i -> rank i mod N over the process group, two frames in flight per GPU, tiles gathered
+    to rank 0 -- and only then runs the serial part on rank 0 alone: compose the sheet, diffuse, split, then per view paste into the
+    LAST cell of the edited sheet (mutated in place, :643-646), diffuse, cut, blend, save.  The sequence of diffuser calls and every
+    tensor handed to them are the reference's.
+
+    ``diffuse(original_image, rendered_image, mask_image, condition_image) -> edited`` stands for ``self.diffuser.diffuse`` (the HTTP
+    client is out of scope); the default is what that method returns when the server is unreachable (``identity_diffuse``).
+    ``group``: the torch.distributed process group to shard over (default group when initialised, else one process).
+    """
+
+    def __init__(self, config: DatasetGeneratorConfig, original_transform_matrix: Optional[Tensor] = None, original_scale_factor: float = 1.0,
+                 transform_poses_to_original_space: Optional[Callable[[Tensor], Tensor]] = None, device="cuda",
+                 diffuse: Optional[Callable[[Tensor, Tensor, Tensor, Tensor], Tensor]] = None, group=None, write_images: bool = True,
+                 save_workers: int = 8, precompute: bool = True, profile: bool = False) -> None:
+        self.config = config
+        self.device = device
+        self.original_transform_matrix = original_transform_matrix if original_transform_matrix is not None else torch.eye(4)[:3]
+        self.original_scale_factor = original_scale_factor
+        self.transform_poses_to_original_space = transform_poses_to_original_space
+        self.path, self.dataset_name = config.path, config.dataset_name
+        self.fx, self.fy, self.cx, self.cy = config.fx, config.fy, config.cx, config.cy
+        self.width, self.height, self.downscale_factor = config.width, config.height, config.downscale_factor
+        self.masking_mode = config.masking_mode
+        self.aabb = torch.tensor([config.aabb_min, config.aabb_max], dtype=torch.float32)
+        self.inverse_mask, self.combine_shape_with_depth = config.inverse_mask, config.combine_shape_with_depth
+        self.rows, self.cols = config.rows, config.cols
+        self.border_width_between_images = config.border_width_between_images
+        self.mask_dialation, self.additional_depth_radius, self.manual_depth = config.mask_dialation, config.additional_depth_radius, config.manual_depth
+        self.diffuse = diffuse or identity_diffuse
+        self.group = group
+        self.write_images, self.save_workers = write_images, save_workers
+        self.precompute, self.profile = precompute, profile
+        self.is_synthetic = False
+        self.dataset: Optional[Any] = None
+        self.dataset_path = self.transforms_path = None
+        self._views: Dict[bytes, Tuple[Tensor, int]] = {}
+        self.timings: Dict[str, float] = {}
+
+    # -- process group ---------------------------------------------------------------------------------------------------
+    def _dist(self) -> Tuple[int, int]:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(self.group), dist.get_world_size(self.group)
+        return 0, 1
+
+    def _tick(self, name: str, t0: float) -> float:
+        if self.profile and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        now = time.perf_counter()
+        self.timings[name] = self.timings.get(name, 0.0) + (now - t0)
+        return now
+
+    # -- datasetgenerator.py:146-182 ---------------------------------------------------------------------------------------
+    def init_directory(self) -> None:
+        from .dataset_io import GeneratedDataset
+
+        self.dataset = GeneratedDataset(self.config.path, self.dataset_name, self.downscale_factor, write_images=self.write_images,
+                                        save_workers=self.save_workers)
+        self.dataset.init_directory()
+        self.dataset_path, self.transforms_path = self.dataset.dataset_path, self.dataset.transforms_path
+        for key, d in self.dataset.dirs.items():  # images_path, masks_scaled_path, ... as attributes, like the reference's
+            setattr(self, f"{key}_path", d)
+        import dataclasses
+
+        import yaml
+
+        # the reference dumps its config OBJECT (a yaml python/object tag of its own class); here the same fields as a plain mapping
+        plain = {k: (str(v) if isinstance(v, Path) else (list(v) if isinstance(v, tuple) else v)) for k, v in dataclasses.asdict(self.config).items()}
+        (self.dataset_path / "config.yml").write_text(yaml.safe_dump(plain), "utf8")
+
+    # -- the pre-computed render stage -------------------------------------------------------------------------------------
+    def precompute_views(self, graph, cameras: List) -> None:
+        """render + mask + condition of every camera, sharded over the ranks (``sheet.render_views``: camera i -> rank i mod N, two
+        frames in flight per GPU), [n,H,W,5] tiles gathered to rank 0, which keeps them for ``render_camera``."""
+        from . import sheet
+
+        t0 = time.perf_counter()
+        rank, world = self._dist()
+        tiles = sheet.render_views(graph, cameras, self.config, group=self.group, dst=0 if world > 1 else None,
+                                   render_camera_fn=lambda cfg, g, cam: render_camera(cfg, g, cam))
+        if tiles is not None:
+            for i, cam in enumerate(cameras):
+                self._views[_camera_key(cam)] = (tiles, i)
+        self._tick("render_s", t0)
+
+    def render_camera(self, graph, camera, with_mask: bool = True, with_condition: bool = True, combine_shape_with_depth: bool = False):
+        """datasetgenerator.py:677-820 (aabb mode): a pre-computed view when there is one, else rendered now."""
+        hit = self._views.get(_camera_key(camera)) if (with_mask and with_condition) else None
+        if hit is None:
+            return render_camera(self.config, graph, camera, with_mask, with_condition)
+        tiles, i = hit
+        return tiles[i, :, :, 0:3].contiguous(), tiles[i, :, :, 3:4] > 0.5, tiles[i, :, :, 4:5].contiguous()
+
+    def _render_hook(self, config, graph, camera):
+        return self.render_camera(graph, camera, combine_shape_with_depth=self.combine_shape_with_depth)
+
+    # -- datasetgenerator.py:470-593, :597-674 -----------------------------------------------------------------------------
+    def generate_reference_sheet(self, graph, cameras, scaled_image_width: int, scaled_image_height: int):
+        return generate_reference_sheet(self.config, graph, cameras, scaled_image_width, scaled_image_height, self.diffuse,
+                                        render_camera_fn=self._render_hook)
+
+    def generate_with_reference_sheet(self, graph, camera, filename, scaled_image_width: int, scaled_image_height: int,
+                                      image_reference_sheet: Tensor, condition_reference_sheet: Tensor) -> Dict[str, Tensor]:
+        original = None
+        if filename is not None:  # :628-630
+            from PIL import Image
+
+            from .dataset_io import image_to_tensor
+
+            original = image_to_tensor(Image.open(filename))
+        return generate_with_reference_sheet(self.config, graph, camera, original, scaled_image_width, scaled_image_height,
+                                             image_reference_sheet, condition_reference_sheet, self.diffuse, render_camera_fn=self._render_hook)
+
+    # -- datasetgenerator.py:398-468 -----------------------------------------------------------------------------------------
+    def save_generated_images(self, idx: int, images: Dict[str, Tensor], camera, current_transforms: Dict[str, Any],
+                              is_original: bool = False) -> Dict[str, Any]:
+        return self.dataset.save_generated_images(idx, images, camera, current_transforms, is_original)
+
+    # -- datasetgenerator.py:185-393 -----------------------------------------------------------------------------------------
+    def generate_dataset(self, graph, reference_camera_to_worlds: Tensor, original_dataset=None,
+                         synthetic_camera_to_worlds: Optional[Tensor] = None, merge_with_original_dataset: bool = False) -> None:
+        from .cameras import Cameras
+        from .ops import resize_bilinear
+
+        if original_dataset is None and synthetic_camera_to_worlds is None:
+            raise ValueError("Either original dataset or camera_to_worlds must be given")
+        if merge_with_original_dataset and (original_dataset is None or synthetic_camera_to_worlds is None):
+            raise ValueError("Original dataset and camera_to_worlds must be given to merge with original dataset")
+        rank, world = self._dist()
+        self.timings = {}
+        if synthetic_camera_to_worlds is not None:
+            self.is_synthetic = True
+        scaled_image_width = int(self.width // self.downscale_factor)
+        scaled_image_height = int(self.height // self.downscale_factor)
+
+        reference_cameras = Cameras(reference_camera_to_worlds, self.fx, self.fy, self.cx, self.cy, self.width, self.height).to(self.device)
+        cameras, original_filenames = None, None
+        if original_dataset is not None:
+            cameras = original_dataset.cameras
+            original_filenames = original_dataset._dataparser_outputs.image_filenames  # pylint: disable=protected-access
+        if synthetic_camera_to_worlds is not None:
+            cameras = Cameras(synthetic_camera_to_worlds, self.fx, self.fy, self.cx, self.cy, self.width, self.height)
+            original_filenames = [None] * synthetic_camera_to_worlds.shape[0]
+        cameras = cameras.to(self.device)
+
+        # Stage 1 (every rank): all NeRF renders.  One tile shape per gather: cameras of another size (an original dataset whose
+        # images differ from the generator's width x height) are rendered inside the serial loop instead.
+        self._views = {}
+        if self.precompute:
+            todo = [reference_cameras[i] for i in range(len(reference_cameras))] + [cameras[i] for i in range(len(cameras))]
+            if merge_with_original_dataset:
+                merged = original_dataset.cameras.to(graph.device)
+                todo += [merged[i] for i in range(len(merged))]
+            same = [c for c in todo if (int(c._host[0, 16]), int(c._host[0, 17])) == (int(self.width), int(self.height))] \
+                if all(hasattr(c, "_host") for c in todo) else []
+            if same:
+                self.precompute_views(graph, same)
+        if rank != 0:  # the serial stage belongs to the rank that talks to the diffuser and the disk
+            self._finish(world)
+            return
+
+        # Stage 2 (rank 0): the reference's sequence
+        self.init_directory()
+        transforms = self.dataset.new_transforms(self.original_transform_matrix, self.original_scale_factor, self.is_synthetic,
+                                                 merge_with_original_dataset)
+        t0 = time.perf_counter()
+        image_sheet, mask_sheet, condition_sheet, edited_sheet, references = self.generate_reference_sheet(
+            graph, reference_cameras, scaled_image_width, scaled_image_height)
+        t0 = self._tick("sheet_s", t0)
+        refs = self.dataset.dirs["references"]
+        self.dataset.save_image(image_sheet, refs / "image_reference_sheet.png")
+        self.dataset.save_image(mask_sheet, refs / "mask_reference_sheet.png")
+        self.dataset.save_image(condition_sheet, refs / "condition_reference_sheet.png")
+        self.dataset.save_image(edited_sheet, refs / "edited_reference_sheet.png")
+        edited_image_idx = 0
+        transforms["reference_indices"] = []
+        for i, camera in enumerate(reference_cameras):
+            transforms = self.save_generated_images(edited_image_idx, references[i], camera, transforms)
+            transforms["reference_indices"].append(edited_image_idx)
+            edited_image_idx += 1
+        self.dataset.write_transforms(transforms)
+        t0 = self._tick("save_s", t0)
+
+        transforms["generated_indices"] = []
+        for i, camera in enumerate(cameras):
+            filename = original_filenames[i]
+            images = self.generate_with_reference_sheet(graph, camera, filename, scaled_image_width, scaled_image_height, edited_sheet,
+                                                        condition_sheet)
+            t0 = self._tick("views_s", t0)
+            transforms = self.save_generated_images(edited_image_idx, images, camera, transforms, filename is not None)
+            transforms["generated_indices"].append(edited_image_idx)
+            edited_image_idx += 1
+            t0 = self._tick("save_s", t0)
+        self.dataset.write_transforms(transforms)
+        t0 = self._tick("save_s", t0)
+
+        if merge_with_original_dataset:  # :344-388
+            transforms["original_indices"] = []
+            merged = original_dataset.cameras
+            for idx in range(len(merged)):
+                image = original_dataset.get_image_float32(idx).to(graph.device)
+                camera = merged[idx].to(graph.device)
+                render, mask, condition = self.render_camera(graph, camera, combine_shape_with_depth=self.combine_shape_with_depth)
+                mask = ~mask  # the original views do not contain the object
+                images = {"render": render, "mask": mask, "condition": condition, "edited": image,
+                          "render_scaled": resize_bilinear(render, scaled_image_height, scaled_image_width),
+                          "mask_scaled": resize_bilinear(mask, scaled_image_height, scaled_image_width, threshold=True) > 0.5,
+                          "condition_scaled": resize_bilinear(condition, scaled_image_height, scaled_image_width),
+                          "edited_scaled": resize_bilinear(image, scaled_image_height, scaled_image_width)}
+                t0 = self._tick("views_s", t0)
+                transforms = self.save_generated_images(edited_image_idx, images, camera, transforms, True)
+                transforms["original_indices"].append(edited_image_idx)
+                edited_image_idx += 1
+                t0 = self._tick("save_s", t0)
+            self.dataset.write_transforms(transforms)
+            self._tick("save_s", t0)
+        self.edited_reference_sheet, self.condition_reference_sheet = edited_sheet, condition_sheet  # (as left by the last view, :643-646)
+        self._views = {}
+        self._finish(world)
+
+    def _finish(self, world: int) -> None:
+        if world > 1:  # every rank returns once the dataset is on disk
+            import torch.distributed as dist
+
+            dist.barrier(group=self.group)

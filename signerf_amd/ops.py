@@ -188,3 +188,10 @@ def debug_read(model, which: int, what: int) -> Tensor:
         _lib.check(lib.sn_debug_read(model._handle, which, what, buf.data_ptr(), nbytes, _lib.current_stream()), model._handle, "sn_debug_read")
         torch.cuda.synchronize(model.device)
     return buf
+
+
+def reload_env(model) -> None:
+    """Has the handle re-read the SN_* diagnostic switches of the environment (they are otherwise read at sn_create /
+    sn_finalize_weights only) -- for tests that flip one between two renders of the same model."""
+    lib = model._ensure_engine()
+    _lib.check(lib.sn_debug_reload_env(model._handle), model._handle, "sn_debug_reload_env")

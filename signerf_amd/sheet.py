@@ -28,19 +28,22 @@ def _stage_through_host(t: Tensor, group=None) -> bool:
 
 
 class TileGather:
-    """An all-gather of tiles in flight (``gather_tiles_async``).  ``wait()`` orders the caller's stream behind the collective
-    (RCCL: a stream wait, the host does not block) and returns the tiles in item order."""
+    """An all-gather (or gather-to-root) of tiles in flight (``gather_tiles_async``).  ``wait()`` orders the caller's stream behind the
+    collective (RCCL: a stream wait, the host does not block) and returns the tiles in item order -- ``None`` on the ranks that are
+    not the destination of a gather-to-root."""
 
-    def __init__(self, work, gathered: Tensor, n_items: int, device=None):
+    def __init__(self, work, gathered: Optional[Tensor], n_items: int, device=None):
         self._work, self._gathered, self._n_items, self._device = work, gathered, n_items, device
 
-    def wait(self) -> Tensor:
+    def wait(self) -> Optional[Tensor]:
         if self._work is not None:
             self._work.wait()
             self._work = None
-            if self._gathered.is_cuda:
+            if self._gathered is not None and self._gathered.is_cuda:
                 # the buffer may have been allocated on a frame's stream (FrameStreams) and is read from the waiting stream from here on
                 self._gathered.record_stream(torch.cuda.current_stream(self._gathered.device))
+        if self._gathered is None:
+            return None
         if self._device is not None:  # staged through the host (gloo): back to the GPU the tiles came from
             self._gathered, self._device = self._gathered.to(self._device), None
         g = self._gathered
@@ -51,10 +54,14 @@ class TileGather:
         return g.transpose(0, 1).reshape(world * per, *g.shape[2:])[: self._n_items].contiguous()
 
 
-def gather_tiles_async(local_tiles: Tensor, n_items: int, group=None) -> TileGather:
+def gather_tiles_async(local_tiles: Tensor, n_items: int, group=None, dst: Optional[int] = None) -> TileGather:
     """Starts the all-gather of per-rank tiles and returns at once, so that the next camera's render overlaps the exchange
     (the collective runs on RCCL's own stream; xGMI is point to point, a ring all-gather of 8 x 10 MB tiles is per-link bound
-    and would otherwise add ~1 ms to every 3 ms frame).  Keep ``local_tiles`` unmodified until ``wait()``."""
+    and would otherwise add ~1 ms to every 3 ms frame).  Keep ``local_tiles`` unmodified until ``wait()``.
+
+    ``dst``: gather to that rank only (``dist.gather``) -- in the generator loop only rank 0 composes the sheets and talks to the
+    diffuser (/root/reference/signerf/datasetgenerator/datasetgenerator.py:558), so the other ranks need no tiles: 1/world of the
+    bytes of the all-gather cross the links, and every sender uses its own xGMI link to the root."""
     if not (dist.is_available() and dist.is_initialized()):
         assert local_tiles.shape[0] == n_items
         return TileGather(None, local_tiles, n_items)
@@ -67,18 +74,37 @@ def gather_tiles_async(local_tiles: Tensor, n_items: int, group=None) -> TileGat
     device = None
     if _stage_through_host(local_tiles, group):
         device, local_tiles = local_tiles.device, local_tiles.cpu()
-    gathered = local_tiles.new_empty((world, per, *local_tiles.shape[1:]))
-    work = dist.all_gather_into_tensor(gathered.view(world * per, *local_tiles.shape[1:]), local_tiles, group=group, async_op=True)
-    return TileGather(work, gathered, n_items, device)
+    if dst is None:
+        gathered = local_tiles.new_empty((world, per, *local_tiles.shape[1:]))
+        work = dist.all_gather_into_tensor(gathered.view(world * per, *local_tiles.shape[1:]), local_tiles, group=group, async_op=True)
+        return TileGather(work, gathered, n_items, device)
+    if dist.get_rank(group) == dst:
+        gathered = local_tiles.new_empty((world, per, *local_tiles.shape[1:]))
+        work = dist.gather(local_tiles, list(gathered.unbind(0)), dst=dist.get_global_rank(group, dst) if group is not None else dst,
+                           group=group, async_op=True)
+        return TileGather(work, gathered, n_items, device)
+    work = dist.gather(local_tiles, None, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group, async_op=True)
+    return TileGather(_KeepAlive(work, local_tiles), None, n_items, None)
 
 
-def gather_tiles(local_tiles: Tensor, n_items: int, group=None) -> Tensor:
+class _KeepAlive:
+    """A collective's work handle together with the send buffer it reads (a host staging copy must outlive the send)."""
+
+    def __init__(self, work, *tensors):
+        self._work, self._tensors = work, tensors
+
+    def wait(self):
+        self._work.wait()
+        self._tensors = ()
+
+
+def gather_tiles(local_tiles: Tensor, n_items: int, group=None, dst: Optional[int] = None) -> Optional[Tensor]:
     """All-gather per-rank tiles back into item order.
 
     local_tiles: [n_local, H, W, C] -- this rank's tiles for items rank, rank+world, ... (n_local may differ by one
-    between ranks).  Returns [n_items, H, W, C] on every rank.
+    between ranks).  Returns [n_items, H, W, C] on every rank (``dst`` given: on that rank only, None elsewhere).
     """
-    return gather_tiles_async(local_tiles, n_items, group).wait()
+    return gather_tiles_async(local_tiles, n_items, group, dst).wait()
 
 
 class FrameStreams:
@@ -90,30 +116,45 @@ class FrameStreams:
     measured r02 (tools/two_stream_probe.py) 2.89 -> 2.68 ms per 800x800x64 frame, 14.68 -> 14.40 ms per 1080p nerfacto frame; a third
     stream adds nothing.  Renders of one handle are unordered and re-entrant (include/signerf_hip.h), results are bit-identical.
 
-        fs = FrameStreams(device)                 # a CPU device (the gloo tests) degrades to plain in-order execution
-        for k, cam in enumerate(cams):
-            with fs.frame(k):
-                tiles.append(fs.keep(render(cam)))
-        fs.join()                                 # the caller's stream now waits for every frame
+        with FrameStreams(device) as fs:          # a CPU device (the gloo tests) degrades to plain in-order execution
+            for k, cam in enumerate(cams):
+                with fs.frame(k):
+                    tiles.append(fs.keep(render(cam)))
+        # leaving the block joins: the caller's stream now waits for every frame (also when a render raised)
     """
+
+    _pool: dict = {}   # (device index, k) -> side stream k of that device: one set per process, not one per call (every new stream
+    #                    opens its own pool of the caching allocator)
 
     def __init__(self, device, frames_in_flight: int = 2):
         self._cur = None
         self._streams: List = []
         if device is not None and torch.device(device).type == "cuda" and frames_in_flight > 1 and torch.cuda.is_available():
+            device = torch.device(device)
+            index = device.index if device.index is not None else torch.cuda.current_device()
             self._cur = torch.cuda.current_stream(device)
-            self._streams = [torch.cuda.Stream(device=device) for _ in range(frames_in_flight)]
+            for k in range(frames_in_flight):
+                if (index, k) not in FrameStreams._pool:
+                    FrameStreams._pool[(index, k)] = torch.cuda.Stream(device=device)
+                self._streams.append(FrameStreams._pool[(index, k)])
             for st in self._streams:
                 st.wait_stream(self._cur)  # inputs prepared on the caller's stream (uploads, camera tensors)
+
+    def __enter__(self) -> "FrameStreams":
+        return self
+
+    def __exit__(self, exc_type, exc, tb) -> bool:
+        self.join()   # also on an exception inside a frame: nothing the caller already holds may be read ahead of the side streams
+        return False
 
     def frame(self, k: int):
         import contextlib
 
         return torch.cuda.stream(self._streams[k % len(self._streams)]) if self._streams else contextlib.nullcontext()
 
-    def keep(self, t: Tensor) -> Tensor:
+    def keep(self, t: Optional[Tensor]) -> Optional[Tensor]:
         """Marks a tensor produced inside ``frame`` as consumed on the caller's stream (caching-allocator bookkeeping)."""
-        if self._streams and t.is_cuda:
+        if t is not None and self._streams and t.is_cuda:
             t.record_stream(self._cur)
         return t
 
@@ -123,23 +164,23 @@ class FrameStreams:
 
 
 def render_cameras_sharded(render_fn: Callable[[int], Tuple[Tensor, Tensor]], n_cameras: int, group=None, device=None,
-                           frames_in_flight: int = 2) -> Tensor:
+                           frames_in_flight: int = 2, dst: Optional[int] = None) -> Optional[Tensor]:
     """Renders cameras round-robin over the ranks and all-gathers the tiles.
 
     render_fn(i) -> (rgb [H,W,3], depth [H,W,1]) for camera i, on this rank's device.  ``device``: this rank's GPU -- its cameras are
     then issued on ``frames_in_flight`` alternating streams (FrameStreams); None keeps one stream.
-    Returns [n_cameras, H, W, 4] (rgb ++ depth) on every rank, identical to a single-rank run.
+    Returns [n_cameras, H, W, 4] (rgb ++ depth) on every rank, identical to a single-rank run (``dst`` given: gather to that rank
+    only, None on the others).
     """
     rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     mine = shard_indices(n_cameras, world, rank)
     tiles = []
-    fs = FrameStreams(device, frames_in_flight)
-    for k, i in enumerate(mine):
-        with fs.frame(k):
-            rgb, depth = render_fn(i)
-            tiles.append(fs.keep(torch.cat([rgb, depth], dim=-1)))
-    fs.join()
+    with FrameStreams(device, frames_in_flight) as fs:
+        for k, i in enumerate(mine):
+            with fs.frame(k):
+                rgb, depth = render_fn(i)
+                tiles.append(fs.keep(torch.cat([rgb, depth], dim=-1)))
     if tiles:
         local = torch.stack(tiles, dim=0)
     else:  # fewer cameras than ranks: learn the tile shape from rank 0's broadcast
@@ -151,7 +192,7 @@ def render_cameras_sharded(render_fn: Callable[[int], Tuple[Tensor, Tensor]], n_
         dist.broadcast(shape, src=0, group=group)
         if local is None:
             local = torch.zeros((0, *shape.tolist()), dtype=torch.float32, device=dev)
-    return gather_tiles(local, n_cameras, group)
+    return gather_tiles(local, n_cameras, group, dst)
 
 
 def _default_device():
@@ -160,19 +201,24 @@ def _default_device():
     return torch.device("cpu")
 
 
-def render_views(model, cameras, generator_config, group=None, frames_in_flight: int = 2) -> Tensor:
+def render_views(model, cameras, generator_config, group=None, frames_in_flight: int = 2, dst: Optional[int] = None,
+                 render_camera_fn=None) -> Optional[Tensor]:
     """BASELINE.json configs[4]: the per-view work of the dataset-generator loops
     (/root/reference/signerf/datasetgenerator/datasetgenerator.py:331-338 and :517-519): for every camera, render ->
-    mask -> condition (``render_camera``, aabb mode), sharded round-robin over the ranks, tiles all-gathered.
+    mask -> condition (``render_camera``, aabb mode), sharded round-robin over the ranks, tiles all-gathered (``dst``: gathered to
+    that rank only).
     -> [n_cameras, H, W, 5] = rgb (3) ++ mask (1, 0/1) ++ condition (1) on every rank.  The diffusion call that follows
     each view in the reference is a remote HTTP service and stays where it is (rank 0)."""
-    from .datasetgenerator import render_camera
+    from . import datasetgenerator
+
+    render_camera = render_camera_fn or datasetgenerator.render_camera
 
     def render_fn(i: int):
         rgb, mask, cond = render_camera(generator_config, model, cameras[i])
         return rgb, torch.cat([mask.to(rgb.dtype), cond], dim=-1)
 
-    return render_cameras_sharded(render_fn, len(cameras), group, device=getattr(model, "device", None), frames_in_flight=frames_in_flight)
+    return render_cameras_sharded(render_fn, len(cameras), group, device=getattr(model, "device", None), frames_in_flight=frames_in_flight,
+                                  dst=dst)
 
 
 def render_reference_sheet(model, cameras, group=None) -> Tensor:

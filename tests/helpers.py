@@ -64,6 +64,39 @@ def rmse(a: torch.Tensor, b: torch.Tensor) -> float:
     return float(torch.sqrt(torch.mean((a.double().cpu() - b.double().cpu()) ** 2)))
 
 
+def ulp_distance(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Distance in units in the last place between two fp32 tensors (monotone integer mapping of the bit patterns; inf for NaN)."""
+    def key(t):
+        i = t.detach().cpu().contiguous().view(torch.int32).to(torch.int64)
+        return torch.where(i < 0, -(i & 0x7FFFFFFF), i)
+
+    d = (key(a.float()) - key(b.float())).abs().double()
+    bad = torch.isnan(a.cpu()) | torch.isnan(b.cpu())
+    return torch.where(bad, torch.full_like(d, float("inf")), d)
+
+
+def depth_error_report(got: torch.Tensor, want: torch.Tensor) -> dict:
+    """Scale-free error of a depth-like quantity (nerfacto's eval depths span [0, far_plane = 1000] ray-distance units, so an absolute
+    RMSE weighs a pixel at depth 300 by 1e5 x a pixel at depth 0.3): absolute RMSE (north_star's gate) beside the relative error
+    |got - want| / |want| and the distance in fp32 ulps."""
+    g, w = got.detach().double().cpu().reshape(-1), want.detach().double().cpu().reshape(-1)
+    ok = torch.isfinite(g) & torch.isfinite(w)
+    g, w = g[ok], w[ok]
+    rel = (g - w).abs() / w.abs().clamp_min(1e-30)
+    ulp = ulp_distance(got.reshape(-1)[ok], want.reshape(-1)[ok])
+    q = lambda t, p: float(torch.quantile(t, p)) if t.numel() else 0.0  # noqa: E731
+    return {"n": int(g.numel()), "abs_rmse": float(torch.sqrt(torch.mean((g - w) ** 2))), "abs_max": float((g - w).abs().max()),
+            "rel_rmse": float(torch.sqrt(torch.mean(rel**2))), "rel_p50": q(rel, 0.5), "rel_p99": q(rel, 0.99), "rel_max": float(rel.max()),
+            "ulp_p50": q(ulp, 0.5), "ulp_p99": q(ulp, 0.99), "ulp_max": float(ulp.max()), "bitwise_equal": int((ulp == 0).sum()),
+            "depth_min": float(w.min()), "depth_p50": q(w, 0.5), "depth_max": float(w.max())}
+
+
+def fmt_report(name: str, r: dict) -> str:
+    return (f"{name}: abs rmse {r['abs_rmse']:.2e} (max {r['abs_max']:.2e}) | rel rmse {r['rel_rmse']:.2e} p50 {r['rel_p50']:.1e} p99 {r['rel_p99']:.1e} "
+            f"max {r['rel_max']:.1e} | ulp p50 {r['ulp_p50']:.0f} p99 {r['ulp_p99']:.0f} max {r['ulp_max']:.0f} | bitwise equal "
+            f"{r['bitwise_equal']}/{r['n']} | values in [{r['depth_min']:.3g}, {r['depth_max']:.3g}], median {r['depth_p50']:.3g}")
+
+
 # ---- tiny-cuda-nn layout (SURVEY §8(f) row 2): synthetic checkpoints in the flat-vector layout -------------------------------
 def synthetic_tcnn_checkpoint(cfg, seed=0, base_gain=2.0, head_gain=3.0, num_images=50):
     """A random "ns-train nerfacto" style state dict: one flat fp32 vector per tiny-cuda-nn module (network matrices, then grid

@@ -1,0 +1,270 @@
+"""``DatasetGenerator.generate_dataset`` (BASELINE.json configs[4]; /root/reference/signerf/datasetgenerator/datasetgenerator.py:185-393)
+on the CPU: the ORCHESTRATION -- pre-computed sharded renders, the serial diffusion sequence with the in-place last cell (:643-646),
+the directory and transforms.json -- with test-only stand-ins for the three HIP-only pieces (render_camera, the bilinear resize, the
+uint8 cast).  The same loop with real renders across two processes is tests/test_gpu_generate_dataset.py."""
+import hashlib
+import json
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIZE = 32
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+RENDERED = []   # (per process) the cameras this process rendered
+
+
+def _fake_render_camera(config, graph, camera, with_mask=True, with_condition=True):
+    host = camera._host.reshape(-1)
+    seed = int.from_bytes(hashlib.sha1(host.numpy().tobytes()).digest()[:4], "little")
+    RENDERED.append(seed)
+    g = torch.Generator().manual_seed(seed)
+    H, W = int(host[17]), int(host[16])
+    rgb = torch.rand(H, W, 3, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    cy, cx = (torch.rand(2, generator=g) * 0.5 + 0.25) * torch.tensor([H, W])
+    mask = (((yy - cy) ** 2 + (xx - cx) ** 2) < (0.3 * H) ** 2)[..., None]
+    cond = torch.rand(H, W, 1, generator=g) * mask
+    return rgb, mask, cond
+
+
+def _fake_resize(src, out_h, out_w, threshold=False, out=None):
+    r = F.interpolate(src.float().permute(2, 0, 1)[None], (out_h, out_w), mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+    if threshold:
+        r = (r > 0.5).float()
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r.contiguous()
+
+
+def install_cpu_standins():
+    from signerf_amd import dataset_io, datasetgenerator, ops
+
+    datasetgenerator.render_camera = _fake_render_camera
+    ops.resize_bilinear = _fake_resize
+    dataset_io.tensor_to_uint8 = lambda t: (t.detach().float() * 255).to(torch.uint8)
+
+
+@pytest.fixture()
+def standins(monkeypatch):
+    from signerf_amd import dataset_io, datasetgenerator, ops
+
+    monkeypatch.setattr(datasetgenerator, "render_camera", _fake_render_camera)
+    monkeypatch.setattr(ops, "resize_bilinear", _fake_resize)
+    monkeypatch.setattr(dataset_io, "tensor_to_uint8", lambda t: (t.detach().float() * 255).to(torch.uint8))
+    RENDERED.clear()
+
+
+class _Graph:
+    device = torch.device("cpu")
+    render_aabb = None
+
+
+def _poses(n_ref=5, n_views=7):
+    from signerf_amd import circle_poses, random_sphere_poses
+
+    ref = circle_poses(n_ref, torch.device("cpu"), 0.5, 90.0, (0.0, 300.0), [0.0, 0.0, 0.0], [0.0, 0.0, 0.0])[:, :3]
+    torch.manual_seed(1)
+    syn = random_sphere_poses(n_views, torch.device("cpu"), 0.5, (30.0, 120.0), (0.0, 360.0), [0.0, 0.0, 0.0], [0.0, 0.0, 0.0])[:, :3]
+    return ref, syn
+
+
+def _generator(path, name, diffuse=None, **kw):
+    from signerf_amd.datasetgenerator import DatasetGenerator, DatasetGeneratorConfig
+
+    cfg = DatasetGeneratorConfig(path=path, dataset_name=name, fx=40.0, fy=40.0, cx=SIZE / 2, cy=SIZE / 2, width=SIZE, height=SIZE,
+                                 mask_dialation=(5, 5))
+    return DatasetGenerator(cfg, torch.eye(4)[:3], 1.0, None, device="cpu", diffuse=diffuse, **kw)
+
+
+def _tree(root):
+    out = {}
+    for d, _, files in os.walk(root):
+        for f in files:
+            p = os.path.join(d, f)
+            out[os.path.relpath(p, root)] = open(p, "rb").read()
+    return out
+
+
+def test_generate_dataset_layout_and_transforms(tmp_path, standins):
+    from signerf_amd.dataset_io import load_previous_experiment_cameras
+
+    ref, syn = _poses()
+    gen = _generator(tmp_path, "exp")
+    gen.generate_dataset(_Graph(), ref, synthetic_camera_to_worlds=syn)
+    root = tmp_path / "exp"
+    t = json.load(open(root / "transforms.json"))
+    assert t["method"] == "SIGNeRF" and t["is_synthetic"] is True and t["is_combined"] is False and t["camera_model"] == "OPENCV"
+    assert t["reference_indices"] == list(range(5)) and t["generated_indices"] == list(range(5, 12)) and "original_indices" not in t
+    assert len(t["frames"]) == 12 and t["frames"][7]["file_path"] == "./images/image_7.png" and t["frames"][7]["_mask_path"] == "./masks/mask_7.png"
+    assert t["frames"][0]["w"] == SIZE and t["frames"][0]["fl_x"] == 40.0
+    for sub, stem in (("images", "image"), ("rendered", "image"), ("masks", "mask"), ("conditions", "condition"),
+                      ("images_2", "image"), ("rendered_2", "image"), ("masks_2", "mask"), ("conditions_2", "condition")):
+        assert sorted(os.listdir(root / sub)) == sorted(f"{stem}_{i}.png" for i in range(12)), sub
+    assert os.listdir(root / "originals") == [] and os.listdir(root / "originals_2") == []
+    assert sorted(os.listdir(root / "references")) == ["condition_reference_sheet.png", "edited_reference_sheet.png",
+                                                       "image_reference_sheet.png", "mask_reference_sheet.png"]
+    assert (root / "config.yml").exists()
+    # the reader of the same file (load_previous_experiment_cameras.py) gets the cameras back
+    r, s, combined = load_previous_experiment_cameras(root / "transforms.json")
+    assert torch.equal(r, ref) and torch.equal(s, syn) and combined is False
+    assert len(RENDERED) == 12 and len(set(RENDERED)) == 12          # every camera rendered exactly once (pre-computed, then looked up)
+    from PIL import Image
+
+    assert Image.open(root / "images" / "image_3.png").size == (SIZE, SIZE) and Image.open(root / "images_2" / "image_3.png").size == (SIZE // 2,) * 2
+    sheet = Image.open(root / "references" / "image_reference_sheet.png")
+    assert sheet.size == (3 * SIZE // 2, 2 * SIZE // 2) and sheet.mode == "RGB"
+
+
+def test_diffuser_sequence_and_in_place_last_cell(tmp_path, standins):
+    """datasetgenerator.py:558 and :643-650: one call for the reference sheet, then one per generated view on the EDITED sheet whose
+    last cell holds that view (mutated in place: the same tensor objects every call), mask sheet zero outside the last cell."""
+    from signerf_amd.datasetgenerator import cell_window
+
+    calls = []
+
+    def diffuse(original, rendered, mask, condition):
+        assert original is rendered
+        calls.append((original, original.clone(), mask.clone(), condition.clone(), condition))
+        return 1.0 - original   # a visible "edit"
+
+    ref, syn = _poses()
+    gen = _generator(tmp_path, "exp", diffuse=diffuse, write_images=False)
+    gen.generate_dataset(_Graph(), ref, synthetic_camera_to_worlds=syn)
+    assert len(calls) == 1 + 7
+    cfg, half = gen.config, SIZE // 2
+    r0, r1, c0, c1 = cell_window(cfg, 5, half, half)
+    first_img, first_mask = calls[0][1], calls[0][2]
+    assert torch.equal(first_img[r0:r1, c0:c1], torch.ones(half, half, 3)) and float(first_mask[r0:r1, c0:c1].abs().max()) == 0   # empty last cell
+    edited_ref = first_img * (1 - first_mask) + (1 - first_img) * first_mask      # what the sheet stage keeps: the edit inside the mask
+    sheets = {id(c[0]) for c in calls[1:]}
+    conds = {id(c[4]) for c in calls[1:]}
+    assert len(sheets) == 1 and len(conds) == 1                                    # the per-view calls see ONE image sheet / condition sheet object
+    from signerf_amd import Cameras
+
+    cams = Cameras(syn, 40.0, 40.0, SIZE / 2, SIZE / 2, SIZE, SIZE)
+    for k in range(7):
+        _, img, mask, cond, _ = calls[1 + k]
+        rgb, m, cnd = _fake_render_camera(cfg, None, cams[k])
+        assert torch.equal(img[r0:r1, c0:c1], _fake_resize(rgb, half, half))       # this view in the last cell
+        assert torch.equal(mask[r0:r1, c0:c1], _fake_resize(m, half, half, threshold=True))
+        assert torch.equal(cond[r0:r1, c0:c1], _fake_resize(cnd, half, half))
+        outside = torch.ones_like(mask, dtype=torch.bool)
+        outside[r0:r1, c0:c1] = False
+        assert float(mask[outside].abs().max()) == 0                               # fresh mask sheet per view (:644)
+        for cell in range(5):                                                      # the edited reference cells are what every view sees
+            a0, a1, b0, b1 = cell_window(cfg, cell, half, half)
+            assert torch.allclose(img[a0:a1, b0:b1], edited_ref[a0:a1, b0:b1], atol=1e-6)
+            assert torch.equal(cond[a0:a1, b0:b1], calls[0][3][a0:a1, b0:b1])
+    # as the reference leaves them: the sheets hold the LAST view
+    assert torch.equal(gen.edited_reference_sheet[r0:r1, c0:c1], calls[-1][1][r0:r1, c0:c1])
+
+
+def test_precompute_off_writes_the_same_dataset(tmp_path, standins):
+    ref, syn = _poses()
+    _generator(tmp_path, "a", save_workers=0).generate_dataset(_Graph(), ref, synthetic_camera_to_worlds=syn)
+    _generator(tmp_path, "b", precompute=False, save_workers=4).generate_dataset(_Graph(), ref, synthetic_camera_to_worlds=syn)
+    a, b = _tree(tmp_path / "a"), _tree(tmp_path / "b")
+    a.pop("config.yml"), b.pop("config.yml")   # (holds the dataset name)
+    assert a.keys() == b.keys() and all(a[k] == b[k] for k in a)
+
+
+def test_argument_errors(tmp_path, standins):
+    ref, syn = _poses()
+    gen = _generator(tmp_path, "exp")
+    with pytest.raises(ValueError, match="Either original dataset or camera_to_worlds"):
+        gen.generate_dataset(_Graph(), ref)
+    with pytest.raises(ValueError, match="to merge with original dataset"):
+        gen.generate_dataset(_Graph(), ref, synthetic_camera_to_worlds=syn, merge_with_original_dataset=True)
+    with pytest.raises(ValueError, match="is not equal to"):
+        gen.generate_dataset(_Graph(), ref[:4], synthetic_camera_to_worlds=syn)
+
+
+class _Original:
+    """Duck-typed nerfstudio InputDataset: .cameras, ._dataparser_outputs.image_filenames, .get_image_float32."""
+
+    def __init__(self, cameras, filenames, images):
+        self.cameras, self._images = cameras, images
+        self._dataparser_outputs = type("O", (), {"image_filenames": filenames})()
+
+    def get_image_float32(self, idx):
+        return self._images[idx]
+
+
+def test_merge_with_original_dataset(tmp_path, standins):
+    """:344-388: the original views are appended with INVERTED masks, their renders under originals/, the photo as the image."""
+    from PIL import Image
+
+    from signerf_amd import Cameras
+
+    ref, syn = _poses(n_views=3)
+    torch.manual_seed(3)
+    from signerf_amd import random_sphere_poses
+
+    orig_c2w = random_sphere_poses(2, torch.device("cpu"), 0.6, (40.0, 100.0), (0.0, 360.0), [0.0, 0.0, 0.0], [0.0, 0.0, 0.0])[:, :3]
+    photos = [torch.rand(SIZE, SIZE, 3) for _ in range(2)]
+    ds = _Original(Cameras(orig_c2w, 40.0, 40.0, SIZE / 2, SIZE / 2, SIZE, SIZE), [None, None], photos)
+    gen = _generator(tmp_path, "exp")
+    gen.generate_dataset(_Graph(), ref, original_dataset=ds, synthetic_camera_to_worlds=syn, merge_with_original_dataset=True)
+    root = tmp_path / "exp"
+    t = json.load(open(root / "transforms.json"))
+    assert t["is_combined"] is True and t["original_indices"] == [8, 9] and len(t["frames"]) == 10
+    assert sorted(os.listdir(root / "originals")) == ["image_8.png", "image_9.png"]
+    import numpy as np
+
+    assert len(RENDERED) == 10 and len(set(RENDERED)) == 10      # 5 + 3 + 2 cameras, each rendered once (all pre-computed)
+    got = np.array(Image.open(root / "images" / "image_8.png"))
+    assert np.array_equal(got, (photos[0] * 255).to(torch.uint8).numpy())
+    _, m, _ = _fake_render_camera(None, None, ds.cameras[0])
+    assert np.array_equal(np.array(Image.open(root / "masks" / "mask_8.png")) > 0, (~m).squeeze(-1).numpy())
+
+
+# ---- world 2 over gloo: the written dataset equals the single-process one ----------------------------------------------------------
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import test_generate_dataset as me
+
+    me.install_cpu_standins()
+    ref, syn = me._poses()
+    gen = me._generator(out_dir, "sharded")
+    gen.generate_dataset(me._Graph(), ref, synthetic_camera_to_worlds=syn)
+    json.dump({"rendered": me.RENDERED, "wrote": os.path.exists(os.path.join(out_dir, "sharded", "transforms.json"))},
+              open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_generate_dataset_sharded_over_gloo_equals_single_process(tmp_path, standins, world):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref, syn = _poses()
+    _generator(tmp_path, "single").generate_dataset(_Graph(), ref, synthetic_camera_to_worlds=syn)
+    a, b = _tree(tmp_path / "sharded"), _tree(tmp_path / "single")
+    a.pop("config.yml"), b.pop("config.yml")
+    assert a.keys() == b.keys()
+    for k in a:
+        assert a[k] == b[k], f"{k} differs between the {world}-rank and the single-process dataset"
+    per_rank = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+    assert all(p["wrote"] for p in per_rank)                                        # every rank returns after the dataset is on disk
+    counts = [len(p["rendered"]) for p in per_rank]
+    assert sum(counts) == 12 and max(counts) - min(counts) <= 1                     # 5 + 7 cameras, camera i -> rank i mod N
+    assert sorted(x for p in per_rank for x in p["rendered"]) == sorted(RENDERED)   # together: exactly the single-process renders

@@ -256,12 +256,9 @@ def test_config2_fused_indices_full_size_crop(bench_model, gpu, cam, y0, x0):
     _run_uniform(cfg, model, sd, gpu, _bundle_crop(cams[cam], y0, x0, 40, 40), f"config 2 (40x40 crop of camera {cam}'s 800x800 frame)")
 
 
-def test_config4_fused_indices_proposal_path(full_model, gpu):
-    """72x128, two proposal nets (256 + 96) + 48 main samples: K2's fetches and searchsorted indices, K1's fetches in bins mode."""
-    cfg, model, sd = full_model
-    H, W = 72, 128
-    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 150.0, 150.0, W / 2, H / 2, W, H).to(gpu)
-    bundle = cams[3].generate_rays(camera_indices=0)
+def _run_proposal(cfg, model, sd, bundle, name):
+    """Two proposal nets (256 + 96) + 48 main samples: K2's fetches and searchsorted indices, K1's fetches in bins mode."""
+    H, W = bundle.origins.shape[:2]
     model.eval()
     out, dump = ops.render_rays_debug(model, bundle)
     prod = model.get_outputs_for_camera_ray_bundle(bundle)
@@ -287,7 +284,7 @@ def test_config4_fused_indices_proposal_path(full_model, gpu):
         assert int((rows != rows_f1).sum()) == 0
         differs = rows != idx_ceil
         assert not bool(differs.any()) or float(w[differs].abs().max()) == 0.0
-        print(f"config 4 proposal net {k}: {rows.numel()} fetched rows bit-exact given the hashed positions ({int(differs.sum())} zero-weight floor+1 corners)")
+        print(f"{name} proposal net {k}: {rows.numel()} fetched rows bit-exact given the hashed positions ({int(differs.sum())} zero-weight floor+1 corners)")
     # level 0 samples come from the fixed initial sampler: their positions can be compared with the oracle's directly
     # (the oracle's debug dict keeps the main field's q only; recompute level-0 positions with its own functions)
     nears, fars = onf.collider_near_far(n, ocfg)
@@ -302,16 +299,35 @@ def test_config4_fused_indices_proposal_path(full_model, gpu):
         assert got.shape == want.shape and int(got.min()) >= 0
         diff = got != want
         n_diff = int(diff.sum())
-        print(f"config 4 searchsorted indices, step {k}: {n_diff} / {got.numel()} differ ({n_diff / got.numel():.2e}), max |delta| "
+        print(f"{name} searchsorted indices, step {k}: {n_diff} / {got.numel()} differ ({n_diff / got.numel():.2e}), max |delta| "
               f"{int((got - want).abs().max())}")
         assert n_diff / got.numel() <= (2e-4 if k == 0 else 5e-3) and int((got - want).abs().max()) <= 1
     # K1 (bins mode): rows given the hashed positions; positions follow K2's bins, which differ from the oracle's by ~1e-6 relative
     S = cfg.num_nerf_samples_per_ray
     sc = onf.hash_scalings(cfg.num_levels, cfg.base_res, cfg.max_res)
     lay = ops.debug_layout(model, -1)
-    _check_rows("config 4 main field (72x128x48, bins mode)", dump["main_fetch"].view(n * S, 16, 8), dump["main_q"].view(-1, 3),
+    _check_rows(f"{name} main field (bins mode)", dump["main_fetch"].view(n * S, 16, 8), dump["main_q"].view(-1, 3),
                 dbg["q"].reshape(-1, 3), lay, sc, cfg.log2_hashmap_size, flip_bound=(2e-2, 0.2, 2e-5))
     med = dump["median_index"].cpu().to(torch.int64)
     n_med = int((med != dbg["median_index"].view(-1)).sum())
-    print(f"config 4: median-index mismatches {n_med} / {med.numel()} (documented ties at exact 0.5 crossings)")
+    print(f"{name}: median-index mismatches {n_med} / {med.numel()} (documented ties at exact 0.5 crossings)")
     assert n_med <= max(5, med.numel() // 500)
+
+
+def test_config4_fused_indices_proposal_path(full_model, gpu):
+    """BASELINE.json configs[3] at 72x128."""
+    cfg, model, sd = full_model
+    H, W = 72, 128
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 150.0, 150.0, W / 2, H / 2, W, H).to(gpu)
+    _run_proposal(cfg, model, sd, cams[3].generate_rays(camera_indices=0), "config 4 (72x128)")
+
+
+@pytest.mark.parametrize("cam,y0,x0", [(0, 516, 936), (6, 200, 1500)])
+def test_config4_fused_indices_full_size_crop(full_model, gpu, cam, y0, x0):
+    """48x48 crops of the 1920x1080 nerfacto frame itself (the `bench.py --workload nerfacto1080` scene and camera model: fx = fy =
+    1.2 * 1080): the pixel footprint -- and with it the gather pattern, the coefficient-cache hit pattern and the wave-uniform paths of
+    K2 -- of the full-size frame."""
+    cfg, model, sd = full_model
+    W, H = 1920, 1080
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 1.2 * H, 1.2 * H, W / 2, H / 2, W, H).to(gpu)
+    _run_proposal(cfg, model, sd, _bundle_crop(cams[cam], y0, x0, 48, 48), f"config 4 (48x48 crop of camera {cam}'s 1920x1080 frame)")

@@ -4,13 +4,14 @@ Gate (north_star): per-pixel RMSE(rgb) <= 1e-3 and RMSE(depth) <= 1e-3."""
 import pytest
 import torch
 
-from helpers import make_model, oracle_config, rmse, small_config
+from helpers import depth_error_report, fmt_report, make_model, oracle_config, rmse, small_config
 from oracle import nerfacto as onf
-from signerf_amd import Cameras, SceneBox, scene
+from signerf_amd import Cameras, SceneBox, ops, scene
 from signerf_amd.cameras import RayBundle
 
 pytestmark = pytest.mark.gpu
 RMSE_TOL = 1e-3
+EXPECTED_DEPTH_TOL = 1e-3   # expected depth and the proposal depths: the same gate as rgb / median depth (r02: 5e-3)
 
 
 def _render_pair(cfg, model, sd, gpu, H, W, cam=0, focal=None, aabb=None):
@@ -40,7 +41,9 @@ def _check(out, ref, keys=("rgb", "depth", "accumulation", "expected_depth")):
           f"median-depth mismatches {flips}/{ref['depth'].numel()}")
     assert e_rgb <= RMSE_TOL and e_depth <= RMSE_TOL
     assert rmse(out["accumulation"], ref["accumulation"]) <= RMSE_TOL
-    assert rmse(out["expected_depth"], ref["expected_depth"]) <= 5e-3
+    for k in ("depth", "expected_depth"):
+        print(fmt_report(k, depth_error_report(out[k], ref[k])))
+    assert rmse(out["expected_depth"], ref["expected_depth"]) <= EXPECTED_DEPTH_TOL
     assert float(ref["rgb"].std()) > 0.05 and float(ref["depth"].std()) > 0.01   # non-vacuous
 
 
@@ -91,7 +94,8 @@ def test_config4_reduced_proposal_path(gpu, precision):
     out, ref = _render_pair(cfg, model, sd, gpu, 72, 128, cam=3, focal=150.0)
     _check(out, ref)
     for i in (0, 1):
-        assert rmse(out[f"prop_depth_{i}"], ref[f"prop_depth_{i}"]) <= 5e-3
+        print(fmt_report(f"prop_depth_{i}", depth_error_report(out[f"prop_depth_{i}"], ref[f"prop_depth_{i}"])))
+        assert rmse(out[f"prop_depth_{i}"], ref[f"prop_depth_{i}"]) <= EXPECTED_DEPTH_TOL
 
 
 def test_flat_bundle_get_outputs(gpu):
@@ -147,6 +151,66 @@ def test_full_size_properties_800x800x64(gpu):
     ref = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg), crop.origins.cpu(), crop.directions.cpu())
     assert rmse(oc["rgb"], ref["rgb"]) <= RMSE_TOL and rmse(oc["depth"], ref["depth"]) <= RMSE_TOL
     assert float(out["rgb"].std()) > 0.05
+
+
+@pytest.mark.parametrize("cam,y0,x0", [(0, 516, 936), (6, 200, 1500)])
+def test_full_size_properties_1920x1080_nerfacto(gpu, cam, y0, x0):
+    """BASELINE.json configs[3] at FULL size (1920x1080, proposal nets 256 + 96, 48 main samples, full tables: the scene and camera
+    model of `bench.py --workload nerfacto1080`): (1) determinism of the whole frame; (2) a 48x48 crop re-rendered as its own bundle
+    is bit-identical in rgb / median depth / accumulation / both proposal depths (rays are independent; K2's persistent waves,
+    coefficient cache and wave-uniform paths see a different tile set); (3) that crop against the oracle within the 1e-3 gate, with
+    the depth errors also reported scale-free (relative, ulp); (4) finite, in range."""
+    cfg = scene.proposal_config()
+    model, sd = make_model(cfg, gpu)
+    W, H = 1920, 1080
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 1.2 * H, 1.2 * H, W / 2, H / 2, W, H).to(gpu)
+    b = cams[cam].generate_rays(0)
+    out = model.get_outputs_for_camera_ray_bundle(b)
+    out2 = model.get_outputs_for_camera_ray_bundle(b)
+    keys = ("rgb", "depth", "accumulation", "prop_depth_0", "prop_depth_1")
+    for k in keys + ("expected_depth",):
+        assert out[k].shape[:2] == (H, W)
+        assert torch.equal(out[k], out2[k]), k
+        assert torch.isfinite(out[k]).all(), k
+    assert float(out["rgb"].min()) >= 0 and float(out["rgb"].max()) <= 1 and float(out["rgb"].std()) > 0.05
+    assert float(out["depth"].min()) >= 0 and float(out["depth"].max()) <= cfg.far_plane
+    crop = b._map(lambda t: t[y0:y0 + 48, x0:x0 + 48].contiguous())
+    oc = model.get_outputs_for_camera_ray_bundle(crop)
+    for k in keys:   # (expected_depth is clipped to the chunk's min / max sample position: chunk-dependent by definition, A17)
+        assert torch.equal(oc[k], out[k][y0:y0 + 48, x0:x0 + 48]), k
+    ref = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg), crop.origins.cpu(), crop.directions.cpu())
+    print(f"config 4 full size, camera {cam}, crop ({y0}, {x0}) + 48x48:")
+    _check(oc, ref)
+    for i in (0, 1):
+        r = depth_error_report(oc[f"prop_depth_{i}"], ref[f"prop_depth_{i}"])
+        print(fmt_report(f"prop_depth_{i}", r))
+        assert r["abs_rmse"] <= EXPECTED_DEPTH_TOL
+
+
+@pytest.mark.parametrize("density_bias", [4.0, 0.0, -1.0])
+def test_config4_depth_error_is_scale_free(gpu, density_bias):
+    """nerfacto's eval depths live on [0, far_plane = 1000] and the sampler is uniform in s = 1 - 1/(2d): one ulp of s is
+    2 d^2 * 6e-8 of depth, i.e. 1e-7 at d = 1 and 5e-3 at d = 200 -- an ABSOLUTE 1e-3 gate measures the scene's scale, not the
+    arithmetic.  The same field with thinner media (sigma = 0.01 exp(h0 + bias); bias 4 is the benchmark scene) moves the median depth
+    from ~1 to ~60 and ~170 ray-distance units: the RELATIVE error of every depth output stays at the 1e-6 level (most pixels bit-equal),
+    while the absolute RMSE grows with d.  Median-index flips (a 0.5 crossing decided differently: the depth jumps by a whole bin)
+    are counted separately, as SURVEY 8(d) prescribes for ties.  profiles/r03_depth_error.txt holds the per-decade table."""
+    cfg = scene.proposal_config()
+    model, sd = make_model(cfg, gpu, density_bias=density_bias)
+    out, ref = _render_pair(cfg, model, sd, gpu, 72, 128, cam=3, focal=150.0)
+    n = ref["depth"].numel()
+    for k, rel_gate in (("depth", 1e-5), ("expected_depth", 2e-5), ("prop_depth_0", 1e-5), ("prop_depth_1", 1e-5)):
+        g, w = out[k].double().cpu().reshape(-1), ref[k].double().reshape(-1)
+        rel = (g - w).abs() / w.abs().clamp_min(1e-30)
+        flips = rel > 1e-3                      # a whole-bin jump (bins are >= 0.4 % apart); never the case for expected_depth
+        r = depth_error_report(out[k].reshape(-1)[~flips], ref[k].reshape(-1)[~flips])
+        print(fmt_report(f"bias {density_bias:+.0f} {k} ({int(flips.sum())} median flips excluded)", r))
+        assert int(flips.sum()) <= max(2, n // 2000), (k, int(flips.sum()))
+        assert k != "expected_depth" or int(flips.sum()) == 0
+        assert r["rel_rmse"] <= rel_gate and r["rel_max"] <= 1e-3, (k, r)
+        if density_bias >= 4.0:                 # depth O(1): north_star's absolute gate applies as it stands
+            assert r["abs_rmse"] <= RMSE_TOL
+    assert rmse(out["rgb"], ref["rgb"]) <= RMSE_TOL and rmse(out["accumulation"], ref["accumulation"]) <= RMSE_TOL
 
 
 def test_state_dict_boundary(gpu):
@@ -341,8 +405,10 @@ def test_proposal_coefficient_cache_is_bit_identical(gpu, monkeypatch):
         b = cams[i].generate_rays(0)
         out = {k: v.clone() for k, v in model.get_outputs_for_camera_ray_bundle(b).items() if k in keys}
         monkeypatch.setenv("SN_PROP_CACHE_OFF", "1")
+        ops.reload_env(model)
         ref = model.get_outputs_for_camera_ray_bundle(b)
         monkeypatch.delenv("SN_PROP_CACHE_OFF")
+        ops.reload_env(model)
         for k in keys:
             assert torch.equal(out[k], ref[k]), k
 
@@ -361,8 +427,10 @@ def test_resampler_reciprocal_division_is_bit_identical(gpu, monkeypatch):
             b = cams[i].generate_rays(0)
             out = {k: v.clone() for k, v in model.get_outputs_for_camera_ray_bundle(b).items() if k in keys}
             monkeypatch.setenv("SN_PDF_IEEE", "1")
+            ops.reload_env(model)
             ref = model.get_outputs_for_camera_ray_bundle(b)
             monkeypatch.delenv("SN_PDF_IEEE")
+            ops.reload_env(model)
             for k in keys:
                 assert torch.equal(out[k], ref[k]), k
 

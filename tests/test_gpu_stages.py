@@ -111,9 +111,11 @@ def test_hash_encode_indices_bit_exact(model_full, gpu, which):
         # table (8-byte gathers) holds the same values -- the two code paths differ only in how hipcc fuses the blend's FMAs
         os.environ["SN_HASH_PLAIN"] = "1"
         try:
+            ops.reload_env(model)
             plain = ops.hash_encode(model, q.to(gpu), which)
         finally:
             del os.environ["SN_HASH_PLAIN"]
+            ops.reload_env(model)
         assert float((plain - feat).abs().max()) <= 5e-7
 
 

@@ -152,9 +152,11 @@ def test_tcnn_render_full_size_grids(gpu, precision):
     import os
     os.environ["SN_PROP_CACHE_OFF"] = "1"
     try:
+        ops.reload_env(model)
         plain = model.get_outputs_for_camera_ray_bundle(b)
     finally:
         del os.environ["SN_PROP_CACHE_OFF"]
+        ops.reload_env(model)
     for k in ("rgb", "depth", "accumulation", "expected_depth", "prop_depth_0", "prop_depth_1"):
         assert torch.equal(out[k], plain[k]), k
 

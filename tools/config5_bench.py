@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] / SURVEY §8(d) "Config 5": the DatasetGenerator loop -- 8 reference cameras (circle_poses, 3x3 sheet) + 50
+random_sphere_poses views, nerfacto defaults (256 + 96 proposal + 48 main samples), aabb masking with the DEFAULT +-0.1 box and the
+50x50 elliptical dilation, condition image, 1/2 down-scale + paste, diffuser unreachable => identity
+(/root/reference/signerf/diffuser/diffuser.py:182-185), transforms.json -- through signerf_amd.datasetgenerator.DatasetGenerator.
+PNG writes on / off are reported separately.
+
+    python tools/config5_bench.py [--size 800] [--reps 3]                                            (one GPU)
+    python -m torch.distributed.run --nproc-per-node N ... tools/config5_bench.py [--backend nccl]    (camera i -> rank i mod N)
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from signerf_amd import random_sphere_poses, scene  # noqa: E402
+from signerf_amd.datasetgenerator import DatasetGenerator, DatasetGeneratorConfig  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=800)
+ap.add_argument("--views", type=int, default=50)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+ap.add_argument("--save-workers", type=int, default=8)
+a = ap.parse_args()
+world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+torch.cuda.set_device(dev)
+if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(a.backend, **({"device_id": dev} if a.backend == "nccl" else {}))
+cfg = scene.proposal_config()
+model = cfg.setup()
+model.load_state_dict(scene.synthetic_state_dict(cfg, seed=0, density_bias=5.0), strict=False)
+model = model.to(dev).eval()
+ref = scene.benchmark_cameras(8)[:, :3]
+torch.manual_seed(1)
+syn = random_sphere_poses(a.views, torch.device("cpu"), 0.5, (30.0, 120.0), (0.0, 360.0), [0.0, 0.0, 0.0], [0.0, 0.0, 0.0])[:, :3]
+S = a.size
+tmp = tempfile.mkdtemp(prefix="signerf_config5_") if rank == 0 else None
+if world > 1:
+    box = [tmp]
+    dist.broadcast_object_list(box, src=0)
+    tmp = box[0]
+
+
+def run(write_images: bool, tag: str):
+    best = None
+    for rep in range(a.reps + 1):   # the first repetition warms the handle, the streams and the allocator
+        gcfg = DatasetGeneratorConfig(path=tmp, dataset_name=f"{tag}{rep}", fx=1.2 * S, fy=1.2 * S, cx=S / 2, cy=S / 2, width=S, height=S,
+                                      rows=3, cols=3)   # aabb +-0.1, dilation (50, 50), downscale 2: the reference's defaults
+        gen = DatasetGenerator(gcfg, torch.eye(4)[:3], 1.0, None, device=dev, write_images=write_images, save_workers=a.save_workers, profile=True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t = time.perf_counter()
+        gen.generate_dataset(model, ref, synthetic_camera_to_worlds=syn)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        if rep > 0 and (best is None or dt < best[0]):
+            best = (dt, dict(gen.timings))
+    return best
+
+
+n = 8 + a.views
+out = {"views": n, "size": [S, S], "ranks": world, "backend": (dist.get_backend() if world > 1 else None),
+       "workload": "8 reference + %d random_sphere_poses views, 256+96+48 samples, aabb +-0.1, dilation 50x50, downscale 2, identity diffuser" % a.views}
+for write, tag in ((False, "nopng"), (True, "png")):
+    dt, tm = run(write, tag)
+    out["png_writes_" + ("on" if write else "off")] = {
+        "total_ms": dt * 1e3, "ms_per_view": dt * 1e3 / n,
+        "render_stage_ms": tm.get("render_s", 0) * 1e3, "render_ms_per_view": tm.get("render_s", 0) * 1e3 / n,
+        "field_evaluations_per_s": n * S * S * 400 / max(tm.get("render_s", 0), 1e-9),
+        "sheet_compose_diffuse_split_ms": tm.get("sheet_s", 0) * 1e3, "per_view_paste_diffuse_blend_ms": tm.get("views_s", 0) * 1e3,
+        "save_ms": tm.get("save_s", 0) * 1e3}
+if rank == 0:
+    from PIL import Image
+    import numpy as np
+
+    m = np.array(Image.open(os.path.join(tmp, "png1", "masks", "mask_10.png"))) > 0
+    out["mask_coverage_view_10"] = float(m.mean())
+    out["files_written"] = sum(len(f) for _, _, f in os.walk(os.path.join(tmp, "png1")))
+    print(json.dumps(out, indent=1))
+    shutil.rmtree(tmp, ignore_errors=True)
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
