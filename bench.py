@@ -36,6 +36,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+PEAK_CLOCK_GHZ = 2.4            # MI355X_MICROARCH.md: peak engine clock (the chip sustains 1.75-1.85 GHz under these kernels: power)
 BYTES_PER_MAIN_SAMPLE = 1024.0  # 16 levels x 8 corners x 2 features x 4 B
 N_CUS, N_SIMDS = 256, 1024      # MI355X_MICROARCH.md chip-level parameters
 VALU_ISSUE_CYCLES = 4.0         # one VALU / MFMA issue slot per SIMD every 4 cycles (measured 3.86 with several waves, profiles/r02_overlap2_probe.txt)
@@ -81,10 +82,12 @@ def physical_cores():
     return min(n, logical), logical
 
 
-def cpu_baseline(main_cfg, main_sd, width, height, samples):
-    """The CPU oracle (kind "port": nerfstudio itself cannot be installed here) timed on bounded samples of the BASELINE
-    configurations: a centred crop of the headline frame (config 2), config 1 in full, a 160x90 crop of config 4.
-    Threads = physical cores, set explicitly."""
+def cpu_baseline(main_cfg, main_sd, width, height, samples, runs=3, runs_config4=1):
+    """The CPU oracle (kind "port": nerfstudio itself cannot be installed here) timed on the bounded samples BASELINE.md §2 names
+    (SURVEY §8(d)): a centred 200x200 crop of the headline frame (config 2), config 1 in full, a centred 240x135 crop of config 4;
+    `time.perf_counter` around the render, one warm-up, MEDIAN of `runs` timed renders (the plan says 5; the default run bounds the
+    CPU leg to ~1.5 min: 3 renders of configs 2 and 1, one 45 s render of config 4 -- `--cpu-runs 5 --cpu-runs-config4 5` gives the
+    plan's figures, profiles/r03_cpu_baseline.json).  Threads = physical cores, set explicitly."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_config, small_config
     from oracle import nerfacto as onf
@@ -100,33 +103,42 @@ def cpu_baseline(main_cfg, main_sd, width, height, samples):
     except (OSError, StopIteration):
         pass
 
-    def timed(cfg, sd, W, H, focal, crop_w, crop_h, cam=0, chunk=None):
+    def timed(cfg, sd, W, H, focal, crop_w, crop_h, n_runs, cam=0, chunk=None):
         c2w = scene.benchmark_cameras(8)[cam]
         rays = onf.generate_rays(c2w[:3], focal, focal, W / 2, H / 2, H, W)
         y0, x0 = (H - crop_h) // 2, (W - crop_w) // 2
         o = rays["origins"][y0:y0 + crop_h, x0:x0 + crop_w].contiguous()
         d = rays["directions"][y0:y0 + crop_h, x0:x0 + crop_w].contiguous()
         ocfg = oracle_config(cfg)
-        onf.get_outputs_for_camera_ray_bundle(sd, ocfg, o[:8, :8].contiguous(), d[:8, :8].contiguous())  # warm-up
-        t = time.perf_counter()
-        onf.get_outputs_for_camera_ray_bundle(sd, ocfg, o, d, chunk=chunk)
-        return time.perf_counter() - t
+        wh = min(16, crop_h)
+        onf.get_outputs_for_camera_ray_bundle(sd, ocfg, o[:wh].contiguous(), d[:wh].contiguous(), chunk=chunk)  # warm-up: threads, allocator, code paths
+        times = []
+        for _ in range(max(1, n_runs)):
+            t = time.perf_counter()
+            onf.get_outputs_for_camera_ray_bundle(sd, ocfg, o, d, chunk=chunk)
+            times.append(time.perf_counter() - t)
+        return statistics.median(times), times
 
     crop = 200
-    dt2 = timed(main_cfg, main_sd, width, height, float(width), crop, crop)
+    dt2, all2 = timed(main_cfg, main_sd, width, height, float(width), crop, crop, runs)
     out = {"value": crop * crop * samples / dt2, "unit": "ray-samples/s", "cores": cores, "threads": cores, "logical_cpus": logical,
-           "kind": "port", "host_cpu": cpu,
-           "sample": f"config 2: centred {crop}x{crop} crop of the {width}x{height}x{samples} frame, {dt2:.1f} s, torch CPU fp32 oracle",
+           "kind": "port", "host_cpu": cpu, "timer": "time.perf_counter around the render, 1 warm-up + median of the timed renders",
+           "sample": f"config 2: centred {crop}x{crop} crop of the {width}x{height}x{samples} frame, median of {len(all2)} renders = {dt2:.1f} s, "
+                     "torch CPU fp32 oracle",
+           "runs": len(all2), "seconds_each": all2,
+           "rays_per_s": crop * crop / dt2,
            "ms_per_frame_extrapolated": dt2 * 1e3 * (width * height) / (crop * crop), "others": []}
     c1 = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=32)
-    dt1 = timed(c1, scene.synthetic_state_dict(c1, seed=0), 64, 64, 64.0, 64, 64)
-    out["others"].append({"config": "config 1: 64x64 image, 32 samples/ray, in full", "seconds": dt1, "ray_samples_per_s": 64 * 64 * 32 / dt1,
-                          "ms_per_frame": dt1 * 1e3})
+    dt1, all1 = timed(c1, scene.synthetic_state_dict(c1, seed=0), 64, 64, 64.0, 64, 64, max(runs, 5))
+    out["others"].append({"config": "config 1: 64x64 image, 32 samples/ray, in full", "runs": len(all1), "seconds": dt1, "seconds_each": all1,
+                          "rays_per_s": 64 * 64 / dt1, "ray_samples_per_s": 64 * 64 * 32 / dt1, "ms_per_frame": dt1 * 1e3})
     c4 = scene.proposal_config()
     sd4 = scene.synthetic_state_dict(c4, seed=0)
-    dt4 = timed(c4, sd4, 1920, 1080, 1.2 * 1080, 160, 90, chunk=8192)  # chunked: bounds the oracle's memory (352 proposal samples per ray)
-    n4 = 160 * 90
-    out["others"].append({"config": "config 4: centred 160x90 crop of the 1920x1080 frame, proposal nets 256 + 96 + 48 main samples", "seconds": dt4,
+    cw, ch = 240, 135
+    dt4, all4 = timed(c4, sd4, 1920, 1080, 1.2 * 1080, cw, ch, runs_config4, chunk=8192)  # chunked: bounds the oracle's memory (352 proposal samples per ray)
+    n4 = cw * ch
+    out["others"].append({"config": f"config 4: centred {cw}x{ch} crop of the 1920x1080 frame, proposal nets 256 + 96 + 48 main samples",
+                          "runs": len(all4), "seconds": dt4, "seconds_each": all4, "rays_per_s": n4 / dt4,
                           "ray_samples_per_s": n4 * 48 / dt4, "field_evaluations_per_s": n4 * 400 / dt4,
                           "ms_per_frame_extrapolated": dt4 * 1e3 * (1920 * 1080) / n4})
     torch.set_num_threads(old_threads)
@@ -156,6 +168,15 @@ def main():
                          "1 = one stream, every launch waits for the previous one to drain")
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the extra (untimed-region) run of the other precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="timed CPU-oracle renders of configs 2 and 1 (median reported; BASELINE.md §2: 5)")
+    ap.add_argument("--cpu-runs-config4", type=int, default=1, help="timed CPU-oracle renders of the 240x135 config-4 crop (~45 s each)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, the driver's command): every rank renders ONE camera per step.  strong: a step is the whole "
+                         "8-camera reference sheet of BASELINE.json configs[2] (datasetgenerator.py:517-519), camera i -> rank i mod N, "
+                         "one tile gather per sheet; total work is fixed, `ms_per_step` is ms per sheet")
+    ap.add_argument("--gather", default="all", choices=["all", "root"],
+                    help="N > 1: all-gather the tiles (every rank holds the sheet; north_star's collective) or gather them to rank 0 "
+                         "only (the rank that composes the sheet and talks to the diffuser; 1/N of the bytes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -259,7 +280,7 @@ def main():
             if world > 1:
                 # depth-1 pipeline: this frame's all-gather (RCCL's own stream, ordered behind this step's stream) overlaps the next
                 # frames' renders; every gather is waited for inside the timed region (drain() below)
-                handle = sheet.gather_tiles_async(tile, world)
+                handle = sheet.gather_tiles_async(tile, world, dst=dst)
         issued[0] += 1
         if timed:
             render_ms.append((e0, e1))
@@ -269,28 +290,83 @@ def main():
         pending[0] = handle
         return done
 
+    n_sheet = 8                                   # BASELINE.json configs[2]: the 3x3 sheet's eight reference cameras
+    strong = args.scaling == "strong"
+    dst = 0 if (args.gather == "root" and world > 1) else None
+    mine = sheet.shard_indices(n_sheet, world, rank)
+
+    def sheet_step(timed: bool):
+        """--scaling strong: one whole sheet.  This rank renders its cameras (i mod N == rank) on the alternating streams, the caller's
+        stream joins them, ONE gather moves the tiles; the gather of sheet k overlaps the renders of sheet k + 1 (depth-1 pipeline)."""
+        tiles = []
+        for i in mine:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with frames.frame(issued[0]):
+                bundle = cams[i].generate_rays(camera_indices=0, aabb_box=model.render_aabb)
+                e0.record()
+                out = model.get_outputs_for_camera_ray_bundle(bundle)
+                e1.record()
+                tiles.append(frames.keep(torch.cat([out["rgb"], out["depth"]], dim=-1)))
+            issued[0] += 1
+            if timed:
+                render_ms.append((e0, e1))
+        frames.join()                             # the caller's stream (where the gather is issued) waits for this sheet's renders
+        local = torch.stack(tiles) if tiles else torch.zeros((0, H, W, 4), dtype=torch.float32, device=dev)
+        if world == 1:
+            return local
+        handle = sheet.gather_tiles_async(local, n_sheet, dst=dst)
+        done = pending[0].wait() if pending[0] is not None else None
+        pending[0] = handle
+        return done
+
     def drain():
         if pending[0] is not None:
             tiles = pending[0].wait()
             pending[0] = None
             return tiles
 
+    def exposed_gather_ms(n: int = 5):
+        """The tile exchange on its own (N > 1): renders complete, then the gather is issued and waited for at once -- what every step
+        would pay if the exchange were not overlapped with the next renders.  HIP events on the caller's stream."""
+        ev = []
+        for _ in range(n + 1):
+            if strong:
+                tl = []
+                for i in mine:
+                    o_ = model.get_outputs_for_camera_ray_bundle(cams[i].generate_rays(camera_indices=0, aabb_box=model.render_aabb))
+                    tl.append(torch.cat([o_["rgb"], o_["depth"]], dim=-1))
+                local = torch.stack(tl) if tl else torch.zeros((0, H, W, 4), dtype=torch.float32, device=dev)
+                n_items = n_sheet
+            else:
+                o_ = model.get_outputs_for_camera_ray_bundle(cam.generate_rays(camera_indices=0, aabb_box=model.render_aabb))
+                local, n_items = torch.cat([o_["rgb"], o_["depth"]], dim=-1)[None], world
+            torch.cuda.synchronize()
+            dist.barrier()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            sheet.gather_tiles_async(local, n_items, dst=dst).wait()
+            b.record()
+            ev.append((a, b))
+        torch.cuda.synchronize()
+        return statistics.median(x.elapsed_time(y) for x, y in ev[1:])
+
     model._ensure_engine()  # library load, weight upload and de-hashed copies are set-up, not a step (matters only for --warmup 0)
     torch.cuda.synchronize()
+    step_fn = sheet_step if strong else step
     if args.warmup < args.frames_in_flight:
         # every render stream allocates its output / workspace blocks on first use (hipMalloc): one priming frame per stream is set-up
         # like the upload above (matters only for --warmup 0 / 1)
         for _ in range(max(1, args.frames_in_flight)):
-            step(False)
+            step_fn(False)
     for _ in range(args.warmup):
-        step(False)
+        step_fn(False)
     drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tiles = step(True)
+        tiles = step_fn(True)
     tiles = drain() if world > 1 else tiles
     frames.join()
     if world > 1:
@@ -298,7 +374,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        assert tiles is not None and tuple(tiles.shape) == (world, H, W, 4), "the gathered sheet must hold one tile per rank"
+        if dst is None or rank == dst:
+            assert tiles is not None and tuple(tiles.shape) == (n_sheet if strong else world, H, W, 4), "the gathered sheet must hold every tile"
+        else:
+            assert tiles is None
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -321,17 +400,19 @@ def main():
     else:
         per_step = latency
     kernel_ms = sum(per_step) / max(len(per_step), 1)
+    gather_ms = exposed_gather_ms() if world > 1 else None
 
     if rank == 0:
         n_steps = len(per_step)
         pct = lambda q: per_step[min(n_steps - 1, int(q * n_steps))]  # noqa: E731
         k_med = statistics.median(per_step)
-        samples_per_step = world * W * H * S
+        cams_per_step = n_sheet if strong else world          # cameras rendered by the whole job in one step
+        samples_per_step = cams_per_step * W * H * S
         value = samples_per_step * args.steps / elapsed
         line = {
             "metric": "ray-samples/sec (%dx%d reference-sheet camera render)" % (W, H),
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else
                      "f32 (MLP operands carried as fp16 hi+lo pairs on the matrix cores, f32 accumulate; every layer range-conditioned into "
                      "fp16's [2^-3, 65504] by exact power-of-two scales at sn_finalize_weights, exact-fp32 MFMA fallback otherwise; validated "
@@ -343,13 +424,30 @@ def main():
                        (f"BASELINE.json configs[3]: {W}x{H} rays, proposal nets 256 + 96 samples (L=5, T=2^17) + {S} main samples "
                         "(L=16, T=2^19), random-weight synthetic scene, one camera per GPU + tile all-gather"),
                        "rays_per_gpu": W * H, "samples_per_ray": S,
-                       "parallelism": f"camera-sharded x{world}" + (", tile all-gather overlapped with the next render" if world > 1 else ""),
-                       "backend": (args.backend if world > 1 else None), "ranks_share_a_gpu": shared_gpu},
-            "ms_per_frame": elapsed / args.steps * 1e3,
+                       "step": ("one 8-camera reference sheet (configs[2]; datasetgenerator.py:517-519), camera i -> rank i mod N, one tile gather"
+                                if strong else "one camera per rank + tile gather"),
+                       "cameras_per_step": cams_per_step,
+                       "parallelism": f"camera-sharded x{world}" + (f", tile {'gather to rank 0' if dst is not None else 'all-gather'} overlapped "
+                                                                    "with the next renders" if world > 1 else ""),
+                       "backend": (args.backend if world > 1 else None), "ranks_share_a_gpu": shared_gpu,
+                       # what the process group itself reports (an N > 1 line must show the backend saw N ranks)
+                       "dist_world_size": dist.get_world_size() if world > 1 else 1,
+                       "dist_backend": dist.get_backend() if world > 1 else None,
+                       "cuda_device_count": n_dev, "gather": (args.gather if world > 1 else None)},
+            "ms_per_frame": elapsed / args.steps * 1e3 / (len(mine) if strong else 1) if (not strong or mine) else None,
+            "ms_per_sheet": (elapsed / args.steps * 1e3) if strong else None,
+            "gather_ms": None if gather_ms is None else {
+                "exposed": gather_ms, "in_timed_region": "overlapped with the next step's renders (depth-1 pipeline); every gather completes inside it",
+                "what": "HIP-event time on the caller's stream of issuing the tile gather and waiting for it with nothing to overlap "
+                        "(median of 5, after a barrier), i.e. what each step would pay without the pipeline",
+                "bytes_sent_per_rank": (len(mine) if strong else 1) * H * W * 16},
             "timed_region_s": elapsed,
             "frames_in_flight": max(1, args.frames_in_flight),
             # for comparison with one-launch-at-a-time figures (r01's lines, rocprofv3): samples of one frame over the per-launch time
             "one_stream_ray_samples_per_s_per_gpu": W * H * S / (k_med * 1e-3),
+            # SURVEY 8(d) metric (1) as written: samples of one frame over the HIP-event time of ONE get_outputs_for_camera_ray_bundle call
+            # with nothing else in flight (median); `value` above is the job's pipelined rate (frames_in_flight)
+            "value_one_launch_at_a_time": (W * H * S / (k_med * 1e-3)) if world == 1 else None,
             "kernel_ms": {"mean": kernel_ms, "median": k_med, "min": per_step[0], "max": per_step[-1], "p05": pct(0.05), "p95": pct(0.95), "n": n_steps,
                           "what": "HIP-event time of a render call on its launch stream with nothing else in flight (K1 + two memsets + the clip "
                                   "kernel; + K2 with proposal nets)" + ("; measured in a one-stream leg after the timed region -- the timed steps "
@@ -357,22 +455,26 @@ def main():
             "frame_latency_ms": {"median": statistics.median(latency), "p05": latency[int(0.05 * len(latency))], "p95": latency[int(0.95 * len(latency))],
                                  "what": "HIP-event span of each TIMED render call on its own stream (with %d frames in flight a call shares the "
                                          "chip with its neighbours: the span grows, the frame period ms_per_step shrinks)" % max(1, args.frames_in_flight)},
-            "rays_per_sec": world * W * H * args.steps / elapsed,
+            "rays_per_sec": cams_per_step * W * H * args.steps / elapsed,
             # SURVEY §8(d) metric (3): every field evaluation of a ray (proposal nets + main field)
-            "field_evaluations_per_sec": world * W * H * (S + (sum(cfg.num_proposal_samples_per_ray[:cfg.num_proposal_iterations])
+            "field_evaluations_per_sec": cams_per_step * W * H * (S + (sum(cfg.num_proposal_samples_per_ray[:cfg.num_proposal_iterations])
                                                                if args.workload != "sheet64" else 0)) * args.steps / elapsed,
         }
         achieved_gbps = (W * H * bytes_per_ray) / (k_med * 1e-3) / 1e9
         traffic, traffic_commit = measured_traffic(args.precision) if args.workload == "sheet64" else (None, None)
+        # HBM-side bytes per launch are NOT measured in this run (bench.py cannot run rocprofv3 on itself): `traffic` inside the roofline
+        # objects is null; the figure of the committed PMC passes is quoted here, labelled with the commit it was profiled at
+        line["traffic_committed_profile"] = {"bytes_per_launch": traffic, "profiled_at": traffic_commit,
+                                             "source": "profiles/traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ_* / TCC_EA0_WRREQ_*, tools/pmc_summary.py)"}
         line["roofline_hbm"] = {
             "bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved_gbps / HBM_PEAK_GBPS,
-            "traffic": traffic, "traffic_profiled_at": traffic_commit,
+            "traffic": None,
             "kernel": ("sn_render_main_kernel<0,%d>" % (0 if args.precision == "fp32" else 1)) if args.workload == "sheet64"
             else "sn_proposal_kernel + sn_render_main_kernel<1,*> (whole render call)",
             "kernel_ms": k_med, "algorithmic_bytes_per_launch": W * H * bytes_per_ray,
             "note": "SURVEY 8(d)'s definition (1024 algorithmic bytes per main-field sample).  frac > 1 is NOT a fraction of a binding "
-                    "roof: the 64 MiB table never leaves L1/L2/Infinity Cache (`traffic` = fabric bytes per launch from the committed "
-                    "rocprofv3 PMC passes, ~0.17x the algorithmic bytes).  The roofs that bind are in `roofline`."}
+                    "roof: the 64 MiB table never leaves L1/L2/Infinity Cache (`traffic_committed_profile`: fabric bytes per launch from "
+                    "the committed rocprofv3 PMC passes, ~0.13x the algorithmic bytes).  The roofs that bind are in `roofline`."}
         if args.workload == "sheet64":
             # The issue roofs of K1.  Per wave-step (64 samples) the kernel issues a fixed instruction mix -- counted from the
             # disassembly of the library that is loaded -- and every resource below serves one such instruction per so many cycles.
@@ -380,7 +482,7 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import kernel_counts
 
-                cnt = kernel_counts.loop_counts("sn_render_main_kernelILi0ELi%dELi0ELi0ELi11ELb0E" % (0 if args.precision == "fp32" else 1))
+                cnt = kernel_counts.loop_counts("sn_render_main_kernelILi0ELi%dELi0ELi0ELi11E" % (0 if args.precision == "fp32" else 1))
             except Exception as e:  # noqa: BLE001  (no llvm-objdump: the roofs are then unavailable, the throughput line is not)
                 cnt = {"error": repr(e)}
             clock = sustained_clock_ghz()
@@ -401,6 +503,8 @@ def main():
                     r["achieved"] = r["per_wave_step"] * wave_steps / t_kernel / 1e9                  # G instructions / s, whole chip
                     r["peak"] = r["units"] * clock / r["cycles_each"]                                # G instructions / s at the sustained clock
                     r["frac"] = r["achieved"] / r["peak"]
+                    r["peak_at_peak_clock"] = r["units"] * PEAK_CLOCK_GHZ / r["cycles_each"]         # ... at the part's 2.4 GHz
+                    r["frac_at_peak_clock"] = r["achieved"] / r["peak_at_peak_clock"]
                     r["roof_ms"] = r["per_wave_step"] * wave_steps * r["cycles_each"] / (r["units"] * clock * 1e9) * 1e3
                 bound = max(roofs, key=lambda k: roofs[k]["frac"])
                 # Empirical issue model (NOT a roof): in the probes an f16 32x32x16 MFMA keeps the SIMD's vector issue port for ~12-17 cycles
@@ -409,7 +513,9 @@ def main():
                 model_ms = model_cycles * wave_steps / (N_SIMDS * clock * 1e9) * 1e3
                 line["roofline"] = {
                     "bound": bound, "achieved": roofs[bound]["achieved"], "peak": roofs[bound]["peak"], "unit": "G wave-instructions/s",
-                    "frac": roofs[bound]["frac"], "traffic": traffic, "traffic_profiled_at": traffic_commit,
+                    "frac": roofs[bound]["frac"], "traffic": None,
+                    "frac_at_peak_clock": roofs[bound]["frac_at_peak_clock"], "peak_at_peak_clock": roofs[bound]["peak_at_peak_clock"],
+                    "peak_clock_ghz": PEAK_CLOCK_GHZ,
                     "kernel": cnt["kernel"], "kernel_ms": k_med, "sustained_clock_ghz": clock,
                     "instructions_per_wave_step": {k: cnt[k] for k in ("valu", "mfma", "vmem_load", "lds", "packed_f32") if k in cnt} | {"gather": n_gather},
                     "roofs": roofs,
@@ -417,13 +523,14 @@ def main():
                                               "what": "VALU x 4 cycles + MFMA x %g cycles of vector-issue-port time per wave-step at the sustained clock "
                                                       "(measured port cost of an MFMA; the f32-input MFMA holds the port for its whole 64 cycles)"
                                                       % (MFMA_PORT_CYCLES if args.precision != "fp32" else MFMA_F32_CYCLES)},
-                    "note": "bound = the hardware resource with the largest busy fraction at the clock the chip sustains under this kernel "
-                            "(power-limited, well below the 2.4 GHz peak).  The matrix pipe hides plain VALU issued beside it only in part "
+                    "note": "bound = the hardware resource with the largest busy fraction.  `frac` prices it at the clock the chip SUSTAINS "
+                            "under this kernel (measured in this run; power-limited), `frac_at_peak_clock` at the part's 2.4 GHz: the "
+                            "difference between the two is power, not scheduling.  The matrix pipe hides plain VALU issued beside it only in part "
                             "(profiles/r02_overlap2_probe.txt, r02_mlp_probe.txt), so the simd-issue and matrix-pipe fractions sum to more "
                             "than 1 and neither reaches it."}
             else:
                 line["roofline"] = {"bound": "simd-issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None,
-                                    "traffic": traffic, "error": cnt.get("error", "clock probe failed")}
+                                    "traffic": None, "error": cnt.get("error", "clock probe failed")}
             # Secondary view (north_star: "MFMA utilisation against gfx950 peak"): matrix-core instructions issued per launch are
             # fixed by the kernel (per wave-step of 64 samples: 120 v_mfma_f32_32x32x16_f16 in split precision, 320
             # v_mfma_f32_32x32x2_f32 in exact fp32; rocprofv3 SQ_INSTS_MFMA agrees, profiles/) -- issued flops / kernel time
@@ -431,7 +538,8 @@ def main():
             per_step, flop, peak = (120, 2 * 32 * 32 * 16, 2500.0) if args.precision == "fp16x2" else (320, 2 * 32 * 32 * 2, 157.3)
             issued = (W * H * S / 64) * per_step * flop
             line["roofline_mfma"] = {"bound": "mfma", "achieved": issued / (k_med * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                                     "frac": issued / (k_med * 1e-3) / 1e12 / peak,
+                                     "frac": issued / (k_med * 1e-3) / 1e12 / peak, "frac_at_peak_clock": issued / (k_med * 1e-3) / 1e12 / peak,
+                                     "frac_at_sustained_clock": (issued / (k_med * 1e-3) / 1e12 / (peak * clock / PEAK_CLOCK_GHZ)) if clock == clock else None,
                                      "algorithmic_tflops": W * H * S * 22784 / (k_med * 1e-3) / 1e12,
                                      "note": "issued MFMA flops (3-term fp16 split, 32-row tile padding) = matrix-pipe busy fraction at the 2.4 GHz "
                                              "peak clock; algorithmic = 22 784 FLOP per sample (SURVEY 8(d))"}
@@ -443,8 +551,8 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import kernel_counts
 
-                k2 = kernel_counts.mfma_loops("sn_proposal_kernelILi0ELi5ELi4ELb0ELb0E")
-                k1 = kernel_counts.loop_counts("sn_render_main_kernelILi1ELi%dELi0ELi0ELi11ELb0E" % (0 if args.precision == "fp32" else 1))
+                k2 = kernel_counts.mfma_loops("sn_proposal_kernelILi0ELi5ELi4E")
+                k1 = kernel_counts.loop_counts("sn_render_main_kernelILi1ELi%dELi0ELi0ELi11E" % (0 if args.precision == "fp32" else 1))
                 steps_k2 = list(cfg.num_proposal_samples_per_ray[:cfg.num_proposal_iterations])
                 if len(k2) != len(steps_k2):
                     raise RuntimeError("expected one marching loop per proposal net, found %d" % len(k2))
@@ -455,6 +563,7 @@ def main():
                 peak = N_SIMDS * clock / VALU_ISSUE_CYCLES
                 line["roofline"] = {
                     "bound": "simd-issue", "achieved": achieved, "peak": peak, "unit": "G wave-instructions/s", "frac": achieved / peak,
+                    "frac_at_peak_clock": achieved / (N_SIMDS * PEAK_CLOCK_GHZ / VALU_ISSUE_CYCLES), "peak_clock_ghz": PEAK_CLOCK_GHZ,
                     "traffic": None, "kernel": "sn_proposal_kernel<0,5,4> + sn_render_main_kernel<1,*> (whole render call)", "kernel_ms": k_med,
                     "sustained_clock_ghz": clock,
                     "instructions_per_wave_step": {"K2 net %d (%d steps)" % (i, n): {k: c.get(k, 0) for k in ("valu", "mfma", "gather")}
@@ -475,7 +584,7 @@ def main():
             line["alt_precision"] = {"precision": other, "kernel_ms": ms, "ray_samples_per_s_per_gpu": W * H * S / (ms * 1e-3),
                                      "roofline_hbm_frac": (W * H * bytes_per_ray) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         if world == 1 and not args.no_cpu_baseline and args.workload == "sheet64":
-            line["cpu_baseline"] = cpu_baseline(cfg, sd, W, H, S)
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, W, H, S, args.cpu_runs, args.cpu_runs_config4)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -34,16 +34,18 @@ PRECISIONS = {"fp32": 0, "fp16x2": 1}
 class _RWLock:
     """Many render calls, or one weight upload.  The C ABI orders uploads against renders ON THE DEVICE, but the host-side sequence
     sn_upload_weights ... sn_finalize_weights leaves the handle un-finalized in between, so a render CALL of another thread (the viewer
-    rendering on the shared model while the generator thread reloads weights) must not start inside it."""
+    rendering on the shared model while the generator thread reloads weights) must not start inside it.  Writers have preference: a
+    waiting upload blocks NEW readers, so a viewer that renders back to back cannot starve it."""
 
     def __init__(self):
         self._cond = threading.Condition()
         self._readers = 0
         self._writer = False
+        self._writers_waiting = 0
 
     def acquire_read(self):
         with self._cond:
-            while self._writer:
+            while self._writer or self._writers_waiting:
                 self._cond.wait()
             self._readers += 1
 
@@ -55,8 +57,12 @@ class _RWLock:
 
     def acquire_write(self):
         with self._cond:
-            while self._writer or self._readers:
-                self._cond.wait()
+            self._writers_waiting += 1
+            try:
+                while self._writer or self._readers:
+                    self._cond.wait()
+            finally:
+                self._writers_waiting -= 1
             self._writer = True
 
     def release_write(self):
@@ -352,9 +358,13 @@ class NerfactoModel(nn.Module):
     def effective_precision(self) -> str:
         """What ``config.precision`` resolves to for the uploaded parameters ("fp16x2" falls back to "fp32" for a handle whose split-
         precision MLPs cannot be range-conditioned; sn_effective_precision)."""
-        if not self._handle or self._weights_dirty:
-            return self.config.precision
-        eff = _lib.load().sn_effective_precision(self._handle, PRECISIONS[self.config.precision], 0)
+        self._engine_rw.acquire_read()
+        try:
+            if not self._handle or self._weights_dirty:
+                return self.config.precision
+            eff = _lib.load().sn_effective_precision(self._handle, PRECISIONS[self.config.precision], 0)
+        finally:
+            self._engine_rw.release_read()
         return {0: "fp32", 1: "fp16x2"}.get(eff, self.config.precision)
 
     def _ensure_engine(self):
@@ -362,22 +372,24 @@ class NerfactoModel(nn.Module):
         if self.device.type != "cuda":
             raise _lib.SignerfHipError("NerfactoModel renders on the GPU only: move it with .to('cuda') (no CPU fallback)")
         with self._weights_lock:
-            if self._handle and self._handle_device != self.device:
-                # model.to("cuda:N") after the first render: the handle and all its buffers live on the old GPU -- start over there
-                lib.sn_destroy(self._handle)
-                self._handle = C.c_void_p(None)
-                self._weights_dirty = True
-                self._grid_cache.clear()
-            if not self._handle:
-                desc = self._field_desc()
-                with torch.cuda.device(self.device):
-                    _lib.check(lib.sn_create(C.byref(desc), C.byref(self._handle)), None, "sn_create")
-                self._handle_device = self.device
-            if self._weights_dirty:
-                self._engine_rw.acquire_write()   # no render call of another thread between the first upload and finalize
+            if (self._handle and self._handle_device != self.device) or not self._handle or self._weights_dirty:
+                # the handle is replaced / its weights rewritten: no render CALL of another thread may hold or take the handle meanwhile
+                self._engine_rw.acquire_write()
                 try:
-                    self._upload(lib)
-                    self._weights_dirty = False
+                    if self._handle and self._handle_device != self.device:
+                        # model.to("cuda:N") after the first render: the handle and all its buffers live on the old GPU -- start over
+                        lib.sn_destroy(self._handle)
+                        self._handle = C.c_void_p(None)
+                        self._weights_dirty = True
+                        self._grid_cache.clear()
+                    if not self._handle:
+                        desc = self._field_desc()
+                        with torch.cuda.device(self.device):
+                            _lib.check(lib.sn_create(C.byref(desc), C.byref(self._handle)), None, "sn_create")
+                        self._handle_device = self.device
+                    if self._weights_dirty:
+                        self._upload(lib)
+                        self._weights_dirty = False
                 finally:
                     self._engine_rw.release_write()
         if not self._fallback_warned and self.effective_precision != self.config.precision:
@@ -511,17 +523,16 @@ class NerfactoModel(nn.Module):
         f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
         origins, directions, nears, fars = f32(b.origins), f32(b.directions), f32(b.nears), f32(b.fars)
         with torch.cuda.device(dev):
-            o, keep = self._opts(H, W, lib)
             normals = torch.empty((H * W, 3), dtype=torch.float32, device=dev)
             pred = torch.empty((H * W, 3), dtype=torch.float32, device=dev) if self._has_pred_normals else None
             self._engine_rw.acquire_read()
             try:
+                o, keep = self._opts(H, W, lib)   # (sn_workspace_bytes reads the handle: inside the read lock)
                 st = lib.sn_render_normals(self._handle, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(nears), _lib.ptr(fars), H, W,
                                            C.byref(o), _lib.ptr(normals), _lib.ptr(pred), _lib.current_stream())
                 _lib.check(st, self._handle, "sn_render_normals")
             finally:
                 self._engine_rw.release_read()
-            del keep
         return {"normals": normals, "pred_normals": pred} if pred is not None else {"normals": normals}
 
     def _render(self, b: RayBundle, H: int, W: int, single_chunk: bool = False) -> Dict[str, Tensor]:
@@ -536,22 +547,21 @@ class NerfactoModel(nn.Module):
         origins, directions, nears, fars = f32(b.origins), f32(b.directions), f32(b.nears), f32(b.fars)
         n = H * W
         with torch.cuda.device(dev):
-            o, keep = self._opts(H, W, lib, single_chunk)
             new = lambda c: torch.empty((n, c), dtype=torch.float32, device=dev)  # noqa: E731
             rgb, depth, acc, exp = new(3), new(1), new(1), new(1)
             props = [new(1) for _ in range(self.config.num_proposal_iterations)]
             pp = [_lib.ptr(p) for p in props] + [None] * (2 - len(props))
             self._engine_rw.acquire_read()
             try:
+                o, keep = self._opts(H, W, lib, single_chunk)   # (sn_workspace_bytes reads the handle: inside the read lock)
                 st = lib.sn_render_rays(self._handle, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(nears), _lib.ptr(fars), H, W,
                                         C.byref(o), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc), _lib.ptr(exp), pp[0], pp[1],
                                         _lib.current_stream())
                 _lib.check(st, self._handle, "sn_render_rays")
             finally:
                 self._engine_rw.release_read()
-            # the workspace and grids are consumed by work already enqueued on this stream; the caching allocator
-            # is stream-ordered, so dropping `keep` here is safe.
-            del keep
+            # (the workspace and grids in `keep` are consumed by work already enqueued on this stream; the caching allocator is
+            # stream-ordered, so letting them go when this frame returns is safe)
         out = {"rgb": rgb, "accumulation": acc, "depth": depth, "expected_depth": exp}
         for i, p in enumerate(props):
             out[f"prop_depth_{i}"] = p

@@ -611,3 +611,37 @@ def test_weight_reupload_while_another_thread_renders(gpu):
     assert not errors, errors
     print(f"viewer frames: {seen}")
     assert seen["other"] == 0 and seen["a"] + seen["b"] > 20
+
+
+def test_upload_waits_for_a_long_render_behind_many_short_ones(gpu):
+    """the handle used to remember the completion events of its 8 most recent renders only.  One long render on
+    stream A (three 1080p nerfacto frames, ~45 ms) followed by more than 8 short renders on stream B evicted A's event, and a weight
+    upload then overwrote (or freed) the tables A was still reading.  The handle now keeps the last render of EVERY stream: A's frames
+    must be the frames of the old weights, bit for bit, and a render after the upload must be the new weights' frame."""
+    cfg = scene.proposal_config()
+    model, sd_a = make_model(cfg, gpu, seed=0)
+    sd_b = {k: v.to(gpu) for k, v in scene.synthetic_state_dict(cfg, seed=7).items()}       # resident: the reload below is a device copy
+    W, H = 1920, 1080
+    big = Cameras(scene.benchmark_cameras(8)[:, :3], 1.2 * H, 1.2 * H, W / 2, H / 2, W, H).to(gpu)[2].generate_rays(0)
+    small = Cameras(scene.benchmark_cameras(8)[:, :3], 40.0, 40.0, 16.0, 16.0, 32, 32).to(gpu)[5].generate_rays(0)
+    keys = ("rgb", "depth", "accumulation")
+    expect_a = {k: v.clone() for k, v in model.get_outputs_for_camera_ray_bundle(big).items() if k in keys}
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(device=gpu), torch.cuda.Stream(device=gpu)
+    for trial in range(3):
+        with torch.cuda.stream(sa):
+            long_frames = [model.get_outputs_for_camera_ray_bundle(big) for _ in range(3)]
+        with torch.cuda.stream(sb):
+            for _ in range(20):
+                model.get_outputs_for_camera_ray_bundle(small)
+        assert not sa.query(), "the long render finished before the upload was issued: the test would prove nothing"
+        model.load_state_dict(sd_b, strict=False)
+        after = model.get_outputs_for_camera_ray_bundle(small)["rgb"]                     # re-uploads on this (the default) stream
+        torch.cuda.synchronize()
+        for f in long_frames:
+            for k in keys:
+                assert torch.equal(f[k], expect_a[k]), f"trial {trial}: a frame in flight during the upload changed in {k}"
+        model.load_state_dict(sd_a, strict=False)                                         # back to A for the next trial
+        again = model.get_outputs_for_camera_ray_bundle(small)["rgb"]
+        torch.cuda.synchronize()
+        assert not torch.equal(after, again)

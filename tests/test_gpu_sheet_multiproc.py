@@ -99,3 +99,34 @@ def test_bench_n2_branch_dry_run(gpu, tmp_path):
     assert d["config"]["backend"] == "gloo" and "camera-sharded x2" in d["config"]["parallelism"]
     assert d["value"] > 0 and abs(d["value"] - 2 * 200 * 200 * 64 * 4 / d["timed_region_s"]) / d["value"] < 1e-6   # whole-job aggregate
     assert "cpu_baseline" not in d                                                            # N = 1 only
+
+
+@pytest.mark.parametrize("gather", ["all", "root"])
+def test_bench_strong_scaling_dry_run(gpu, gather):
+    """bench.py --scaling strong at world 2 (gloo, both ranks on the one GPU): a step is the whole 8-camera sheet
+    (datasetgenerator.py:517-519), four cameras per rank, ONE tile gather per sheet (all-gather, or gather to rank 0)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--width", "160", "--height", "160", "--no-cpu-baseline", "--no-alt-precision", "--scaling", "strong",
+           "--gather", gather]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["cameras_per_step"] == 8 and d["config"]["gather"] == gather
+    assert d["config"]["dist_world_size"] == 2 and d["config"]["dist_backend"] == "gloo" and d["config"]["cuda_device_count"] >= 1
+    assert abs(d["ms_per_sheet"] - d["ms_per_step"]) < 1e-9 and d["gather_ms"]["exposed"] > 0
+    assert abs(d["value"] - 8 * 160 * 160 * 64 * 3 / d["timed_region_s"]) / d["value"] < 1e-6      # total work fixed: 8 cameras per step
+
+
+def test_bench_strong_scaling_single_gpu(gpu):
+    """The N = 1 point of the strong-scaling curve: all eight cameras on one GPU, no exchange."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--width", "160", "--height", "160",
+           "--no-cpu-baseline", "--no-alt-precision", "--scaling", "strong"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["gather_ms"] is None and d["config"]["dist_world_size"] == 1
+    assert abs(d["value"] - 8 * 160 * 160 * 64 * 3 / d["timed_region_s"]) / d["value"] < 1e-6
+    assert d["roofline"]["frac_at_peak_clock"] < d["roofline"]["frac"] <= 1.0 and d["roofline"]["traffic"] is None

@@ -61,6 +61,16 @@ def _disassemble(kernel_substr: str, lib: str):
         syms = subprocess.run([OBJDUMP, "-t", co], capture_output=True, text=True, check=True).stdout
         names = [ln.split()[-1] for ln in syms.splitlines() if kernel_substr in ln and " F " in ln and ".text" in ln]
         names = [n for n in names if not n.endswith(".kd")]
+        if len(names) > 1:
+            # a prefix of the template argument list was given: take the instantiation whose REMAINING arguments are all 0 / false
+            # (the production one; DUMP and experiment flags are trailing bools), so that adding a defaulted template parameter does
+            # not silently break the callers
+            def rest_is_default(n):
+                rest = n.split(kernel_substr, 1)[1]
+                args = rest.split("EvT", 1)[0] if "EvT" in rest else rest.split("Ev", 1)[0]
+                return re.fullmatch(r"(L[bi]0E)*", args) is not None
+
+            names = [n for n in names if rest_is_default(n)] or names
         if len(names) != 1:
             raise RuntimeError(f"{kernel_substr!r} matches {len(names)} kernels: {names[:4]}")
         dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f"--disassemble-symbols={names[0]}", co], capture_output=True, text=True,
@@ -112,6 +122,16 @@ def loop_counts(kernel_substr: str, lib: str = LIB) -> dict:
         syms = subprocess.run([OBJDUMP, "-t", co], capture_output=True, text=True, check=True).stdout
         names = [ln.split()[-1] for ln in syms.splitlines() if kernel_substr in ln and " F " in ln and ".text" in ln]
         names = [n for n in names if not n.endswith(".kd")]
+        if len(names) > 1:
+            # a prefix of the template argument list was given: take the instantiation whose REMAINING arguments are all 0 / false
+            # (the production one; DUMP and experiment flags are trailing bools), so that adding a defaulted template parameter does
+            # not silently break the callers
+            def rest_is_default(n):
+                rest = n.split(kernel_substr, 1)[1]
+                args = rest.split("EvT", 1)[0] if "EvT" in rest else rest.split("Ev", 1)[0]
+                return re.fullmatch(r"(L[bi]0E)*", args) is not None
+
+            names = [n for n in names if rest_is_default(n)] or names
         if len(names) != 1:
             raise RuntimeError(f"{kernel_substr!r} matches {len(names)} kernels: {names[:4]}")
         dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f"--disassemble-symbols={names[0]}", co], capture_output=True, text=True,

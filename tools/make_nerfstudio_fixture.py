@@ -9,7 +9,14 @@ the build container and never on the GPU box).  It pins what i
   tests/golden/nerfstudio_nerfacto_tcnn.npz    (needs CUDA + tinycudann) a tiny `implementation="tcnn"` model's flat parameter
                                                vectors and its render: pins oracle/tcnn_layout.py::ASSUMPTIONS and tcnn_import
 
+  tests/golden/opencv_morphology.npz           (--cv2; needs only `pip install opencv-python`, no nerfstudio)
+                                               cv2.getStructuringElement(cv2.MORPH_ELLIPSE, ksize) for the kernel sizes SIGNeRF uses
+                                               ((50, 50) today, (20, 20) before, datasetgenerator.py:70) and small / odd / non-square
+                                               ones, plus cv2.dilate of seeded masks with them (datasetgenerator.py:776-777): pins
+                                               oracle/signerf_utils.py::ellipse_element / dilate, which the GPU mask step is tested against
+
     python tools/make_nerfstudio_fixture.py [--tcnn]
+    python tools/make_nerfstudio_fixture.py --cv2        (only the OpenCV fixture; nerfstudio is not imported)
 
 tests/test_oracle_vs_nerfstudio_fixture.py picks the files up when they exist (and is skipped when they do not).  The parameters are
 this repository's synthetic scene (signerf_amd/scene.py) loaded into the nerfstudio model under the same state-dict keys, so the
@@ -58,10 +65,47 @@ def _render(model, c2w, W, H, focal, device, aabb=None):
     return keep
 
 
+CV2_KSIZES = [(50, 50), (20, 20), (11, 11), (7, 7), (5, 5), (3, 3), (1, 1), (2, 2), (4, 6), (9, 5), (50, 30), (1, 7), (8, 1)]  # (width, height)
+
+
+def emit_cv2_fixture(out_dir):
+    """Inputs + outputs of the two OpenCV calls of datasetgenerator.py:776-777.  No OpenCV source is stored."""
+    import cv2
+
+    fx = {"cv2_version": np.array(cv2.__version__)}
+    rng = np.random.default_rng(0)
+    masks = {
+        "sparse": (rng.random((96, 128)) > 0.995).astype(np.uint8),                 # isolated pixels: every element is stamped whole
+        "blob": np.zeros((96, 128), np.uint8),
+        "border": np.zeros((64, 80), np.uint8),                                     # set pixels on the image border (anchor / padding)
+        "empty": np.zeros((40, 40), np.uint8),
+        "full": np.ones((40, 40), np.uint8),
+    }
+    masks["blob"][30:50, 40:90] = 1
+    masks["blob"][60:62, 10:12] = 1
+    masks["border"][0, :] = 1
+    masks["border"][:, -1] = 1
+    masks["border"][-1, 5] = 1
+    for name, m in masks.items():
+        fx[f"mask.{name}"] = m
+    for (w, h) in CV2_KSIZES:
+        elem = cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (w, h))
+        fx[f"ellipse.{w}x{h}"] = elem
+        for name, m in masks.items():
+            fx[f"dilate.{name}.{w}x{h}"] = cv2.dilate(m, elem)
+    path = os.path.join(out_dir, "opencv_morphology.npz")
+    np.savez_compressed(path, **fx)
+    print(f"wrote {path} (OpenCV {cv2.__version__}): {len(CV2_KSIZES)} elements x {len(masks)} masks")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tcnn", action="store_true", help="also emit the tiny-cuda-nn fixture (needs CUDA + tinycudann)")
+    ap.add_argument("--cv2", action="store_true", help="emit ONLY the OpenCV morphology fixture (needs opencv-python, not nerfstudio)")
     args = ap.parse_args()
+    if args.cv2:
+        emit_cv2_fixture(os.path.join(ROOT, "tests", "golden"))
+        return
     from nerfstudio.data.scene_box import SceneBox
 
     from helpers import small_config

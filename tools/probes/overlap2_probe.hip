@@ -308,7 +308,7 @@ static void run_phases(int n, uint64_t* cyc, float* out) {
            kind_name[VK], WAVES / 4, NA, NB, NI, ms[1], ms[2], ms[3], ms[1] + ms[2], std::max(ms[1], ms[2]));
 }
 
-int main() {
+int main(int argc, char** argv) {
     uint64_t* cyc;
     uint32_t* ids;
     float* out;
@@ -316,6 +316,20 @@ int main() {
     hipMalloc(&ids, 32);
     hipMalloc(&out, 4);
     const int n = 20000;
+    if (argc > 1 && argv[1][0] == 'p') {
+        // r03: packed-fp32 THROUGHPUT with 3 waves per SIMD (r02 measured the packed ops with one wave per SIMD, where every kind issues
+        // once per ~4.75 cycles, and beside MFMA waves).  K2 issues 6 MFMAs per ~280 VALU: is a packed blend worth it there?
+        run_phases<F_FMA, 512, 1, 0, 12>(1000, cyc, out);
+        run_phases<F_PKFMA, 512, 1, 0, 12>(1000, cyc, out);
+        run_phases<F_PKADD, 512, 1, 0, 12>(1000, cyc, out);
+        run_phases<F_FMA, 272, 6, 0, 12>(2000, cyc, out);      // K2-shaped step, plain: 272 VALU + 6 MFMA
+        run_phases<F_PKFMA, 272, 6, 0, 12>(2000, cyc, out);    // ... if every VALU were packed (the exclusion with the matrix pipe at K2's MFMA share)
+        run_phases<F_PKFMA, 232, 6, 0, 12>(2000, cyc, out);    // ... 40 instructions fewer (the blend of 5 levels packed: 80 -> 40)
+        run_phases<F_FMA, 232, 6, 0, 12>(2000, cyc, out);
+        run_phases<F_FMA, 512, 120, 0, 12>(1000, cyc, out);    // K1-shaped, for the same box
+        run_phases<F_PKFMA, 512, 120, 0, 12>(1000, cyc, out);
+        return 0;
+    }
     // A: fillers alone (issue cost of each kind), then beside the f16 MFMA and the f32 MFMA
     sweep_same<0, F_FMA>(n, cyc, out);
     sweep_same<1, F_FMA>(n, cyc, out);
