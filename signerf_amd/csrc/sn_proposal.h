@@ -216,10 +216,13 @@ struct SnPdfNorm {
 // entry point sn_pdf_sample does.
 // RECIP (the fused kernel, r02): the per-weight division num / denom has a loop-invariant denominator, so the IEEE quotient is formed
 // from its correctly rounded reciprocal y = RN(1 / denom) (one IEEE division per ray) as  q0 = RN(num y);  e = num - q0 denom (exact,
-// one fma);  q = RN(q0 + e y)  -- Markstein's theorem: q == RN(num / denom) for every num, unless the significand of denom is all
-// ones (then y is not accurate enough).  Such a denominator (1 in 8 M), or one outside [2^-60, 2^60] (residual underflow; never the
-// case: 1e-5 <= denom <= ~260), sends the whole wave down the plain IEEE path.  3 instead of ~10 VALU per weight, bit-identical
-// (tests/test_gpu_render.py::test_resampler_reciprocal_division_is_bit_identical; SN_PDF_IEEE=1 forces the plain path).
+// one fma);  q = RN(q0 + e y).  Markstein's theorem gives q == RN(num / denom) when q0 is a FAITHFUL rounding of the quotient and the
+// significand of denom is not all ones; q0 = RN(num RN(1 / denom)) can be 1.5 ulp off when the quotient sits just below a power of two
+// (ADVICE r02), so the identity is held as MEASURED, not proven: tests/test_recip_division.py emulates the three instructions exactly
+// and finds 0 mismatches over random operands of the resampler's range and over quotients within 64 ulps below a power of two (r03:
+// 80 M + 400 M pairs), and tests/test_gpu_render.py::test_resampler_reciprocal_division_is_bit_identical compares whole renders with
+// SN_PDF_IEEE=1 (the plain divisions).  A denominator with an all-ones significand (1 in 8 M), or one outside [2^-60, 2^60] (residual
+// underflow; never the case: 1e-5 <= denom <= ~260), sends the whole wave down the plain IEEE path.  3 instead of ~10 VALU per weight.
 template <bool FAST = false, bool RECIP = false, typename SB, typename EMIT>
 SN_DEV void sn_pdf_lane(const float* __restrict__ w, int wstride, int N, int M, const float* u, float pad, const SnPdfNorm& nm, SB sb,
                         EMIT emit, bool force_ieee = false) {

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from signerf_amd import Cameras, scene  # noqa: E402
+from signerf_amd import Cameras, ops, scene  # noqa: E402
 
 
 def main():
@@ -39,11 +39,13 @@ def main():
     times = {v: [] for v in a.values}
     for v in a.values:  # warm-up each variant
         os.environ[a.knob] = v
+        ops.reload_env(model)   # (the SN_* switches are read at sn_create / sn_finalize_weights, not per render)
         model.get_outputs_for_camera_ray_bundle(b)
     torch.cuda.synchronize()
     for _ in range(a.rounds):
         for v in a.values:
             os.environ[a.knob] = v
+            ops.reload_env(model)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             model.get_outputs_for_camera_ray_bundle(b)

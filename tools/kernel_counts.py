@@ -111,6 +111,8 @@ def mfma_loops(kernel_substr: str, lib: str = LIB) -> list:
                 c[k] = c.get(k, 0) + 1
                 if op.startswith(("buffer_load_dwordx2", "buffer_load_dwordx4")):
                     c["gather"] = c.get("gather", 0) + 1
+                if op.startswith("v_pk_") and op.endswith("_f32"):
+                    c["packed_f32"] = c.get("packed_f32", 0) + 1
         out.append(c)
     return out
 
