@@ -47,11 +47,11 @@ def test_quotients_just_below_a_power_of_two():
             assert _mismatches((num.view(np.int32) + d).view(f32), den) == 0
 
 
-def test_the_guard_is_needed_nowhere_else():
-    """An all-ones significand is the one documented failure of the scheme: show that it does fail there (the guard is not decoration)."""
-    den = np.array([np.float32(2.0) - np.float32(2.0**-23)] * 4096, dtype=f32) * np.ldexp(1.0, np.arange(4096) % 8 - 4).astype(f32)
-    rng = np.random.default_rng(2)
-    num = rng.uniform(0.01, 1.0, 4096).astype(f32)
-    q, ref = _recip_quotient(num, den), (num / den).astype(f32)
+def test_all_ones_denominators_hold_too():
+    """The kernel sends a wave with an all-ones denominator significand down the plain divisions (Markstein's condition for a reciprocal
+    refined by Newton steps).  Here y comes from an IEEE division, and the identity holds for those denominators as well: the guard is
+    conservative, not load-bearing."""
+    den = (np.float32(2.0) - np.float32(2.0**-23)) * np.ldexp(1.0, np.arange(1 << 20) % 8 - 4).astype(f32)
     assert ((den.view(np.uint32) & 0x7FFFFF) == 0x7FFFFF).all()
-    assert int((q != ref).sum()) >= 0   # (may or may not differ for a given numerator; the kernel never takes this path)
+    num = np.random.default_rng(2).uniform(0.01, 1.0, den.size).astype(f32)
+    assert int((_recip_quotient(num, den) != (num / den).astype(f32)).sum()) == 0
