@@ -184,8 +184,9 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
  * fp16's range with exact power-of-two scales derived from the uploaded parameters (bounds of the activations over all inputs with
  * |feature| <= max|table row|), which keeps the arithmetic fp32-grade for tables and weights of any magnitude; if a conditioned weight
  * still leaves the fp16 range the handle renders such requests with the exact-fp32 MFMA path instead.  Returns the precision that
- * `requested` resolves to (0 or 1) for kernel 0 = sn_render_rays / sn_field_forward, 1 = sn_render_normals (which splits
- * unconditioned operands and therefore falls back as soon as max|table row| < 1/8 or an activation bound exceeds 65504); -1 on error. */
+ * `requested` resolves to (0 or 1) for kernel 0 = sn_render_rays / sn_field_forward, 1 = sn_render_normals (conditioned the same way
+ * since r03: the density MLP's layers as in kernel 0, the pred-normal MLP and the transposed layer of the reverse pass with their own
+ * power-of-two scales -- tables initialised at 1e-3 / 1e-4, as real checkpoints are, stay on the split-precision path); -1 on error. */
 int sn_effective_precision(SnHandle h, int32_t requested, int32_t kernel);
 
 /* ---- stage-level entry points (used by parity tests).  They run the LITERAL torch-path arithmetic (IEEE divisions in the

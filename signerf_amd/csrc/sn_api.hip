@@ -69,7 +69,8 @@ struct SnContext {
     float feat_scale_prop[SN_MAX_PROPOSALS] = {1.0f, 1.0f};  // ... by a proposal net's de-hashed copies and paired tables
     bool split_ok = true;        // false: some scaled weight leaves the fp16 range -> precision 1 requests render with exact fp32 MFMA
     std::string split_why;
-    bool normals_split_ok = true;  // the normals kernel splits UNconditioned operands: allowed only while table and bounds sit in range
+    bool normals_split_ok = true;  // the normals kernel's own conditioned operands fit fp16 (sn_finalize_weights)
+    float grad_scale_normals = 1.0f;  // power of two carried by the split-precision reverse-pass layer of the normals kernel
     bool finalized = false;
     // ordering of weight uploads against renders in flight (RenderGuard below): the completion event of the LAST render of every
     // stream that rendered with this handle (a stream is in-order, so its last render covers its earlier ones)
@@ -481,6 +482,7 @@ struct MainSplitPlan {
     bool ok = true;
     std::string why;
     double max_bound = 0.0;  // largest interval bound of an (unscaled) activation
+    double B2[16] = {};      // interval bounds of the (unscaled) layer-2 outputs: row 0 = h0, rows 1..15 = the geo features
 };
 
 MainSplitPlan plan_split_scales(const SnFieldDesc& d, float table_absmax, bool scale_features, const float* W1, const float* b1, const float* W2,
@@ -506,6 +508,7 @@ MainSplitPlan plan_split_scales(const SnFieldDesc& d, float table_absmax, bool s
         double a = std::fabs(b2[r]);
         for (int n = 0; n < 64; ++n) a += std::fabs(W2[r * 64 + n]) * B1[n];
         B2[r] = a;
+        pl.B2[r] = a;
         m2 = std::max(m2, a);
     }
     for (int n = 0; n < 64; ++n) {
@@ -813,7 +816,7 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
     h->feat_scale_main = pl.t0;
     h->split_ok = pl.ok;
     h->split_why = pl.why;
-    h->normals_split_ok = pl.ok && absmax_main >= 0.125f && pl.max_bound <= 65504.0;
+    h->normals_split_ok = pl.ok;  // refined below, once the normals kernel's own conditioned operands exist
     auto scaled = [](const std::vector<float>& v, double f) {
         std::vector<float> o(v.size());
         for (size_t i = 0; i < v.size(); ++i) o[i] = (float)((double)v[i] * f);  // f is a power of two: exact (barring under / overflow)
@@ -899,10 +902,51 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
             h->wimg_normals.bytes = nimg.size() * 4;
         }
         SN_HIP(h, hipMemcpyAsync(h->wimg_normals.ptr, nimg.data(), nimg.size() * 4, hipMemcpyHostToDevice, st));
-        // fp16 hi+lo form: the main-image builder on the same matrices, then the reverse-pass layer in k-slot order
-        // (slot (s, h, e) <-> hidden (s/2)*32 + rho(8 (s%2) + e) + 4h, as layer 2's input)
-        std::vector<float> nh = build_main_image_h(dn, t[0]->data(), t[2]->data(), P1.data(),
-                                                   h->has_pred_normals ? w1->data() : z6464.data(), nimg);
+        // fp16 hi+lo form, RANGE-CONDITIONED like the main image (r03; r02 split the unconditioned matrices and fell back to exact fp32
+        // as soon as max|table| < 1/8 -- i.e. for every real checkpoint: nerfstudio initialises its tables at 1e-3, tiny-cuda-nn at
+        // 1e-4).  The density MLP's layers are the main image's (W1 s1 / t0, b1 s1, W2 s2 / s1, b2 s2: features come in times t0, h0
+        // leaves through the 1 / s2 slot); the pred-normal MLP gets its own output scales from interval bounds over |pe| <= 1 and the
+        // geo bounds B2: layer 1 -> s3n, layer 2 -> s4n, the fp32 (layer 3 . head) weights carry 1 / s4n; the reverse-pass layer
+        // W1^T diag(W2[0,:]) is lifted by gsc so that its largest entry sits at ~2^10.
+        const double tgt = SN_RELU_FOLD ? 1024.0 : 16384.0;
+        double m3n = 0.0, m4n = 0.0, mwb = 0.0;
+        std::vector<double> Bp1(64, 0.0);
+        if (h->has_pred_normals) {
+            for (int n = 0; n < 64; ++n) {
+                double a = std::fabs((*c0)[n]);
+                for (int k = 0; k < 12; ++k) a += std::fabs((*w0)[(size_t)n * pin + k]);
+                for (int j = 0; j < d.geo_feat_dim; ++j) a += std::fabs((*w0)[(size_t)n * pin + 12 + j]) * pl.B2[1 + j];
+                Bp1[n] = a;
+                m3n = std::max(m3n, a);
+            }
+            for (int n = 0; n < 64; ++n) {
+                double a = std::fabs((*c1)[n]);
+                for (int k = 0; k < 64; ++k) a += std::fabs((*w1)[(size_t)n * 64 + k]) * Bp1[k];
+                m4n = std::max(m4n, a);
+            }
+        }
+        for (int hid = 0; hid < 64; ++hid)
+            for (int f = 0; f < 32; ++f) mwb = std::max(mwb, (double)std::fabs((*t[0])[hid * 32 + f] * (*t[2])[hid]));
+        const bool finite_n = std::isfinite(m3n) && std::isfinite(m4n) && std::isfinite(mwb);
+        const float s3n = finite_n && m3n > 0 ? pow2_floor(tgt / m3n) : 1.0f, s4n = finite_n && m4n > 0 ? pow2_floor(tgt / m4n) : 1.0f;
+        const float gsc = finite_n && mwb > 0 ? pow2_floor(1024.0 / mwb) : 1.0f;
+        h->grad_scale_normals = gsc;
+        std::vector<float> P1n(P1.size(), 0.0f);
+        for (int n = 0; n < 64; ++n) {
+            for (int k = 0; k < sh; ++k) P1n[(size_t)n * cin_n + k] = (float)((double)P1[(size_t)n * cin_n + k] * s3n);
+            for (int k = 0; k < d.geo_feat_dim; ++k) P1n[(size_t)n * cin_n + sh + k] = (float)((double)P1[(size_t)n * cin_n + sh + k] * ((double)s3n / pl.s2));
+        }
+        const std::vector<float> c0n = scaled(h->has_pred_normals ? *c0 : z64, s3n);
+        const std::vector<float> w1n = scaled(h->has_pred_normals ? *w1 : z6464, (double)s4n / s3n), c1n = scaled(h->has_pred_normals ? *c1 : z64, s4n);
+        const std::vector<float> Wfn = scaled(Wf, 1.0 / s4n);
+        std::vector<float> nimg_s = build_main_image(dn, W1s.data(), b1s.data(), W2s.data(), b2s.data(), P1n.data(), c0n.data(), w1n.data(), c1n.data(),
+                                                     Wfn.data(), bf.data(), nullptr);
+        nimg_s[SnMainImg::B3 + 3] = 1.0f / pl.s2;
+        std::vector<float> wbs((size_t)64 * 32);
+        for (int hid = 0; hid < 64; ++hid)
+            for (int f = 0; f < 32; ++f) wbs[(size_t)hid * 32 + f] = (float)((double)((*t[0])[hid * 32 + f] * (*t[2])[hid]) * gsc);
+        h->normals_split_ok = pl.ok && finite_n && fits_half(W1s) && fits_half(W2s) && fits_half(P1n) && fits_half(w1n) && fits_half(wbs);
+        std::vector<float> nh = build_main_image_h(dn, W1s.data(), W2s.data(), P1n.data(), w1n.data(), nimg_s);
         nh.resize(SnNormImgH::TOTAL_BYTES / 4, 0.0f);
         {
             uint16_t* hw = (uint16_t*)nh.data();
@@ -911,7 +955,7 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
                     for (int e = 0; e < 8; ++e) {
                         const int f = lane & 31, hh = lane >> 5;
                         const int hid = (s4 / 2) * 32 + rho(8 * (s4 % 2) + e) + 4 * hh;
-                        const float w = (*t[0])[hid * 32 + f] * (*t[2])[hid];
+                        const float w = wbs[(size_t)hid * 32 + f];
                         const uint16_t hi = f32_to_f16_rne(w), lo = f32_to_f16_rne(w - f16_to_f32(hi));
                         const size_t off = (size_t)SnNormImgH::WB / 2 + ((size_t)(s4 * 2) * 64 + lane) * 8 + e;
                         hw[off] = hi;
@@ -1471,6 +1515,8 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
         p.dense = h->dense_info;
         p.inv_feat_scale = 1.0f / h->feat_scale_main;
     }
+    p.feat_scale = split ? h->feat_scale_main : 1.0f;
+    p.grad_scale = split ? h->grad_scale_normals : 1.0f;
     if (nprop > 0) {
         if (tcnn) { SN_LAUNCH_NORMALS(1, 1, -1); } else if (copies) { SN_LAUNCH_NORMALS(1, 0, 11); } else { SN_LAUNCH_NORMALS(1, 0, -1); }
     } else {

@@ -51,7 +51,14 @@ struct SnNormalsParams {
     float near_plane, far_plane, avg_density;
     SnGridLevels grid;
     SnDenseCopy dense;     // ND > 0: the main grid's de-hashed copies (r02: the normals kernel was gather-issue bound with 256 hashed gathers per step)
-    float inv_feat_scale;  // ND > 0: the copies carry the power-of-two feature scale of the split-precision render; this kernel's images do not
+    float inv_feat_scale;  // ND > 0: the copies carry the power-of-two feature scale t0 of the split-precision render; the exact-fp32 image does not
+    // Range conditioning of the split-precision form (PREC = 1; r03, as K1's -- sn_api.hip plan_split_scales): the fp16 hi+lo image holds
+    // W1 s1 / t0, W2 s2 / s1, ... so the kernel feeds it features TIMES t0 (`feat_scale`: the copies' own values; the hashed levels are
+    // multiplied), reads h0 through the image's 1 / s2 slot, and gets the reverse pass's d h0 / d feat times `grad_scale` (a power of two
+    // that lifts the transposed layer W1^T diag(W2[0,:]) into fp16's normal range; the analytic normal is a direction, so the factor
+    // only moves the 1e-12 clamp of F.normalize with it).  Both are 1 for the exact-fp32 form.
+    float feat_scale;
+    float grad_scale;
     float pe_rev_scale;  // position encoding: 1 = nerfstudio's torch NeRFEncoding, sin(2 pi x 2^k); 0.5 = tiny-cuda-nn's Frequency, sin(pi x 2^k)
 };
 
@@ -209,7 +216,7 @@ SN_DEV void sn_normals_field_h(const char* __restrict__ ldsb, const float* feat,
     }
     f32x16 g0[1], g1[1];
     sn_mlp_layer_h<1, 4>(ldsb + SnMainImgH::W2, tail + SnMainImgH::B2, op0, op1, g0, g1, lane);
-    h0 = upper ? g1[0][8] : g0[0][0];
+    h0 = (upper ? g1[0][8] : g0[0][0]) * tail[SnMainImgH::B3 + 3];  // the image's 1 / s2 (range conditioning)
     __builtin_amdgcn_sched_barrier(0);
     {
         f32x16 b0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b1 = b0;
@@ -470,12 +477,16 @@ __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormals
         float feat[32];
         constexpr int NBC = ND > SN_BC_MAIN ? SN_BC_MAIN : (ND > 0 ? ND : 0);
         if (ND > 0) {
-            // values of the copies are the table's own times the feature scale (an exact power of two), divided out again here
-            sn_hash_encode<16, 4, 1, ND, false, NBC>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense);
+            // values of the copies are the table's own times the feature scale t0 (an exact power of two).  Split precision: the
+            // conditioned image expects t0 x feature, so the copies' values go in as they are and the hashed levels are multiplied
+            // (sn_hash_encode's plain_scale); exact fp32: divided out again here
+            sn_hash_encode<16, 4, 1, ND, false, NBC>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, nullptr, PREC ? p.feat_scale : 1.0f);
+            if (!PREC) {
 #pragma unroll
-            for (int k = 0; k < 2 * (ND > 0 ? ND : 0); ++k) feat[k] *= p.inv_feat_scale;
+                for (int k = 0; k < 2 * (ND > 0 ? ND : 0); ++k) feat[k] *= p.inv_feat_scale;
+            }
         } else {
-            sn_hash_encode<16, 4, (GRID ? 2 : 1), -1>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, nullptr);
+            sn_hash_encode<16, 4, (GRID ? 2 : 1), -1>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, nullptr, nullptr, PREC ? p.feat_scale : 1.0f);
         }
         float pe[12];
         {
@@ -495,7 +506,7 @@ __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormals
         sn_hash_encode_grad<GRID, ND, NBC>(rsrc, p.scal, p.log2_t, q, gfeat, &p.grid, g, &p.dense, p.inv_feat_scale);
         __builtin_amdgcn_sched_barrier(0);
         // Field.get_normals: -F.normalize(grad) = -grad / max(|grad|, 1e-12)
-        const float gl = fmaxf(sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), 1e-12f);
+        const float gl = fmaxf(sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), PREC ? 1e-12f * p.grad_scale : 1e-12f);  // (g carries grad_scale)
         const float igl = -__builtin_amdgcn_rcpf(gl);  // (1-ulp reciprocals: the per-sample normals are weighted, summed and renormalised)
         const float an[3] = {g[0] * igl, g[1] * igl, g[2] * igl};
         // PredNormalsFieldHead: tanh, then F.normalize

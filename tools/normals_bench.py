@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Times the normals kernel (row a16, csrc/sn_normals.h) next to the colour render on the bench workloads.
 
-    python tools/normals_bench.py [--workload sheet64|nerfacto1080] [--steps 10]
+    python tools/normals_bench.py [--workload sheet64|nerfacto1080] [--steps 10] [--table-scale 1e-3]
+
+--table-scale multiplies every hash table (and divides the first layers: the same field through small features, what a real checkpoint
+looks like -- nerfstudio initialises its tables at 1e-3, tiny-cuda-nn at 1e-4).  r02's normals kernel fell back to exact fp32 there; the
+line says which arithmetic ran (sn_effective_precision, kernel 1) and times both.
 """
 import argparse
 import os
@@ -15,6 +19,7 @@ from signerf_amd import Cameras, scene  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="sheet64", choices=["sheet64", "nerfacto1080"])
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--table-scale", type=float, default=1.0)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 if a.workload == "sheet64":
@@ -24,7 +29,13 @@ else:
     W, H, cfg = 1920, 1080, scene.proposal_config()
     focal = 1.2 * H
 model = cfg.setup()
-model.load_state_dict(scene.synthetic_state_dict(cfg, seed=0), strict=False)
+sd = scene.synthetic_state_dict(cfg, seed=0)
+if a.table_scale != 1.0:
+    for k in [k for k in sd if k.endswith("encoder.hash_table")]:
+        pre = k[: -len("encoder.hash_table")]
+        sd[k] = sd[k] * a.table_scale
+        sd[pre + "mlp.layers.0.weight"] = sd[pre + "mlp.layers.0.weight"] / a.table_scale
+model.load_state_dict(sd, strict=False)
 model = model.to(dev).eval()
 cam = Cameras(scene.benchmark_cameras(8)[:, :3], focal, focal, W / 2, H / 2, W, H).to(dev)[0]
 bundle = cam.generate_rays(camera_indices=0)
@@ -43,8 +54,14 @@ def timed(fn):
 
 
 flat = bundle
-colour = timed(lambda: model._render(flat, H, W))
-normals = timed(lambda: model._render_normals(flat, H, W))
+from signerf_amd import _lib  # noqa: E402
+
 S = cfg.num_nerf_samples_per_ray
-print(f"{a.workload} {W}x{H}x{S}: colour render {colour:.2f} ms, normals render {normals:.2f} ms "
-      f"({W * H * S / normals / 1e6:.2f} G ray-samples/s)")
+colour = timed(lambda: model._render(flat, H, W))
+eff = _lib.load().sn_effective_precision(model._handle, 1, 1)
+line = f"{a.workload} {W}x{H}x{S}, tables x{a.table_scale:g}: colour render {colour:.2f} ms"
+for prec in ("fp16x2", "fp32"):
+    model.config.precision = prec
+    t = timed(lambda: model._render_normals(flat, H, W))
+    line += f"; normals render precision={prec}: {t:.2f} ms ({W * H * S / t / 1e6:.2f} G ray-samples/s)"
+print(line + f"; a split-precision request resolves to {'fp16x2' if eff == 1 else 'EXACT FP32 (fallback)'} for the normals kernel")
