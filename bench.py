@@ -400,7 +400,12 @@ def main():
     else:
         per_step = latency
     kernel_ms = sum(per_step) / max(len(per_step), 1)
-    gather_ms = exposed_gather_ms() if world > 1 else None
+    gather_ms = gather_err = None
+    if world > 1:
+        try:  # a diagnostic leg after the timed region: it must never cost the line
+            gather_ms = exposed_gather_ms()
+        except Exception as e:  # noqa: BLE001
+            gather_err = repr(e)
 
     if rank == 0:
         n_steps = len(per_step)
@@ -436,7 +441,7 @@ def main():
                        "cuda_device_count": n_dev, "gather": (args.gather if world > 1 else None)},
             "ms_per_frame": elapsed / args.steps * 1e3 / (len(mine) if strong else 1) if (not strong or mine) else None,
             "ms_per_sheet": (elapsed / args.steps * 1e3) if strong else None,
-            "gather_ms": None if gather_ms is None else {
+            "gather_ms": ({"exposed": None, "error": gather_err} if gather_err else None) if gather_ms is None else {
                 "exposed": gather_ms, "in_timed_region": "overlapped with the next step's renders (depth-1 pipeline); every gather completes inside it",
                 "what": "HIP-event time on the caller's stream of issuing the tile gather and waiting for it with nothing to overlap "
                         "(median of 5, after a barrier), i.e. what each step would pay without the pipeline",

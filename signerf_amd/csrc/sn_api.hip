@@ -41,6 +41,7 @@ struct DevBuf {
 struct SnContext {
     SnFieldDesc desc;
     int device = 0;
+    int n_cus = 256;  // compute units of the device (the split-depth tail plan of the main kernel sizes its last round from it)
     std::mutex mu;  // guards weights + error text only; render calls do not take it
     std::string error;
     std::map<std::string, std::vector<float>> host;  // small tensors (MLP layers, appearance mean)
@@ -83,7 +84,7 @@ struct SnContext {
     // diagnostic / test switches of the environment, read when the handle is created, when its weights are finalized and by
     // sn_debug_reload_env -- not by every render call (getenv on the render path of several threads)
     struct Switches {
-        std::atomic<int> render_chain{0}, prop_cache_off{0}, pdf_ieee{0}, pdf_fast{0}, ablate{0}, hash_plain{0};
+        std::atomic<int> render_chain{0}, prop_cache_off{0}, pdf_ieee{0}, pdf_fast{0}, ablate{0}, hash_plain{0}, tail_split_off{0};
     } sw;
 };
 
@@ -122,6 +123,10 @@ void load_switches(SnHandle h) {
     h->sw.pdf_fast = env_int("SN_PDF_FAST") != 0;              // A/B knob (sn_pdf_lane): reciprocal multiplications instead of IEEE divisions
     h->sw.ablate = env_int("SN_ABLATE");                       // profiling only: non-zero gives WRONG images (see sn_main.h)
     h->sw.hash_plain = env_int("SN_HASH_PLAIN") != 0;          // stage kernel: plain table instead of the x-paired one
+    {
+        const char* e = getenv("SN_TAIL_SPLIT");                  // test / A-B switch: SN_TAIL_SPLIT=0 renders the last round of workgroups whole
+        h->sw.tail_split_off = e && atoi(e) == 0;
+    }
 }
 
 struct RenderGuard {
@@ -611,12 +616,55 @@ TileGeom tile_geometry(int height, int width) {
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WorkspacePlan {
-    size_t off_exp_raw, off_minmax, off_ebins, off_prop_scratch, total;
+    size_t off_exp_raw, off_minmax, off_ebins, off_prop_scratch, off_seg, total;
     int prop_blocks;
     int n_chunks;
+    int seg_first_block, n_seg, seg_len;  // split-depth tail of the main kernel (n_seg <= 1: none)
 };
 
-WorkspacePlan plan_workspace(int height, int width, const SnRenderOpts& o) {
+// Split-depth tail of the main kernel (sn_main.h SnMainParams).  A launch is whole workgroups (2x2 tiles, 4 waves) on a fixed number of
+// slots (CUs x SN_MAIN_WAVES_PER_SIMD workgroups = 768): its last round may hold a handful of workgroups -- a 64x64 viewer frame is 16 of
+// them, the tail of a 640x640 frame 64 -- each still marching all S samples with the chip nearly empty.  Such a tail's workgroups are cut
+// into n segment jobs of ceil(S / n) samples, so that the round fills more of the chip and is ~1/n as long; a small kernel composites
+// the stored samples in order (bit-identical).
+// WHEN (measured r03, frames back to back on one stream, profiles/r03_tail_split.txt): it pays when the tail is SMALL -- at most 1/8 of
+// the slots: 64x64 0.79 -> 0.25 ms, 128x128 0.69 -> 0.41, 640x640 2.06 -> 1.88 (-9 %).  A tail that already fills a quarter of the chip
+// gains nothing or loses: its lone waves step ~2x faster than waves that share a SIMD AND run at the boost clock (the chip is power-
+// limited when full), segment jobs pay the prologue n times -- 800x800 (196 of 768) -1 % per launch but +1 % with two frames in flight,
+// 200x200 (169) +11 %, 512x512 (256) +8 %.  So: tails above slots / 8 stay whole.
+// n minimises a cost model in units of sample steps: rounds of jobs x (samples per job + ~1.5 steps of prologue), a partly filled round
+// priced at 0.25 + 0.75 x fill.
+struct TailPlan {
+    int first_block, n_seg, seg_len;
+};
+TailPlan plan_tail(int total_wgs, int n_cus, int S, bool enabled) {
+    TailPlan t{total_wgs, 1, S};
+    const int slots = n_cus * SN_MAIN_WAVES_PER_SIMD;
+    if (!enabled || slots <= 0 || S < 8) return t;
+    const int tail = total_wgs % slots;
+    if (tail == 0 || tail > slots / 8) return t;
+    auto cost = [&](int n) {
+        const long jobs = (long)tail * n;
+        const double len = (double)((S + n - 1) / n) + 1.5;
+        const long full = jobs / slots, rest = jobs % slots;
+        return (double)full * len + (rest ? len * (0.25 + 0.75 * (double)rest / slots) : 0.0) + 0.5 * (n - 1);  // (+ a little per extra segment: scratch, launch)
+    };
+    int best = 1;
+    double best_cost = cost(1);
+    for (int n = 2; n <= 8 && (S + n - 1) / n >= 4; ++n)
+        if (cost(n) < best_cost - 1e-9) {
+            best = n;
+            best_cost = cost(n);
+        }
+    if (best == 1 || best_cost > 0.9 * cost(1)) return t;  // not worth a second kernel
+    t.first_block = total_wgs - tail;
+    if (t.first_block % 8 != 0) return TailPlan{total_wgs, 1, S};  // (the XCD-affine job order needs whole rows of 8 in front; true for 256 CUs)
+    t.n_seg = best;
+    t.seg_len = (S + best - 1) / best;
+    return t;
+}
+
+WorkspacePlan plan_workspace(int height, int width, const SnRenderOpts& o, int n_cus, bool tail_split) {
     WorkspacePlan w;
     const size_t n = (size_t)height * width;
     const TileGeom g = tile_geometry(height, width);
@@ -636,6 +684,15 @@ WorkspacePlan plan_workspace(int height, int width, const SnRenderOpts& o) {
         w.prop_blocks = std::min((ntiles + SN_PROP_WAVES - 1) / SN_PROP_WAVES, 256 * SN_PROP_WG_PER_CU);
         w.off_prop_scratch = off;
         off += align256((size_t)w.prop_blocks * SN_PROP_WAVES * SN_PROP_SCRATCH_FLOATS * 4);
+    }
+    {
+        const int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
+        const TailPlan t = plan_tail(gbx * gby, n_cus, o.num_nerf_samples, tail_split);
+        w.seg_first_block = t.first_block;
+        w.n_seg = t.n_seg;
+        w.seg_len = t.seg_len;
+        w.off_seg = off;
+        if (t.n_seg > 1) off += align256((size_t)(gbx * gby - t.first_block) * 4 * (size_t)o.num_nerf_samples * 64 * 16);  // (density, r, g, b) per sample
     }
     w.total = off;
     return w;
@@ -679,6 +736,10 @@ int sn_create(const SnFieldDesc* desc, SnHandle* out) {
     if (hipGetDevice(&c->device) != hipSuccess) {
         delete c;
         return fail(nullptr, SN_ERR_HIP, "hipGetDevice failed (no HIP device?)");
+    }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->n_cus = cus;
     }
     load_switches(c);
     *out = c;
@@ -1138,7 +1199,7 @@ int sn_intersect_obb(const float* origins, const float* directions, int64_t n_ra
 
 size_t sn_workspace_bytes(SnHandle h, int32_t height, int32_t width, const SnRenderOpts* opts) {
     if (!h || !opts || height <= 0 || width <= 0 || opts->chunk_rays < 1) return 0;
-    return plan_workspace(height, width, *opts).total;
+    return plan_workspace(height, width, *opts, h->n_cus, true).total;  // (the size with the tail split on covers both settings of SN_TAIL_SPLIT)
 }
 
 // K2: proposal sampler (rows a8-a12) -> final euclidean bins [tile][S+1][64] in the workspace.  Shared by the colour render and
@@ -1235,7 +1296,7 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     if (!h->finalized) return fail(h, SN_ERR_STATE, "sn_render_rays: weights not finalized");
     std::string why;
     if (!valid_opts(h->desc, *opts, why)) return fail(h, SN_ERR_INVALID, "sn_render_rays: " + why);
-    const WorkspacePlan wp = plan_workspace(height, width, *opts);
+    WorkspacePlan wp = plan_workspace(height, width, *opts, h->n_cus, true);
     if (!opts->workspace || opts->workspace_bytes < wp.total)
         return fail(h, SN_ERR_WORKSPACE, "sn_render_rays: workspace too small, need " + std::to_string(wp.total) + " bytes");
     hipStream_t st = (hipStream_t)stream;
@@ -1308,11 +1369,25 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     }
     const int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
     // weight image + (uniform sampler) the frame's S + 1 euclidean bins
-    const size_t lds_bytes = (size_t)SnMainImg::TOTAL * 4 + (nprop == 0 ? ((size_t)opts->num_nerf_samples + 1 + 3) / 4 * 16 : 0);
-    const dim3 grid((unsigned)(gbx * gby)), block(256);
+    const size_t etab_bytes = nprop == 0 ? ((size_t)opts->num_nerf_samples + 1 + 3) / 4 * 16 : 0;
+    const size_t lds_bytes = (size_t)SnMainImg::TOTAL * 4 + etab_bytes;
+    // split-depth tail (plan_tail): the workgroups of the last, partly filled round become n_seg segment jobs each
+    const int ablate = h->sw.ablate.load(std::memory_order_relaxed);
+    const bool tail_split = !dump && ablate == 0 && !h->sw.tail_split_off.load(std::memory_order_relaxed) && wp.n_seg > 1;
+    p.seg_first_block = gbx * gby;
+    p.n_seg = 1;
+    p.seg_len = opts->num_nerf_samples;
+    int n_tail = 0;
+    if (tail_split) {
+        n_tail = gbx * gby - wp.seg_first_block;
+        p.seg_first_block = wp.seg_first_block;
+        p.n_seg = wp.n_seg;
+        p.seg_len = wp.seg_len;
+        p.seg_scratch = (f32x4*)(ws + wp.off_seg);
+    }
+    const dim3 grid((unsigned)(gbx * gby - n_tail + ((n_tail + 7) / 8 * 8) * p.n_seg)), block(256);  // (segment jobs: the tail padded to whole XCD rows)
 #define SN_LAUNCH_MAIN(MODE, PREC, ABL, GRID, ND) \
     hipLaunchKernelGGL((sn_render_main_kernel<MODE, PREC, ABL, GRID, ND>), grid, block, lds_bytes, st, p)
-    const int ablate = h->sw.ablate.load(std::memory_order_relaxed);
     const int nd_launch = use_copies ? h->nd_torch : -1;
 #define SN_LAUNCH_MAIN_ND(MODE, PREC, GRID)                          \
     switch (nd_launch) {                                             \
@@ -1360,6 +1435,11 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
 #undef SN_LAUNCH_MAIN_ND
 #undef SN_LAUNCH_MAIN
     SN_HIP(h, hipGetLastError());
+    if (tail_split) {
+        if (nprop > 0) hipLaunchKernelGGL((sn_main_combine_kernel<1>), dim3((unsigned)n_tail), block, 0, st, p);
+        else hipLaunchKernelGGL((sn_main_combine_kernel<0>), dim3((unsigned)n_tail), block, etab_bytes, st, p);
+        SN_HIP(h, hipGetLastError());
+    }
     if (expected_depth) {
         hipLaunchKernelGGL(sn_clip_expected_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_exp_raw, d_minmax, n,
                            opts->chunk_rays, wp.n_chunks, expected_depth);
@@ -1461,7 +1541,7 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
     std::string why;
     if (!valid_opts(h->desc, *opts, why)) return fail(h, SN_ERR_INVALID, "sn_render_normals: " + why);
     if (!normals && !pred_normals) return SN_OK;
-    const WorkspacePlan wp = plan_workspace(height, width, *opts);
+    const WorkspacePlan wp = plan_workspace(height, width, *opts, h->n_cus, true);
     if (!opts->workspace || opts->workspace_bytes < wp.total)
         return fail(h, SN_ERR_WORKSPACE, "sn_render_normals: workspace too small, need " + std::to_string(wp.total) + " bytes");
     hipStream_t st = (hipStream_t)stream;

@@ -495,6 +495,12 @@ struct SnMainParams {
     SnPairInfo pinfo;
     SnGridLevels grid;  // ND > 0: R of the de-hashed coarse copies; GRID 1, ND = -1: dense-level resolutions of the tiny-cuda-nn grid
     SnDenseCopy dense;  // ND > 0
+    // Split-depth tail (r03): workgroups [0, seg_first_block) march whole rays; every later block is a SEGMENT job -- workgroup
+    // seg_first_block + j / n_seg of the image, samples [k seg_len, (k + 1) seg_len) with k = j % n_seg -- that stores (density, r, g, b)
+    // per sample to seg_scratch [tail workgroup][wave][sample][lane] instead of compositing; sn_main_combine_kernel composites them in
+    // sample order with the same arithmetic (bit-identical outputs).  n_seg <= 1: no segment jobs.
+    int seg_first_block, n_seg, seg_len;
+    f32x4* seg_scratch;
     // test instrumentation (DUMP = 1 instantiations only; sn_render_rays_debug)
     uint32_t* dump_fetch;  // [H*W][S][16][8] fetch records (sn_hash_encode) or null
     float* dump_q;         // [H*W][S][3] normalised positions that were hashed, or null
@@ -509,6 +515,76 @@ SN_DEV int sn_xcd_remap(int b, int n) {
     int qn = n / nx, rn = n % nx;
     int base = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
     return base + k;
+}
+
+// logical workgroup index (dispatch order) -> workgroup coordinates in units of 2x2 tiles.  SN_STRIP_W > 0: column strips SN_STRIP_W
+// workgroups wide, each walked row by row, so that the ~96 workgroups an XCD runs at a time cover a squarer patch of the image (more
+// voxels shared in its L2) than two full-width rows
+SN_DEV void sn_main_wg_coords(const SnMainParams& p, int logical_block, int& bx, int& by) {
+    const int gbx = (p.tiles_x + 1) >> 1, gby = (p.tiles_y + 1) >> 1;
+    const int blk = sn_xcd_remap(logical_block, gbx * gby);
+    if (SN_STRIP_W > 0) {
+        const int full = (gbx / SN_STRIP_W) * SN_STRIP_W * gby;  // workgroups inside complete strips
+        if (blk < full) {
+            const int strip = blk / (SN_STRIP_W * gby), r = blk % (SN_STRIP_W * gby);
+            bx = strip * SN_STRIP_W + r % SN_STRIP_W;
+            by = r / SN_STRIP_W;
+        } else {
+            const int w = gbx - (gbx / SN_STRIP_W) * SN_STRIP_W, r = blk - full;  // the narrower last strip
+            bx = (gbx / SN_STRIP_W) * SN_STRIP_W + r % w;
+            by = r / w;
+        }
+    } else {
+        bx = blk % gbx;
+        by = blk / gbx;
+    }
+}
+
+// What a ray's compositing state becomes: outputs + the chunk-global [min, max] of the sample mid-points.  Shared by the main kernel
+// (whole-ray workgroups) and sn_main_combine_kernel (the tail's segment jobs).  bin(k) = euclidean bin k of this lane's ray.
+template <bool DUMP, typename BIN>
+SN_DEV void sn_main_epilogue(const SnMainParams& p, SnComposite& comp, float r, float g, float b, BIN bin, int S, bool valid, int px, int py, int lane) {
+    float out_rgb[3], depth, acc, exp_raw;
+    // the mid-points the outputs need -- first, last, median sample -- from the same bins with the loop's own arithmetic, once per ray
+    const int mi = comp.median_index(S);
+    const float first_mid = sn_mid(bin(0), bin(1));
+    const float last_mid = sn_mid(bin(S - 1), bin(S));
+    comp.finish_fused(S, sn_mid(bin(mi), bin(mi + 1)), r, g, b, out_rgb, depth, acc, exp_raw);
+    if (valid) {
+        const int64_t pix = (int64_t)py * p.width + px;
+        if (p.rgb) {
+            p.rgb[pix * 3 + 0] = out_rgb[0];
+            p.rgb[pix * 3 + 1] = out_rgb[1];
+            p.rgb[pix * 3 + 2] = out_rgb[2];
+        }
+        if (p.depth) p.depth[pix] = depth;
+        if (DUMP && p.dump_median) p.dump_median[pix] = comp.median_idx;
+        if (p.acc) p.acc[pix] = acc;
+        if (p.exp_raw) p.exp_raw[pix] = exp_raw;
+    }
+    // chunk-global [min, max] of the sample mid-points (A17 quirk): bins are monotone along a ray, so a
+    // ray contributes its first and last mid-point.  A tile straddles at most a few chunks.
+    if (p.chunk_minmax) {
+        const int my_chunk = valid ? (int)(((int64_t)py * p.width + px) / p.chunk_rays) : -1;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int c = __shfl(my_chunk, leader);
+            const bool mine = valid && my_chunk == c;
+            uint32_t lo = mine ? sn_float_ordered(first_mid) : 0xffffffffu;
+            uint32_t hi = mine ? sn_float_ordered(last_mid) : 0u;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) {
+                lo = min(lo, (uint32_t)__shfl_xor((int)lo, s));
+                hi = max(hi, (uint32_t)__shfl_xor((int)hi, s));
+            }
+            if (lane == leader) {
+                atomicMin(&p.chunk_minmax[c], lo);
+                atomicMax(&p.chunk_minmax[p.n_chunks + c], hi);
+            }
+            todo &= ~__ballot(mine);
+        }
+    }
 }
 
 // ABLATE (profiling only, images are WRONG when non-zero; selected by the SN_ABLATE environment variable): 2 = hash phase
@@ -536,27 +612,26 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // workgroup = 2x2 tiles
-    const int gbx = (p.tiles_x + 1) >> 1, gby = (p.tiles_y + 1) >> 1;
-    const int blk = sn_xcd_remap(blockIdx.x, gbx * gby);
-    // linear index -> workgroup coordinates.  SN_STRIP_W > 0: column strips SN_STRIP_W workgroups wide, each walked row by row, so that the
-    // ~96 workgroups an XCD runs at a time cover a squarer patch of the image (more voxels shared in its L2) than two full-width rows
-    int bx, by;
-    if (SN_STRIP_W > 0) {
-        const int full = (gbx / SN_STRIP_W) * SN_STRIP_W * gby;  // workgroups inside complete strips
-        if (blk < full) {
-            const int strip = blk / (SN_STRIP_W * gby), r = blk % (SN_STRIP_W * gby);
-            bx = strip * SN_STRIP_W + r % SN_STRIP_W;
-            by = r / SN_STRIP_W;
-        } else {
-            const int w = gbx - (gbx / SN_STRIP_W) * SN_STRIP_W, r = blk - full;  // the narrower last strip
-            bx = (gbx / SN_STRIP_W) * SN_STRIP_W + r % w;
-            by = r / w;
-        }
-    } else {
-        bx = blk % gbx;
-        by = blk / gbx;
+    // workgroup = 2x2 tiles.  Blocks past seg_first_block are segment jobs of the launch's last, partly filled round of workgroups: the
+    // same tiles, a slice of the samples each, so that the round fills the chip (SnMainParams "Split-depth tail")
+    int logical_block = blockIdx.x, i_lo = 0, i_hi = p.n_samples;
+    f32x4* seg_out = nullptr;  // wave-uniform: non-null <=> this workgroup stores samples instead of compositing them
+    if (p.n_seg > 1 && (int)blockIdx.x >= p.seg_first_block) {
+        // The dispatcher places block b on XCD b % 8 and sn_xcd_remap gives logical block L the tiles of XCD L % 8's band: the segments of a
+        // tail workgroup must therefore stay on ITS XCD (seg_first_block is a multiple of 8), one after the other, so that they share
+        // its L2 like a whole-ray workgroup does (spread over the XCDs, every segment re-fetched the tile's voxels into another L2: +8 %
+        // instead of -5 % at 512x512).  The grid pads the tail to a multiple of 8 workgroups; the padding returns here.
+        const int j = (int)blockIdx.x - p.seg_first_block, xcd = j & 7, m = j >> 3;
+        const int tail_wg = (m / p.n_seg) * 8 + xcd, k = m % p.n_seg;
+        logical_block = p.seg_first_block + tail_wg;
+        if (logical_block >= ((p.tiles_x + 1) >> 1) * ((p.tiles_y + 1) >> 1)) return;
+        i_lo = k * p.seg_len;
+        i_hi = min(p.n_samples, i_lo + p.seg_len);
+        seg_out = p.seg_scratch + ((int64_t)(tail_wg * 4 + wave) * p.n_samples) * 64 + lane;
+        if (i_lo >= i_hi) return;  // (n_seg * seg_len may exceed S by a segment)
     }
+    int bx, by;
+    sn_main_wg_coords(p, logical_block, bx, by);
     const int tx = bx * 2 + (wave & 1);
     const int ty = by * 2 + (wave >> 1);
     if (tx >= p.tiles_x || ty >= p.tiles_y) return;  // wave-uniform
@@ -588,16 +663,18 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
 
     SnComposite comp;
     comp.init();
-    float t0 = MODE == 0 ? (shared_bins ? etab[0] : sn_euclid(p.sbins ? p.sbins[0] : 0.0f, s_near, s_far)) : eb[0];
-    float first_mid = 0.f, last_mid = 0.f;
+    // euclidean bin k of this lane's ray, with the loop's own arithmetic
+    auto bin = [&](int k) -> float {
+        return MODE == 0 ? (shared_bins ? etab[k] : sn_euclid(p.sbins ? p.sbins[k] : (float)k / (float)S, s_near, s_far)) : eb[(int64_t)k * 64];
+    };
+    float t0 = bin(i_lo);
     float r = 0.f, g = 0.f, b = 0.f;
 #pragma unroll 1
-    for (int i = 0; i < S; ++i) {
+    for (int i = i_lo; i < i_hi; ++i) {
         // The LDS weight reads are loop-invariant; LICM would hoist them all (368 VGPRs) and spill.  A compiler-only
         // memory clobber per iteration keeps them inside the loop.
         asm volatile("" ::: "memory");
-        const float t1 = MODE == 0 ? (shared_bins ? etab[i + 1] : sn_euclid(p.sbins ? p.sbins[i + 1] : (float)(i + 1) / (float)S, s_near, s_far))
-                                   : eb[(int64_t)(i + 1) * 64];
+        const float t1 = bin(i + 1);
         float q[3];
         const bool sel = sn_sample_q_fast(o, d, t0, t1, q);
         float feat[32];
@@ -686,55 +763,77 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
         r = rgb[0] + nan_term;
         g = rgb[1] + nan_term;
         b = rgb[2] + nan_term;
-        comp.step_fused(t0, t1, density, r, g, b);
+#if defined(SN_EXP_NO_SEG_STORE)  // experiment (wrong images): what does the per-sample store cost the segment jobs?
+        if (seg_out) { if (density == 12345.678f) seg_out[(int64_t)i * 64] = f32x4{density, r, g, b}; }
+#else
+        if (seg_out) seg_out[(int64_t)i * 64] = f32x4{density, r, g, b};  // (wave-uniform branch) composited later, in sample order
+#endif
+        else comp.step_fused(t0, t1, density, r, g, b);
         t0 = t1;
     }
-    float out_rgb[3], depth, acc, exp_raw;
-    {
-        // the mid-points the outputs need -- first, last, median sample -- from the same bins with the loop's own arithmetic, once per ray
-        auto bin = [&](int k) -> float {
-            return MODE == 0 ? (shared_bins ? etab[k] : sn_euclid(p.sbins ? p.sbins[k] : (float)k / (float)S, s_near, s_far)) : eb[(int64_t)k * 64];
-        };
-        const int mi = comp.median_index(S);
-        first_mid = sn_mid(bin(0), bin(1));
-        last_mid = sn_mid(bin(S - 1), bin(S));
-        comp.finish_fused(S, sn_mid(bin(mi), bin(mi + 1)), r, g, b, out_rgb, depth, acc, exp_raw);
+    if (seg_out) return;
+    sn_main_epilogue<DUMP>(p, comp, r, g, b, bin, S, valid, px, py, lane);
+}
+
+// Composites the samples the segment jobs stored (SnMainParams "Split-depth tail"): one wave per tile of the tail workgroups, the
+// samples in order through SnComposite::step_fused -- the arithmetic, and therefore every output bit, of a whole-ray workgroup.
+template <int MODE>
+__global__ __launch_bounds__(256) void sn_main_combine_kernel(SnMainParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    float* etab = lds;
+    const bool shared_bins = MODE == 0 && p.nears == nullptr;
+    if (shared_bins) {
+        const float sn = sn_spacing(p.near_plane), sf = sn_spacing(p.far_plane);
+        for (int i = tid; i <= p.n_samples; i += 256) etab[i] = sn_euclid(p.sbins ? p.sbins[i] : (float)i / (float)p.n_samples, sn, sf);
     }
-    if (valid) {
-        const int64_t pix = (int64_t)py * p.width + px;
-        if (p.rgb) {
-            p.rgb[pix * 3 + 0] = out_rgb[0];
-            p.rgb[pix * 3 + 1] = out_rgb[1];
-            p.rgb[pix * 3 + 2] = out_rgb[2];
-        }
-        if (p.depth) p.depth[pix] = depth;
-        if (DUMP && p.dump_median) p.dump_median[pix] = comp.median_idx;
-        if (p.acc) p.acc[pix] = acc;
-        if (p.exp_raw) p.exp_raw[pix] = exp_raw;
-    }
-    // chunk-global [min, max] of the sample mid-points (A17 quirk): bins are monotone along a ray, so a
-    // ray contributes its first and last mid-point.  A tile straddles at most a few chunks.
-    if (p.chunk_minmax) {
-        const int my_chunk = valid ? (int)(((int64_t)py * p.width + px) / p.chunk_rays) : -1;
-        unsigned long long todo = __ballot(valid);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int c = __shfl(my_chunk, leader);
-            const bool mine = valid && my_chunk == c;
-            uint32_t lo = mine ? sn_float_ordered(first_mid) : 0xffffffffu;
-            uint32_t hi = mine ? sn_float_ordered(last_mid) : 0u;
+    __syncthreads();
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx, by;
+    sn_main_wg_coords(p, p.seg_first_block + (int)blockIdx.x, bx, by);
+    const int tx = bx * 2 + (wave & 1);
+    const int ty = by * 2 + (wave >> 1);
+    if (tx >= p.tiles_x || ty >= p.tiles_y) return;  // wave-uniform
+    const int tw = 1 << p.tile_w_log2;
+    const int px = (tx << p.tile_w_log2) + (lane & (tw - 1));
+    const int py = (ty << p.tile_h_log2) + (lane >> p.tile_w_log2);
+    const bool valid = px < p.width && py < p.height;
+    const int64_t ray = (int64_t)min(py, p.height - 1) * p.width + min(px, p.width - 1);
+    const float s_near = sn_spacing(p.nears ? p.nears[ray] : p.near_plane), s_far = sn_spacing(p.fars ? p.fars[ray] : p.far_plane);
+    const int S = p.n_samples;
+    const float* eb = nullptr;
+    if (MODE == 1) eb = p.ebins + ((int64_t)(ty * p.tiles_x + tx) * (S + 1)) * 64 + lane;
+    auto bin = [&](int k) -> float {
+        return MODE == 0 ? (shared_bins ? etab[k] : sn_euclid(p.sbins ? p.sbins[k] : (float)k / (float)S, s_near, s_far)) : eb[(int64_t)k * 64];
+    };
+    const f32x4* in = p.seg_scratch + ((int64_t)((int)blockIdx.x * 4 + wave) * S) * 64 + lane;
+    SnComposite comp;
+    comp.init();
+    float t0 = bin(0), r = 0.f, g = 0.f, b = 0.f;
+    // the compositing chain is sequential, its inputs are not: 8 samples (and their bins) are fetched at a time, so that the wave waits
+    // for memory S / 8 times instead of S times
+    constexpr int B = 8;
+    for (int i0 = 0; i0 < S; i0 += B) {
+        f32x4 v[B];
+        float t[B];
 #pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) {
-                lo = min(lo, (uint32_t)__shfl_xor((int)lo, s));
-                hi = max(hi, (uint32_t)__shfl_xor((int)hi, s));
-            }
-            if (lane == leader) {
-                atomicMin(&p.chunk_minmax[c], lo);
-                atomicMax(&p.chunk_minmax[p.n_chunks + c], hi);
-            }
-            todo &= ~__ballot(mine);
+        for (int k = 0; k < B; ++k) {
+            const int i = min(i0 + k, S - 1);
+            v[k] = in[(int64_t)i * 64];
+            t[k] = bin(i + 1);
         }
+#pragma unroll
+        for (int k = 0; k < B; ++k)
+            if (i0 + k < S) {  // wave-uniform
+                r = v[k].y;
+                g = v[k].z;
+                b = v[k].w;
+                comp.step_fused(t0, t[k], v[k].x, r, g, b);
+                t0 = t[k];
+            }
     }
+    sn_main_epilogue<false>(p, comp, r, g, b, bin, S, valid, px, py, lane);
 }
 
 // expected_depth = clip(raw, chunk min, chunk max)

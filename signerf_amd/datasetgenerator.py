@@ -262,7 +262,7 @@ class DatasetGenerator:
     def __init__(self, config: DatasetGeneratorConfig, original_transform_matrix: Optional[Tensor] = None, original_scale_factor: float = 1.0,
                  transform_poses_to_original_space: Optional[Callable[[Tensor], Tensor]] = None, device="cuda",
                  diffuse: Optional[Callable[[Tensor, Tensor, Tensor, Tensor], Tensor]] = None, group=None, write_images: bool = True,
-                 save_workers: int = 8, precompute: bool = True, profile: bool = False) -> None:
+                 save_workers: Optional[int] = None, precompute: bool = True, profile: bool = False) -> None:
         self.config = config
         self.device = device
         self.original_transform_matrix = original_transform_matrix if original_transform_matrix is not None else torch.eye(4)[:3]
@@ -279,6 +279,10 @@ class DatasetGenerator:
         self.mask_dialation, self.additional_depth_radius, self.manual_depth = config.mask_dialation, config.additional_depth_radius, config.manual_depth
         self.diffuse = diffuse or identity_diffuse
         self.group = group
+        if save_workers is None:  # PNG encoding (PIL, zlib: releases the GIL) is the slowest stage of the loop by 10x: spread it over the host's cores
+            import os
+
+            save_workers = max(1, min(32, (os.cpu_count() or 8) // 2))
         self.write_images, self.save_workers = write_images, save_workers
         self.precompute, self.profile = precompute, profile
         self.is_synthetic = False

@@ -645,3 +645,45 @@ def test_upload_waits_for_a_long_render_behind_many_short_ones(gpu):
         again = model.get_outputs_for_camera_ray_bundle(small)["rgb"]
         torch.cuda.synchronize()
         assert not torch.equal(after, again)
+
+
+@pytest.mark.parametrize("case", ["bench 64x64", "bench 128x128", "bench 40x40 fp32", "bench 8x8", "bench 640x640", "bench 800x800", "ragged aabb 45x59",
+                                  "proposal 128x96", "proposal 1024x592"])
+def test_split_depth_tail_is_bit_identical(gpu, monkeypatch, case):
+    """r03: when the last round of a launch's workgroups is nearly empty (at most 1/8 of the chip's 768 workgroup slots: a 64x64 viewer
+    frame is 16 workgroups, the tail of a 640x640 frame 64, of a 1024x592 nerfacto frame 64), its workgroups are cut into segment jobs -- a
+    slice of the samples each -- and a small kernel composites the stored (density, colour) samples in order.  SN_TAIL_SPLIT=0 renders every
+    workgroup whole: all outputs must be bit-identical -- uniform and proposal sampler, shared and per-ray bins, both precisions, frames
+    smaller than one round (every workgroup is a tail workgroup), frames of several rounds, and a frame whose tail is left whole (800x800)."""
+    if case.startswith("bench"):
+        cfg = scene.benchmark_config(64)
+        if "fp32" in case:
+            cfg.precision = "fp32"
+        size = int(case.split()[1].split("x")[0])
+        model, _ = make_model(cfg, gpu)
+        b = Cameras(scene.benchmark_cameras(8)[:, :3], float(size), float(size), size / 2, size / 2, size, size).to(gpu)[2].generate_rays(0)
+    elif case.startswith("ragged"):
+        cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=40)
+        model, _ = make_model(cfg, gpu)
+        model.render_aabb = SceneBox(aabb=torch.tensor([[-0.15, -0.12, -0.1], [0.12, 0.15, 0.1]]))
+        b = Cameras(scene.benchmark_cameras(8)[:, :3], 70.0, 70.0, 29.5, 22.5, 59, 45).to(gpu)[2].generate_rays(0, aabb_box=model.render_aabb)
+    elif case == "proposal 128x96":
+        cfg = small_config(num_proposal_samples_per_ray=(48, 24), num_nerf_samples_per_ray=16)
+        model, _ = make_model(cfg, gpu)
+        b = Cameras(scene.benchmark_cameras(8)[:, :3], 140.0, 140.0, 64.0, 48.0, 128, 96).to(gpu)[1].generate_rays(0)
+    else:
+        cfg = scene.proposal_config()
+        model, _ = make_model(cfg, gpu)
+        W, H = 1024, 592      # 128 x 74 tiles = 64 x 37 workgroups = 3 x 768 + 64
+        b = Cameras(scene.benchmark_cameras(8)[:, :3], 1.2 * H, 1.2 * H, W / 2, H / 2, W, H).to(gpu)[4].generate_rays(0)
+    keys = ("rgb", "depth", "accumulation", "expected_depth")
+    split = {k: v.clone() for k, v in model.get_outputs_for_camera_ray_bundle(b).items() if k in keys}
+    monkeypatch.setenv("SN_TAIL_SPLIT", "0")
+    ops.reload_env(model)
+    whole = model.get_outputs_for_camera_ray_bundle(b)
+    monkeypatch.delenv("SN_TAIL_SPLIT")
+    ops.reload_env(model)
+    for k in keys:
+        same = torch.equal(torch.nan_to_num(split[k], nan=-7.0), torch.nan_to_num(whole[k], nan=-7.0))
+        assert same, f"{case}: {k} differs in {int((split[k] != whole[k]).sum())} values between the split-depth tail and whole-ray workgroups"
+    assert float(torch.nan_to_num(whole["rgb"]).std()) > 0.02

@@ -29,7 +29,7 @@ ap.add_argument("--size", type=int, default=800)
 ap.add_argument("--views", type=int, default=50)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
-ap.add_argument("--save-workers", type=int, default=8)
+ap.add_argument("--save-workers", type=int, default=None, help="host threads for PNG encoding (default: min(32, cores / 2))")
 a = ap.parse_args()
 world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
 dev = torch.device("cuda", local_rank % torch.cuda.device_count())

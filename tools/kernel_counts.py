@@ -144,16 +144,25 @@ def loop_counts(kernel_substr: str, lib: str = LIB) -> dict:
         if m:
             insts.append((int(m.group(3), 16), m.group(1), ln))
     base = insts[0][0]
-    best = None
+    spans = []
     for addr, op, ln in insts:
         if op.startswith(("s_branch", "s_cbranch")):
             m = re.search(r"\+0x([0-9a-fA-F]+)>", ln)
             if m:
                 tgt = base + int(m.group(1), 16)
-                if tgt < addr and (best is None or addr - tgt > best[1] - best[0]):
-                    best = (tgt, addr)
-    if best is None:
+                if tgt < addr:
+                    spans.append((tgt, addr))
+    if not spans:
         raise RuntimeError("no backward branch in " + names[0])
+    # The sample loop: the back-edges of the loop that holds the matrix-core instructions (a loop may close through several branches
+    # a few instructions apart); NOT simply the largest backward branch -- an enclosing branch of the epilogue can span the whole kernel.
+    with_mfma = [sp for sp in spans if any(o.startswith("v_mfma") for a, o, _ in insts if sp[0] <= a <= sp[1])]
+    if with_mfma:
+        inner = min(with_mfma, key=lambda sp: sp[1] - sp[0])
+        same = [sp for sp in with_mfma if abs(sp[1] - inner[1]) <= 0x40 and inner[0] - sp[0] <= 0x200]
+        best = max(same, key=lambda sp: sp[1] - sp[0])
+    else:
+        best = max(spans, key=lambda sp: sp[1] - sp[0])
     out = {"kernel": names[0], "loop_bytes": best[1] - best[0]}
     for addr, op, ln in insts:
         if best[0] <= addr <= best[1]:
