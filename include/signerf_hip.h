@@ -112,6 +112,11 @@ typedef struct SnRenderOpts {
      * closed form).  NULL => the library falls back to i/N and (k+0.5)/(M+1). */
     const float* initial_spacing_bins;             /* [n0+1] = torch.linspace(0, 1, n0+1), n0 = first level's count */
     const float* pdf_u[SN_MAX_PROPOSALS];          /* pdf_u[k]: [m+1] eval-mode u grid of resampling step k (m = next level's count) */
+    /* RGBRenderer's background (NerfactoModelConfig.background_color; appended in r03, zero = the nerfacto default):
+     * 0 = "last_sample" (the colour of the ray's last sample), 1 = the constant colour below ("black", "white"; "random" is a training
+     * device and composites like black in eval mode).  rgb = sum w c + background (1 - sum w), clamped to [0, 1]. */
+    int32_t background_mode;
+    float background_rgb[3];
 } SnRenderOpts;
 
 /* ---- lifetime -------------------------------------------------------------------------- */

@@ -76,6 +76,9 @@ class NerfactoConfig:
     hidden_dim_color: int = 64
     sh_levels: int = 4
     sh_remap: str = "torch"
+    background_color: str = "last_sample"
+    """RGBRenderer's background [NS]: "last_sample" (nerfacto's default; SIGNeRF does not override it), "black", "white", or "random" (a
+    training device: in eval mode combine_rgb returns the composited colour as it is, i.e. a black background)."""
     predict_normals: bool = False
     """signerf_config.py:33 sets it; adds "normals" (analytic) and "pred_normals" to the outputs (row a16)."""
     main: HashMLPConfig = field(
@@ -517,12 +520,19 @@ def render_normals(normals: Tensor, weights: Tensor) -> Tensor:
 # ----------------------------------------------------------------------------
 
 
-def render_rgb(rgb: Tensor, weights: Tensor) -> Tensor:
-    """RGBRenderer, background 'last_sample', eval mode."""
+def render_rgb(rgb: Tensor, weights: Tensor, background_color: str = "last_sample") -> Tensor:
+    """RGBRenderer, eval mode: nan_to_num on the per-sample colours, composite, add the background, clamp to [0, 1]."""
     rgb = torch.nan_to_num(rgb)
-    background = rgb[..., -1, :]
     comp = torch.sum(weights * rgb, dim=-2)
     acc = torch.sum(weights, dim=-2)
+    if background_color == "last_sample":
+        background = rgb[..., -1, :]
+    elif background_color == "white":
+        background = torch.ones_like(comp)
+    elif background_color in ("black", "random"):
+        background = torch.zeros_like(comp)
+    else:
+        raise ValueError(background_color)
     comp = comp + background * (1.0 - acc)
     return torch.clamp(comp, min=0.0, max=1.0)
 
@@ -588,7 +598,7 @@ def get_outputs(params: Dict[str, Tensor], cfg: NerfactoConfig, origins: Tensor,
     density, h, q, selector = density_field(params, "field.mlp_base", cfg.main, pos, cfg.average_init_density)
     rgb_s = field_rgb(params, cfg, directions, h)
     weights = get_weights(ends - starts, density)
-    rgb = render_rgb(rgb_s, weights)
+    rgb = render_rgb(rgb_s, weights, cfg.background_color)
     depth, med_idx = render_depth_median(weights, starts, ends)
     out = {
         "rgb": rgb,

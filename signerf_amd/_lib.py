@@ -59,6 +59,8 @@ class SnRenderOpts(C.Structure):
         ("workspace_bytes", C.c_size_t),
         ("initial_spacing_bins", C.c_void_p),
         ("pdf_u", C.c_void_p * SN_MAX_PROPOSALS),
+        ("background_mode", C.c_int32),
+        ("background_rgb", C.c_float * 3),
     ]
 
 

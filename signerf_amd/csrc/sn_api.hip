@@ -703,6 +703,7 @@ bool valid_opts(const SnFieldDesc& d, const SnRenderOpts& o, std::string& why) {
     else if (o.num_nerf_samples < 1 || o.num_nerf_samples > 1024) why = "num_nerf_samples out of range [1,1024]";
     else if (o.chunk_rays < 1) why = "chunk_rays must be positive";
     else if (o.precision != 0 && o.precision != 1) why = "precision must be 0 (fp32) or 1 (split fp16)";
+    else if (o.background_mode != 0 && o.background_mode != 1) why = "background_mode must be 0 (last sample) or 1 (constant colour)";
     else {
         for (int i = 0; i < o.num_proposal_iterations; ++i)
             if (o.num_proposal_samples[i] < 2 || o.num_proposal_samples[i] > SN_PROP_MAX_SAMPLES) {
@@ -1357,6 +1358,8 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     p.avg_density = d.average_init_density;
     p.sh_remap = d.sh_remap;
     p.chunk_rays = opts->chunk_rays;
+    p.bg_mode = opts->background_mode;
+    for (int c = 0; c < 3; ++c) p.bg[c] = opts->background_rgb[c];
     const bool tcnn = d.main_field.grid_mode == 1;
     // de-hashed copies are used when they cover every level tiny-cuda-nn indexes densely (always true for torch grids and for nerfacto's
     // tcnn shapes); otherwise the run-time variant (ND = -1) reads the uploaded table

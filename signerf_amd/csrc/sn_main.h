@@ -501,6 +501,8 @@ struct SnMainParams {
     // sample order with the same arithmetic (bit-identical outputs).  n_seg <= 1: no segment jobs.
     int seg_first_block, n_seg, seg_len;
     f32x4* seg_scratch;
+    int bg_mode;      // RGBRenderer background: 0 = the ray's last sample, 1 = the constant colour bg
+    float bg[3];
     // test instrumentation (DUMP = 1 instantiations only; sn_render_rays_debug)
     uint32_t* dump_fetch;  // [H*W][S][16][8] fetch records (sn_hash_encode) or null
     float* dump_q;         // [H*W][S][3] normalised positions that were hashed, or null
@@ -545,6 +547,11 @@ SN_DEV void sn_main_wg_coords(const SnMainParams& p, int logical_block, int& bx,
 template <bool DUMP, typename BIN>
 SN_DEV void sn_main_epilogue(const SnMainParams& p, SnComposite& comp, float r, float g, float b, BIN bin, int S, bool valid, int px, int py, int lane) {
     float out_rgb[3], depth, acc, exp_raw;
+    if (p.bg_mode) {  // a constant background instead of the last sample's colour (wave-uniform)
+        r = p.bg[0];
+        g = p.bg[1];
+        b = p.bg[2];
+    }
     // the mid-points the outputs need -- first, last, median sample -- from the same bins with the loop's own arithmetic, once per ray
     const int mi = comp.median_index(S);
     const float first_mid = sn_mid(bin(0), bin(1));

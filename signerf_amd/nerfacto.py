@@ -29,6 +29,9 @@ from .cameras import RayBundle, SceneBox
 from .config import NerfactoModelConfig, SIGNeRFModelConfig
 
 PRECISIONS = {"fp32": 0, "fp16x2": 1}
+# RGBRenderer's background in EVAL mode [NS]: "last_sample" (nerfacto's default, what SIGNeRF runs), a named constant colour, or "random" --
+# a training device: combine_rgb returns the composited colour without a background, i.e. black
+BACKGROUNDS = {"last_sample": None, "black": (0.0, 0.0, 0.0), "white": (1.0, 1.0, 1.0), "random": (0.0, 0.0, 0.0)}
 
 
 class _RWLock:
@@ -285,8 +288,8 @@ class NerfactoModel(nn.Module):
         if cfg.disable_scene_contraction:
             raise NotImplementedError("only the L-inf scene contraction path is built")
         # the kernels implement the values SIGNeRF runs with (nerfacto's defaults); anything else must not render silently wrong
-        if cfg.background_color != "last_sample":
-            raise NotImplementedError(f"background_color={cfg.background_color!r}: only 'last_sample' (nerfacto's default) is built")
+        if cfg.background_color not in BACKGROUNDS:
+            raise NotImplementedError(f"background_color={cfg.background_color!r}: one of {sorted(BACKGROUNDS)} expected")
         if cfg.proposal_initial_sampler != "piecewise":
             raise NotImplementedError(f"proposal_initial_sampler={cfg.proposal_initial_sampler!r}: only 'piecewise' is built")
         self.field = NerfactoField(cfg, self.num_train_data)
@@ -460,6 +463,10 @@ class NerfactoModel(nn.Module):
         # (Model.get_outputs_for_camera_ray_bundle's loop), over the whole bundle for Model.get_outputs / forward
         o.chunk_rays = max(H * W, 1) if single_chunk else cfg.eval_num_rays_per_chunk
         o.precision = PRECISIONS[cfg.precision]
+        bg = BACKGROUNDS[cfg.background_color]
+        o.background_mode = 0 if bg is None else 1
+        for c in range(3):
+            o.background_rgb[c] = 0.0 if bg is None else bg[c]
         bins0, us = self._grids(n_levels)
         o.initial_spacing_bins = bins0.data_ptr()
         for i, u in enumerate(us):

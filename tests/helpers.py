@@ -31,6 +31,7 @@ def oracle_config(cfg: NerfactoModelConfig) -> onf.NerfactoConfig:
         appearance_embed_dim=cfg.appearance_embed_dim,
         hidden_dim_color=cfg.hidden_dim_color,
         sh_remap="torch" if cfg.implementation == "torch" else "tcnn",
+        background_color=cfg.background_color,
         main=onf.HashMLPConfig(cfg.num_levels, cfg.base_res, cfg.max_res, cfg.log2_hashmap_size, cfg.features_per_level,
                                cfg.hidden_dim, 2, 16, grid),
         proposals=props,

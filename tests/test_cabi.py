@@ -47,8 +47,9 @@ int main(void) {
   printf("%zu %zu %zu\n", sizeof(SnHashMlpDesc), sizeof(SnFieldDesc), sizeof(SnRenderOpts));
   printf("%zu %zu %zu %zu\n", offsetof(SnHashMlpDesc, scalings), offsetof(SnFieldDesc, proposals),
          offsetof(SnFieldDesc, average_init_density), offsetof(SnFieldDesc, num_proposals));
-  printf("%zu %zu %zu %zu %zu\n", offsetof(SnRenderOpts, num_nerf_samples), offsetof(SnRenderOpts, chunk_rays),
-         offsetof(SnRenderOpts, workspace), offsetof(SnRenderOpts, initial_spacing_bins), offsetof(SnRenderOpts, pdf_u));
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", offsetof(SnRenderOpts, num_nerf_samples), offsetof(SnRenderOpts, chunk_rays),
+         offsetof(SnRenderOpts, workspace), offsetof(SnRenderOpts, initial_spacing_bins), offsetof(SnRenderOpts, pdf_u),
+         offsetof(SnRenderOpts, background_mode), offsetof(SnRenderOpts, background_rgb));
   printf("%zu %zu %zu %zu %zu %zu\n", sizeof(SnDebugDump), offsetof(SnDebugDump, prop_q), offsetof(SnDebugDump, pdf_index),
          sizeof(SnDebugLayout), offsetof(SnDebugLayout, dense_bytes), offsetof(SnDebugLayout, pair_bytes));
   return 0;
@@ -64,6 +65,7 @@ int main(void) {
             _lib.SnFieldDesc.num_proposals.offset,
             _lib.SnRenderOpts.num_nerf_samples.offset, _lib.SnRenderOpts.chunk_rays.offset, _lib.SnRenderOpts.workspace.offset,
             _lib.SnRenderOpts.initial_spacing_bins.offset, _lib.SnRenderOpts.pdf_u.offset,
+            _lib.SnRenderOpts.background_mode.offset, _lib.SnRenderOpts.background_rgb.offset,
             C.sizeof(_lib.SnDebugDump), _lib.SnDebugDump.prop_q.offset, _lib.SnDebugDump.pdf_index.offset,
             C.sizeof(_lib.SnDebugLayout), _lib.SnDebugLayout.dense_bytes.offset, _lib.SnDebugLayout.pair_bytes.offset]
     assert got == want
@@ -158,10 +160,12 @@ def test_unbuilt_config_values_are_rejected_at_model_set_up():
     """Values of nerfstudio's config that the kernels do not implement raise instead of rendering something else."""
     from signerf_amd import SIGNeRFModelConfig
 
-    for kw in ({"background_color": "black"}, {"proposal_initial_sampler": "uniform"}, {"disable_scene_contraction": True}):
+    for kw in ({"background_color": "#ff0000"}, {"proposal_initial_sampler": "uniform"}, {"disable_scene_contraction": True}):
         with pytest.raises(NotImplementedError):
             SIGNeRFModelConfig(**kw).setup()
     SIGNeRFModelConfig(log2_hashmap_size=12).setup()   # the defaults build (CPU-side module set-up only)
+    for bg in ("last_sample", "black", "white", "random"):   # RGBRenderer's named backgrounds (r03)
+        SIGNeRFModelConfig(log2_hashmap_size=12, background_color=bg).setup()
 
 
 def test_method_registration_entry_point():

@@ -687,3 +687,22 @@ def test_split_depth_tail_is_bit_identical(gpu, monkeypatch, case):
         same = torch.equal(torch.nan_to_num(split[k], nan=-7.0), torch.nan_to_num(whole[k], nan=-7.0))
         assert same, f"{case}: {k} differs in {int((split[k] != whole[k]).sum())} values between the split-depth tail and whole-ray workgroups"
     assert float(torch.nan_to_num(whole["rgb"]).std()) > 0.02
+
+
+@pytest.mark.parametrize("background", ["black", "white", "random"])
+@pytest.mark.parametrize("proposals", [False, True])
+def test_constant_background_colours(gpu, background, proposals):
+    """NerfactoModelConfig.background_color other than nerfacto's "last_sample" (SIGNeRF never overrides it, signerf_config.py:31-36; built in
+    r03 so that the model no longer refuses it): a thin medium (density bias 0: accumulation well below 1) so that the background shows."""
+    cfg = small_config(num_proposal_samples_per_ray=(48, 24), num_nerf_samples_per_ray=16, far_plane=6.0, background_color=background) if proposals else \
+        small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=24, far_plane=6.0, background_color=background)
+    model, sd = make_model(cfg, gpu, density_bias=0.0)
+    out, ref = _render_pair(cfg, model, sd, gpu, 40, 56, cam=2, focal=60.0)
+    acc = float(ref["accumulation"].mean())
+    assert 0.02 < acc < 0.9, acc                                               # the background carries weight
+    assert rmse(out["rgb"], ref["rgb"]) <= RMSE_TOL and rmse(out["accumulation"], ref["accumulation"]) <= RMSE_TOL
+    cfg_ls = small_config(**{**({"num_proposal_samples_per_ray": (48, 24), "num_nerf_samples_per_ray": 16} if proposals else
+                                {"num_proposal_iterations": 0, "num_nerf_samples_per_ray": 24}), "far_plane": 6.0})
+    ref_ls = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg_ls), *[t.cpu() for t in (lambda b: (b.origins, b.directions))(
+        Cameras(scene.benchmark_cameras(8)[:, :3], 60.0, 60.0, 28.0, 20.0, 56, 40).to(gpu)[2].generate_rays(0))])
+    assert rmse(ref["rgb"], ref_ls["rgb"]) > 0.02                              # ... and differs from the last-sample background

@@ -268,3 +268,18 @@ def test_sh_basis_against_scipy_on_unit_directions():
             got = comp[:, l * l + l + m]
             err = min(np.abs(got - real).max(), np.abs(got + real).max())   # equal up to the sign convention
             assert err <= 1e-12, (l, m, err)
+
+
+def test_background_colours_in_empty_space_and_behind_a_thin_medium():
+    """RGBRenderer [NS], eval mode: rgb = sum w c + background (1 - sum w).  Zero weights return the background itself; weights that sum to
+    0.25 leave 0.75 of it; "random" is a training device and composites like black."""
+    rgb_s = torch.rand(5, 7, 3)
+    zero = torch.zeros(5, 7, 1)
+    assert torch.equal(onf.render_rgb(rgb_s, zero, "white"), torch.ones(5, 3))
+    assert torch.equal(onf.render_rgb(rgb_s, zero, "black"), torch.zeros(5, 3))
+    assert torch.equal(onf.render_rgb(rgb_s, zero, "last_sample"), rgb_s[:, -1])
+    w = torch.zeros(5, 7, 1)
+    w[:, 2] = 0.25
+    want = 0.25 * rgb_s[:, 2] + 0.75
+    assert torch.allclose(onf.render_rgb(rgb_s, w, "white"), want, atol=1e-7)
+    assert torch.equal(onf.render_rgb(rgb_s, w, "random"), onf.render_rgb(rgb_s, w, "black"))
