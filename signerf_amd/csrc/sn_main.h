@@ -850,5 +850,7 @@ __global__ void sn_clip_expected_kernel(const float* raw, const uint32_t* chunk_
     if (i >= n) return;
     int c = (int)(i / chunk_rays);
     float lo = sn_ordered_float(chunk_minmax[c]), hi = sn_ordered_float(chunk_minmax[n_chunks + c]);
-    out[i] = fminf(fmaxf(raw[i], lo), hi);
+    const float x = raw[i];
+    // torch.clip keeps a NaN (a ray with no weight at all: 0 / 1e-10 x an infinite mid-point); fminf / fmaxf would return the bound
+    out[i] = x != x ? x : fminf(fmaxf(x, lo), hi);
 }

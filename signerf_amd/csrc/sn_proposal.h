@@ -146,8 +146,20 @@ SN_DEV float sn_prop_mlp_mfma(const float* __restrict__ w, const float* feat, in
 // then take the feature scale here: `plain_scale`).
 template <int GRID = 0, int ND = -1, bool DUMP = false, int NCACHE = 0>
 SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, const SnScal5& scal, int log2_t, const float* __restrict__ w,
-                        const float q[3], const SnGridLevels* grid = nullptr, __amdgpu_buffer_rsrc_t plain = __amdgpu_buffer_rsrc_t(),
+                        const float qin[3], const SnGridLevels* grid = nullptr, __amdgpu_buffer_rsrc_t plain = __amdgpu_buffer_rsrc_t(),
                         const SnDenseCopy* dense = nullptr, uint32_t* rec = nullptr, float plain_scale = 1.0f, SnBcCache* cache = nullptr) {
+    // A NaN position (a ray that misses render_aabb / the viewer's crop box carries the 1e10 sentinel: its samples overflow to inf * 0)
+    // is NaN through the reference's whole field.  HERE it must not reach the matrix cores: sn_prop_mlp_mfma serves the rays of lanes j
+    // and j + 32 with ONE tile whose other half is multiplied by zero weights, and 0 * NaN = NaN would hand the partner lane's NaN to a
+    // healthy ray (r03, found by tests/test_gpu_random_parity.py: hit rays next to missing ones lost all their proposal weights and were
+    // resampled uniformly).  So the features of a NaN lane are computed at q = 0 (finite) and its NaN is restored on the result --
+    // q * 0 is +-0 for a finite position and NaN for a NaN one; the branch is wave-uniform and taken only where a wave holds such a ray.
+    const float nanq = fmaf(qin[2], 0.0f, fmaf(qin[1], 0.0f, qin[0] * 0.0f));
+    float q[3] = {qin[0], qin[1], qin[2]};
+    if (__any(nanq != nanq)) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q[c] = nanq != nanq ? 0.0f : q[c];
+    }
     float feat[10];
     if (ND > 0) {
         constexpr int NBCP = ND > SN_BC_PROP ? SN_BC_PROP : ND;
@@ -189,9 +201,9 @@ SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, cons
     }
     float out = o2.x + o2.y;
 #endif
-    // v_max-based ReLU launders NaN; the reference's field is NaN all the way for a NaN position.  Restored by arithmetic (q * 0 is +-0
-    // or NaN), not by a select -- sn_sample_q_fast explains why.
-    return out + fmaf(q[2], 0.0f, fmaf(q[1], 0.0f, q[0] * 0.0f));
+    // the reference's field is NaN all the way for a NaN position (and a v_max-based ReLU would launder it anyway): restored by arithmetic
+    // (+-0 or NaN), not by a select -- sn_sample_q_fast explains why
+    return out + nanq;
 }
 
 // ---- PDFSampler, eval mode (A11), one ray per lane --------------------------------------------------------------------

@@ -27,7 +27,18 @@ def _random_c2w(g):
     return torch.cat([R, t[:, None]], dim=1)
 
 
-def _compare(model, sd, cfg, bundle, tag):
+def _look_at(pos, target):
+    """c2w [3,4] of a camera at `pos` looking at `target` (nerfstudio convention: the camera looks along -z)."""
+    z = pos - target
+    z = z / z.norm()
+    up = torch.tensor([0.0, 0.0, 1.0]) if abs(float(z[2])) < 0.95 else torch.tensor([0.0, 1.0, 0.0])
+    x = torch.linalg.cross(up, z)
+    x = x / x.norm()
+    y = torch.linalg.cross(z, x)
+    return torch.stack([x, y, z, pos], dim=1)
+
+
+def _compare(model, sd, cfg, bundle, tag, min_finite_depth=0.0):
     out = model.get_outputs_for_camera_ray_bundle(bundle)
     n = None if bundle.nears is None else bundle.nears.cpu()
     f = None if bundle.fars is None else bundle.fars.cpu()
@@ -38,6 +49,8 @@ def _compare(model, sd, cfg, bundle, tag):
         assert got.shape == want.shape, (tag, k)
         ok = torch.isfinite(want)
         assert torch.equal(torch.isfinite(got), ok), f"{tag}: {k}: the non-finite pixels differ"
+        if k == "depth":
+            assert float(ok.float().mean()) >= min_finite_depth, f"{tag}: only {float(ok.float().mean()):.2f} of the rays hit the render box: vacuous"
         if not bool(ok.any()):
             continue
         d = (got[ok].double() - want[ok].double())
@@ -69,13 +82,17 @@ def test_random_uniform_sampler_scenarios(gpu, seed):
             c2w = torch.tensor([[1.0, 0, 0, 0.3], [0, 1.0, 0, -0.2], [0, 0, 1.0, 1.1]])
         cams = Cameras(c2w[None], focal, focal, W / 2, H / 2, W, H).to(gpu)
         box = None
-        if trial == 1:
+        if trial == 1:   # a random render box, the camera aimed at it from a random position outside: some rays hit it, some miss (sentinel)
             lo = (torch.rand(3, generator=g) - 1.0) * 0.4
-            box = SceneBox(aabb=torch.stack([lo, lo + torch.rand(3, generator=g) * 0.6 + 0.05]))
+            hi = lo + torch.rand(3, generator=g) * 0.6 + 0.05
+            box = SceneBox(aabb=torch.stack([lo, hi]))
+            pos = (lo + hi) / 2 + torch.nn.functional.normalize(torch.randn(3, generator=g), dim=0) * float(torch.rand(1, generator=g) * 1.0 + 0.8)
+            cams = Cameras(_look_at(pos, (lo + hi) / 2)[None], focal, focal, W / 2, H / 2, W, H).to(gpu)
         model.render_aabb = box
         bundle = cams[0].generate_rays(camera_indices=0, aabb_box=box)
         model.eval()
-        print(f"seed {seed} trial {trial}: {H}x{W}x{S}, far {cfg.far_plane}, box {box is not None}: " + _compare(model, sd, cfg, bundle, f"seed {seed} trial {trial}"))
+        print(f"seed {seed} trial {trial}: {H}x{W}x{S}, far {cfg.far_plane}, box {box is not None}: " +
+              _compare(model, sd, cfg, bundle, f"seed {seed} trial {trial}", min_finite_depth=0.02 if box is not None else 0.0))
     model.render_aabb = None
 
 
@@ -93,8 +110,11 @@ def test_random_proposal_scenarios(gpu, seed):
         box = None
         if trial == 1 and seed % 2 == 0:
             box = SceneBox(aabb=torch.tensor([[-0.3, -0.25, -0.2], [0.2, 0.3, 0.25]]))
+            pos = torch.nn.functional.normalize(torch.randn(3, generator=g), dim=0) * 1.2
+            cams = Cameras(_look_at(pos, torch.zeros(3))[None], focal, focal, W / 2, H / 2, W, H).to(gpu)
         model.render_aabb = box
         bundle = cams[0].generate_rays(camera_indices=0, aabb_box=box)
         model.eval()
-        print(f"seed {seed} trial {trial}: {H}x{W}, samples {(n0, n1)[:iters]} + {S}, box {box is not None}: " + _compare(model, sd, cfg, bundle, f"seed {seed} trial {trial}"))
+        print(f"seed {seed} trial {trial}: {H}x{W}, samples {(n0, n1)[:iters]} + {S}, box {box is not None}: " +
+              _compare(model, sd, cfg, bundle, f"seed {seed} trial {trial}", min_finite_depth=0.02 if box is not None else 0.0))
     model.render_aabb = None

@@ -706,3 +706,36 @@ def test_constant_background_colours(gpu, background, proposals):
     ref_ls = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg_ls), *[t.cpu() for t in (lambda b: (b.origins, b.directions))(
         Cameras(scene.benchmark_cameras(8)[:, :3], 60.0, 60.0, 28.0, 20.0, 56, 40).to(gpu)[2].generate_rays(0))])
     assert rmse(ref["rgb"], ref_ls["rgb"]) > 0.02                              # ... and differs from the last-sample background
+
+
+@pytest.mark.parametrize("precision", ["fp16x2", "fp32"])
+def test_proposal_path_with_render_box_rays_that_miss(gpu, precision):
+    """r03 regression (found by tests/test_gpu_random_parity.py): with proposal nets AND a render box, a ray that misses the box carries the 1e10
+    sentinel and is NaN all the way through the field.  The proposal kernel serves the rays of lanes j and j + 32 with one matrix-core tile
+    whose other half is multiplied by zero weights -- 0 * NaN handed the missing ray's NaN to its healthy partner, whose proposal weights all
+    became 0 (uniform resampling: rgb off by up to 0.1 in those pixels).  Hit rays must match the oracle whatever their neighbours do, the
+    missing rays must be NaN / empty exactly where the reference's are -- expected depth included (torch.clip keeps a NaN)."""
+    cfg = small_config(num_proposal_samples_per_ray=(48, 24), num_nerf_samples_per_ray=16)
+    cfg.precision = precision
+    model, sd = make_model(cfg, gpu)
+    box = SceneBox(aabb=torch.tensor([[-0.3, -0.25, -0.2], [0.2, 0.3, 0.25]]))
+    # a camera off to the side, 1.2 units out: the box covers a band of the 64 x 48 frame, so most 8x8 tiles mix hits and misses
+    c2w = torch.tensor([[0.0, 0.2425, 0.9701, 1.1642], [1.0, 0.0, 0.0, 0.0], [0.0, 0.9701, -0.2425, -0.291]])
+    cam = Cameras(c2w[None], 70.0, 70.0, 32.0, 24.0, 64, 48).to(gpu)[0]
+    model.render_aabb = box
+    b = cam.generate_rays(0, aabb_box=box)
+    model.eval()
+    out = model.get_outputs_for_camera_ray_bundle(b)
+    ref = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg), b.origins.cpu(), b.directions.cpu(), b.nears.cpu(), b.fars.cpu())
+    model.render_aabb = None
+    hit = (b.fars.cpu() < 1e9)
+    frac = float(hit.float().mean())
+    assert 0.05 < frac < 0.7, frac
+    for k, c in (("rgb", 3), ("depth", 1), ("accumulation", 1), ("expected_depth", 1), ("prop_depth_0", 1), ("prop_depth_1", 1)):
+        h = hit.expand(-1, -1, c)
+        got, want = out[k].cpu(), ref[k]
+        assert torch.equal(torch.isnan(got), torch.isnan(want)), f"{k}: NaN pattern differs ({int(torch.isnan(got).sum())} vs {int(torch.isnan(want).sum())})"
+        e = rmse(got[h], want[h])
+        print(f"{k}: rmse on the {int(hit.sum())} hit rays {e:.2e}")
+        assert e <= RMSE_TOL, k
+        assert torch.equal(torch.nan_to_num(got[~h], nan=-1.0, posinf=-2.0), torch.nan_to_num(want[~h], nan=-1.0, posinf=-2.0)), f"{k}: missing rays differ"
