@@ -280,7 +280,7 @@ int sn_clock_probe(uint64_t* out, double seconds, SnStream stream);
  * `torch.sum(visible_mask) > 1e-6` (:770). */
 typedef struct SnMaskOpts {
     int32_t inverse_mask;            /* DatasetGeneratorConfig.inverse_mask */
-    int32_t dilate_w, dilate_h;      /* mask_dialation, cv2.MORPH_ELLIPSE size; 0 = no dilation; each <= 64 */
+    int32_t dilate_w, dilate_h;      /* mask_dialation, cv2.MORPH_ELLIPSE size; 0 = no dilation; each <= 256 */
     int32_t has_manual_depth;        /* manual_depth is not None */
     double manual_min, manual_max;   /* Python numbers in the reference: (max - min) is formed in double, then cast to fp32 */
     float additional_depth_radius;   /* 0.1 */

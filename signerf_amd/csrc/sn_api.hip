@@ -1772,7 +1772,7 @@ int sn_aabb_mask_condition(const float* origins, const float* directions, const 
         return fail(nullptr, SN_ERR_INVALID, "sn_aabb_mask_condition: bad argument");
     if (opts->dilate_w < 0 || opts->dilate_h < 0 || opts->dilate_w > SN_MASK_MAX_K || opts->dilate_h > SN_MASK_MAX_K ||
         ((opts->dilate_w == 0) != (opts->dilate_h == 0)))
-        return fail(nullptr, SN_ERR_INVALID, "sn_aabb_mask_condition: dilation size must be 0 or within [1,64] in both dimensions");
+        return fail(nullptr, SN_ERR_INVALID, "sn_aabb_mask_condition: dilation size must be 0 or within [1," + std::to_string(SN_MASK_MAX_K) + "] in both dimensions");
     if (!workspace || workspace_bytes < sn_mask_workspace_bytes(height, width))
         return fail(nullptr, SN_ERR_WORKSPACE, "sn_aabb_mask_condition: workspace too small");
     hipStream_t st = (hipStream_t)stream;

@@ -8,7 +8,7 @@
 #pragma once
 #include "sn_device.h"
 
-#define SN_MASK_MAX_K 64
+#define SN_MASK_MAX_K 256  // largest structuring element (the reference uses (50, 50), (20, 20) before; 2 x 256 shorts of kernel arguments)
 
 struct SnEllipse {
     int kw, kh, ax, ay;       // size and anchor (cv2 default anchor = ksize / 2)
@@ -151,7 +151,8 @@ __global__ void sn_mask_condition_kernel(SnMaskParams p) {
             range = dmax - dmin;
         }
         const float dn = (p.depth[i] - dmin) / range;
-        p.condition[i] = 1.0f - fminf(fmaxf(dn, 0.0f), 1.0f);
+        // torch.clamp keeps a NaN (the depth of a ray that missed render_aabb, inf / inf of an unbounded selection); fminf / fmaxf would drop it
+        p.condition[i] = 1.0f - (dn != dn ? dn : fminf(fmaxf(dn, 0.0f), 1.0f));
     }
 }
 
