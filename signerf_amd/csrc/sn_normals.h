@@ -461,8 +461,9 @@ __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormals
     const float* eb = nullptr;
     if (MODE == 1) eb = p.ebins + ((int64_t)(ty * p.tiles_x + tx) * (S + 1)) * 64 + lane;
 
-    SnComposite comp;  // its colour channels carry the analytic normals
-    comp.init();
+    SnComposite comp;  // weights only: NormalsRenderer sums w * n WITHOUT the nan_to_num RGBRenderer applies to colours (a ray that misses
+    comp.init();       // the render box has NaN normals and zero weights: its rendered normal is NaN in the reference, not 0.5)
+    float an_acc[3] = {0.f, 0.f, 0.f};
     float pn[3] = {0.f, 0.f, 0.f};
     float t0 = MODE == 0 ? sn_euclid(p.sbins ? p.sbins[0] : 0.0f, s_near, s_far) : eb[0];
 #pragma unroll 1
@@ -510,21 +511,27 @@ __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormals
         const float igl = -__builtin_amdgcn_rcpf(gl);  // (1-ulp reciprocals: the per-sample normals are weighted, summed and renormalised)
         const float an[3] = {g[0] * igl, g[1] * igl, g[2] * igl};
         // PredNormalsFieldHead: tanh, then F.normalize
-        const float tx3[3] = {sn_tanh(x[0]), sn_tanh(x[1]), sn_tanh(x[2])};
+        // (a NaN position -- a ray that misses the render box -- is NaN through the reference's MLPs; the v_max-based ReLUs here launder it, so
+        // it is restored on the result: q * 0 is +-0 for a finite position and NaN for a NaN one)
+        const float nan_term = fmaf(q[2], 0.0f, fmaf(q[1], 0.0f, q[0] * 0.0f));
+        const float tx3[3] = {sn_tanh(x[0]) + nan_term, sn_tanh(x[1]) + nan_term, sn_tanh(x[2]) + nan_term};
         const float itl = __builtin_amdgcn_rcpf(fmaxf(sqrtf(tx3[0] * tx3[0] + tx3[1] * tx3[1] + tx3[2] * tx3[2]), 1e-12f));
         const float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
-        const float w = comp.step<true>(i, t0, t1, density, an[0], an[1], an[2]);
+        const float w = comp.step<true>(i, t0, t1, density, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) pn[c] = fmaf(w * itl, tx3[c], pn[c]);
+        for (int c = 0; c < 3; ++c) {
+            an_acc[c] = fmaf(w, an[c], an_acc[c]);
+            pn[c] = fmaf(w * itl, tx3[c], pn[c]);
+        }
         t0 = t1;
     }
     if (valid) {
         const int64_t pix = (int64_t)py * p.width + px;
         // NormalsRenderer (normalize=True): n / (|n| + 1e-10); NormalsShader: (n + 1) / 2
         if (p.normals) {
-            const float l = sqrtf(comp.c[0] * comp.c[0] + comp.c[1] * comp.c[1] + comp.c[2] * comp.c[2]) + 1e-10f;
+            const float l = sqrtf(an_acc[0] * an_acc[0] + an_acc[1] * an_acc[1] + an_acc[2] * an_acc[2]) + 1e-10f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) p.normals[pix * 3 + c] = (comp.c[c] / l + 1.0f) / 2.0f;
+            for (int c = 0; c < 3; ++c) p.normals[pix * 3 + c] = (an_acc[c] / l + 1.0f) / 2.0f;
         }
         if (p.pred_normals) {
             const float l = sqrtf(pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2]) + 1e-10f;

@@ -118,3 +118,108 @@ def test_random_proposal_scenarios(gpu, seed):
         print(f"seed {seed} trial {trial}: {H}x{W}, samples {(n0, n1)[:iters]} + {S}, box {box is not None}: " +
               _compare(model, sd, cfg, bundle, f"seed {seed} trial {trial}", min_finite_depth=0.02 if box is not None else 0.0))
     model.render_aabb = None
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_normals_scenarios(gpu, seed):
+    """The `predict_normals` outputs (kernel K3) in random scenarios, with and without a render box whose rays partly miss (NaN positions),
+    uniform sampler (identical bins: the plain gate applies to both outputs)."""
+    import dataclasses
+
+    from helpers import rmse
+
+    g = torch.Generator().manual_seed(5000 + seed)
+    S = [24, 7, 40, 16][seed]
+    cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=S, far_plane=[1000.0, 6.0, 1000.0, 30.0][seed])
+    model, sd = make_model(cfg, gpu, seed=seed)
+    ocfg = dataclasses.replace(oracle_config(cfg), predict_normals=True)
+    for trial in range(2):
+        H, W = int(torch.randint(2, 50, (1,), generator=g)), int(torch.randint(2, 50, (1,), generator=g))
+        focal = float(torch.rand(1, generator=g) * 60 + 20)
+        box = None
+        if trial == 1:
+            box = SceneBox(aabb=torch.tensor([[-0.3, -0.25, -0.2], [0.2, 0.3, 0.25]]))
+            pos = torch.nn.functional.normalize(torch.randn(3, generator=g), dim=0) * 1.2
+            cams = Cameras(_look_at(pos, torch.zeros(3))[None], focal, focal, W / 2, H / 2, W, H).to(gpu)
+        else:
+            pos = torch.nn.functional.normalize(torch.randn(3, generator=g), dim=0) * 0.6
+            cams = Cameras(_look_at(pos, torch.zeros(3))[None], focal, focal, W / 2, H / 2, W, H).to(gpu)
+        model.render_aabb = box
+        b = cams[0].generate_rays(camera_indices=0, aabb_box=box)
+        model.eval()
+        out = model.get_outputs_for_camera_ray_bundle(b)
+        n_ = None if b.nears is None else b.nears.cpu()
+        f_ = None if b.fars is None else b.fars.cpu()
+        ref = onf.get_outputs_for_camera_ray_bundle(sd, ocfg, b.origins.cpu(), b.directions.cpu(), n_, f_)
+        hit = torch.ones(H, W, dtype=torch.bool) if box is None else (f_ < 1e9).squeeze(-1)
+        assert int(hit.sum()) >= 4
+        msg = []
+        for k in ("normals", "pred_normals"):
+            got, want = out[k].cpu(), ref[k]
+            e = rmse(got[hit], want[hit])
+            msg.append(f"{k} {e:.1e}")
+            assert e <= 1e-3, f"seed {seed} trial {trial}: {k} rmse {e:.2e} on the hit rays"
+            assert torch.equal(torch.isnan(got[~hit]), torch.isnan(want[~hit])), f"seed {seed} trial {trial}: {k}: NaN pattern of the missing rays differs"
+        print(f"seed {seed} trial {trial}: {H}x{W}x{S}, box {box is not None} ({int(hit.sum())} hits): " + ", ".join(msg))
+    model.render_aabb = None
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_tcnn_scenarios(gpu, seed):
+    """tiny-cuda-nn grid semantics (`implementation="tcnn"`) in random scenarios incl. a render box, proposal path on two of the four seeds."""
+    from helpers import oracle_params_from_tcnn, synthetic_tcnn_checkpoint
+
+    g = torch.Generator().manual_seed(6000 + seed)
+    props = seed % 2 == 1
+    kw = dict(num_proposal_samples_per_ray=(40, 20), num_nerf_samples_per_ray=12) if props else dict(num_proposal_iterations=0, num_nerf_samples_per_ray=[20, 0, 33, 0][seed])
+    cfg = small_config(implementation="tcnn", average_init_density=3.0, **kw)
+    sd = synthetic_tcnn_checkpoint(cfg, seed=seed)
+    model = cfg.setup()
+    model.load_state_dict(sd, strict=False)
+    model = model.to(gpu).eval()
+    params = oracle_params_from_tcnn(sd, cfg)
+    for trial in range(2):
+        H, W = int(torch.randint(1, 49, (1,), generator=g)), int(torch.randint(1, 49, (1,), generator=g))
+        focal = float(torch.rand(1, generator=g) * 60 + 15)
+        box = SceneBox(aabb=torch.tensor([[-0.3, -0.25, -0.2], [0.2, 0.3, 0.25]])) if trial == 1 else None
+        pos = torch.nn.functional.normalize(torch.randn(3, generator=g), dim=0) * (1.2 if box is not None else 0.7)
+        cams = Cameras(_look_at(pos, torch.zeros(3))[None], focal, focal, W / 2, H / 2, W, H).to(gpu)
+        model.render_aabb = box
+        bundle = cams[0].generate_rays(camera_indices=0, aabb_box=box)
+        print(f"tcnn seed {seed} trial {trial}: {H}x{W}, proposals {props}, box {box is not None}: " +
+              _compare(model, params, cfg, bundle, f"tcnn seed {seed} trial {trial}", min_finite_depth=0.02 if box is not None else 0.0))
+    model.render_aabb = None
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_viewer_crop_with_proposals(gpu, seed):
+    """`Model.get_outputs_for_camera(camera, obb_box)` (the viewer's crop box) with proposal nets: rays that miss the oriented box are NaN
+    lanes inside the proposal kernel's waves (the r03 regression), at the viewer's small frame sizes (where K1's split-depth tail is active)."""
+    import math
+
+    from signerf_amd import OrientedBox
+
+    g = torch.Generator().manual_seed(7000 + seed)
+    cfg = small_config(num_proposal_samples_per_ray=[(64, 32), (48, 24), (96, 40)][seed], num_nerf_samples_per_ray=[24, 16, 20][seed], predict_normals=False)
+    model, sd = make_model(cfg, gpu, seed=seed)
+    a = float(torch.rand(1, generator=g) * math.pi)
+    R = torch.tensor([[math.cos(a), -math.sin(a), 0.0], [math.sin(a), math.cos(a), 0.0], [0.0, 0.0, 1.0]])
+    box = OrientedBox(R=R, T=(torch.rand(3, generator=g) - 0.5) * 0.1, S=torch.rand(3, generator=g) * 0.3 + 0.15)
+    H, W = int(torch.randint(24, 80, (1,), generator=g)), int(torch.randint(24, 80, (1,), generator=g))
+    pos = torch.nn.functional.normalize(torch.randn(3, generator=g), dim=0) * 1.0
+    cam = Cameras(_look_at(pos, box.T)[None], 1.1 * W, 1.1 * W, W / 2, H / 2, W, H).to(gpu)[0]
+    b = cam.generate_rays(0, obb_box=box)
+    model.eval()
+    out = model.get_outputs_for_camera(cam, obb_box=box)
+    ref = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg), b.origins.cpu(), b.directions.cpu(), b.nears.cpu(), b.fars.cpu())
+    hit = (b.fars.cpu() < 1e9)
+    frac = float(hit.float().mean())
+    assert 0.03 < frac < 0.98, frac
+    for k, c in (("rgb", 3), ("depth", 1), ("accumulation", 1)):
+        h = hit.expand(-1, -1, c)
+        d = (out[k].cpu()[h].double() - ref[k][h].double())
+        if k == "depth":
+            d = d[(d.abs() / ref[k][h].double().abs().clamp_min(1e-6)) <= 1e-3]     # (median flips are whole-bin jumps: counted elsewhere)
+        e = float(torch.sqrt(torch.mean(d ** 2)))
+        assert e <= 1e-3, f"seed {seed}: {k} rmse {e:.2e} on the {int(hit.sum())} rays inside the crop"
+    print(f"viewer crop seed {seed}: {H}x{W}, {frac:.2f} of the rays inside the box: ok")
