@@ -87,3 +87,35 @@ def test_random_tensor_to_uint8(gpu):
     x = torch.rand(257, 131, 3, generator=g)
     x.view(-1)[:7] = torch.tensor([0.0, 1.0, 254.9 / 255, 0.5, 1 / 255, 0.999999, 127.5 / 255])
     assert torch.equal(tensor_to_uint8(x.to(gpu)).cpu(), torch.from_numpy(su.tensor_to_uint8(x)))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_cameras_generate_rays_and_box_bounds(gpu, seed):
+    """Row a5 for arbitrary pin-hole cameras: any pose, fx != fy, principal point off centre (even outside the frame), frames down to 1x1;
+    with a render box the bundle's nears / fars against nerfstudio's clamped slab test (oracle), the SIGNeRF helper `intersect_with_aabb`
+    (row a4, no clamp, 1 / (d + 1e-6)) bit for bit on the same rays."""
+    from signerf_amd import Cameras, SceneBox, intersect_with_aabb
+
+    g = torch.Generator().manual_seed(8000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    H, W = [(1, 1), (1, 64), (64, 1), (7, 9)][seed] if seed < 4 else (ri(2, 120), ri(2, 120))
+    fx, fy = float(torch.rand(1, generator=g) * 200 + 5), float(torch.rand(1, generator=g) * 200 + 5)
+    cx, cy = float((torch.rand(1, generator=g) * 1.4 - 0.2) * W), float((torch.rand(1, generator=g) * 1.4 - 0.2) * H)
+    c2w = _random_c2w(g)
+    cam = Cameras(c2w[None], fx, fy, cx, cy, W, H).to(gpu)[0]
+    lo = (torch.rand(3, generator=g) - 0.5) * 2.0
+    box = SceneBox(aabb=torch.stack([lo, lo + torch.rand(3, generator=g) * 1.5 + 0.05]))
+    b = cam.generate_rays(camera_indices=0, aabb_box=box)
+    ref = onf.generate_rays(c2w, fx, fy, cx, cy, H, W)
+    assert b.origins.shape == (H, W, 3) and torch.equal(b.origins.cpu(), ref["origins"])
+    assert float((b.directions.cpu() - ref["directions"]).abs().max()) <= 3e-7
+    assert float((b.metadata["directions_norm"].cpu() - ref["directions_norm"]).abs().max() / ref["directions_norm"].abs().max()) <= 1e-6
+    o, d = b.origins.cpu().reshape(-1, 3), b.directions.cpu().reshape(-1, 3)
+    tmin, tmax = onf.intersect_aabb_ns(o, d, box.aabb.flatten())
+    miss = tmin >= 1e9
+    assert torch.equal((b.nears.cpu().reshape(-1) >= 1e9), miss), "the rays that miss the box differ"
+    assert torch.allclose(b.nears.cpu().reshape(-1)[~miss], tmin[~miss], rtol=2e-6, atol=1e-6) and torch.allclose(b.fars.cpu().reshape(-1)[~miss], tmax[~miss], rtol=2e-6, atol=1e-6)
+    n, f = intersect_with_aabb(b.origins, b.directions, box.aabb)
+    rn, rf = su.intersect_with_aabb(b.origins.cpu(), b.directions.cpu(), box.aabb)
+    assert torch.equal(torch.nan_to_num(n.cpu(), nan=-7.0), torch.nan_to_num(rn, nan=-7.0)) and torch.equal(torch.nan_to_num(f.cpu(), nan=-7.0), torch.nan_to_num(rf, nan=-7.0))
+    print(f"seed {seed}: {H}x{W}, fx {fx:.1f} fy {fy:.1f} c ({cx:.1f}, {cy:.1f}): {int((~miss).sum())} of {miss.numel()} rays hit the box")
