@@ -32,9 +32,9 @@ struct SnMainImg {
     static constexpr int B2 = 10304;    // [1][2][16]
     static constexpr int BC1 = 10336;   // [2][2][16]
     static constexpr int BC2 = 10400;   // [2][2][16]
-    static constexpr int W3 = 10464;    // [n=3][h=2][32]
-    static constexpr int B3 = 10656;    // [4]: the 3 biases; [3] = 1 / (output scale of layer 2) of the split-precision image (h0 = row 0 * that)
-    static constexpr int TOTAL = 10660; // floats (multiple of 4)
+    static constexpr int W3 = 10464;    // [n=4][h=2][32]; n = 3 is a row of zeros (the A operand of the 4x4x1 MFMAs of colour layer 3 reads row lane & 3)
+    static constexpr int B3 = 10720;    // [4]: the 3 biases; [3] = 1 / (output scale of layer 2) of the split-precision image (h0 = row 0 * that)
+    static constexpr int TOTAL = 10724; // floats (multiple of 4)
 };
 
 // acc[rt] (tile 0) / acc[rt] (tile 1) <- bias + W . op     (exact fp32 MFMA)
@@ -250,6 +250,16 @@ struct SnOpH {  // one B operand (8 k-slots of one 32-sample tile), hi and lo pa
 #ifndef SN_MFMA_PRIO
 #define SN_MFMA_PRIO 1
 #endif
+// EXPERIMENT (r03, measured and NOT adopted; profiles/r03_l3_mfma_ab.txt): colour layer 3 of the split-precision kernel as 64 x
+// v_mfma_f32_4x4x1_16b_f32 instead of 192 v_fmac (sn_main_field_h).  1428 -> 1236 VALU per wave-step, bit-identical with 2 accumulator
+// chains -- and 6 % SLOWER (2.83 -> 2.99-3.08 ms; 4 chains spill: 3.29 ms): the fp32-input MFMA holds the vector port like the 32x32x2
+// form does (r02), and every one of them waits for a v_max (its ReLU'd operand) and for its predecessor's accumulator.
+#ifndef SN_L3_MFMA
+#define SN_L3_MFMA 0
+#endif
+#ifndef SN_L3_CHAINS
+#define SN_L3_CHAINS 2
+#endif
 #ifndef SN_MFMA_H  // (tools/probes/mlp_probe.hip overrides it to time the VALU part of the MLP alone)
 #define SN_MFMA_H(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, ACC, 0, 0, 0)
 #endif
@@ -392,8 +402,52 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
         sn_acc_to_ops<SN_RELU_FOLD != 0>(a0[rt], true, op0[2 * rt], op0[2 * rt + 1]);
         sn_acc_to_ops<SN_RELU_FOLD != 0>(a1[rt], true, op1[2 * rt], op1[2 * rt + 1]);
     }
-    // ---- colour layer 2 (two 32-row passes: halves the live accumulators, same MFMAs) + colour layer 3 on the VALU ----
+    // ---- colour layer 2 (two 32-row passes: halves the live accumulators, same MFMAs) + colour layer 3 ----
     const int h = lane >> 5;
+#if SN_L3_MFMA
+    // Colour layer 3 (64 -> 3) on the matrix cores as 64 x v_mfma_f32_4x4x1_16b_f32 (r03): fp32 operands (no hi / lo split), 16 blocks of
+    // 4 lanes, D[i][j] += A[i] B[j] with A from lane 4 b + i, B from lane 4 b + j, D[i][j] in register i of lane 4 b + j.  Register j of a
+    // layer-2 accumulator tile already holds "hidden unit rho(j) + 4 h (+ 32 rt) of the lane's own sample": B = relu of it, A = the
+    // layer-3 weight of THAT unit for channel (lane & 3) -- the four lanes of a block share h -- read from the image's W3 rows [n][h]
+    // (row n = 3 is zeros), and register n of the 4-register accumulator is channel n of the lane's sample, summed over the lane half's
+    // 32 units in the order the VALU form used (each step a fused multiply-add: the results are bit-identical to it).  192 v_fmac leave the
+    // vector port; tools/probes/mfma4x4_probe.hip (K1-shaped mix of INDEPENDENT instructions, 3 waves per SIMD) promised 5.39 -> 4.94 ms --
+    // the real kernel is slower (see SN_L3_MFMA above).
+    // SN_L3_CHAINS independent accumulators per tile: a 4x4x1 MFMA that reads the previous one's result waits for it
+    constexpr int NCH = SN_L3_CHAINS;
+    f32x4 q0[NCH], q1[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) q0[k] = q1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4* w3 = (const f32x4*)(tail + SnMainImgH::W3 + ((lane & 3) * 2 + h) * 32);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        f32x16 c0[1], c1[1];
+        sn_mlp_layer_h<1, 4>(ldsb + SnMainImgH::WC2 + rt * 8192, tail + SnMainImgH::BC2 + rt * 32, op0, op1, c0, c1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 wv = w3[rt * 4 + r4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                q0[e % NCH] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], sn_relu(c0[0][4 * r4 + e]), q0[e % NCH], 0, 0, 0);
+                q1[e % NCH] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], sn_relu(c1[0][4 * r4 + e]), q1[e % NCH], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float p0[3], p1[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        float a = q0[0][n], b = q1[0][n];
+#pragma unroll
+        for (int k = 1; k < NCH; ++k) {
+            a += q0[k][n];
+            b += q1[k][n];
+        }
+        p0[n] = a;
+        p1[n] = b;
+    }
+#else
     // plain fp32 FMAs (NOT v_pk_fma_f32: packed fp32 ops are mutually exclusive with the matrix pipe on gfx950 and would stall
     // behind the other waves' MFMAs -- tools/probes/overlap2_probe.hip); two accumulators per channel and tile for issue distance
     float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
@@ -423,6 +477,7 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+#endif
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
         float a = p0[n], b = p1[n];
