@@ -739,3 +739,40 @@ def test_proposal_path_with_render_box_rays_that_miss(gpu, precision):
         print(f"{k}: rmse on the {int(hit.sum())} hit rays {e:.2e}")
         assert e <= RMSE_TOL, k
         assert torch.equal(torch.nan_to_num(got[~h], nan=-1.0, posinf=-2.0), torch.nan_to_num(want[~h], nan=-1.0, posinf=-2.0)), f"{k}: missing rays differ"
+
+
+def test_more_render_streams_than_the_handle_tracks(gpu):
+    """The handle keeps one completion event per stream that rendered with it, at most 64: with more distinct streams an entry is retired by
+    making the NEW render's stream wait for it first (so its render is still covered by an event an upload waits for).  70 streams render one
+    frame each, then the weights change: every frame must be the old weights' frame, the next render the new weights'."""
+    cfg = small_config(num_proposal_samples_per_ray=(32, 16), num_nerf_samples_per_ray=12)
+    model, sd_a = make_model(cfg, gpu, seed=0)
+    sd_b = {k: v.to(gpu) for k, v in scene.synthetic_state_dict(cfg, seed=5).items()}
+    b = Cameras(scene.benchmark_cameras(8)[:, :3], 160.0, 160.0, 64.0, 48.0, 128, 96).to(gpu)[3].generate_rays(0)
+    expect = model.get_outputs_for_camera_ray_bundle(b)["rgb"].clone()
+    torch.cuda.synchronize()
+    # torch.cuda.Stream() hands out streams of a pool of 32: 70 DISTINCT streams come from the HIP runtime itself
+    import ctypes
+    import os
+
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    raw = []
+    for _ in range(70):
+        sp = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(sp)) == 0
+        raw.append(sp)
+    assert len({sp.value for sp in raw}) == 70
+    streams = [torch.cuda.ExternalStream(sp.value, device=gpu) for sp in raw]
+    frames = []
+    for st in streams:
+        with torch.cuda.stream(st):
+            frames.append(model.get_outputs_for_camera_ray_bundle(b)["rgb"])
+    model.load_state_dict(sd_b, strict=False)
+    after = model.get_outputs_for_camera_ray_bundle(b)["rgb"]       # re-uploads on the default stream while the 70 renders may still run
+    torch.cuda.synchronize()
+    assert all(torch.equal(f, expect) for f in frames)
+    assert not torch.equal(after, expect)
+    del frames, streams
+    torch.cuda.synchronize()
+    for sp in raw:
+        hip.hipStreamDestroy(sp)
