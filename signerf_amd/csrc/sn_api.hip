@@ -110,7 +110,7 @@ RenderChain g_chain;
 
 // What IS ordered, per handle: weight uploads against the renders that read the buffers they overwrite.
 //   * every render makes its stream wait for the handle's last upload / finalize (weights_ev) and, when its kernels are enqueued,
-//     records one of the handle's render events (a small ring: the N most recent renders, whichever streams they ran on);
+//     records its STREAM's render event (SnContext::render_ev: one event per stream, re-recorded by every render of that stream);
 //   * sn_upload_weights / sn_finalize_weights make their stream wait for all of those before touching a buffer.
 int env_int(const char* name) {
     const char* e = getenv(name);

@@ -76,7 +76,11 @@ SN_DEV bool sn_sample_q(const float o[3], const float d[3], float start, float e
 
 // Fused-kernel form: the same map with v_rcp_f32 (1 ulp) instead of four IEEE divisions in the contraction.  Positions only
 // feed the fields (float work); the bins themselves (sn_euclid) stay strict.  Saves ~36 VALU instructions per sample.
-SN_DEV bool sn_sample_q_fast(const float o[3], const float d[3], float start, float end, float q[3]) {
+// NANFREE (the proposal kernel, whose one-tile MLP must not see a NaN operand -- sn_prop_h0): q comes back finite, a NaN position as
+// q = 0, and *nanq carries it: +-0 for a finite position, NaN otherwise.  The NaN is dropped by the `clamp` modifier of the selector
+// multiply itself (q m is in [0, 1); a compute kernel runs with DX10_CLAMP set: NaN clamps to 0) -- no instruction added, no select.
+template <bool NANFREE = false>
+SN_DEV bool sn_sample_q_fast(const float o[3], const float d[3], float start, float end, float q[3], float* nanq = nullptr) {
     const float t = (start + end) * 0.5f;
     float p[3];
 #pragma unroll
@@ -98,6 +102,12 @@ SN_DEV bool sn_sample_q_fast(const float o[3], const float d[3], float start, fl
         sel = sel && (q[c] > 0.0f) && (q[c] < 1.0f);
     }
     const float m = sel ? 1.0f : 0.0f;
+    if (NANFREE) {
+        *nanq = fmaf(q[2], 0.0f, fmaf(q[1], 0.0f, q[0] * 0.0f));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(q[c]) : "v"(q[c]), "v"(m));
+        return sel;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) q[c] = q[c] * m;
     return sel;

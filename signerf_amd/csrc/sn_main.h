@@ -462,6 +462,13 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
             r0[j] = sn_relu(c0[0][j]);
             r1[j] = sn_relu(c1[0][j]);
         }
+#if defined(SN_EXP_NO_L3)  // experiment (wrong images): the ceiling of moving colour layer 3 off the vector port
+        for (int n = 0; n < 3; ++n) {
+            p0[n] += r0[n] + r0[4 + n] + r0[8 + n] + r0[12 + n];
+            p1[n] += r1[n] + r1[4 + n] + r1[8 + n] + r1[12 + n];
+        }
+        if (false)
+#endif
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             const f32x4* w = (const f32x4*)(tail + SnMainImgH::W3 + (n * 2 + h) * 32);

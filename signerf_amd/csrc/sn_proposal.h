@@ -147,18 +147,24 @@ SN_DEV float sn_prop_mlp_mfma(const float* __restrict__ w, const float* feat, in
 template <int GRID = 0, int ND = -1, bool DUMP = false, int NCACHE = 0>
 SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, const SnScal5& scal, int log2_t, const float* __restrict__ w,
                         const float qin[3], const SnGridLevels* grid = nullptr, __amdgpu_buffer_rsrc_t plain = __amdgpu_buffer_rsrc_t(),
-                        const SnDenseCopy* dense = nullptr, uint32_t* rec = nullptr, float plain_scale = 1.0f, SnBcCache* cache = nullptr) {
+                        const SnDenseCopy* dense = nullptr, uint32_t* rec = nullptr, float plain_scale = 1.0f, SnBcCache* cache = nullptr,
+                        const float* nanq_in = nullptr) {
     // A NaN position (a ray that misses render_aabb / the viewer's crop box carries the 1e10 sentinel: its samples overflow to inf * 0)
     // is NaN through the reference's whole field.  HERE it must not reach the matrix cores: sn_prop_mlp_mfma serves the rays of lanes j
     // and j + 32 with ONE tile whose other half is multiplied by zero weights, and 0 * NaN = NaN would hand the partner lane's NaN to a
     // healthy ray (r03, found by tests/test_gpu_random_parity.py: hit rays next to missing ones lost all their proposal weights and were
     // resampled uniformly).  So the features of a NaN lane are computed at q = 0 (finite) and its NaN is restored on the result --
-    // q * 0 is +-0 for a finite position and NaN for a NaN one; the branch is wave-uniform and taken only where a wave holds such a ray.
-    const float nanq = fmaf(qin[2], 0.0f, fmaf(qin[1], 0.0f, qin[0] * 0.0f));
+    // q * 0 is +-0 for a finite position and NaN for a NaN one.
+    // The marching loop hands over a NaN-free q and the NaN separately (sn_sample_q_fast<true>: no instruction spent); the stage-level
+    // entry point passes the raw position and pays three v_max here (max(NaN, 0) = 0; q >= 0 otherwise).
     float q[3] = {qin[0], qin[1], qin[2]};
-    if (__any(nanq != nanq)) {
+    float nanq;
+    if (nanq_in) {
+        nanq = *nanq_in;
+    } else {
+        nanq = fmaf(qin[2], 0.0f, fmaf(qin[1], 0.0f, qin[0] * 0.0f));
 #pragma unroll
-        for (int c = 0; c < 3; ++c) q[c] = nanq != nanq ? 0.0f : q[c];
+        for (int c = 0; c < 3; ++c) q[c] = __builtin_fmaxf(qin[c], 0.0f);
     }
     float feat[10];
     if (ND > 0) {
@@ -376,19 +382,20 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
         // keep the (loop-invariant) MLP weight loads inside the loop: hoisted, they cost ~200 registers (see sn_main.h)
         asm volatile("" ::: "memory");
         const float e1 = eb_shared ? eb_shared[i + 1] : sn_euclid(sb(i + 1), s_near, s_far);
-        float q[3];
-        const bool sel = sn_sample_q_fast(o, d, e0, e1, q);
+        float q[3], nanq;
+        const bool sel = sn_sample_q_fast<true>(o, d, e0, e1, q, &nanq);
         uint32_t* rec = nullptr;
         if (DUMP && dump_ray >= 0) {
             const size_t smp = (size_t)dump_ray * (size_t)N + (size_t)i;
             if (p.dump_fetch[LV]) rec = p.dump_fetch[LV] + smp * 40;
-            if (p.dump_q[LV]) {
-                p.dump_q[LV][smp * 3 + 0] = q[0];
-                p.dump_q[LV][smp * 3 + 1] = q[1];
-                p.dump_q[LV][smp * 3 + 2] = q[2];
+            if (p.dump_q[LV]) {  // the position as the reference holds it (NaN for a missing ray)
+                p.dump_q[LV][smp * 3 + 0] = q[0] + nanq;
+                p.dump_q[LV][smp * 3 + 1] = q[1] + nanq;
+                p.dump_q[LV][smp * 3 + 2] = q[2] + nanq;
             }
         }
-        const float h0 = sn_prop_h0<GRID, ND, DUMP, NCACHE>(rsrc, pi, scal, log2_t, wp, q, &p.grid[LV], plain, &p.dense[LV], rec, p.feat_scale[LV], cache);
+        const float h0 = sn_prop_h0<GRID, ND, DUMP, NCACHE>(rsrc, pi, scal, log2_t, wp, q, &p.grid[LV], plain, &p.dense[LV], rec, p.feat_scale[LV], cache,
+                                                            &nanq);
         const float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
         float wt;
         {

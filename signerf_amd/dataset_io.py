@@ -72,10 +72,13 @@ class GeneratedDataset:
 
     SUBDIRS = ("images", "masks", "conditions", "rendered", "originals")
 
-    def __init__(self, path: Union[str, Path], dataset_name: str, downscale_factor: int = 2, write_images: bool = True, save_workers: int = 0):
+    def __init__(self, path: Union[str, Path], dataset_name: str, downscale_factor: int = 2, write_images: bool = True, save_workers: int = 0,
+                 png_compress_level: Optional[int] = None):
         """write_images=False: directories and transforms.json only (the bench's "PNG writes off" leg).  save_workers > 0: PNG encoding
         and the file writes run on that many host threads (zlib releases the GIL) while the caller goes on to the next view; the
-        bytes of a file do not depend on it.  ``flush()`` waits for them."""
+        bytes of a file do not depend on it.  ``flush()`` waits for them.  png_compress_level: None = the reference's call
+        (``Image.save(path)``, zlib level 6); 1 encodes ~2.3x faster into ~15 % larger files holding the same pixels."""
+        self.png_compress_level = png_compress_level
         self.dataset_path = Path(path) / dataset_name
         self.downscale_factor = downscale_factor
         self.write_images = write_images
@@ -108,8 +111,10 @@ class GeneratedDataset:
         assert len(tensor.shape) == 3 and tensor.shape[2] in (1, 3), "Tensor must be of shape (H, W, 1) or (H, W, 3)"
         u8 = tensor_to_uint8(tensor).cpu().numpy()
 
+        kw = {} if self.png_compress_level is None else {"compress_level": int(self.png_compress_level)}
+
         def write():
-            (Image.fromarray(u8.squeeze(), "L") if u8.shape[2] == 1 else Image.fromarray(u8)).save(path)
+            (Image.fromarray(u8.squeeze(), "L") if u8.shape[2] == 1 else Image.fromarray(u8)).save(path, **kw)
 
         if self._pool is None:
             write()

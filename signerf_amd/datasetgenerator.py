@@ -262,8 +262,10 @@ class DatasetGenerator:
     def __init__(self, config: DatasetGeneratorConfig, original_transform_matrix: Optional[Tensor] = None, original_scale_factor: float = 1.0,
                  transform_poses_to_original_space: Optional[Callable[[Tensor], Tensor]] = None, device="cuda",
                  diffuse: Optional[Callable[[Tensor, Tensor, Tensor, Tensor], Tensor]] = None, group=None, write_images: bool = True,
-                 save_workers: Optional[int] = None, precompute: bool = True, profile: bool = False) -> None:
+                 save_workers: Optional[int] = None, precompute: bool = True, profile: bool = False,
+                 png_compress_level: Optional[int] = None) -> None:
         self.config = config
+        self.png_compress_level = png_compress_level   # None: PIL's default, the files the reference writes (dataset_io.GeneratedDataset)
         self.device = device
         self.original_transform_matrix = original_transform_matrix if original_transform_matrix is not None else torch.eye(4)[:3]
         self.original_scale_factor = original_scale_factor
@@ -311,7 +313,7 @@ class DatasetGenerator:
         from .dataset_io import GeneratedDataset
 
         self.dataset = GeneratedDataset(self.config.path, self.dataset_name, self.downscale_factor, write_images=self.write_images,
-                                        save_workers=self.save_workers)
+                                        save_workers=self.save_workers, png_compress_level=self.png_compress_level)
         self.dataset.init_directory()
         self.dataset_path, self.transforms_path = self.dataset.dataset_path, self.dataset.transforms_path
         for key, d in self.dataset.dirs.items():  # images_path, masks_scaled_path, ... as attributes, like the reference's

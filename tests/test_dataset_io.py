@@ -66,3 +66,26 @@ def test_dataset_directory_round_trip(gpu, tmp_path):
     frame = json.load(open(ds.transforms_path))["frames"][1]
     assert set(frame) == {"fl_x", "fl_y", "cx", "cy", "w", "h", "file_path", "_mask_path", "transform_matrix", "scene_transform_matrix"}
     assert frame["fl_y"] == 52.0 and frame["w"] == 32 and frame["file_path"] == "./images/image_1.png"
+
+
+@pytest.mark.gpu
+def test_png_compress_level_changes_bytes_not_pixels(gpu, tmp_path):
+    """GeneratedDataset(png_compress_level=1): the faster encoding of the bench's third leg holds the pixels the reference's default call
+    writes; written from the thread pool or inline."""
+    from PIL import Image
+
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(96, 128, 3, generator=g) * 0.2 + torch.linspace(0, 0.8, 128)[None, :, None]).to(gpu)
+    m = (torch.rand(96, 128, 1, generator=g) > 0.5).float().to(gpu)
+    out = {}
+    for name, kw in (("default", {}), ("fast", {"png_compress_level": 1, "save_workers": 4})):
+        ds = dataset_io.GeneratedDataset(tmp_path, name, **kw)
+        ds.init_directory()
+        ds.save_image(x, ds.dirs["images"] / "a.png")
+        ds.save_image(m, ds.dirs["masks"] / "m.png")
+        ds.flush()
+        out[name] = [(np.array(Image.open(p)), os.path.getsize(p)) for p in (ds.dirs["images"] / "a.png", ds.dirs["masks"] / "m.png")]
+    for (a, na), (b, nb) in zip(out["default"], out["fast"]):
+        assert np.array_equal(a, b)
+    assert out["fast"][0][1] != out["default"][0][1]
+    assert np.array_equal(out["default"][0][0], (x.cpu().numpy() * 255).astype(np.uint8))

@@ -52,12 +52,13 @@ if world > 1:
     tmp = box[0]
 
 
-def run(write_images: bool, tag: str):
+def run(write_images: bool, tag: str, png_level=None):
     best = None
     for rep in range(a.reps + 1):   # the first repetition warms the handle, the streams and the allocator
         gcfg = DatasetGeneratorConfig(path=tmp, dataset_name=f"{tag}{rep}", fx=1.2 * S, fy=1.2 * S, cx=S / 2, cy=S / 2, width=S, height=S,
                                       rows=3, cols=3)   # aabb +-0.1, dilation (50, 50), downscale 2: the reference's defaults
-        gen = DatasetGenerator(gcfg, torch.eye(4)[:3], 1.0, None, device=dev, write_images=write_images, save_workers=a.save_workers, profile=True)
+        gen = DatasetGenerator(gcfg, torch.eye(4)[:3], 1.0, None, device=dev, write_images=write_images, save_workers=a.save_workers, profile=True,
+                               png_compress_level=png_level)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -73,9 +74,9 @@ def run(write_images: bool, tag: str):
 n = 8 + a.views
 out = {"views": n, "size": [S, S], "ranks": world, "backend": (dist.get_backend() if world > 1 else None),
        "workload": "8 reference + %d random_sphere_poses views, 256+96+48 samples, aabb +-0.1, dilation 50x50, downscale 2, identity diffuser" % a.views}
-for write, tag in ((False, "nopng"), (True, "png")):
-    dt, tm = run(write, tag)
-    out["png_writes_" + ("on" if write else "off")] = {
+for write, tag, level in ((False, "nopng", None), (True, "png", None), (True, "pngl1", 1)):
+    dt, tm = run(write, tag, level)
+    out["png_writes_" + (("on" if level is None else "on_compress_level_%d" % level) if write else "off")] = {
         "total_ms": dt * 1e3, "ms_per_view": dt * 1e3 / n,
         "render_stage_ms": tm.get("render_s", 0) * 1e3, "render_ms_per_view": tm.get("render_s", 0) * 1e3 / n,
         "field_evaluations_per_s": n * S * S * 400 / max(tm.get("render_s", 0), 1e-9),
