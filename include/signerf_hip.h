@@ -93,6 +93,11 @@ typedef struct SnFieldDesc {
     SnHashMlpDesc proposals[SN_MAX_PROPOSALS];
     float average_init_density;   /* signerf_config.py:35 -> 0.01 */
     float histogram_padding;      /* PDFSampler: 0.01 */
+    /* Position -> grid coordinate of every field (appended in r03; zero = nerfacto's default): 0 = SceneContraction(order=inf) then
+     * (p + 2) / 4; 1 = NerfactoModelConfig.disable_scene_contraction: SceneBox.get_normalized_positions, (p - aabb[0]) / (aabb[1] -
+     * aabb[0]) with the model's scene box below (min xyz, max xyz).  The (0, 1) selector follows in both cases. */
+    int32_t disable_scene_contraction;
+    float aabb[6];
 } SnFieldDesc;
 
 /* Per-call render options (NerfactoModelConfig values that shape one eval render). */
@@ -117,6 +122,10 @@ typedef struct SnRenderOpts {
      * device and composites like black in eval mode).  rgb = sum w c + background (1 - sum w), clamped to [0, 1]. */
     int32_t background_mode;
     float background_rgb[3];
+    /* The initial sampler (NerfactoModelConfig.proposal_initial_sampler; appended in r03, zero = the nerfacto default): 0 = "piecewise",
+     * UniformLinDispPiecewiseSampler (s(x) = x / 2 below 1, 1 - 1 / (2 x) above); 1 = "uniform", UniformSampler (s(x) = x).  Every
+     * spacing bin of the proposal chain maps to a distance through it: t = s^-1(b s(far) + (1 - b) s(near)). */
+    int32_t spacing_mode;
 } SnRenderOpts;
 
 /* ---- lifetime -------------------------------------------------------------------------- */

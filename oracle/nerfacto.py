@@ -79,6 +79,14 @@ class NerfactoConfig:
     background_color: str = "last_sample"
     """RGBRenderer's background [NS]: "last_sample" (nerfacto's default; SIGNeRF does not override it), "black", "white", or "random" (a
     training device: in eval mode combine_rgb returns the composited colour as it is, i.e. a black background)."""
+    proposal_initial_sampler: str = "piecewise"
+    """NerfactoModelConfig.proposal_initial_sampler [NS]: "piecewise" (UniformLinDispPiecewiseSampler, the default; SIGNeRF does not
+    override it) or "uniform" (UniformSampler: spacing_fn = spacing_fn_inv = identity)."""
+    disable_scene_contraction: bool = False
+    """NerfactoModelConfig.disable_scene_contraction [NS]: the fields get ``spatial_distortion=None`` and normalise positions with
+    ``SceneBox.get_normalized_positions(positions, aabb)`` = (p - aabb[0]) / (aabb[1] - aabb[0]) instead of contraction + (p + 2) / 4."""
+    scene_aabb: Tuple[Tuple[float, float, float], Tuple[float, float, float]] = ((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0))
+    """the model's ``scene_box.aabb`` (only read when the contraction is disabled)."""
     predict_normals: bool = False
     """signerf_config.py:33 sets it; adds "normals" (analytic) and "pred_normals" to the outputs (row a16)."""
     main: HashMLPConfig = field(
@@ -201,25 +209,30 @@ def collider_near_far(num_rays: int, cfg: NerfactoConfig, training: bool = False
     return ones * near, ones * cfg.far_plane
 
 
-def spacing_fn(x: Tensor) -> Tensor:
-    """s(x) of UniformLinDispPiecewiseSampler (A4)."""
+def spacing_fn(x: Tensor, sampler: str = "piecewise") -> Tensor:
+    """s(x) of UniformLinDispPiecewiseSampler (A4); UniformSampler ("uniform"): the identity."""
+    if sampler == "uniform":
+        return x
     return torch.where(x < 1, x / 2, 1 - 1 / (2 * x))
 
 
-def spacing_fn_inv(x: Tensor) -> Tensor:
+def spacing_fn_inv(x: Tensor, sampler: str = "piecewise") -> Tensor:
     """s^-1(y) (A4)."""
+    if sampler == "uniform":
+        return x
     return torch.where(x < 0.5, 2 * x, 1 / (2 - 2 * x))
 
 
-def spacing_to_euclidean(bins: Tensor, nears: Tensor, fars: Tensor) -> Tensor:
-    s_near, s_far = spacing_fn(nears), spacing_fn(fars)
-    return spacing_fn_inv(bins * s_far + (1 - bins) * s_near)
+def spacing_to_euclidean(bins: Tensor, nears: Tensor, fars: Tensor, sampler: str = "piecewise") -> Tensor:
+    """SpacedSampler's ``spacing_to_euclidean_fn``: s^-1(x s_far + (1 - x) s_near)."""
+    s_near, s_far = spacing_fn(nears, sampler), spacing_fn(fars, sampler)
+    return spacing_fn_inv(bins * s_far + (1 - bins) * s_near, sampler)
 
 
-def initial_sampler(nears: Tensor, fars: Tensor, num_samples: int):
+def initial_sampler(nears: Tensor, fars: Tensor, num_samples: int, sampler: str = "piecewise"):
     """SpacedSampler in eval mode (no jitter) -> (spacing_bins [1,N+1], euclid_bins [R,N+1])."""
     bins = torch.linspace(0.0, 1.0, num_samples + 1)[None, ...]
-    return bins, spacing_to_euclidean(bins, nears, fars)
+    return bins, spacing_to_euclidean(bins, nears, fars, sampler)
 
 
 # ----------------------------------------------------------------------------
@@ -238,10 +251,19 @@ def contract_inf(x: Tensor) -> Tensor:
     return torch.where(mag < 1, x, (2 - (1 / mag)) * (x / mag))
 
 
-def normalized_positions(positions: Tensor):
-    """Contraction, (p+2)/4, selector, masking (A6) -> (q, selector)."""
-    q = contract_inf(positions)
-    q = (q + 2.0) / 4.0
+def scene_aabb(cfg) -> Optional[Tensor]:
+    """The box the fields normalise with when the contraction is disabled (None: contraction)."""
+    return torch.tensor(cfg.scene_aabb, dtype=torch.float32) if cfg.disable_scene_contraction else None
+
+
+def normalized_positions(positions: Tensor, aabb: Optional[Tensor] = None):
+    """Contraction, (p+2)/4 -- or, with ``spatial_distortion=None``, SceneBox.get_normalized_positions --, selector, masking (A6)
+    -> (q, selector)."""
+    if aabb is not None:
+        q = (positions - aabb[0]) / (aabb[1] - aabb[0])
+    else:
+        q = contract_inf(positions)
+        q = (q + 2.0) / 4.0
     selector = ((q > 0.0) & (q < 1.0)).all(dim=-1)
     q = q * selector[..., None]
     return q, selector
@@ -336,9 +358,10 @@ def mlp_forward(x: Tensor, params: Dict[str, Tensor], prefix: str, num_layers: i
     return x
 
 
-def density_field(params: Dict[str, Tensor], prefix: str, hcfg: HashMLPConfig, positions: Tensor, average_init_density: float):
-    """positions [R,N,3] (world) -> density [R,N,1], mlp_out [R,N,out_dim], q, selector  (A6-A9)."""
-    q, selector = normalized_positions(positions)
+def density_field(params: Dict[str, Tensor], prefix: str, hcfg: HashMLPConfig, positions: Tensor, average_init_density: float,
+                  aabb: Optional[Tensor] = None):
+    """positions [R,N,3] (world) -> density [R,N,1], mlp_out [R,N,out_dim], q, selector  (A6-A9).  aabb: see scene_aabb()."""
+    q, selector = normalized_positions(positions, aabb)
     if hcfg.grid == "tcnn":
         from . import tcnn_layout
 
@@ -466,7 +489,7 @@ def field_analytic_normals(params: Dict[str, Tensor], cfg: NerfactoConfig, posit
     ``_sample_locations`` -- the contracted, [0,1]-normalised, selector-masked positions, not the world positions.
     positions [R,N,3] (world) -> [R,N,3].  autograd through the hash grid = the gradient of the trilinear blend."""
     hcfg = cfg.main
-    q, _ = normalized_positions(positions)
+    q, _ = normalized_positions(positions, scene_aabb(cfg))
     with torch.enable_grad():
         q = q.detach().clone().requires_grad_(True)
         if hcfg.grid == "tcnn":
@@ -579,23 +602,24 @@ def get_outputs(params: Dict[str, Tensor], cfg: NerfactoConfig, origins: Tensor,
         is_prop = level < n_prop
         n = cfg.num_proposal_samples_per_ray[level] if is_prop else cfg.num_nerf_samples_per_ray
         if level == 0:
-            sbins, ebins = initial_sampler(nears, fars, n)
+            sbins, ebins = initial_sampler(nears, fars, n, cfg.proposal_initial_sampler)
             sbins = sbins.expand(R, -1)
         else:
             annealed = torch.pow(weights, 1.0)
             sbins, inds, _ = pdf_sample(sbins, annealed[..., 0], n, cfg.histogram_padding)
-            ebins = spacing_to_euclidean(sbins, nears, fars)
+            ebins = spacing_to_euclidean(sbins, nears, fars, cfg.proposal_initial_sampler)
             if return_debug:
                 dbg[f"pdf_inds_{level}"] = inds
         starts, ends = ebins[:, :-1, None], ebins[:, 1:, None]
         if is_prop:
             pos = sample_positions(origins, directions, starts, ends)
-            density, _, _, _ = density_field(params, f"proposal_networks.{level}.mlp_base", cfg.proposals[level], pos, cfg.average_init_density)
+            density, _, _, _ = density_field(params, f"proposal_networks.{level}.mlp_base", cfg.proposals[level], pos, cfg.average_init_density,
+                                             scene_aabb(cfg))
             weights = get_weights(ends - starts, density)
             d, _ = render_depth_median(weights, starts, ends)
             prop_depths.append(d)
     pos = sample_positions(origins, directions, starts, ends)
-    density, h, q, selector = density_field(params, "field.mlp_base", cfg.main, pos, cfg.average_init_density)
+    density, h, q, selector = density_field(params, "field.mlp_base", cfg.main, pos, cfg.average_init_density, scene_aabb(cfg))
     rgb_s = field_rgb(params, cfg, directions, h)
     weights = get_weights(ends - starts, density)
     rgb = render_rgb(rgb_s, weights, cfg.background_color)

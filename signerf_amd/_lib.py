@@ -43,6 +43,8 @@ class SnFieldDesc(C.Structure):
         ("proposals", SnHashMlpDesc * SN_MAX_PROPOSALS),
         ("average_init_density", C.c_float),
         ("histogram_padding", C.c_float),
+        ("disable_scene_contraction", C.c_int32),
+        ("aabb", C.c_float * 6),
     ]
 
 
@@ -61,6 +63,7 @@ class SnRenderOpts(C.Structure):
         ("pdf_u", C.c_void_p * SN_MAX_PROPOSALS),
         ("background_mode", C.c_int32),
         ("background_rgb", C.c_float * 3),
+        ("spacing_mode", C.c_int32),
     ]
 
 

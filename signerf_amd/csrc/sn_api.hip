@@ -73,6 +73,7 @@ struct SnContext {
     bool normals_split_ok = true;  // the normals kernel's own conditioned operands fit fp16 (sn_finalize_weights)
     float grad_scale_normals = 1.0f;  // power of two carried by the split-precision reverse-pass layer of the normals kernel
     bool finalized = false;
+    SnPosMap pos_map{};  // SnFieldDesc.disable_scene_contraction + aabb, as the kernels take it (sn_create)
     // ordering of weight uploads against renders in flight (RenderGuard below): the completion event of the LAST render of every
     // stream that rendered with this handle (a stream is in-order, so its last render covers its earlier ones)
     static constexpr size_t kMaxRenderStreams = 64;
@@ -704,6 +705,7 @@ bool valid_opts(const SnFieldDesc& d, const SnRenderOpts& o, std::string& why) {
     else if (o.chunk_rays < 1) why = "chunk_rays must be positive";
     else if (o.precision != 0 && o.precision != 1) why = "precision must be 0 (fp32) or 1 (split fp16)";
     else if (o.background_mode != 0 && o.background_mode != 1) why = "background_mode must be 0 (last sample) or 1 (constant colour)";
+    else if (o.spacing_mode != 0 && o.spacing_mode != 1) why = "spacing_mode must be 0 (piecewise) or 1 (uniform)";
     else {
         for (int i = 0; i < o.num_proposal_iterations; ++i)
             if (o.num_proposal_samples[i] < 2 || o.num_proposal_samples[i] > SN_PROP_MAX_SAMPLES) {
@@ -732,8 +734,21 @@ int sn_create(const SnFieldDesc* desc, SnHandle* out) {
     for (int i = 0; i < desc->num_proposals; ++i)
         if (!check_hashmlp(desc->proposals[i], 5, 16, 1, why))
             return fail(nullptr, SN_ERR_INVALID, "proposal net " + std::to_string(i) + ": " + why);
+    if (desc->disable_scene_contraction != 0 && desc->disable_scene_contraction != 1)
+        return fail(nullptr, SN_ERR_INVALID, "disable_scene_contraction must be 0 or 1");
+    if (desc->disable_scene_contraction)
+        for (int k = 0; k < 3; ++k)
+            if (!(desc->aabb[3 + k] - desc->aabb[k] > 0.0f) || !std::isfinite(desc->aabb[3 + k] - desc->aabb[k]))
+                return fail(nullptr, SN_ERR_INVALID, "disable_scene_contraction needs a scene box with positive finite extents (SnFieldDesc.aabb)");
     SnContext* c = new SnContext();
     c->desc = *desc;
+    c->pos_map.box = desc->disable_scene_contraction;
+    for (int k = 0; k < 3; ++k) {
+        const float len = desc->disable_scene_contraction ? desc->aabb[3 + k] - desc->aabb[k] : 1.0f;  // (aabb[1] - aabb[0] in fp32, as SceneBox does)
+        c->pos_map.lo[k] = desc->disable_scene_contraction ? desc->aabb[k] : 0.0f;
+        c->pos_map.len[k] = len;
+        c->pos_map.inv_len[k] = 1.0f / len;
+    }
     if (hipGetDevice(&c->device) != hipSuccess) {
         delete c;
         return fail(nullptr, SN_ERR_HIP, "hipGetDevice failed (no HIP device?)");
@@ -1223,6 +1238,8 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     pp.ebins_out = d_ebins;
     pp.scratch = (float*)(ws + wp.off_prop_scratch);
     pp.cache_off = h->sw.prop_cache_off.load(std::memory_order_relaxed);
+    pp.spacing_uniform = opts->spacing_mode;
+    pp.pm = h->pos_map;
     pp.pdf_ieee = h->sw.pdf_ieee.load(std::memory_order_relaxed);
     pp.prop_depth[0] = prop_depth_0;
     pp.prop_depth[1] = prop_depth_1;
@@ -1253,6 +1270,14 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     pp.avg_density = d.average_init_density;
     pp.hist_pad = d.histogram_padding;
     const dim3 pgrid((unsigned)wp.prop_blocks), pblock(64 * SN_PROP_WAVES);
+    // the non-default sampler / position map (SnRenderOpts.spacing_mode, SnFieldDesc.disable_scene_contraction) run in their own
+    // instantiations -- the run-time-generic ones: uploaded tables, no de-hashed copies -- so the production kernels' code does not change
+    const bool alt = opts->spacing_mode != 0 || h->pos_map.box != 0;
+    if (dump && alt) return fail(h, SN_ERR_INVALID, "sn_render_rays_debug: the dump exists for the default sampler and scene contraction only");
+    if (alt) {
+        if (d.proposals[0].grid_mode == 1) hipLaunchKernelGGL((sn_proposal_kernel<1, -1, -1, false, false, true>), pgrid, pblock, 0, st, pp);
+        else hipLaunchKernelGGL((sn_proposal_kernel<0, -1, -1, false, false, true>), pgrid, pblock, 0, st, pp);
+    } else
     if (dump) {
         // the instrumented instantiation exists for the production variant of nerfacto's proposal nets only
         if (!(d.proposals[0].grid_mode == 0 && nprop == 2 && h->nd_prop[0] == 5 && h->nd_prop[1] == 4))
@@ -1331,6 +1356,8 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     p.fars = fars;
     p.sbins = d_sbins;
     p.ebins = d_ebins;
+    p.spacing_uniform = opts->spacing_mode;
+    p.pm = h->pos_map;
     p.table = (const float*)h->table_main.ptr;
     const bool split = opts->precision == 1 && h->split_ok;  // (a handle whose weights cannot be range-conditioned renders in exact fp32)
     p.wimg = (const float*)(split ? h->wimg_main_h.ptr : h->wimg_main.ptr);
@@ -1364,7 +1391,8 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     // de-hashed copies are used when they cover every level tiny-cuda-nn indexes densely (always true for torch grids and for nerfacto's
     // tcnn shapes); otherwise the run-time variant (ND = -1) reads the uploaded table
     const int td = tcnn ? leading_dense(d.main_field) : 0;
-    const bool use_copies = h->nd_torch > 0 && (!tcnn || (td >= 0 && td <= h->nd_torch));
+    const bool alt = opts->spacing_mode != 0 || h->pos_map.box != 0;  // (launch_proposals: the generic instantiations)
+    const bool use_copies = !alt && h->nd_torch > 0 && (!tcnn || (td >= 0 && td <= h->nd_torch));
     p.grid = grid_levels(d.main_field);
     if (use_copies) {
         p.grid = h->dense_res;
@@ -1408,8 +1436,8 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
 #define SN_LAUNCH_MAIN_TCNN(MODE, PREC) SN_LAUNCH_MAIN_ND(MODE, PREC, 1)
     if (dump) {
         // instrumented instantiations: the production variant (torch grid, 11 de-hashed levels), both samplers, both precisions
-        if (tcnn || h->nd_torch != 11)
-            return fail(h, SN_ERR_INVALID, "sn_render_rays_debug: the main-kernel dump exists for the default variant only (torch grid, 11 de-hashed levels)");
+        if (tcnn || h->nd_torch != 11 || alt)
+            return fail(h, SN_ERR_INVALID, "sn_render_rays_debug: the main-kernel dump exists for the default variant only (torch grid, 11 de-hashed levels, default sampler and scene contraction)");
         p.dump_fetch = dump->main_fetch;
         p.dump_q = dump->main_q;
         p.dump_median = dump->median_index;
@@ -1420,6 +1448,16 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
             if (split) hipLaunchKernelGGL((sn_render_main_kernel<0, 1, 0, 0, 11, true>), grid, block, lds_bytes, st, p);
             else hipLaunchKernelGGL((sn_render_main_kernel<0, 0, 0, 0, 11, true>), grid, block, lds_bytes, st, p);
         }
+    } else if (alt) {
+#define SN_LAUNCH_MAIN_ALT(MODE, PREC, GRID) hipLaunchKernelGGL((sn_render_main_kernel<MODE, PREC, 0, GRID, -1, false, true>), grid, block, lds_bytes, st, p)
+        if (nprop > 0) {
+            if (split) { if (tcnn) SN_LAUNCH_MAIN_ALT(1, 1, 1); else SN_LAUNCH_MAIN_ALT(1, 1, 0); }
+            else { if (tcnn) SN_LAUNCH_MAIN_ALT(1, 0, 1); else SN_LAUNCH_MAIN_ALT(1, 0, 0); }
+        } else {
+            if (split) { if (tcnn) SN_LAUNCH_MAIN_ALT(0, 1, 1); else SN_LAUNCH_MAIN_ALT(0, 1, 0); }
+            else { if (tcnn) SN_LAUNCH_MAIN_ALT(0, 0, 1); else SN_LAUNCH_MAIN_ALT(0, 0, 0); }
+        }
+#undef SN_LAUNCH_MAIN_ALT
     } else
     if (ablate == 12 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 1, 2, 0, 11);        // fp16x2 kernel: hash phase (11 de-hashed levels) only
     else if (ablate == 14 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 1, 4, 0, -1);   // fp16x2 kernel: MLP phase only
@@ -1565,6 +1603,8 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
     p.fars = fars;
     p.sbins = opts->initial_spacing_bins;
     p.ebins = d_ebins;
+    p.spacing_uniform = opts->spacing_mode;
+    p.pm = h->pos_map;
     p.table = (const float*)h->table_main.ptr;
     const bool split = opts->precision == 1 && h->normals_split_ok;
     p.wimg = (const float*)(split ? h->wimg_normals_h.ptr : h->wimg_normals.ptr);
@@ -1593,18 +1633,27 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
     else hipLaunchKernelGGL((sn_normals_kernel<MODE, GRID, 0, ND>), grid, block, lds_bytes, st, p)
     // nerfacto's torch grid with its default 11 de-hashed levels reads them (168 gathers per step instead of 256); other shapes and the
     // tiny-cuda-nn grid read the uploaded table
-    const bool copies = !tcnn && h->nd_torch == 11 && h->dense_main.ptr;
+    const bool alt = opts->spacing_mode != 0 || h->pos_map.box != 0;
+    const bool copies = !alt && !tcnn && h->nd_torch == 11 && h->dense_main.ptr;
     if (copies) {
         p.dense = h->dense_info;
         p.inv_feat_scale = 1.0f / h->feat_scale_main;
     }
     p.feat_scale = split ? h->feat_scale_main : 1.0f;
     p.grad_scale = split ? h->grad_scale_normals : 1.0f;
+#define SN_LAUNCH_NORMALS_ALT(MODE, GRID)                                                                         \
+    if (split) hipLaunchKernelGGL((sn_normals_kernel<MODE, GRID, 1, -1, true>), grid, block, lds_bytes, st, p);   \
+    else hipLaunchKernelGGL((sn_normals_kernel<MODE, GRID, 0, -1, true>), grid, block, lds_bytes, st, p)
+    if (alt) {
+        if (nprop > 0) { if (tcnn) { SN_LAUNCH_NORMALS_ALT(1, 1); } else { SN_LAUNCH_NORMALS_ALT(1, 0); } }
+        else { if (tcnn) { SN_LAUNCH_NORMALS_ALT(0, 1); } else { SN_LAUNCH_NORMALS_ALT(0, 0); } }
+    } else
     if (nprop > 0) {
         if (tcnn) { SN_LAUNCH_NORMALS(1, 1, -1); } else if (copies) { SN_LAUNCH_NORMALS(1, 0, 11); } else { SN_LAUNCH_NORMALS(1, 0, -1); }
     } else {
         if (tcnn) { SN_LAUNCH_NORMALS(0, 1, -1); } else if (copies) { SN_LAUNCH_NORMALS(0, 0, 11); } else { SN_LAUNCH_NORMALS(0, 0, -1); }
     }
+#undef SN_LAUNCH_NORMALS_ALT
 #undef SN_LAUNCH_NORMALS
     SN_HIP(h, hipGetLastError());
     return SN_OK;
@@ -1653,6 +1702,7 @@ int sn_field_forward(SnHandle h, int32_t which, const float* positions, const fl
     hipStream_t st = (hipStream_t)stream;
     if (which < 0) {
         SnFieldStageParams p;
+        p.pm = h->pos_map;
         p.positions = positions;
         p.directions = directions;
         p.n = n;
@@ -1674,6 +1724,7 @@ int sn_field_forward(SnHandle h, int32_t which, const float* positions, const fl
             hipLaunchKernelGGL(sn_main_field_stage_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)SnMainImg::TOTAL * 4, st, p);
     } else {
         SnPropStageParams p;
+        p.pm = h->pos_map;
         p.positions = positions;
         p.n = n;
         p.pairs = (const float*)h->pairs_prop[which].ptr;

@@ -23,15 +23,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // strict (no-FMA) helpers
 // ------------------------------------------------------------------------------------------
 
-// s(x) of UniformLinDispPiecewiseSampler
-SN_DEV float sn_spacing(float x) {
+// s(x) of the initial sampler: UniformLinDispPiecewiseSampler, or -- `uniform`, SnRenderOpts.spacing_mode = 1 --
+// UniformSampler's identity.  `uniform` is the same for every lane of a launch (a scalar branch).
+SN_DEV float sn_spacing(float x, int uniform = 0) {
 #pragma clang fp contract(off)
+    if (uniform) return x;
     return x < 1.0f ? x / 2.0f : 1.0f - 1.0f / (2.0f * x);
 }
 
 // s^-1(y)
-SN_DEV float sn_spacing_inv(float x) {
+SN_DEV float sn_spacing_inv(float x, int uniform = 0) {
 #pragma clang fp contract(off)
+    if (uniform) return x;
     return x < 0.5f ? 2.0f * x : 1.0f / (2.0f - 2.0f * x);
 }
 
@@ -42,30 +45,40 @@ SN_DEV float sn_mid(float a, float b) {
 }
 
 // spacing bin -> euclidean distance along the ray: s^-1(b * s_far + (1 - b) * s_near)
-SN_DEV float sn_euclid(float b, float s_near, float s_far) {
+SN_DEV float sn_euclid(float b, float s_near, float s_far, int uniform = 0) {
 #pragma clang fp contract(off)
     float x = b * s_far + (1.0f - b) * s_near;
-    return sn_spacing_inv(x);
+    return sn_spacing_inv(x, uniform);
 }
+
+// Position -> grid coordinate of the fields (SnFieldDesc.disable_scene_contraction): box = 0, SceneContraction(inf) then (p + 2) / 4
+// (nerfacto's default); box = 1, SceneBox.get_normalized_positions: (p - lo) / len.  The same for every lane of a launch.
+struct SnPosMap {
+    int box;
+    float lo[3], len[3], inv_len[3];  // inv_len: the correctly rounded 1 / len, for the fused kernels' reciprocal form
+};
 
 // Frustums.get_positions + SceneContraction(inf) + (p+2)/4 + selector (A5, A6).
 // Returns q (already multiplied by the selector) and the selector.
-SN_DEV bool sn_sample_q(const float o[3], const float d[3], float start, float end, float q[3]) {
+SN_DEV bool sn_sample_q(const float o[3], const float d[3], float start, float end, float q[3], const SnPosMap* pm = nullptr) {
 #pragma clang fp contract(off)
     float t = start + end;
     float p[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) p[c] = o[c] + (d[c] * t) / 2.0f;
-    float mag = fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2]));
-    if (!(mag < 1.0f)) {
-        float k = 2.0f - (1.0f / mag);
+    const bool box = pm && pm->box;
+    if (!box) {
+        float mag = fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2]));
+        if (!(mag < 1.0f)) {
+            float k = 2.0f - (1.0f / mag);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) p[c] = k * (p[c] / mag);
+            for (int c = 0; c < 3; ++c) p[c] = k * (p[c] / mag);
+        }
     }
     bool sel = true;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        q[c] = (p[c] + 2.0f) / 4.0f;
+        q[c] = box ? (p[c] - pm->lo[c]) / pm->len[c] : (p[c] + 2.0f) / 4.0f;
         sel = sel && (q[c] > 0.0f) && (q[c] < 1.0f);
     }
     float m = sel ? 1.0f : 0.0f;
@@ -80,27 +93,28 @@ SN_DEV bool sn_sample_q(const float o[3], const float d[3], float start, float e
 // q = 0, and *nanq carries it: +-0 for a finite position, NaN otherwise.  The NaN is dropped by the `clamp` modifier of the selector
 // multiply itself (q m is in [0, 1); a compute kernel runs with DX10_CLAMP set: NaN clamps to 0) -- no instruction added, no select.
 template <bool NANFREE = false>
-SN_DEV bool sn_sample_q_fast(const float o[3], const float d[3], float start, float end, float q[3], float* nanq = nullptr) {
+SN_DEV bool sn_sample_q_fast(const float o[3], const float d[3], float start, float end, float q[3], float* nanq = nullptr,
+                             const SnPosMap* pm = nullptr) {
     const float t = (start + end) * 0.5f;
     float p[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) p[c] = fmaf(d[c], t, o[c]);
-    const float mag = fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2]));
-    // No selects: r = min(1 / mag, 1) makes k = (2 - r) r exactly 1 inside the unit box, where the contraction is the identity (NaN
-    // positions stay NaN: min returns 1, NaN * 1).  v_cndmask_b32 in its VCC form issues ~5x slower than other VALU instructions on gfx950
-    // (tools/probes/overlap2_probe.hip, r02), so the fused kernels avoid per-step selects.
-    {
+    if (pm && pm->box) {  // no contraction (wave-uniform): (p - lo) / len with the reciprocal of len
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q[c] = (p[c] - pm->lo[c]) * pm->inv_len[c];
+    } else {
+        const float mag = fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2]));
+        // No selects: r = min(1 / mag, 1) makes k = (2 - r) r exactly 1 inside the unit box, where the contraction is the identity (NaN
+        // positions stay NaN: min returns 1, NaN * 1).  v_cndmask_b32 in its VCC form issues ~5x slower than other VALU instructions on
+        // gfx950 (tools/probes/overlap2_probe.hip, r02), so the fused kernels avoid per-step selects.
         const float r = fminf(__builtin_amdgcn_rcpf(mag), 1.0f);
         const float k = (2.0f - r) * r;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) p[c] = k * p[c];
+        for (int c = 0; c < 3; ++c) q[c] = fmaf(k * p[c], 0.25f, 0.5f);
     }
     bool sel = true;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        q[c] = fmaf(p[c], 0.25f, 0.5f);
-        sel = sel && (q[c] > 0.0f) && (q[c] < 1.0f);
-    }
+    for (int c = 0; c < 3; ++c) sel = sel && (q[c] > 0.0f) && (q[c] < 1.0f);
     const float m = sel ? 1.0f : 0.0f;
     if (NANFREE) {
         *nanq = fmaf(q[2], 0.0f, fmaf(q[1], 0.0f, q[0] * 0.0f));
@@ -114,19 +128,22 @@ SN_DEV bool sn_sample_q_fast(const float o[3], const float d[3], float start, fl
 }
 
 // Same, from a world position (stage-level field_forward).
-SN_DEV bool sn_position_q(const float pin[3], float q[3]) {
+SN_DEV bool sn_position_q(const float pin[3], float q[3], const SnPosMap* pm = nullptr) {
 #pragma clang fp contract(off)
     float p[3] = {pin[0], pin[1], pin[2]};
-    float mag = fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2]));
-    if (!(mag < 1.0f)) {
-        float k = 2.0f - (1.0f / mag);
+    const bool box = pm && pm->box;
+    if (!box) {
+        float mag = fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2]));
+        if (!(mag < 1.0f)) {
+            float k = 2.0f - (1.0f / mag);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) p[c] = k * (p[c] / mag);
+            for (int c = 0; c < 3; ++c) p[c] = k * (p[c] / mag);
+        }
     }
     bool sel = true;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        q[c] = (p[c] + 2.0f) / 4.0f;
+        q[c] = box ? (p[c] - pm->lo[c]) / pm->len[c] : (p[c] + 2.0f) / 4.0f;
         sel = sel && (q[c] > 0.0f) && (q[c] < 1.0f);
     }
     float m = sel ? 1.0f : 0.0f;

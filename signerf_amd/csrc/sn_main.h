@@ -565,6 +565,8 @@ struct SnMainParams {
     f32x4* seg_scratch;
     int bg_mode;      // RGBRenderer background: 0 = the ray's last sample, 1 = the constant colour bg
     float bg[3];
+    int spacing_uniform;  // SnRenderOpts.spacing_mode: the initial sampler's s(x) is the identity (sn_spacing)
+    SnPosMap pm;          // SnFieldDesc.disable_scene_contraction (sn_sample_q_fast)
     // test instrumentation (DUMP = 1 instantiations only; sn_render_rays_debug)
     uint32_t* dump_fetch;  // [H*W][S][16][8] fetch records (sn_hash_encode) or null
     float* dump_q;         // [H*W][S][3] normalised positions that were hashed, or null
@@ -662,10 +664,13 @@ SN_DEV void sn_main_epilogue(const SnMainParams& p, SnComposite& comp, float r, 
 template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int PREC /*0 fp32 MFMA, 1 fp16 hi+lo split MFMA*/, int ABLATE = 0,
           int GRID = 0 /*0 nerfstudio torch-path hash grid, 1 tiny-cuda-nn grid semantics*/,
           int ND = -1 /*GRID 1: number of leading dense levels, fixed at compile time (-1: run-time decision per level)*/,
-          bool DUMP = false /*test instrumentation: record what every sample fetches (SnMainParams::dump_*)*/>
+          bool DUMP = false /*test instrumentation: record what every sample fetches (SnMainParams::dump_*)*/,
+          bool ALT = false /*the non-default sampler / position map: SnMainParams::spacing_uniform and pm are honoured*/>
 __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_kernel(SnMainParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
+    const int su = ALT ? p.spacing_uniform : 0;          // (constants in the production instantiations: their code is what it was
+    const SnPosMap* pm = ALT ? &p.pm : nullptr;          //  before the two options existed)
     // both weight images are SnMainImg::TOTAL floats (42 640 B)
     for (int i = tid * 4; i < SnMainImg::TOTAL; i += 256 * 4) *(f32x4*)(lds + i) = *(const f32x4*)(p.wimg + i);
     // Uniform sampler without per-ray nears / fars (the collider's constants): the S + 1 euclidean bins are the same for every ray
@@ -674,8 +679,8 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
     float* etab = lds + SnMainImg::TOTAL;
     const bool shared_bins = MODE == 0 && p.nears == nullptr;
     if (shared_bins) {
-        const float sn = sn_spacing(p.near_plane), sf = sn_spacing(p.far_plane);
-        for (int i = tid; i <= p.n_samples; i += 256) etab[i] = sn_euclid(p.sbins ? p.sbins[i] : (float)i / (float)p.n_samples, sn, sf);
+        const float sn = sn_spacing(p.near_plane, su), sf = sn_spacing(p.far_plane, su);
+        for (int i = tid; i <= p.n_samples; i += 256) etab[i] = sn_euclid(p.sbins ? p.sbins[i] : (float)i / (float)p.n_samples, sn, sf, su);
     }
     __syncthreads();
 
@@ -719,7 +724,7 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
     }
     const float near = p.nears ? p.nears[ray] : p.near_plane;
     const float far = p.fars ? p.fars[ray] : p.far_plane;
-    const float s_near = sn_spacing(near), s_far = sn_spacing(far);
+    const float s_near = sn_spacing(near, su), s_far = sn_spacing(far, su);
     SnShOps sh;
     SnShOpsH shh;
     if (PREC == 0) sh.build(d, p.sh_remap);
@@ -734,7 +739,7 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
     comp.init();
     // euclidean bin k of this lane's ray, with the loop's own arithmetic
     auto bin = [&](int k) -> float {
-        return MODE == 0 ? (shared_bins ? etab[k] : sn_euclid(p.sbins ? p.sbins[k] : (float)k / (float)S, s_near, s_far)) : eb[(int64_t)k * 64];
+        return MODE == 0 ? (shared_bins ? etab[k] : sn_euclid(p.sbins ? p.sbins[k] : (float)k / (float)S, s_near, s_far, su)) : eb[(int64_t)k * 64];
     };
     float t0 = bin(i_lo);
     float r = 0.f, g = 0.f, b = 0.f;
@@ -745,7 +750,7 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
         asm volatile("" ::: "memory");
         const float t1 = bin(i + 1);
         float q[3];
-        const bool sel = sn_sample_q_fast(o, d, t0, t1, q);
+        const bool sel = sn_sample_q_fast(o, d, t0, t1, q, nullptr, pm);
         float feat[32];
         if (ABLATE & 4) {  // no hash phase at all: the MLP phase alone
 #pragma unroll
@@ -853,8 +858,8 @@ __global__ __launch_bounds__(256) void sn_main_combine_kernel(SnMainParams p) {
     float* etab = lds;
     const bool shared_bins = MODE == 0 && p.nears == nullptr;
     if (shared_bins) {
-        const float sn = sn_spacing(p.near_plane), sf = sn_spacing(p.far_plane);
-        for (int i = tid; i <= p.n_samples; i += 256) etab[i] = sn_euclid(p.sbins ? p.sbins[i] : (float)i / (float)p.n_samples, sn, sf);
+        const float sn = sn_spacing(p.near_plane, p.spacing_uniform), sf = sn_spacing(p.far_plane, p.spacing_uniform);
+        for (int i = tid; i <= p.n_samples; i += 256) etab[i] = sn_euclid(p.sbins ? p.sbins[i] : (float)i / (float)p.n_samples, sn, sf, p.spacing_uniform);
     }
     __syncthreads();
     const int lane = tid & 63;
@@ -869,12 +874,12 @@ __global__ __launch_bounds__(256) void sn_main_combine_kernel(SnMainParams p) {
     const int py = (ty << p.tile_h_log2) + (lane >> p.tile_w_log2);
     const bool valid = px < p.width && py < p.height;
     const int64_t ray = (int64_t)min(py, p.height - 1) * p.width + min(px, p.width - 1);
-    const float s_near = sn_spacing(p.nears ? p.nears[ray] : p.near_plane), s_far = sn_spacing(p.fars ? p.fars[ray] : p.far_plane);
+    const float s_near = sn_spacing(p.nears ? p.nears[ray] : p.near_plane, p.spacing_uniform), s_far = sn_spacing(p.fars ? p.fars[ray] : p.far_plane, p.spacing_uniform);
     const int S = p.n_samples;
     const float* eb = nullptr;
     if (MODE == 1) eb = p.ebins + ((int64_t)(ty * p.tiles_x + tx) * (S + 1)) * 64 + lane;
     auto bin = [&](int k) -> float {
-        return MODE == 0 ? (shared_bins ? etab[k] : sn_euclid(p.sbins ? p.sbins[k] : (float)k / (float)S, s_near, s_far)) : eb[(int64_t)k * 64];
+        return MODE == 0 ? (shared_bins ? etab[k] : sn_euclid(p.sbins ? p.sbins[k] : (float)k / (float)S, s_near, s_far, p.spacing_uniform)) : eb[(int64_t)k * 64];
     };
     const f32x4* in = p.seg_scratch + ((int64_t)((int)blockIdx.x * 4 + wave) * S) * 64 + lane;
     SnComposite comp;

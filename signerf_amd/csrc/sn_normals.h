@@ -60,6 +60,8 @@ struct SnNormalsParams {
     float feat_scale;
     float grad_scale;
     float pe_rev_scale;  // position encoding: 1 = nerfstudio's torch NeRFEncoding, sin(2 pi x 2^k); 0.5 = tiny-cuda-nn's Frequency, sin(pi x 2^k)
+    int spacing_uniform;  // SnRenderOpts.spacing_mode (sn_spacing)
+    SnPosMap pm;          // SnFieldDesc.disable_scene_contraction (sn_sample_q)
 };
 
 // NeRFEncoding(in_dim 3, 2 frequencies 2^0, 2^1): [sin(2 pi x_a 2^k)] for (a, k) a-major, then the same with a pi/2 phase.
@@ -426,11 +428,14 @@ SN_DEV void sn_hash_encode_grad(__amdgpu_buffer_rsrc_t rsrc, const float* scal, 
 }
 
 template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int GRID /*0 torch grid, 1 tiny-cuda-nn grid*/,
-          int PREC /*0 exact fp32 MFMA, 1 fp16 hi+lo split MFMA*/, int ND = -1 /*torch grid: leading levels read from the de-hashed copies*/>
+          int PREC /*0 exact fp32 MFMA, 1 fp16 hi+lo split MFMA*/, int ND = -1 /*torch grid: leading levels read from the de-hashed copies*/,
+          bool ALT = false /*the non-default sampler / position map (SnNormalsParams::spacing_uniform, pm)*/>
 // (the run-time dense / hashed branch of the tiny-cuda-nn grid needs more registers than 2 waves per SIMD leave: 1 wave there)
 __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormalsParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
+    const int su = ALT ? p.spacing_uniform : 0;
+    const SnPosMap* pm = ALT ? &p.pm : nullptr;
     for (int i = tid * 4; i < (PREC ? SnNormImgH::TOTAL_BYTES / 4 : SnNormImg::TOTAL); i += 256 * 4) *(f32x4*)(lds + i) = *(const f32x4*)(p.wimg + i);
     __syncthreads();
 
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormals
     }
     const float near = p.nears ? p.nears[ray] : p.near_plane;
     const float far = p.fars ? p.fars[ray] : p.far_plane;
-    const float s_near = sn_spacing(near), s_far = sn_spacing(far);
+    const float s_near = sn_spacing(near, su), s_far = sn_spacing(far, su);
     const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table, (16u << p.log2_t) * 8u);
     const int S = p.n_samples;
     const float* eb = nullptr;
@@ -465,16 +470,16 @@ __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormals
     comp.init();       // the render box has NaN normals and zero weights: its rendered normal is NaN in the reference, not 0.5)
     float an_acc[3] = {0.f, 0.f, 0.f};
     float pn[3] = {0.f, 0.f, 0.f};
-    float t0 = MODE == 0 ? sn_euclid(p.sbins ? p.sbins[0] : 0.0f, s_near, s_far) : eb[0];
+    float t0 = MODE == 0 ? sn_euclid(p.sbins ? p.sbins[0] : 0.0f, s_near, s_far, su) : eb[0];
 #pragma unroll 1
     for (int i = 0; i < S; ++i) {
         asm volatile("" ::: "memory");  // keeps the loop-invariant LDS weight reads inside the loop (sn_main.h)
-        const float t1 = MODE == 0 ? sn_euclid(p.sbins ? p.sbins[i + 1] : (float)(i + 1) / (float)S, s_near, s_far)
+        const float t1 = MODE == 0 ? sn_euclid(p.sbins ? p.sbins[i + 1] : (float)(i + 1) / (float)S, s_near, s_far, su)
                                    : eb[(int64_t)(i + 1) * 64];
         float q[3];
         // the STRICT position arithmetic (not K1's rcp form): the gradient is discontinuous across voxel faces, and a position
         // one ulp off lands in the neighbouring voxel of a fine level about once per thousand samples
-        const bool sel = sn_sample_q(o, d, t0, t1, q);
+        const bool sel = sn_sample_q(o, d, t0, t1, q, pm);
         float feat[32];
         constexpr int NBC = ND > SN_BC_MAIN ? SN_BC_MAIN : (ND > 0 ? ND : 0);
         if (ND > 0) {

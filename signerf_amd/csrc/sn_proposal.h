@@ -336,6 +336,8 @@ struct SnPropParams {
     float near_plane, far_plane, avg_density, hist_pad;
     int pdf_ieee;   // test switch (SN_PDF_IEEE=1): the resampler divides with the plain IEEE sequence instead of sn_pdf_lane's RECIP form
     int cache_off;  // test switch: the coefficient cache re-fetches on every step (tests/test_gpu_render.py compares the two bit for bit)
+    int spacing_uniform;  // SnRenderOpts.spacing_mode (sn_spacing)
+    SnPosMap pm;          // SnFieldDesc.disable_scene_contraction (sn_sample_q_fast)
 };
 
 // per-wave scratch: weights [256][64] + two spacing-bin arrays [257][64]
@@ -358,9 +360,11 @@ struct SnPropLds {
 // One proposal level for this lane's ray: density net LV at the N samples whose spacing bins are sb(0..N); writes the
 // weights to w[i * 64] and returns sum(w + pad) (fp64) and the level's median depth.
 // eb_shared: LV 0 only -- the level's euclidean bins from LDS (frames without per-ray nears / fars), else null
-template <int LV, int GRID, int ND, bool DUMP, typename SB>
+template <int LV, int GRID, int ND, bool DUMP, bool ALT, typename SB>
 SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* __restrict__ w, int N, const float o[3], const float d[3], float s_near,
                           float s_far, double& sum_wp, float& median_out, int64_t dump_ray = -1, const float* eb_shared = nullptr) {
+    const int su = ALT ? p.spacing_uniform : 0;
+    const SnPosMap* pm = ALT ? &p.pm : nullptr;
     SnScal5 scal;
 #pragma unroll
     for (int l = 0; l < 5; ++l) scal.v[l] = p.scal[LV][l];
@@ -376,14 +380,14 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
     SnBcCache cache[NCACHE > 0 ? NCACHE : 1];
 #pragma unroll
     for (int l = 0; l < (NCACHE > 0 ? NCACHE : 1); ++l) cache[l].reset(p.cache_off != 0);
-    float e0 = eb_shared ? eb_shared[0] : sn_euclid(sb(0), s_near, s_far);
+    float e0 = eb_shared ? eb_shared[0] : sn_euclid(sb(0), s_near, s_far, su);
 #pragma unroll 1
     for (int i = 0; i < N; ++i) {
         // keep the (loop-invariant) MLP weight loads inside the loop: hoisted, they cost ~200 registers (see sn_main.h)
         asm volatile("" ::: "memory");
-        const float e1 = eb_shared ? eb_shared[i + 1] : sn_euclid(sb(i + 1), s_near, s_far);
+        const float e1 = eb_shared ? eb_shared[i + 1] : sn_euclid(sb(i + 1), s_near, s_far, su);
         float q[3], nanq;
-        const bool sel = sn_sample_q_fast<true>(o, d, e0, e1, q, &nanq);
+        const bool sel = sn_sample_q_fast<true>(o, d, e0, e1, q, &nanq, pm);
         uint32_t* rec = nullptr;
         if (DUMP && dump_ray >= 0) {
             const size_t smp = (size_t)dump_ray * (size_t)N + (size_t)i;
@@ -413,16 +417,17 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
     sum_wp = swp;
     {
         const int mi = min((int)below, N - 1);
-        const float ea = eb_shared ? eb_shared[mi] : sn_euclid(sb(mi), s_near, s_far);
-        const float ec = eb_shared ? eb_shared[mi + 1] : sn_euclid(sb(mi + 1), s_near, s_far);
+        const float ea = eb_shared ? eb_shared[mi] : sn_euclid(sb(mi), s_near, s_far, su);
+        const float ec = eb_shared ? eb_shared[mi + 1] : sn_euclid(sb(mi + 1), s_near, s_far, su);
         median_out = sn_mid(ea, ec);
     }
 }
 
 // GRID 1: ND0 / ND1 = leading dense levels of the two nets (-1: run-time decision per level)
-template <int GRID, int ND0 = -1, int ND1 = -1, bool DUMP = false, bool FASTPDF = false>
+template <int GRID, int ND0 = -1, int ND1 = -1, bool DUMP = false, bool FASTPDF = false, bool ALT = false>
 __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_proposal_kernel(SnPropParams p) {
     __shared__ __attribute__((aligned(16))) SnPropLds L;
+    const int su = ALT ? p.spacing_uniform : 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
     for (int i = tid; i <= n0; i += 64 * SN_PROP_WAVES) {
         const float sb = p.sbins0 ? p.sbins0[i] : (float)i / (float)n0;
         L.sb0[i] = sb;
-        if (shared_bins) L.eb0[i] = sn_euclid(sb, sn_spacing(p.near_plane), sn_spacing(p.far_plane));  // the same strict arithmetic as per lane
+        if (shared_bins) L.eb0[i] = sn_euclid(sb, sn_spacing(p.near_plane, su), sn_spacing(p.far_plane, su), su);  // the same strict arithmetic as per lane
     }
     for (int k = 0; k < p.n_levels; ++k) {
         const int m = k + 1 < p.n_levels ? p.n_samples[k + 1] : p.n_final;
@@ -466,8 +471,8 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
             o[c] = p.origins[ray * 3 + c];
             d[c] = p.directions[ray * 3 + c];
         }
-        const float s_near = sn_spacing(p.nears ? p.nears[ray] : p.near_plane);
-        const float s_far = sn_spacing(p.fars ? p.fars[ray] : p.far_plane);
+        const float s_near = sn_spacing(p.nears ? p.nears[ray] : p.near_plane, su);
+        const float s_far = sn_spacing(p.fars ? p.fars[ray] : p.far_plane, su);
         float* eb_tile = p.ebins_out + (int64_t)tile * (p.n_final + 1) * 64 + lane;
         const int64_t pix = (int64_t)py * p.width + px;
 
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
         double sum_wp;
         float med;
         const int64_t dump_ray = DUMP && valid ? pix : -1;
-        sn_prop_level<0, GRID, ND0, DUMP>(p, L.wpack[0], [&](int i) { return L.sb0[i]; }, W, n0, o, d, s_near, s_far, sum_wp, med, dump_ray,
+        sn_prop_level<0, GRID, ND0, DUMP, ALT>(p, L.wpack[0], [&](int i) { return L.sb0[i]; }, W, n0, o, d, s_near, s_far, sum_wp, med, dump_ray,
                                           shared_bins ? L.eb0 : nullptr);
         if (valid && p.prop_depth[0]) p.prop_depth[0][pix] = med;
         SnPdfNorm nm;
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
         };
         if (p.n_levels == 1) {
             sn_pdf_lane<FASTPDF, true>(W, 64, n0, p.n_final, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; }, [&](int j, float v, int idx) {
-                eb_tile[(int64_t)j * 64] = sn_euclid(v, s_near, s_far);
+                eb_tile[(int64_t)j * 64] = sn_euclid(v, s_near, s_far, su);
                 dump_idx(0, p.n_final, j, idx);
             }, p.pdf_ieee != 0);
         } else {
@@ -495,11 +500,11 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
                 B0[(int64_t)j * 64] = v;
                 dump_idx(0, n1, j, idx);
             }, p.pdf_ieee != 0);
-            sn_prop_level<1, GRID, ND1, DUMP>(p, L.wpack[1], [&](int i) { return B0[(int64_t)i * 64]; }, W, n1, o, d, s_near, s_far, sum_wp, med, dump_ray);
+            sn_prop_level<1, GRID, ND1, DUMP, ALT>(p, L.wpack[1], [&](int i) { return B0[(int64_t)i * 64]; }, W, n1, o, d, s_near, s_far, sum_wp, med, dump_ray);
             if (valid && p.prop_depth[1]) p.prop_depth[1][pix] = med;
             nm.set(sum_wp, n1);
             sn_pdf_lane<FASTPDF, true>(W, 64, n1, p.n_final, L.u[1], p.hist_pad, nm, [&](int i) { return B0[(int64_t)i * 64]; }, [&](int j, float v, int idx) {
-                eb_tile[(int64_t)j * 64] = sn_euclid(v, s_near, s_far);
+                eb_tile[(int64_t)j * 64] = sn_euclid(v, s_near, s_far, su);
                 dump_idx(1, p.n_final, j, idx);
             }, p.pdf_ieee != 0);
         }
@@ -524,6 +529,7 @@ struct SnPropStageParams {
     int grid_mode;
     SnGridLevels grid;
     float feat_scale;  // tcnn grid mode: the pack's first layer carries 1 / this; the plain table's rows are multiplied by it here
+    SnPosMap pm;
 };
 
 __global__ void sn_prop_field_stage_kernel(SnPropStageParams p) {
@@ -531,7 +537,7 @@ __global__ void sn_prop_field_stage_kernel(SnPropStageParams p) {
     const int64_t j = i < p.n ? i : p.n - 1;
     const float pos[3] = {p.positions[j * 3], p.positions[j * 3 + 1], p.positions[j * 3 + 2]};
     float q[3];
-    const bool sel = sn_position_q(pos, q);
+    const bool sel = sn_position_q(pos, q, &p.pm);
     SnScal5 scal;
 #pragma unroll
     for (int l = 0; l < 5; ++l) scal.v[l] = p.scal[l];

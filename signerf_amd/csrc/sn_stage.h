@@ -218,6 +218,7 @@ struct SnFieldStageParams {
     int grid_mode;   // 1: tiny-cuda-nn grid semantics
     SnGridLevels grid;
     float feat_scale;  // power-of-two feature scale whose inverse the first layer's weights carry (both images)
+    SnPosMap pm;
 };
 
 template <int PREC>
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void sn_main_field_stage_kernel(SnFieldStag
     if (PREC == 0) sh.build(d, p.sh_remap);
     else shh.build(d, p.sh_remap);
     float q[3];
-    const bool sel = sn_position_q(pos, q);
+    const bool sel = sn_position_q(pos, q, &p.pm);
     const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table, (16u << p.log2_t) * 8u);
     float feat[32];
     if (p.grid_mode) sn_hash_encode<16, 0, 2>(rsrc, p.scal, p.log2_t, q, feat, &p.grid);

@@ -32,6 +32,8 @@ PRECISIONS = {"fp32": 0, "fp16x2": 1}
 # RGBRenderer's background in EVAL mode [NS]: "last_sample" (nerfacto's default, what SIGNeRF runs), a named constant colour, or "random" --
 # a training device: combine_rgb returns the composited colour without a background, i.e. black
 BACKGROUNDS = {"last_sample": None, "black": (0.0, 0.0, 0.0), "white": (1.0, 1.0, 1.0), "random": (0.0, 0.0, 0.0)}
+# NerfactoModelConfig.proposal_initial_sampler [NS] -> SnRenderOpts.spacing_mode: UniformLinDispPiecewiseSampler (the default) or UniformSampler
+INITIAL_SAMPLERS = {"piecewise": 0, "uniform": 1}
 
 
 class _RWLock:
@@ -285,13 +287,11 @@ class NerfactoModel(nn.Module):
     # -- module set-up (names = nerfstudio's; signerf.py:32-39 overrides this and calls super) -------------
     def populate_modules(self):
         cfg = self.config
-        if cfg.disable_scene_contraction:
-            raise NotImplementedError("only the L-inf scene contraction path is built")
         # the kernels implement the values SIGNeRF runs with (nerfacto's defaults); anything else must not render silently wrong
         if cfg.background_color not in BACKGROUNDS:
             raise NotImplementedError(f"background_color={cfg.background_color!r}: one of {sorted(BACKGROUNDS)} expected")
-        if cfg.proposal_initial_sampler != "piecewise":
-            raise NotImplementedError(f"proposal_initial_sampler={cfg.proposal_initial_sampler!r}: only 'piecewise' is built")
+        if cfg.proposal_initial_sampler not in INITIAL_SAMPLERS:
+            raise NotImplementedError(f"proposal_initial_sampler={cfg.proposal_initial_sampler!r}: one of {sorted(INITIAL_SAMPLERS)} expected")
         self.field = NerfactoField(cfg, self.num_train_data)
         self.proposal_networks = nn.ModuleList()
         for i in range(cfg.num_proposal_iterations):
@@ -355,6 +355,12 @@ class NerfactoModel(nn.Module):
             d.proposals[i] = _desc_of(net.mlp_base.encoder, net.mlp_base.mlp.layers[0].out_features, 1)
         d.average_init_density = cfg.average_init_density
         d.histogram_padding = 0.01
+        # nerfacto.py (nerfstudio): disable_scene_contraction -> the fields normalise positions with the model's scene box instead
+        # (SceneBox.get_normalized_positions); nerfstudio's dataparsers hand out [-1, 1]^3 x scene_scale, the default here
+        d.disable_scene_contraction = 1 if cfg.disable_scene_contraction else 0
+        aabb = self.scene_box.aabb if self.scene_box is not None else torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+        for k, v in enumerate(aabb.detach().to(torch.float32).cpu().reshape(6).tolist()):
+            d.aabb[k] = v
         return d
 
     @property
@@ -465,6 +471,7 @@ class NerfactoModel(nn.Module):
         o.precision = PRECISIONS[cfg.precision]
         bg = BACKGROUNDS[cfg.background_color]
         o.background_mode = 0 if bg is None else 1
+        o.spacing_mode = INITIAL_SAMPLERS[cfg.proposal_initial_sampler]
         for c in range(3):
             o.background_rgb[c] = 0.0 if bg is None else bg[c]
         bins0, us = self._grids(n_levels)

@@ -15,7 +15,7 @@ from signerf_amd.config import NerfactoModelConfig  # noqa: E402
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-def oracle_config(cfg: NerfactoModelConfig) -> onf.NerfactoConfig:
+def oracle_config(cfg: NerfactoModelConfig, scene_aabb=None) -> onf.NerfactoConfig:
     grid = "torch" if cfg.implementation == "torch" else "tcnn"
     props = tuple(
         onf.HashMLPConfig(a["num_levels"], a.get("base_res", 16), a["max_res"], a["log2_hashmap_size"], 2, a["hidden_dim"], 2, 1, grid)
@@ -32,6 +32,9 @@ def oracle_config(cfg: NerfactoModelConfig) -> onf.NerfactoConfig:
         hidden_dim_color=cfg.hidden_dim_color,
         sh_remap="torch" if cfg.implementation == "torch" else "tcnn",
         background_color=cfg.background_color,
+        proposal_initial_sampler=cfg.proposal_initial_sampler,
+        disable_scene_contraction=cfg.disable_scene_contraction,
+        scene_aabb=tuple(tuple(float(v) for v in row) for row in scene_aabb) if scene_aabb is not None else ((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)),
         main=onf.HashMLPConfig(cfg.num_levels, cfg.base_res, cfg.max_res, cfg.log2_hashmap_size, cfg.features_per_level,
                                cfg.hidden_dim, 2, 16, grid),
         proposals=props,

@@ -45,11 +45,12 @@ def test_ctypes_struct_layout_matches_c(tmp_path):
 #include "signerf_hip.h"
 int main(void) {
   printf("%zu %zu %zu\n", sizeof(SnHashMlpDesc), sizeof(SnFieldDesc), sizeof(SnRenderOpts));
-  printf("%zu %zu %zu %zu\n", offsetof(SnHashMlpDesc, scalings), offsetof(SnFieldDesc, proposals),
-         offsetof(SnFieldDesc, average_init_density), offsetof(SnFieldDesc, num_proposals));
-  printf("%zu %zu %zu %zu %zu %zu %zu\n", offsetof(SnRenderOpts, num_nerf_samples), offsetof(SnRenderOpts, chunk_rays),
+  printf("%zu %zu %zu %zu %zu %zu\n", offsetof(SnHashMlpDesc, scalings), offsetof(SnFieldDesc, proposals),
+         offsetof(SnFieldDesc, average_init_density), offsetof(SnFieldDesc, num_proposals), offsetof(SnFieldDesc, disable_scene_contraction),
+         offsetof(SnFieldDesc, aabb));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", offsetof(SnRenderOpts, num_nerf_samples), offsetof(SnRenderOpts, chunk_rays),
          offsetof(SnRenderOpts, workspace), offsetof(SnRenderOpts, initial_spacing_bins), offsetof(SnRenderOpts, pdf_u),
-         offsetof(SnRenderOpts, background_mode), offsetof(SnRenderOpts, background_rgb));
+         offsetof(SnRenderOpts, background_mode), offsetof(SnRenderOpts, background_rgb), offsetof(SnRenderOpts, spacing_mode));
   printf("%zu %zu %zu %zu %zu %zu\n", sizeof(SnDebugDump), offsetof(SnDebugDump, prop_q), offsetof(SnDebugDump, pdf_index),
          sizeof(SnDebugLayout), offsetof(SnDebugLayout, dense_bytes), offsetof(SnDebugLayout, pair_bytes));
   return 0;
@@ -62,10 +63,10 @@ int main(void) {
     got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     want = [C.sizeof(_lib.SnHashMlpDesc), C.sizeof(_lib.SnFieldDesc), C.sizeof(_lib.SnRenderOpts),
             _lib.SnHashMlpDesc.scalings.offset, _lib.SnFieldDesc.proposals.offset, _lib.SnFieldDesc.average_init_density.offset,
-            _lib.SnFieldDesc.num_proposals.offset,
+            _lib.SnFieldDesc.num_proposals.offset, _lib.SnFieldDesc.disable_scene_contraction.offset, _lib.SnFieldDesc.aabb.offset,
             _lib.SnRenderOpts.num_nerf_samples.offset, _lib.SnRenderOpts.chunk_rays.offset, _lib.SnRenderOpts.workspace.offset,
             _lib.SnRenderOpts.initial_spacing_bins.offset, _lib.SnRenderOpts.pdf_u.offset,
-            _lib.SnRenderOpts.background_mode.offset, _lib.SnRenderOpts.background_rgb.offset,
+            _lib.SnRenderOpts.background_mode.offset, _lib.SnRenderOpts.background_rgb.offset, _lib.SnRenderOpts.spacing_mode.offset,
             C.sizeof(_lib.SnDebugDump), _lib.SnDebugDump.prop_q.offset, _lib.SnDebugDump.pdf_index.offset,
             C.sizeof(_lib.SnDebugLayout), _lib.SnDebugLayout.dense_bytes.offset, _lib.SnDebugLayout.pair_bytes.offset]
     assert got == want
@@ -160,9 +161,11 @@ def test_unbuilt_config_values_are_rejected_at_model_set_up():
     """Values of nerfstudio's config that the kernels do not implement raise instead of rendering something else."""
     from signerf_amd import SIGNeRFModelConfig
 
-    for kw in ({"background_color": "#ff0000"}, {"proposal_initial_sampler": "uniform"}, {"disable_scene_contraction": True}):
+    for kw in ({"background_color": "#ff0000"}, {"proposal_initial_sampler": "lindisp"}):
         with pytest.raises(NotImplementedError):
             SIGNeRFModelConfig(**kw).setup()
+    for kw in ({"proposal_initial_sampler": "uniform"}, {"disable_scene_contraction": True}):   # built in r03 (tests/test_gpu_options.py)
+        SIGNeRFModelConfig(log2_hashmap_size=12, **kw).setup()
     SIGNeRFModelConfig(log2_hashmap_size=12).setup()   # the defaults build (CPU-side module set-up only)
     for bg in ("last_sample", "black", "white", "random"):   # RGBRenderer's named backgrounds (r03)
         SIGNeRFModelConfig(log2_hashmap_size=12, background_color=bg).setup()

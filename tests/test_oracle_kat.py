@@ -283,3 +283,24 @@ def test_background_colours_in_empty_space_and_behind_a_thin_medium():
     want = 0.25 * rgb_s[:, 2] + 0.75
     assert torch.allclose(onf.render_rgb(rgb_s, w, "white"), want, atol=1e-7)
     assert torch.equal(onf.render_rgb(rgb_s, w, "random"), onf.render_rgb(rgb_s, w, "black"))
+
+
+def test_uniform_sampler_and_box_normalisation_kat():
+    """The two r03 options of the oracle against hand-computed values: UniformSampler's spacing is the identity, so the euclidean bins
+    are the linear blend of near and far; SceneBox.get_normalized_positions is (p - aabb[0]) / (aabb[1] - aabb[0]) and the (0, 1)
+    selector zeroes what falls on or outside the faces."""
+    x = torch.tensor([0.0, 0.25, 1.0, 7.0, 1000.0])
+    assert torch.equal(onf.spacing_fn(x, "uniform"), x) and torch.equal(onf.spacing_fn_inv(x, "uniform"), x)
+    sb, eb = onf.initial_sampler(torch.tensor([[1.0], [0.0]]), torch.tensor([[5.0], [8.0]]), 4, "uniform")
+    assert torch.equal(sb, torch.tensor([[0.0, 0.25, 0.5, 0.75, 1.0]]))
+    assert torch.equal(eb, torch.tensor([[1.0, 2.0, 3.0, 4.0, 5.0], [0.0, 2.0, 4.0, 6.0, 8.0]]))
+    # the same bins through the default sampler are not linear
+    _, eb_pw = onf.initial_sampler(torch.tensor([[0.0]]), torch.tensor([[8.0]]), 4)
+    assert not torch.allclose(eb_pw, eb[1:])
+    aabb = torch.tensor([[-1.0, -2.0, 0.0], [3.0, 2.0, 0.5]])
+    p = torch.tensor([[1.0, 0.0, 0.25], [-1.0, 0.0, 0.25], [3.5, 0.0, 0.25], [0.0, -1.0, 0.125]])
+    q, sel = onf.normalized_positions(p, aabb)
+    assert sel.tolist() == [True, False, False, True]                    # on a face (q = 0) and beyond one (q > 1): dropped
+    assert torch.equal(q, torch.tensor([[0.5, 0.5, 0.5], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.25, 0.25, 0.25]]))
+    cfg = onf.NerfactoConfig(disable_scene_contraction=True, scene_aabb=((-1.0, -2.0, 0.0), (3.0, 2.0, 0.5)))
+    assert torch.equal(onf.scene_aabb(cfg), aabb) and onf.scene_aabb(onf.NerfactoConfig()) is None
