@@ -699,6 +699,14 @@ WorkspacePlan plan_workspace(int height, int width, const SnRenderOpts& o, int n
     return w;
 }
 
+// The non-default sampler / position map run in the ALT instantiations of K1 / K2 / K3 (run-time-generic: uploaded tables, no de-hashed
+// copies, STRICT position arithmetic), so that the production kernels' code does not depend on them.  A far plane beyond 1e7 goes there
+// too: out there the exact contraction rounds onto the face q = 1 (dropped by the selector) and the production kernels' reciprocal
+// form may not (sn_sample_q_fast).
+bool needs_generic_kernels(SnHandle h, const SnRenderOpts* opts) {
+    return opts->spacing_mode != 0 || h->pos_map.box != 0 || !(opts->far_plane <= 1.0e7f);
+}
+
 bool valid_opts(const SnFieldDesc& d, const SnRenderOpts& o, std::string& why) {
     if (o.num_proposal_iterations < 0 || o.num_proposal_iterations > d.num_proposals) why = "num_proposal_iterations exceeds the proposal nets of this handle";
     else if (o.num_nerf_samples < 1 || o.num_nerf_samples > 1024) why = "num_nerf_samples out of range [1,1024]";
@@ -1272,7 +1280,7 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     const dim3 pgrid((unsigned)wp.prop_blocks), pblock(64 * SN_PROP_WAVES);
     // the non-default sampler / position map (SnRenderOpts.spacing_mode, SnFieldDesc.disable_scene_contraction) run in their own
     // instantiations -- the run-time-generic ones: uploaded tables, no de-hashed copies -- so the production kernels' code does not change
-    const bool alt = opts->spacing_mode != 0 || h->pos_map.box != 0;
+    const bool alt = needs_generic_kernels(h, opts);
     if (dump && alt) return fail(h, SN_ERR_INVALID, "sn_render_rays_debug: the dump exists for the default sampler and scene contraction only");
     if (alt) {
         if (d.proposals[0].grid_mode == 1) hipLaunchKernelGGL((sn_proposal_kernel<1, -1, -1, false, false, true>), pgrid, pblock, 0, st, pp);
@@ -1391,7 +1399,7 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     // de-hashed copies are used when they cover every level tiny-cuda-nn indexes densely (always true for torch grids and for nerfacto's
     // tcnn shapes); otherwise the run-time variant (ND = -1) reads the uploaded table
     const int td = tcnn ? leading_dense(d.main_field) : 0;
-    const bool alt = opts->spacing_mode != 0 || h->pos_map.box != 0;  // (launch_proposals: the generic instantiations)
+    const bool alt = needs_generic_kernels(h, opts);  // (launch_proposals: the generic instantiations)
     const bool use_copies = !alt && h->nd_torch > 0 && (!tcnn || (td >= 0 && td <= h->nd_torch));
     p.grid = grid_levels(d.main_field);
     if (use_copies) {
@@ -1633,7 +1641,7 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
     else hipLaunchKernelGGL((sn_normals_kernel<MODE, GRID, 0, ND>), grid, block, lds_bytes, st, p)
     // nerfacto's torch grid with its default 11 de-hashed levels reads them (168 gathers per step instead of 256); other shapes and the
     // tiny-cuda-nn grid read the uploaded table
-    const bool alt = opts->spacing_mode != 0 || h->pos_map.box != 0;
+    const bool alt = needs_generic_kernels(h, opts);
     const bool copies = !alt && !tcnn && h->nd_torch == 11 && h->dense_main.ptr;
     if (copies) {
         p.dense = h->dense_info;

@@ -55,7 +55,7 @@ SN_DEV float sn_euclid(float b, float s_near, float s_far, int uniform = 0) {
 // (nerfacto's default); box = 1, SceneBox.get_normalized_positions: (p - lo) / len.  The same for every lane of a launch.
 struct SnPosMap {
     int box;
-    float lo[3], len[3], inv_len[3];  // inv_len: the correctly rounded 1 / len, for the fused kernels' reciprocal form
+    float lo[3], len[3], inv_len[3];  // (inv_len: 1 / len, unused -- every kernel divides, as SceneBox does)
 };
 
 // Frustums.get_positions + SceneContraction(inf) + (p+2)/4 + selector (A5, A6).
@@ -93,20 +93,19 @@ SN_DEV bool sn_sample_q(const float o[3], const float d[3], float start, float e
 // q = 0, and *nanq carries it: +-0 for a finite position, NaN otherwise.  The NaN is dropped by the `clamp` modifier of the selector
 // multiply itself (q m is in [0, 1); a compute kernel runs with DX10_CLAMP set: NaN clamps to 0) -- no instruction added, no select.
 template <bool NANFREE = false>
-SN_DEV bool sn_sample_q_fast(const float o[3], const float d[3], float start, float end, float q[3], float* nanq = nullptr,
-                             const SnPosMap* pm = nullptr) {
+// Beyond |p| ~ 1.7e7 (1 / |p| below half an ulp of 2) the exact contraction rounds onto the face q = 1, which the selector drops; the
+// reciprocal form may land one ulp inside.  The default sampler never gets there (far_plane 1000; rays that miss a render box are NaN);
+// the ALT instantiations (uniform sampler: such rays sit at a finite 1e10) use the strict sn_sample_q instead.
+SN_DEV bool sn_sample_q_fast(const float o[3], const float d[3], float start, float end, float q[3], float* nanq = nullptr) {
     const float t = (start + end) * 0.5f;
     float p[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) p[c] = fmaf(d[c], t, o[c]);
-    if (pm && pm->box) {  // no contraction (wave-uniform): (p - lo) / len with the reciprocal of len
-#pragma unroll
-        for (int c = 0; c < 3; ++c) q[c] = (p[c] - pm->lo[c]) * pm->inv_len[c];
-    } else {
-        const float mag = fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2]));
-        // No selects: r = min(1 / mag, 1) makes k = (2 - r) r exactly 1 inside the unit box, where the contraction is the identity (NaN
-        // positions stay NaN: min returns 1, NaN * 1).  v_cndmask_b32 in its VCC form issues ~5x slower than other VALU instructions on
-        // gfx950 (tools/probes/overlap2_probe.hip, r02), so the fused kernels avoid per-step selects.
+    const float mag = fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2]));
+    // No selects: r = min(1 / mag, 1) makes k = (2 - r) r exactly 1 inside the unit box, where the contraction is the identity (NaN
+    // positions stay NaN: min returns 1, NaN * 1).  v_cndmask_b32 in its VCC form issues ~5x slower than other VALU instructions on gfx950
+    // (tools/probes/overlap2_probe.hip, r02), so the fused kernels avoid per-step selects.
+    {
         const float r = fminf(__builtin_amdgcn_rcpf(mag), 1.0f);
         const float k = (2.0f - r) * r;
 #pragma unroll

@@ -750,7 +750,7 @@ __global__ __launch_bounds__(256, SN_MAIN_WAVES_PER_SIMD) void sn_render_main_ke
         asm volatile("" ::: "memory");
         const float t1 = bin(i + 1);
         float q[3];
-        const bool sel = sn_sample_q_fast(o, d, t0, t1, q, nullptr, pm);
+        const bool sel = ALT ? sn_sample_q(o, d, t0, t1, q, pm) : sn_sample_q_fast(o, d, t0, t1, q);  // (ALT: the strict form, see sn_sample_q_fast)
         float feat[32];
         if (ABLATE & 4) {  // no hash phase at all: the MLP phase alone
 #pragma unroll

@@ -387,7 +387,15 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
         asm volatile("" ::: "memory");
         const float e1 = eb_shared ? eb_shared[i + 1] : sn_euclid(sb(i + 1), s_near, s_far, su);
         float q[3], nanq;
-        const bool sel = sn_sample_q_fast<true>(o, d, e0, e1, q, &nanq, pm);
+        bool sel;
+        if (ALT) {  // the strict position arithmetic (see sn_sample_q_fast), then the same NaN-free hand-over
+            sel = sn_sample_q(o, d, e0, e1, q, pm);
+            nanq = fmaf(q[2], 0.0f, fmaf(q[1], 0.0f, q[0] * 0.0f));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[c] = __builtin_fmaxf(q[c], 0.0f);
+        } else {
+            sel = sn_sample_q_fast<true>(o, d, e0, e1, q, &nanq);
+        }
         uint32_t* rec = nullptr;
         if (DUMP && dump_ray >= 0) {
             const size_t smp = (size_t)dump_ray * (size_t)N + (size_t)i;

@@ -165,3 +165,25 @@ def test_rejected_values(gpu):
     b = Cameras(scene.benchmark_cameras(8)[:, :3], 16.0, 16.0, 8.0, 8.0, 16, 16).to(gpu)[0].generate_rays(0)
     with pytest.raises(_lib.SignerfHipError, match="scene box"):
         model.get_outputs_for_camera_ray_bundle(b)
+
+
+@pytest.mark.parametrize("proposals", [False, True])
+def test_far_plane_beyond_1e7(gpu, proposals):
+    """Out there (|p| > ~1.7e7) the exact contraction rounds onto the face q = 1, which the selector drops; the production kernels'
+    reciprocal-form position arithmetic may land one ulp inside, so such a far plane is rendered by the strict generic instantiations
+    (sn_api.hip needs_generic_kernels).  A thin medium, so that the far samples carry weight."""
+    kw = dict(far_plane=1.0e9, background_color="white")
+    cfg = small_config(num_proposal_samples_per_ray=(64, 32), num_nerf_samples_per_ray=24, **kw) if proposals else \
+        small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=48, **kw)
+    model, out, ref = _pair(cfg, gpu, 40, 44, cam=4, focal=50.0, density_bias=-2.0)
+    for k in ("rgb", "accumulation"):
+        e = rmse(out[k], ref[k])
+        print(f"{k}: rmse {e:.2e}")
+        assert e <= TOL, k
+    fin = torch.isfinite(ref["depth"])                         # (a medium this thin may never reach half its weight: median depth inf, both sides)
+    assert torch.equal(torch.isfinite(out["depth"].cpu()), fin)
+    if bool(fin.any()):
+        rel = ((out["depth"].cpu()[fin] - ref["depth"][fin]).abs() / ref["depth"][fin].abs().clamp_min(1.0))
+        print(f"depth: max relative error {float(rel.max()):.2e}, median depth range {float(ref['depth'][fin].min()):.3g} .. {float(ref['depth'][fin].max()):.3g}")
+        assert float((rel > 1e-3).float().mean()) <= 0.002 and float(rel.median()) <= 1e-5
+    assert 0.02 < float(ref["accumulation"].mean()) < 0.98

@@ -223,3 +223,63 @@ def test_random_viewer_crop_with_proposals(gpu, seed):
         e = float(torch.sqrt(torch.mean(d ** 2)))
         assert e <= 1e-3, f"seed {seed}: {k} rmse {e:.2e} on the {int(hit.sum())} rays inside the crop"
     print(f"viewer crop seed {seed}: {H}x{W}, {frac:.2f} of the rays inside the box: ok")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_option_scenarios(gpu, seed):
+    """The r03 options in random scenarios: every combination of {piecewise, uniform} initial sampler x {contraction, scene-box
+    normalisation} x {last_sample, white} background, with and without proposal nets, random frame shapes / cameras / far planes / scene
+    boxes, and a render box in the second trial (per-ray nears / fars, rays that miss)."""
+    g = torch.Generator().manual_seed(7000 + seed)
+    sampler = "uniform" if seed & 1 else "piecewise"
+    no_contract = bool(seed & 2)
+    background = "white" if seed & 4 else "last_sample"
+    props = seed in (1, 2, 5, 7)
+    far = [1000.0, 5.0, 40.0, 6.0, 12.0, 4.0, 1000.0, 8.0][seed]
+    kw = dict(far_plane=far, proposal_initial_sampler=sampler, disable_scene_contraction=no_contract, background_color=background)
+    cfg = small_config(num_proposal_samples_per_ray=[(64, 32), (40, 17)][seed % 2], num_nerf_samples_per_ray=[24, 11][seed % 2], **kw) if props else \
+        small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=[33, 48, 20, 64][seed % 4], **kw)
+    lo = -1.0 - torch.rand(3, generator=g) * 0.5
+    hi = 1.0 + torch.rand(3, generator=g) * 0.5
+    scene_box = SceneBox(aabb=torch.stack([lo, hi]))
+    from signerf_amd import scene as _scene
+
+    sd = _scene.synthetic_state_dict(cfg, seed=seed, density_bias=2.0 if (sampler == "uniform" or no_contract) else 4.0)
+    model = cfg.setup(scene_box=scene_box)
+    model.load_state_dict(sd, strict=False)
+    model.field.embedding_appearance.embedding.weight.data.copy_(sd["field.embedding_appearance.embedding.weight"])
+    model = model.to(gpu).eval()
+    ocfg = oracle_config(cfg, scene_aabb=scene_box.aabb.tolist())
+    for trial in range(2):
+        H, W = int(torch.randint(1, 57, (1,), generator=g)), int(torch.randint(1, 57, (1,), generator=g))
+        focal = float(torch.rand(1, generator=g) * 60 + 15)
+        pos = torch.nn.functional.normalize(torch.randn(3, generator=g), dim=0) * float(torch.rand(1, generator=g) * 0.8 + 0.6)
+        cams = Cameras(_look_at(pos, (torch.rand(3, generator=g) - 0.5) * 0.4)[None], focal, focal, W / 2, H / 2, W, H).to(gpu)
+        box = None
+        if trial == 1:
+            blo = (torch.rand(3, generator=g) - 1.0) * 0.4
+            box = SceneBox(aabb=torch.stack([blo, blo + torch.rand(3, generator=g) * 0.6 + 0.1]))
+            cams = Cameras(_look_at(pos, box.aabb.mean(0))[None], focal, focal, W / 2, H / 2, W, H).to(gpu)
+        model.render_aabb = box
+        bundle = cams[0].generate_rays(camera_indices=0, aabb_box=box)
+        out = model.get_outputs_for_camera_ray_bundle(bundle)
+        n = None if bundle.nears is None else bundle.nears.cpu()
+        f = None if bundle.fars is None else bundle.fars.cpu()
+        ref = onf.get_outputs_for_camera_ray_bundle(sd, ocfg, bundle.origins.cpu(), bundle.directions.cpu(), n, f)
+        msgs = []
+        for k in ("rgb", "depth", "accumulation"):
+            got, want = out[k].cpu(), ref[k]
+            ok = torch.isfinite(want)
+            assert torch.equal(torch.isfinite(got), ok), f"seed {seed} trial {trial}: {k}: the non-finite pixels differ"
+            if not bool(ok.any()):
+                continue
+            d = got[ok].double() - want[ok].double()
+            if k == "depth":
+                flips = (d.abs() / want[ok].double().abs().clamp_min(1e-6)) > 1e-3
+                assert int(flips.sum()) <= max(1, ok.sum().item() // 300), f"seed {seed} trial {trial}: {int(flips.sum())} median-depth flips of {int(ok.sum())}"
+                d = (d / want[ok].double().abs().clamp_min(1.0))[~flips]
+            err = float(torch.sqrt(torch.mean(d ** 2))) if d.numel() else 0.0
+            msgs.append(f"{k} {err:.1e}")
+            assert err <= 1e-3, f"seed {seed} trial {trial}: {k} rmse {err:.2e}"
+        print(f"seed {seed} trial {trial}: {sampler}, box-normalised {no_contract}, {background}, proposals {props}, {H}x{W}, far {far}, render box {box is not None}: " + ", ".join(msgs))
+    model.render_aabb = None
