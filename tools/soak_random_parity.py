@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""One-off soak of the render path against the CPU oracle: N seeded random scenarios drawn from a WIDER space than the suite's fixed
+sweeps (tests/test_gpu_random_parity.py) -- sample counts, proposal iterations 0 / 1 / 2, far planes, density levels, frame shapes down
+to 1x1, cameras anywhere, render boxes (rays that miss), both initial samplers, contraction on / off with a random scene box, every named
+background, both MFMA precisions.  Gate per scenario = the suite's: RMSE <= 1e-3 on rgb / accumulation / (relative) median depth over the
+pixels whose reference is finite, identical non-finite pattern, median-depth flips counted (<= 1 in 300).  Failures are printed with
+their seed and do not stop the run.
+
+    python tools/soak_random_parity.py --n 150 [--first 0]          (GPU box; the oracle side runs on the host's cores)
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from helpers import oracle_config, small_config  # noqa: E402
+from oracle import nerfacto as onf  # noqa: E402
+from signerf_amd import Cameras, SceneBox, scene  # noqa: E402
+from test_gpu_random_parity import _look_at, _random_c2w  # noqa: E402
+
+
+def scenario(seed, gpu, inspect=()):
+    g = torch.Generator().manual_seed(910000 + seed)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=g))
+
+    def ru(lo, hi):
+        return float(torch.rand(1, generator=g) * (hi - lo) + lo)
+
+    iters = ri(0, 2)
+    S = [1, 2, 3, 5, 8, 13, 24, 33, 48, 64][ri(0, 9)]
+    props = tuple([2, 3, 9, 17, 32, 48, 64, 96, 128][ri(0, 8)] for _ in range(iters))
+    sampler = "uniform" if ri(0, 3) == 0 else "piecewise"
+    no_contract = ri(0, 3) == 0
+    background = ["last_sample", "last_sample", "white", "black", "random"][ri(0, 4)]
+    far = [1000.0, 1000.0, ru(2.0, 60.0), ru(3.0, 8.0)][ri(0, 3)] if sampler == "piecewise" else ru(3.0, 9.0)
+    precision = "fp32" if ri(0, 2) == 0 else "fp16x2"
+    kw = dict(num_nerf_samples_per_ray=S, far_plane=far, proposal_initial_sampler=sampler, disable_scene_contraction=no_contract,
+              background_color=background, precision=precision)
+    cfg = small_config(num_proposal_iterations=iters, num_proposal_samples_per_ray=props, **kw) if iters else small_config(num_proposal_iterations=0, **kw)
+    lo = -1.0 - torch.rand(3, generator=g) * 0.6
+    hi = 1.0 + torch.rand(3, generator=g) * 0.6
+    sbox = SceneBox(aabb=torch.stack([lo, hi]))
+    sd = scene.synthetic_state_dict(cfg, seed=seed, density_bias=ru(0.0, 6.0))
+    model = cfg.setup(scene_box=sbox)
+    model.load_state_dict(sd, strict=False)
+    model.field.embedding_appearance.embedding.weight.data.copy_(sd["field.embedding_appearance.embedding.weight"])
+    model = model.to(gpu).eval()
+    ocfg = oracle_config(cfg, scene_aabb=sbox.aabb.tolist())
+    H, W = ri(1, 48), ri(1, 48)
+    focal = ru(12.0, 80.0)
+    kind = ri(0, 3)
+    box = None
+    if kind == 0:
+        c2w = _random_c2w(g)
+    else:
+        pos = torch.nn.functional.normalize(torch.randn(3, generator=g), dim=0) * ru(0.3, 1.6)
+        c2w = _look_at(pos, (torch.rand(3, generator=g) - 0.5) * 0.5)
+        if kind == 3:
+            blo = (torch.rand(3, generator=g) - 1.0) * 0.4
+            box = SceneBox(aabb=torch.stack([blo, blo + torch.rand(3, generator=g) * 0.6 + 0.05]))
+            c2w = _look_at(pos, box.aabb.mean(0))
+    cams = Cameras(c2w[None], focal, focal * ru(0.8, 1.25), W / 2 + ru(-2, 2), H / 2 + ru(-2, 2), W, H).to(gpu)
+    model.render_aabb = box
+    bundle = cams[0].generate_rays(camera_indices=0, aabb_box=box)
+    out = model.get_outputs_for_camera_ray_bundle(bundle)
+    n = None if bundle.nears is None else bundle.nears.cpu()
+    f = None if bundle.fars is None else bundle.fars.cpu()
+    ref = onf.get_outputs_for_camera_ray_bundle(sd, ocfg, bundle.origins.cpu(), bundle.directions.cpu(), n, f)
+    tag = (f"seed {seed}: {H}x{W}, samples {props}+{S}, far {far:.3g}, {sampler}, box-normalised {no_contract}, {background}, {precision}, "
+           f"camera kind {kind}, render box {box is not None}")
+    problems, msgs = [], []
+    for k in ["rgb", "depth", "accumulation", "expected_depth"] + [f"prop_depth_{i}" for i in range(iters)]:
+        got, want = out[k].cpu(), ref[k]
+        ok = torch.isfinite(want)
+        if not torch.equal(torch.isfinite(got), ok):
+            problems.append(f"{k}: the non-finite pixels differ ({int((torch.isfinite(got) != ok).sum())})")
+            continue
+        if k == "expected_depth":
+            # sum(w t) / (sum(w) + 1e-10) of a nearly empty ray is rounding noise in the REFERENCE too: its alphas 1 - exp(-tau) are quantised to
+            # 2^-24, so for accumulation ~1e-6 (a ray grazing the render box) a one-quantum difference of one exp moves the quotient by
+            # per cent (seen: 11 % at accumulation 2e-6, both values inside the chunk's clip bounds).  Gated where the ray holds weight.
+            ok = ok & (ref["accumulation"] > 1e-3)
+        if not bool(ok.any()):
+            continue
+        d = got[ok].double() - want[ok].double()
+        if "depth" in k:
+            rel = d.abs() / want[ok].double().abs().clamp_min(1e-6)
+            flips = rel > 1e-3
+            if k != "expected_depth" and int(flips.sum()) > max(1, int(ok.sum()) // 300):
+                problems.append(f"{k}: {int(flips.sum())} flips of {int(ok.sum())}")
+            d = (d / want[ok].double().abs().clamp_min(1.0))[~flips] if k != "expected_depth" else d / want[ok].double().abs().clamp_min(1.0)
+        err = float(torch.sqrt(torch.mean(d ** 2))) if d.numel() else 0.0
+        msgs.append(f"{k} {err:.1e}")
+        if err > 1e-3:
+            problems.append(f"{k}: rmse {err:.2e}")
+    if inspect:
+        for k in inspect:
+            got, want = out[k].cpu(), ref[k]
+            d = (got - want).abs().amax(-1)
+            d = torch.where(torch.isfinite(d), d, torch.full_like(d, -1.0))
+            idx = torch.topk(d.flatten(), min(8, d.numel())).indices
+            print(f"-- {k}: worst pixels (y, x): got / want, with near / far / accumulation / depth of the reference")
+            for i in idx.tolist():
+                y, x = divmod(i, W)
+                print(f"   ({y},{x}) got {got[y, x].tolist()} want {want[y, x].tolist()} near {None if n is None else float(n[y, x])} far "
+                      f"{None if f is None else float(f[y, x])} acc {float(ref['accumulation'][y, x]):.6g} depth {float(ref['depth'][y, x]):.6g} "
+                      f"expected (hip / ref) {float(out['expected_depth'][y, x]):.8g} / {float(ref['expected_depth'][y, x]):.8g}")
+        ed = ref["expected_depth"]
+        print("   reference expected_depth: min %.6g max %.6g, finite %d of %d" % (float(ed[torch.isfinite(ed)].min()), float(ed[torch.isfinite(ed)].max()),
+                                                                                   int(torch.isfinite(ed).sum()), ed.numel()))
+    return tag, msgs, problems
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--inspect", type=int, nargs="*", default=[], help="print the worst pixels of these seeds instead of running the sweep")
+    a = ap.parse_args()
+    gpu = torch.device("cuda", 0)
+    for seed in a.inspect:
+        tag, msgs, problems = scenario(seed, gpu, inspect=("expected_depth", "depth", "rgb"))
+        print(tag, "|", "; ".join(problems), "|", ", ".join(msgs))
+    if a.inspect:
+        return
+    t0 = time.time()
+    bad = 0
+    for seed in range(a.first, a.first + a.n):
+        try:
+            tag, msgs, problems = scenario(seed, gpu)
+        except Exception as e:  # noqa: BLE001
+            tag, msgs, problems = f"seed {seed}", [], [f"EXCEPTION {type(e).__name__}: {str(e)[:300]}"]
+        if problems:
+            bad += 1
+            print("FAIL", tag, "|", "; ".join(problems), "|", ", ".join(msgs), flush=True)
+        else:
+            print("ok  ", tag, "|", ", ".join(msgs), flush=True)
+    print(f"{a.n} scenarios, {bad} with problems, {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
