@@ -25,7 +25,7 @@ from signerf_amd import Cameras, SceneBox, scene  # noqa: E402
 from test_gpu_random_parity import _look_at, _random_c2w  # noqa: E402
 
 
-def scenario(seed, gpu, inspect=()):
+def scenario(seed, gpu, inspect=(), normals=False):
     g = torch.Generator().manual_seed(910000 + seed)
 
     def ri(lo, hi):
@@ -34,7 +34,7 @@ def scenario(seed, gpu, inspect=()):
     def ru(lo, hi):
         return float(torch.rand(1, generator=g) * (hi - lo) + lo)
 
-    iters = ri(0, 2)
+    iters = 0 if normals else ri(0, 2)   # (normals: identical bins on both sides, so the plain gate applies -- tests/test_gpu_normals.py)
     S = [1, 2, 3, 5, 8, 13, 24, 33, 48, 64][ri(0, 9)]
     props = tuple([2, 3, 9, 17, 32, 48, 64, 96, 128][ri(0, 8)] for _ in range(iters))
     sampler = "uniform" if ri(0, 3) == 0 else "piecewise"
@@ -54,6 +54,10 @@ def scenario(seed, gpu, inspect=()):
     model.field.embedding_appearance.embedding.weight.data.copy_(sd["field.embedding_appearance.embedding.weight"])
     model = model.to(gpu).eval()
     ocfg = oracle_config(cfg, scene_aabb=sbox.aabb.tolist())
+    if normals:
+        import dataclasses
+
+        ocfg = dataclasses.replace(ocfg, predict_normals=True)
     H, W = ri(1, 48), ri(1, 48)
     focal = ru(12.0, 80.0)
     kind = ri(0, 3)
@@ -77,7 +81,7 @@ def scenario(seed, gpu, inspect=()):
     tag = (f"seed {seed}: {H}x{W}, samples {props}+{S}, far {far:.3g}, {sampler}, box-normalised {no_contract}, {background}, {precision}, "
            f"camera kind {kind}, render box {box is not None}")
     problems, msgs = [], []
-    for k in ["rgb", "depth", "accumulation", "expected_depth"] + [f"prop_depth_{i}" for i in range(iters)]:
+    for k in ["rgb", "depth", "accumulation", "expected_depth"] + [f"prop_depth_{i}" for i in range(iters)] + (["normals", "pred_normals"] if normals else []):
         got, want = out[k].cpu(), ref[k]
         ok = torch.isfinite(want)
         if not torch.equal(torch.isfinite(got), ok):
@@ -97,6 +101,14 @@ def scenario(seed, gpu, inspect=()):
             if k != "expected_depth" and int(flips.sum()) > max(1, int(ok.sum()) // 300):
                 problems.append(f"{k}: {int(flips.sum())} flips of {int(ok.sum())}")
             d = (d / want[ok].double().abs().clamp_min(1.0))[~flips] if k != "expected_depth" else d / want[ok].double().abs().clamp_min(1.0)
+        if k == "normals":
+            # the analytic normal is discontinuous where a ReLU of the density MLP switches or a sample sits on a voxel face: a tie decided the
+            # other way changes that sample's normal by O(1) (tests/test_gpu_normals.py counts them the same way); pixels, not values
+            px = (got - want).abs().amax(-1)[ok.all(-1)]
+            ties = px > 1e-3
+            if int(ties.sum()) > max(1, px.numel() // 500):
+                problems.append(f"{k}: {int(ties.sum())} pixels of {px.numel()} beyond 1e-3")
+            d = (got - want)[ok.all(-1)][~ties].double().flatten()
         err = float(torch.sqrt(torch.mean(d ** 2))) if d.numel() else 0.0
         msgs.append(f"{k} {err:.1e}")
         if err > 1e-3:
@@ -123,11 +135,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=100)
     ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--normals", action="store_true", help="uniform-sampler scenarios only, with the normals kernel's two outputs checked as well")
     ap.add_argument("--inspect", type=int, nargs="*", default=[], help="print the worst pixels of these seeds instead of running the sweep")
     a = ap.parse_args()
     gpu = torch.device("cuda", 0)
     for seed in a.inspect:
-        tag, msgs, problems = scenario(seed, gpu, inspect=("expected_depth", "depth", "rgb"))
+        tag, msgs, problems = scenario(seed, gpu, inspect=("expected_depth", "depth", "rgb") + (("normals", "pred_normals") if a.normals else ()), normals=a.normals)
         print(tag, "|", "; ".join(problems), "|", ", ".join(msgs))
     if a.inspect:
         return
@@ -135,7 +148,7 @@ def main():
     bad = 0
     for seed in range(a.first, a.first + a.n):
         try:
-            tag, msgs, problems = scenario(seed, gpu)
+            tag, msgs, problems = scenario(seed, gpu, normals=a.normals)
         except Exception as e:  # noqa: BLE001
             tag, msgs, problems = f"seed {seed}", [], [f"EXCEPTION {type(e).__name__}: {str(e)[:300]}"]
         if problems:
