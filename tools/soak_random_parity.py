@@ -25,7 +25,7 @@ from signerf_amd import Cameras, SceneBox, scene  # noqa: E402
 from test_gpu_random_parity import _look_at, _random_c2w  # noqa: E402
 
 
-def scenario(seed, gpu, inspect=(), normals=False):
+def scenario(seed, gpu, inspect=(), normals=False, full_tables=False):
     g = torch.Generator().manual_seed(910000 + seed)
 
     def ri(lo, hi):
@@ -44,6 +44,10 @@ def scenario(seed, gpu, inspect=(), normals=False):
     precision = "fp32" if ri(0, 2) == 0 else "fp16x2"
     kw = dict(num_nerf_samples_per_ray=S, far_plane=far, proposal_initial_sampler=sampler, disable_scene_contraction=no_contract,
               background_color=background, precision=precision)
+    if full_tables:   # nerfacto's own table sizes (T = 2^19 main, 2^17 proposal nets): the shapes the production instantiations are specialised for
+        kw.update(log2_hashmap_size=19, proposal_net_args_list=[
+            {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 128, "use_linear": False},
+            {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 256, "use_linear": False}])
     cfg = small_config(num_proposal_iterations=iters, num_proposal_samples_per_ray=props, **kw) if iters else small_config(num_proposal_iterations=0, **kw)
     lo = -1.0 - torch.rand(3, generator=g) * 0.6
     hi = 1.0 + torch.rand(3, generator=g) * 0.6
@@ -135,12 +139,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=100)
     ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--full-tables", action="store_true", help="nerfacto's table sizes (2^19 / 2^17) instead of the small ones")
     ap.add_argument("--normals", action="store_true", help="uniform-sampler scenarios only, with the normals kernel's two outputs checked as well")
     ap.add_argument("--inspect", type=int, nargs="*", default=[], help="print the worst pixels of these seeds instead of running the sweep")
     a = ap.parse_args()
     gpu = torch.device("cuda", 0)
     for seed in a.inspect:
-        tag, msgs, problems = scenario(seed, gpu, inspect=("expected_depth", "depth", "rgb") + (("normals", "pred_normals") if a.normals else ()), normals=a.normals)
+        tag, msgs, problems = scenario(seed, gpu, inspect=("expected_depth", "depth", "rgb") + (("normals", "pred_normals") if a.normals else ()), normals=a.normals, full_tables=a.full_tables)
         print(tag, "|", "; ".join(problems), "|", ", ".join(msgs))
     if a.inspect:
         return
@@ -148,7 +153,7 @@ def main():
     bad = 0
     for seed in range(a.first, a.first + a.n):
         try:
-            tag, msgs, problems = scenario(seed, gpu, normals=a.normals)
+            tag, msgs, problems = scenario(seed, gpu, normals=a.normals, full_tables=a.full_tables)
         except Exception as e:  # noqa: BLE001
             tag, msgs, problems = f"seed {seed}", [], [f"EXCEPTION {type(e).__name__}: {str(e)[:300]}"]
         if problems:
