@@ -25,7 +25,7 @@ from signerf_amd import Cameras, SceneBox, scene  # noqa: E402
 from test_gpu_random_parity import _look_at, _random_c2w  # noqa: E402
 
 
-def scenario(seed, gpu, inspect=(), normals=False, full_tables=False):
+def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False):
     g = torch.Generator().manual_seed(910000 + seed)
 
     def ri(lo, hi):
@@ -52,11 +52,23 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False):
     lo = -1.0 - torch.rand(3, generator=g) * 0.6
     hi = 1.0 + torch.rand(3, generator=g) * 0.6
     sbox = SceneBox(aabb=torch.stack([lo, hi]))
-    sd = scene.synthetic_state_dict(cfg, seed=seed, density_bias=ru(0.0, 6.0))
-    model = cfg.setup(scene_box=sbox)
-    model.load_state_dict(sd, strict=False)
-    model.field.embedding_appearance.embedding.weight.data.copy_(sd["field.embedding_appearance.embedding.weight"])
-    model = model.to(gpu).eval()
+    if tcnn:   # tiny-cuda-nn grid semantics + checkpoint import (oracle/tcnn_layout.py: unpinned); a milder scene than the suite's (gains 1 / 1.5)
+        import dataclasses
+
+        from helpers import oracle_params_from_tcnn, synthetic_tcnn_checkpoint
+
+        cfg = dataclasses.replace(cfg, implementation="tcnn", average_init_density=ru(0.3, 4.0))
+        ck = synthetic_tcnn_checkpoint(cfg, seed=seed, base_gain=1.0, head_gain=1.5)
+        model = cfg.setup(scene_box=sbox)
+        model.load_state_dict(ck, strict=False)
+        model = model.to(gpu).eval()
+        sd = oracle_params_from_tcnn(ck, cfg)
+    else:
+        sd = scene.synthetic_state_dict(cfg, seed=seed, density_bias=ru(0.0, 6.0))
+        model = cfg.setup(scene_box=sbox)
+        model.load_state_dict(sd, strict=False)
+        model.field.embedding_appearance.embedding.weight.data.copy_(sd["field.embedding_appearance.embedding.weight"])
+        model = model.to(gpu).eval()
     ocfg = oracle_config(cfg, scene_aabb=sbox.aabb.tolist())
     if normals:
         import dataclasses
@@ -147,12 +159,13 @@ def main():
     ap.add_argument("--n", type=int, default=100)
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--full-tables", action="store_true", help="nerfacto's table sizes (2^19 / 2^17) instead of the small ones")
+    ap.add_argument("--tcnn", action="store_true", help="tiny-cuda-nn grid semantics and checkpoint import")
     ap.add_argument("--normals", action="store_true", help="uniform-sampler scenarios only, with the normals kernel's two outputs checked as well")
     ap.add_argument("--inspect", type=int, nargs="*", default=[], help="print the worst pixels of these seeds instead of running the sweep")
     a = ap.parse_args()
     gpu = torch.device("cuda", 0)
     for seed in a.inspect:
-        tag, msgs, problems = scenario(seed, gpu, inspect=("expected_depth", "depth", "rgb") + (("normals", "pred_normals") if a.normals else ()), normals=a.normals, full_tables=a.full_tables)
+        tag, msgs, problems = scenario(seed, gpu, inspect=("expected_depth", "depth", "rgb") + (("normals", "pred_normals") if a.normals else ()), normals=a.normals, full_tables=a.full_tables, tcnn=a.tcnn)
         print(tag, "|", "; ".join(problems), "|", ", ".join(msgs))
     if a.inspect:
         return
@@ -160,7 +173,7 @@ def main():
     bad = 0
     for seed in range(a.first, a.first + a.n):
         try:
-            tag, msgs, problems = scenario(seed, gpu, normals=a.normals, full_tables=a.full_tables)
+            tag, msgs, problems = scenario(seed, gpu, normals=a.normals, full_tables=a.full_tables, tcnn=a.tcnn)
         except Exception as e:  # noqa: BLE001
             tag, msgs, problems = f"seed {seed}", [], [f"EXCEPTION {type(e).__name__}: {str(e)[:300]}"]
         if problems:
