@@ -755,7 +755,6 @@ int sn_create(const SnFieldDesc* desc, SnHandle* out) {
         const float len = desc->disable_scene_contraction ? desc->aabb[3 + k] - desc->aabb[k] : 1.0f;  // (aabb[1] - aabb[0] in fp32, as SceneBox does)
         c->pos_map.lo[k] = desc->disable_scene_contraction ? desc->aabb[k] : 0.0f;
         c->pos_map.len[k] = len;
-        c->pos_map.inv_len[k] = 1.0f / len;
     }
     if (hipGetDevice(&c->device) != hipSuccess) {
         delete c;

@@ -63,7 +63,7 @@ SN_DEV bool sn_in_unit_cube(const float q[3]) {
 // (nerfacto's default); box = 1, SceneBox.get_normalized_positions: (p - lo) / len.  The same for every lane of a launch.
 struct SnPosMap {
     int box;
-    float lo[3], len[3], inv_len[3];  // (inv_len: 1 / len, unused -- every kernel divides, as SceneBox does)
+    float lo[3], len[3];  // every kernel divides by len, as SceneBox does
 };
 
 // Frustums.get_positions + SceneContraction(inf) + (p+2)/4 + selector (A5, A6).
