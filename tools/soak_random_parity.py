@@ -76,8 +76,9 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
         ocfg = dataclasses.replace(ocfg, predict_normals=True)
     H, W = ri(1, 48), ri(1, 48)
     focal = ru(12.0, 80.0)
-    kind = ri(0, 3)
+    kind = ri(0, 4)
     box = None
+    obb = None
     if kind == 0:
         c2w = _random_c2w(g)
     else:
@@ -87,16 +88,41 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
             blo = (torch.rand(3, generator=g) - 1.0) * 0.4
             box = SceneBox(aabb=torch.stack([blo, blo + torch.rand(3, generator=g) * 0.6 + 0.05]))
             c2w = _look_at(pos, box.aabb.mean(0))
+        if kind == 4:   # the viewer's oriented crop box (Model.get_outputs_for_camera(camera, obb_box)), any rotation
+            from signerf_amd import OrientedBox
+
+            obb = OrientedBox(R=_random_c2w(g)[:, :3].contiguous(), T=(torch.rand(3, generator=g) - 0.5) * 0.3, S=torch.rand(3, generator=g) * 0.5 + 0.08)
+            c2w = _look_at(pos, obb.T)
     cams = Cameras(c2w[None], focal, focal * ru(0.8, 1.25), W / 2 + ru(-2, 2), H / 2 + ru(-2, 2), W, H).to(gpu)
     model.render_aabb = box
-    bundle = cams[0].generate_rays(camera_indices=0, aabb_box=box)
-    out = model.get_outputs_for_camera_ray_bundle(bundle)
+    if obb is not None:
+        bundle = cams[0].generate_rays(camera_indices=0, obb_box=obb)
+        out = model.get_outputs_for_camera(cams[0], obb_box=obb)
+    else:
+        bundle = cams[0].generate_rays(camera_indices=0, aabb_box=box)
+        out = model.get_outputs_for_camera_ray_bundle(bundle)
     n = None if bundle.nears is None else bundle.nears.cpu()
     f = None if bundle.fars is None else bundle.fars.cpu()
     ref = onf.get_outputs_for_camera_ray_bundle(sd, ocfg, bundle.origins.cpu(), bundle.directions.cpu(), n, f)
     tag = (f"seed {seed}: {H}x{W}, samples {props}+{S}, far {far:.3g}, {sampler}, box-normalised {no_contract}, {background}, {precision}, "
-           f"camera kind {kind}, render box {box is not None}")
+           f"camera kind {kind}, render box {box is not None}, crop box {obb is not None}")
     problems, msgs = [], []
+    if obb is not None:   # the bounds themselves against the oracle's restatement of nerfstudio's intersect_obb
+        o, d = bundle.origins.cpu().reshape(-1, 3), bundle.directions.cpu().reshape(-1, 3)
+        t0, t1 = onf.intersect_obb(o, d, obb.R, obb.T, obb.S)
+        hit = t1 < 1e9
+        if not torch.equal(bundle.nears.cpu().reshape(-1) >= 1e9, ~hit):
+            # a ray along a face / through an edge may be decided either way by the last ulp of the rotated ray: counted
+            nd = int((((bundle.nears.cpu().reshape(-1) >= 1e9) != ~hit)).sum())
+            if nd > max(1, hit.numel() // 300):
+                problems.append(f"obb: {nd} rays of {hit.numel()} hit / miss differently")
+            hit = hit & (bundle.nears.cpu().reshape(-1) < 1e9)
+        if bool(hit.any()):
+            en = float(((bundle.nears.cpu().reshape(-1)[hit] - t0[hit]).abs() / t0[hit].abs().clamp_min(1e-3)).max())
+            ef = float(((bundle.fars.cpu().reshape(-1)[hit] - t1[hit]).abs() / t1[hit].abs().clamp_min(1e-3)).max())
+            msgs.append(f"obb bounds {max(en, ef):.1e}")
+            if max(en, ef) > 1e-4:
+                problems.append(f"obb: bounds off by {max(en, ef):.2e} relative")
     for k in ["rgb", "depth", "accumulation", "expected_depth"] + [f"prop_depth_{i}" for i in range(iters)] + (["normals", "pred_normals"] if normals else []):
         got, want = out[k].cpu(), ref[k]
         ok = torch.isfinite(want)
