@@ -159,6 +159,32 @@ int sn_generate_rays(const float* c2w, float fx, float fy, float cx, float cy, i
                      float* origins, float* directions, float* pixel_area, float* directions_norm,
                      const float* aabb, float* nears, float* fars, SnStream stream);
 
+/* The same call for the cameras the reference takes from the ORIGINAL dataset -- its default source of the generated views
+ * (datasetgenerator.py:274-275 `cameras = original_dataset.cameras`, :331 the per-view loop, :356-358 the merge loop;
+ * signerf_trainer.py:222 passes `datamanager.train_dataset`): nerfstudio `Cameras` built by its dataparser, with per-camera
+ * intrinsics, a `camera_type` and OPENCV `distortion_params` [k1 k2 k3 k4 p1 p2].  nerfstudio un-distorts the three image-plane
+ * points (pixel centre, +1 px in x, +1 px in y) with 10 fixed Newton steps of the radial-tangential model (step 0 where
+ * |det J| <= 1e-3), then forms the pin-hole direction (u, v, -1) or the fisheye one (u sin t / t, v sin t / t, -cos t), t = |(u, v)|
+ * clipped to [0, pi].  With has_distortion = 0 and camera_type = SN_CAMERA_PERSPECTIVE the result is bit-identical to
+ * sn_generate_rays.
+ *   cam     HOST struct.
+ *   coords  optional DEVICE [n_coords, 2] image coordinates as (y, x) -- `generate_rays(coords=...)`; NULL = every pixel centre
+ *           (row, col) + 0.5 of the height x width image in row-major order (then n_coords is ignored and the outputs are [H,W,.]).
+ * Outputs as sn_generate_rays; with coords they are [n_coords, .].  Other camera types return SN_ERR_INVALID. */
+#define SN_CAMERA_PERSPECTIVE 1   /* nerfstudio CameraType.PERSPECTIVE.value */
+#define SN_CAMERA_FISHEYE 2       /* nerfstudio CameraType.FISHEYE.value */
+typedef struct SnCameraDesc {
+    float c2w[12];           /* 3x4 row-major camera-to-world */
+    float fx, fy, cx, cy;
+    int32_t height, width;
+    int32_t camera_type;     /* SN_CAMERA_* */
+    int32_t has_distortion;  /* 0: skip the un-distortion (distortion_params None / all zero / disable_distortion=True) */
+    float distortion[6];     /* k1 k2 k3 k4 p1 p2 */
+} SnCameraDesc;
+int sn_generate_rays_camera(const SnCameraDesc* cam, const float* coords, int64_t n_coords,
+                            float* origins, float* directions, float* pixel_area, float* directions_norm,
+                            const float* aabb, float* nears, float* fars, SnStream stream);
+
 /* ---- row a4: intersect_with_aabb (signerf/utils/intersection.py:5-56) -------------------- */
 /* aabb: 6 host floats (min xyz, max xyz).  nears/fars: [n_rays]. */
 int sn_intersect_with_aabb(const float* origins, const float* directions, int64_t n_rays, const float* aabb,

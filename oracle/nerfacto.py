@@ -103,17 +103,66 @@ class NerfactoConfig:
 # ----------------------------------------------------------------------------
 
 
-def generate_rays(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, height: int, width: int):
-    """Pin-hole full-image ray bundle (A1).
+def _undistort_residual_and_jacobian(x: Tensor, y: Tensor, xd: Tensor, yd: Tensor, distortion_params: Tensor):
+    """Residual of the OPENCV radial-tangential model and its Jacobian ([NS-RECALL] M-H: nerfstudio.cameras.camera_utils
+    ``_compute_residual_and_jacobian``, itself adapted from MultiNeRF; the operand order below is the order the kernel follows)."""
+    k1, k2, k3, k4, p1, p2 = (distortion_params[..., i] for i in range(6))
+    r = x * x + y * y
+    d = 1.0 + r * (k1 + r * (k2 + r * (k3 + r * k4)))
+    fx = d * x + 2 * p1 * x * y + p2 * (r + 2 * x * x) - xd
+    fy = d * y + 2 * p2 * x * y + p1 * (r + 2 * y * y) - yd
+    d_r = k1 + r * (2.0 * k2 + r * (3.0 * k3 + r * 4.0 * k4))
+    d_x = 2.0 * x * d_r
+    d_y = 2.0 * y * d_r
+    fx_x = d + d_x * x + 2.0 * p1 * y + 6.0 * p2 * x
+    fx_y = d_y * x + 2.0 * p1 * x + 2.0 * p2 * y
+    fy_x = d_x * y + 2.0 * p2 * y + 2.0 * p1 * x
+    fy_y = d + d_y * y + 2.0 * p2 * x + 6.0 * p1 * y
+    return fx, fy, fx_x, fx_y, fy_x, fy_y
+
+
+def radial_and_tangential_undistort(coords: Tensor, distortion_params: Tensor, eps: float = 1e-3, max_iterations: int = 10) -> Tensor:
+    """nerfstudio's ``camera_utils.radial_and_tangential_undistort`` ([NS-RECALL] M-H): Newton's method from the distorted
+    point, a FIXED number of iterations (10), the step zeroed where |det J| <= eps (1e-3).  coords [...,2] = (x, y) in normalised
+    image-plane units; distortion_params [...,6] = k1 k2 k3 k4 p1 p2 (broadcast against coords)."""
+    x = coords[..., 0]
+    y = coords[..., 1]
+    for _ in range(max_iterations):
+        fx, fy, fx_x, fx_y, fy_x, fy_y = _undistort_residual_and_jacobian(x, y, coords[..., 0], coords[..., 1], distortion_params)
+        denominator = fy_x * fx_y - fx_x * fy_y
+        x_numerator = fx * fy_y - fy * fx_y
+        y_numerator = fy * fx_x - fx * fy_x
+        step_x = torch.where(torch.abs(denominator) > eps, x_numerator / denominator, torch.zeros_like(denominator))
+        step_y = torch.where(torch.abs(denominator) > eps, y_numerator / denominator, torch.zeros_like(denominator))
+        x = x + step_x
+        y = y + step_y
+    return torch.stack([x, y], dim=-1)
+
+
+CAMERA_PERSPECTIVE, CAMERA_FISHEYE = 1, 2  # nerfstudio CameraType values
+
+
+def generate_rays(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, height: int, width: int,
+                  distortion_params: Optional[Tensor] = None, camera_type: int = CAMERA_PERSPECTIVE, coords: Optional[Tensor] = None):
+    """Ray bundle of one camera (A1): pin-hole or fisheye, optional OPENCV un-distortion, optional explicit coords.
 
     Returns origins [H,W,3], directions [H,W,3], pixel_area [H,W,1],
     directions_norm [H,W,1], camera_indices [H,W,1] (int64, all 0) and the
-    integer pixel coordinates [H,W,2] as (y, x).
+    integer pixel coordinates [H,W,2] as (y, x).  With ``coords`` [...,2] (float (y, x)) the leading shape is coords'.
+
+    ``distortion_params`` [6] (the cameras of the original dataset, datasetgenerator.py:274-275): the three image-plane points
+    (centre, +1 px in x, +1 px in y) are un-distorted before the direction is formed; all-zero parameters skip the step
+    ([NS-RECALL] M; the Newton steps are exactly zero for them either way).
     """
     c2w = c2w.to(torch.float32)
-    ys, xs = torch.meshgrid(torch.arange(height), torch.arange(width), indexing="ij")
-    coords_int = torch.stack([ys, xs], dim=-1)
-    coords = coords_int.to(torch.float32) + 0.5  # pixel centres, (y, x)
+    if coords is None:
+        ys, xs = torch.meshgrid(torch.arange(height), torch.arange(width), indexing="ij")
+        coords_int = torch.stack([ys, xs], dim=-1)
+        coords = coords_int.to(torch.float32) + 0.5  # pixel centres, (y, x)
+    else:
+        coords = coords.to(torch.float32)
+        coords_int = torch.floor(coords).to(torch.int64)
+    shape = tuple(coords.shape[:-1])
     y = coords[..., 0]
     x = coords[..., 1]
     fx_t, fy_t = torch.tensor(fx, dtype=torch.float32), torch.tensor(fy, dtype=torch.float32)
@@ -121,23 +170,35 @@ def generate_rays(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, heigh
     coord = torch.stack([(x - cx_t) / fx_t, -(y - cy_t) / fy_t], -1)
     coord_x = torch.stack([(x - cx_t + 1) / fx_t, -(y - cy_t) / fy_t], -1)
     coord_y = torch.stack([(x - cx_t) / fx_t, -(y - cy_t + 1) / fy_t], -1)
-    coord_stack = torch.stack([coord, coord_x, coord_y], dim=0)  # [3,H,W,2]
-    dirs = torch.empty((3, height, width, 3), dtype=torch.float32)
-    dirs[..., 0] = coord_stack[..., 0]
-    dirs[..., 1] = coord_stack[..., 1]
-    dirs[..., 2] = -1.0
+    coord_stack = torch.stack([coord, coord_x, coord_y], dim=0)  # [3,...,2]
+    if distortion_params is not None and bool((distortion_params != 0).any()):
+        coord_stack = radial_and_tangential_undistort(coord_stack, distortion_params.to(torch.float32).reshape(6))
+    dirs = torch.empty((3, *shape, 3), dtype=torch.float32)
+    if camera_type == CAMERA_PERSPECTIVE:
+        dirs[..., 0] = coord_stack[..., 0]
+        dirs[..., 1] = coord_stack[..., 1]
+        dirs[..., 2] = -1.0
+    elif camera_type == CAMERA_FISHEYE:
+        theta = torch.sqrt(torch.sum(coord_stack**2, dim=-1))
+        theta = torch.clip(theta, 0.0, math.pi)
+        sin_theta = torch.sin(theta)
+        dirs[..., 0] = coord_stack[..., 0] * sin_theta / theta
+        dirs[..., 1] = coord_stack[..., 1] * sin_theta / theta
+        dirs[..., 2] = -torch.cos(theta)
+    else:
+        raise ValueError(f"camera_type {camera_type} is not restated")
     rotation = c2w[:3, :3]
     dirs = torch.sum(dirs[..., None, :] * rotation, dim=-1)  # d_world = R . d_cam
     norm = torch.maximum(
         torch.linalg.vector_norm(dirs, dim=-1, keepdim=True), torch.tensor([1e-20], dtype=torch.float32)
     )
     dirs = dirs / norm
-    origins = c2w[:3, 3].expand(height, width, 3).contiguous()
+    origins = c2w[:3, 3].expand(*shape, 3).contiguous()
     directions = dirs[0]
     dx = torch.sqrt(torch.sum((directions - dirs[1]) ** 2, dim=-1))
     dy = torch.sqrt(torch.sum((directions - dirs[2]) ** 2, dim=-1))
     pixel_area = (dx * dy)[..., None]
-    camera_indices = torch.zeros((height, width, 1), dtype=torch.int64)
+    camera_indices = torch.zeros((*shape, 1), dtype=torch.int64)
     return {
         "origins": origins,
         "directions": directions.contiguous(),

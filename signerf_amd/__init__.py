@@ -4,7 +4,7 @@ Hot path: ``Cameras.generate_rays`` -> ``NerfactoModel.get_outputs_for_camera_ra
 the C ABI in include/signerf_hip.h), plus the in-tree helpers either side of it.  See DESIGN.md.
 """
 
-from .cameras import Cameras, OrientedBox, RayBundle, SceneBox  # noqa: F401
+from .cameras import Cameras, CameraType, OrientedBox, RayBundle, SceneBox  # noqa: F401
 from .config import NerfactoModelConfig, SIGNeRFModelConfig  # noqa: F401
 from .intersection import intersect_with_aabb  # noqa: F401
 from .nerfacto import NerfactoModel, SIGNeRFModel  # noqa: F401

@@ -67,6 +67,21 @@ class SnRenderOpts(C.Structure):
     ]
 
 
+class SnCameraDesc(C.Structure):
+    _fields_ = [
+        ("c2w", C.c_float * 12),
+        ("fx", C.c_float),
+        ("fy", C.c_float),
+        ("cx", C.c_float),
+        ("cy", C.c_float),
+        ("height", C.c_int32),
+        ("width", C.c_int32),
+        ("camera_type", C.c_int32),
+        ("has_distortion", C.c_int32),
+        ("distortion", C.c_float * 6),
+    ]
+
+
 class SnMaskOpts(C.Structure):
     _fields_ = [
         ("inverse_mask", C.c_int32),
@@ -114,6 +129,8 @@ SIGNATURES = {
     "sn_finalize_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sn_generate_rays": (C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                    _FP, _FP, _FP, _FP, C.POINTER(C.c_float), _FP, _FP, C.c_void_p]),
+    "sn_generate_rays_camera": (C.c_int, [C.POINTER(SnCameraDesc), _FP, C.c_int64, _FP, _FP, _FP, _FP, C.POINTER(C.c_float), _FP, _FP,
+                                          C.c_void_p]),
     "sn_intersect_with_aabb": (C.c_int, [_FP, _FP, C.c_int64, C.POINTER(C.c_float), _FP, _FP, C.c_void_p]),
     "sn_intersect_obb": (C.c_int, [_FP, _FP, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float), _FP, _FP, C.c_void_p]),
     "sn_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SnRenderOpts)]),

@@ -1163,18 +1163,26 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
     return SN_OK;
 }
 
-int sn_generate_rays(const float* c2w, float fx, float fy, float cx, float cy, int32_t height, int32_t width, float* origins,
-                     float* directions, float* pixel_area, float* directions_norm, const float* aabb, float* nears, float* fars,
-                     SnStream stream) {
-    if (!c2w || height <= 0 || width <= 0) return fail(nullptr, SN_ERR_INVALID, "sn_generate_rays: bad argument");
+int sn_generate_rays_camera(const SnCameraDesc* cam, const float* coords, int64_t n_coords, float* origins, float* directions,
+                            float* pixel_area, float* directions_norm, const float* aabb, float* nears, float* fars, SnStream stream) {
+    if (!cam || cam->height <= 0 || cam->width <= 0 || (coords && n_coords < 0))
+        return fail(nullptr, SN_ERR_INVALID, "sn_generate_rays_camera: bad argument");
+    if (cam->camera_type != SN_CAMERA_PERSPECTIVE && cam->camera_type != SN_CAMERA_FISHEYE)
+        return fail(nullptr, SN_ERR_INVALID, "sn_generate_rays_camera: camera_type " + std::to_string(cam->camera_type) +
+                                                 " is not supported (1 = PERSPECTIVE, 2 = FISHEYE)");
     SnRayGenParams p;
-    memcpy(p.c2w, c2w, sizeof(p.c2w));
-    p.fx = fx;
-    p.fy = fy;
-    p.cx = cx;
-    p.cy = cy;
-    p.height = height;
-    p.width = width;
+    memcpy(p.c2w, cam->c2w, sizeof(p.c2w));
+    p.fx = cam->fx;
+    p.fy = cam->fy;
+    p.cx = cam->cx;
+    p.cy = cam->cy;
+    p.height = cam->height;
+    p.width = cam->width;
+    p.camera_type = cam->camera_type;
+    p.has_distortion = cam->has_distortion != 0;
+    memcpy(p.dist, cam->distortion, sizeof(p.dist));
+    p.coords = coords;
+    p.n = coords ? n_coords : (int64_t)cam->height * cam->width;
     p.origins = origins;
     p.directions = directions;
     p.pixel_area = pixel_area;
@@ -1184,11 +1192,33 @@ int sn_generate_rays(const float* c2w, float fx, float fy, float cx, float cy, i
     else memset(p.aabb, 0, sizeof(p.aabb));
     p.nears = nears;
     p.fars = fars;
-    const int64_t n = (int64_t)height * width;
-    hipLaunchKernelGGL(sn_generate_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    if (p.n == 0) return SN_OK;
+    const dim3 grid((unsigned)((p.n + 255) / 256)), block(256);
+    const bool fish = cam->camera_type == SN_CAMERA_FISHEYE;
+    if (fish && p.has_distortion) hipLaunchKernelGGL((sn_generate_rays_kernel<true, true>), grid, block, 0, (hipStream_t)stream, p);
+    else if (fish) hipLaunchKernelGGL((sn_generate_rays_kernel<true, false>), grid, block, 0, (hipStream_t)stream, p);
+    else if (p.has_distortion) hipLaunchKernelGGL((sn_generate_rays_kernel<false, true>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((sn_generate_rays_kernel<false, false>), grid, block, 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_generate_rays launch: ") + hipGetErrorString(e));
     return SN_OK;
+}
+
+int sn_generate_rays(const float* c2w, float fx, float fy, float cx, float cy, int32_t height, int32_t width, float* origins,
+                     float* directions, float* pixel_area, float* directions_norm, const float* aabb, float* nears, float* fars,
+                     SnStream stream) {
+    if (!c2w || height <= 0 || width <= 0) return fail(nullptr, SN_ERR_INVALID, "sn_generate_rays: bad argument");
+    SnCameraDesc cam;
+    memset(&cam, 0, sizeof(cam));
+    memcpy(cam.c2w, c2w, sizeof(cam.c2w));
+    cam.fx = fx;
+    cam.fy = fy;
+    cam.cx = cx;
+    cam.cy = cy;
+    cam.height = height;
+    cam.width = width;
+    cam.camera_type = SN_CAMERA_PERSPECTIVE;
+    return sn_generate_rays_camera(&cam, nullptr, 0, origins, directions, pixel_area, directions_norm, aabb, nears, fars, stream);
 }
 
 int sn_intersect_with_aabb(const float* origins, const float* directions, int64_t n_rays, const float* aabb, float* nears,

@@ -5,12 +5,18 @@
 #include "sn_main.h"
 
 // ------------------------------------------------------------------------------------------
-// row a5: Cameras.generate_rays, pin-hole
+// row a5: Cameras.generate_rays: pin-hole and fisheye cameras, optional OPENCV radial-tangential
+// un-distortion (the cameras of the original dataset, datasetgenerator.py:274-275), optional explicit image coordinates
 // ------------------------------------------------------------------------------------------
 struct SnRayGenParams {
     float c2w[12];
     float fx, fy, cx, cy;
     int height, width;
+    int camera_type;      // 1 perspective, 2 fisheye (nerfstudio CameraType values)
+    int has_distortion;
+    float dist[6];        // k1 k2 k3 k4 p1 p2
+    const float* coords;  // optional [n,2] (y, x); nullptr = pixel centres of the full image
+    int64_t n;
     float* origins;
     float* directions;
     float* pixel_area;
@@ -21,12 +27,51 @@ struct SnRayGenParams {
     float* fars;
 };
 
+// nerfstudio's radial_and_tangential_undistort [NS]: 10 Newton steps from the distorted point, step = 0 where |det J| <= 1e-3.
+// Un-fused IEEE fp32 in the operand order of the torch expressions (oracle/nerfacto.py::radial_and_tangential_undistort).
+SN_DEV void sn_undistort(const float* kk, float xd, float yd, float& xo, float& yo) {
+#pragma clang fp contract(off)
+    const float k1 = kk[0], k2 = kk[1], k3 = kk[2], k4 = kk[3], p1 = kk[4], p2 = kk[5];
+    float x = xd, y = yd;
+    for (int it = 0; it < 10; ++it) {
+        const float r = x * x + y * y;
+        const float d = 1.0f + r * (k1 + r * (k2 + r * (k3 + r * k4)));
+        const float fx = ((d * x + ((2.0f * p1) * x) * y) + p2 * (r + (2.0f * x) * x)) - xd;
+        const float fy = ((d * y + ((2.0f * p2) * x) * y) + p1 * (r + (2.0f * y) * y)) - yd;
+        const float d_r = k1 + r * (2.0f * k2 + r * (3.0f * k3 + (r * 4.0f) * k4));
+        const float d_x = (2.0f * x) * d_r;
+        const float d_y = (2.0f * y) * d_r;
+        const float fx_x = ((d + d_x * x) + (2.0f * p1) * y) + (6.0f * p2) * x;
+        const float fx_y = (d_y * x + (2.0f * p1) * x) + (2.0f * p2) * y;
+        const float fy_x = (d_x * y + (2.0f * p2) * y) + (2.0f * p1) * x;
+        const float fy_y = ((d + d_y * y) + (2.0f * p2) * x) + (6.0f * p1) * y;
+        const float den = fy_x * fx_y - fx_x * fy_y;
+        const float xn = fx * fy_y - fy * fx_y;
+        const float yn = fy * fx_x - fx * fy_x;
+        const bool ok = fabsf(den) > 1e-3f;
+        x = x + (ok ? xn / den : 0.0f);
+        y = y + (ok ? yn / den : 0.0f);
+    }
+    xo = x;
+    yo = y;
+}
+
+// image-plane point -> camera-frame direction -> world direction (d_world = R . d_cam), normalised
+template <bool FISHEYE>
 SN_DEV void sn_cam_dir(const float* c2w, float u, float v, float out[3], float& norm) {
 #pragma clang fp contract(off)
-    // d_world[i] = sum_j d_cam[j] * R[i][j],  d_cam = (u, v, -1)
+    float a = u, b = v, c = -1.0f;
+    if (FISHEYE) {
+        float th = sqrtf(u * u + v * v);
+        th = fminf(fmaxf(th, 0.0f), 3.14159265358979323846f);
+        const float st = sinf(th);
+        a = (u * st) / th;
+        b = (v * st) / th;
+        c = -cosf(th);
+    }
     float w[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) w[i] = (u * c2w[i * 4 + 0] + v * c2w[i * 4 + 1]) + (-1.0f) * c2w[i * 4 + 2];
+    for (int i = 0; i < 3; ++i) w[i] = (a * c2w[i * 4 + 0] + b * c2w[i * 4 + 1]) + c * c2w[i * 4 + 2];
     float n = sqrtf((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]);
     n = fmaxf(n, 1e-20f);
 #pragma unroll
@@ -34,20 +79,33 @@ SN_DEV void sn_cam_dir(const float* c2w, float u, float v, float out[3], float& 
     norm = n;
 }
 
+template <bool FISHEYE, bool DISTORT>
 __global__ void sn_generate_rays_kernel(SnRayGenParams p) {
 #pragma clang fp contract(off)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = (int64_t)p.height * p.width;
-    if (i >= n) return;
-    const int iy = (int)(i / p.width), ix = (int)(i % p.width);
-    const float x = (float)ix + 0.5f, y = (float)iy + 0.5f;
-    const float u = (x - p.cx) / p.fx, v = -((y - p.cy) / p.fy);
-    const float ux = (x - p.cx + 1.0f) / p.fx;
-    const float vy = -((y - p.cy + 1.0f) / p.fy);
+    if (i >= p.n) return;
+    float x, y;
+    if (p.coords) {
+        y = p.coords[i * 2 + 0];
+        x = p.coords[i * 2 + 1];
+    } else {
+        const int iy = (int)(i / p.width), ix = (int)(i % p.width);
+        x = (float)ix + 0.5f;
+        y = (float)iy + 0.5f;
+    }
+    float u = (x - p.cx) / p.fx, v = -((y - p.cy) / p.fy);
+    float ux = (x - p.cx + 1.0f) / p.fx, vx = v;
+    float uy = u, vy = -((y - p.cy + 1.0f) / p.fy);
+    if (DISTORT) {
+        const float u0 = u, v0 = v;
+        sn_undistort(p.dist, u0, v0, u, v);
+        sn_undistort(p.dist, ux, v0, ux, vx);
+        sn_undistort(p.dist, u0, vy, uy, vy);
+    }
     float d[3], dx[3], dy[3], nrm, n1, n2;
-    sn_cam_dir(p.c2w, u, v, d, nrm);
-    sn_cam_dir(p.c2w, ux, v, dx, n1);
-    sn_cam_dir(p.c2w, u, vy, dy, n2);
+    sn_cam_dir<FISHEYE>(p.c2w, u, v, d, nrm);
+    sn_cam_dir<FISHEYE>(p.c2w, ux, vx, dx, n1);
+    sn_cam_dir<FISHEYE>(p.c2w, uy, vy, dy, n2);
     float o[3] = {p.c2w[3], p.c2w[7], p.c2w[11]};
     if (p.origins) {
         p.origins[i * 3 + 0] = o[0];

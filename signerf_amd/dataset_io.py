@@ -85,10 +85,28 @@ class GeneratedDataset:
         self.dirs: Dict[str, Path] = {}
         self._pool = None
         self._pending: List = []
+        # at most this many encodes queued or running: the host copies of a view's 8 PNGs must not pile up when encoding is slower than
+        # the loop; a failed write surfaces at the next save instead of at the end
+        self._max_pending = 16 * max(1, save_workers)
         if save_workers > 0:
             from concurrent.futures import ThreadPoolExecutor
 
             self._pool = ThreadPoolExecutor(max_workers=save_workers)
+
+    def close(self) -> None:
+        """Waits for the pending writes and releases the worker threads (idempotent; also runs when the object is collected)."""
+        pool, self._pool = self._pool, None
+        try:
+            self.flush()
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover  (interpreter shutdown)
+            pass
 
     def init_directory(self) -> None:
         """datasetgenerator.py:146-175 (config.yml is written by DatasetGenerator.init_directory)."""
@@ -119,6 +137,8 @@ class GeneratedDataset:
         if self._pool is None:
             write()
         else:
+            while len(self._pending) >= self._max_pending:
+                self._pending.pop(0).result()
             self._pending.append(self._pool.submit(write))
 
     def flush(self) -> None:

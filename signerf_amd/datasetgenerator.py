@@ -83,7 +83,9 @@ def aabb_mask_and_condition(depth: Tensor, rays_o: Tensor, rays_d: Tensor, aabb:
 
 
 def render_camera(config: DatasetGeneratorConfig, graph, camera, with_mask: bool = True, with_condition: bool = True):
-    """One camera: rgb, mask, condition (datasetgenerator.py:677-820, aabb mode)."""
+    """One camera: rgb, mask, condition (datasetgenerator.py:677-820, aabb mode).  `camera`: a 0-dim ``Cameras`` of this package or
+    any object with nerfstudio's camera accessors (adopted: ray generation always runs in the HIP kernel)."""
+    camera = _adopt(camera)
     camera_ray_bundle = camera.generate_rays(camera_indices=0, aabb_box=graph.render_aabb)
     graph.eval()
     outputs = graph.get_outputs_for_camera_ray_bundle(camera_ray_bundle)
@@ -232,13 +234,17 @@ def identity_diffuse(original_image: Tensor, rendered_image: Tensor, mask_image:
     return original_image
 
 
+def _adopt(camera):
+    """Any camera object with nerfstudio's public accessors -> this package's ``Cameras`` (``original_dataset.cameras`` are nerfstudio
+    objects in a real run, datasetgenerator.py:274-275): its rays then come from the HIP kernel and its view can be pre-computed."""
+    from .cameras import Cameras
+
+    return Cameras.from_cameras(camera)
+
+
 def _camera_key(camera) -> bytes:
-    """Identity of a 0-dim camera (pose + intrinsics), read from the host mirror: no device sync."""
-    host = getattr(camera, "_host", None)
-    if host is None:
-        host = torch.cat([camera.camera_to_worlds.reshape(-1).float().cpu()] +
-                         [torch.as_tensor(getattr(camera, k)).reshape(-1).float().cpu() for k in ("fx", "fy", "cx", "cy", "width", "height")])
-    return host.contiguous().numpy().tobytes()
+    """Identity of a 0-dim camera (pose, intrinsics, lens), read from the host mirror: no device sync for this package's cameras."""
+    return _adopt(camera)._host.contiguous().numpy().tobytes()
 
 
 class DatasetGenerator:
@@ -263,8 +269,11 @@ class DatasetGenerator:
                  transform_poses_to_original_space: Optional[Callable[[Tensor], Tensor]] = None, device="cuda",
                  diffuse: Optional[Callable[[Tensor, Tensor, Tensor, Tensor], Tensor]] = None, group=None, write_images: bool = True,
                  save_workers: Optional[int] = None, precompute: bool = True, profile: bool = False,
-                 png_compress_level: Optional[int] = None) -> None:
+                 png_compress_level: Optional[int] = None, finish_sync: bool = True, serial_stage_timeout_s: float = 24 * 3600.0,
+                 precompute_budget_mb: Optional[int] = None) -> None:
         self.config = config
+        self.finish_sync, self.serial_stage_timeout_s = finish_sync, serial_stage_timeout_s
+        self.precompute_budget_mb, self.precompute_skipped = precompute_budget_mb, 0
         self.png_compress_level = png_compress_level   # None: PIL's default, the files the reference writes (dataset_io.GeneratedDataset)
         self.device = device
         self.original_transform_matrix = original_transform_matrix if original_transform_matrix is not None else torch.eye(4)[:3]
@@ -392,92 +401,136 @@ class DatasetGenerator:
         scaled_image_height = int(self.height // self.downscale_factor)
 
         reference_cameras = Cameras(reference_camera_to_worlds, self.fx, self.fy, self.cx, self.cy, self.width, self.height).to(self.device)
-        cameras, original_filenames = None, None
+        cameras, original_filenames, original_cameras = None, None, None
         if original_dataset is not None:
-            cameras = original_dataset.cameras
+            # nerfstudio `Cameras` in a real run (per-camera intrinsics, OPENCV distortion, camera type): adopted once, so that their rays
+            # come from the HIP kernel and their views shard like the synthetic ones (one read-back of the intrinsics for the batch)
+            original_cameras = Cameras.from_cameras(original_dataset.cameras)
+            cameras = original_cameras
             original_filenames = original_dataset._dataparser_outputs.image_filenames  # pylint: disable=protected-access
         if synthetic_camera_to_worlds is not None:
             cameras = Cameras(synthetic_camera_to_worlds, self.fx, self.fy, self.cx, self.cy, self.width, self.height)
             original_filenames = [None] * synthetic_camera_to_worlds.shape[0]
         cameras = cameras.to(self.device)
 
-        # Stage 1 (every rank): all NeRF renders.  One tile shape per gather: cameras of another size (an original dataset whose
-        # images differ from the generator's width x height) are rendered inside the serial loop instead.
+        sync = self._sync_group(world)   # created while every rank is here: the serial stage below may take hours
+        if rank == 0:
+            self.init_directory()        # before the expensive stage: a missing dependency or an unwritable path fails now
+
+        # Stage 1 (every rank): all NeRF renders, one gather per image size (an original dataset may hold several).  Views beyond the
+        # memory budget are rendered inside the serial loop instead (rank 0 alone): correct, just not sharded.
         self._views = {}
         if self.precompute:
             todo = [reference_cameras[i] for i in range(len(reference_cameras))] + [cameras[i] for i in range(len(cameras))]
             if merge_with_original_dataset:
-                merged = original_dataset.cameras.to(graph.device)
+                merged = original_cameras.to(graph.device)
                 todo += [merged[i] for i in range(len(merged))]
-            same = [c for c in todo if (int(c._host[0, 16]), int(c._host[0, 17])) == (int(self.width), int(self.height))] \
-                if all(hasattr(c, "_host") for c in todo) else []
-            if same:
-                self.precompute_views(graph, same)
+            groups: Dict[Tuple[int, int], List] = {}
+            for c in todo:
+                groups.setdefault((int(c._host[0, 16]), int(c._host[0, 17])), []).append(c)
+            budget = self._precompute_budget_bytes()
+            for (w, h), cams in groups.items():
+                per_view = 3 * 5 * 4 * w * h   # the [n,H,W,5] fp32 tiles + the gather buffer + the reorder copy at their peak
+                fit = int(min(len(cams), budget // per_view))
+                if fit < len(cams):
+                    self.precompute_skipped += len(cams) - fit
+                if fit > 0:
+                    self.precompute_views(graph, cams[:fit])
+                    budget -= fit * per_view
         if rank != 0:  # the serial stage belongs to the rank that talks to the diffuser and the disk
-            self._finish(world)
+            self._finish(world, sync)
             return
 
-        # Stage 2 (rank 0): the reference's sequence
-        self.init_directory()
-        transforms = self.dataset.new_transforms(self.original_transform_matrix, self.original_scale_factor, self.is_synthetic,
-                                                 merge_with_original_dataset)
-        t0 = time.perf_counter()
-        image_sheet, mask_sheet, condition_sheet, edited_sheet, references = self.generate_reference_sheet(
-            graph, reference_cameras, scaled_image_width, scaled_image_height)
-        t0 = self._tick("sheet_s", t0)
-        refs = self.dataset.dirs["references"]
-        self.dataset.save_image(image_sheet, refs / "image_reference_sheet.png")
-        self.dataset.save_image(mask_sheet, refs / "mask_reference_sheet.png")
-        self.dataset.save_image(condition_sheet, refs / "condition_reference_sheet.png")
-        self.dataset.save_image(edited_sheet, refs / "edited_reference_sheet.png")
-        edited_image_idx = 0
-        transforms["reference_indices"] = []
-        for i, camera in enumerate(reference_cameras):
-            transforms = self.save_generated_images(edited_image_idx, references[i], camera, transforms)
-            transforms["reference_indices"].append(edited_image_idx)
-            edited_image_idx += 1
-        self.dataset.write_transforms(transforms)
-        t0 = self._tick("save_s", t0)
-
-        transforms["generated_indices"] = []
-        for i, camera in enumerate(cameras):
-            filename = original_filenames[i]
-            images = self.generate_with_reference_sheet(graph, camera, filename, scaled_image_width, scaled_image_height, edited_sheet,
-                                                        condition_sheet)
-            t0 = self._tick("views_s", t0)
-            transforms = self.save_generated_images(edited_image_idx, images, camera, transforms, filename is not None)
-            transforms["generated_indices"].append(edited_image_idx)
-            edited_image_idx += 1
+        try:
+            # Stage 2 (rank 0): the reference's sequence
+            transforms = self.dataset.new_transforms(self.original_transform_matrix, self.original_scale_factor, self.is_synthetic,
+                                                     merge_with_original_dataset)
+            t0 = time.perf_counter()
+            image_sheet, mask_sheet, condition_sheet, edited_sheet, references = self.generate_reference_sheet(
+                graph, reference_cameras, scaled_image_width, scaled_image_height)
+            t0 = self._tick("sheet_s", t0)
+            refs = self.dataset.dirs["references"]
+            self.dataset.save_image(image_sheet, refs / "image_reference_sheet.png")
+            self.dataset.save_image(mask_sheet, refs / "mask_reference_sheet.png")
+            self.dataset.save_image(condition_sheet, refs / "condition_reference_sheet.png")
+            self.dataset.save_image(edited_sheet, refs / "edited_reference_sheet.png")
+            edited_image_idx = 0
+            transforms["reference_indices"] = []
+            for i, camera in enumerate(reference_cameras):
+                transforms = self.save_generated_images(edited_image_idx, references[i], camera, transforms)
+                transforms["reference_indices"].append(edited_image_idx)
+                edited_image_idx += 1
+            self.dataset.write_transforms(transforms)
             t0 = self._tick("save_s", t0)
-        self.dataset.write_transforms(transforms)
-        t0 = self._tick("save_s", t0)
 
-        if merge_with_original_dataset:  # :344-388
-            transforms["original_indices"] = []
-            merged = original_dataset.cameras
-            for idx in range(len(merged)):
-                image = original_dataset.get_image_float32(idx).to(graph.device)
-                camera = merged[idx].to(graph.device)
-                render, mask, condition = self.render_camera(graph, camera, combine_shape_with_depth=self.combine_shape_with_depth)
-                mask = ~mask  # the original views do not contain the object
-                images = {"render": render, "mask": mask, "condition": condition, "edited": image,
-                          "render_scaled": resize_bilinear(render, scaled_image_height, scaled_image_width),
-                          "mask_scaled": resize_bilinear(mask, scaled_image_height, scaled_image_width, threshold=True) > 0.5,
-                          "condition_scaled": resize_bilinear(condition, scaled_image_height, scaled_image_width),
-                          "edited_scaled": resize_bilinear(image, scaled_image_height, scaled_image_width)}
+            transforms["generated_indices"] = []
+            for i, camera in enumerate(cameras):
+                filename = original_filenames[i]
+                images = self.generate_with_reference_sheet(graph, camera, filename, scaled_image_width, scaled_image_height, edited_sheet,
+                                                            condition_sheet)
                 t0 = self._tick("views_s", t0)
-                transforms = self.save_generated_images(edited_image_idx, images, camera, transforms, True)
-                transforms["original_indices"].append(edited_image_idx)
+                transforms = self.save_generated_images(edited_image_idx, images, camera, transforms, filename is not None)
+                transforms["generated_indices"].append(edited_image_idx)
                 edited_image_idx += 1
                 t0 = self._tick("save_s", t0)
             self.dataset.write_transforms(transforms)
-            self._tick("save_s", t0)
-        self.edited_reference_sheet, self.condition_reference_sheet = edited_sheet, condition_sheet  # (as left by the last view, :643-646)
-        self._views = {}
-        self._finish(world)
+            t0 = self._tick("save_s", t0)
 
-    def _finish(self, world: int) -> None:
-        if world > 1:  # every rank returns once the dataset is on disk
+            if merge_with_original_dataset:  # :344-388
+                transforms["original_indices"] = []
+                merged = original_cameras
+                for idx in range(len(merged)):
+                    image = original_dataset.get_image_float32(idx).to(graph.device)
+                    camera = merged[idx].to(graph.device)
+                    render, mask, condition = self.render_camera(graph, camera, combine_shape_with_depth=self.combine_shape_with_depth)
+                    mask = ~mask  # the original views do not contain the object
+                    images = {"render": render, "mask": mask, "condition": condition, "edited": image,
+                              "render_scaled": resize_bilinear(render, scaled_image_height, scaled_image_width),
+                              "mask_scaled": resize_bilinear(mask, scaled_image_height, scaled_image_width, threshold=True) > 0.5,
+                              "condition_scaled": resize_bilinear(condition, scaled_image_height, scaled_image_width),
+                              "edited_scaled": resize_bilinear(image, scaled_image_height, scaled_image_width)}
+                    t0 = self._tick("views_s", t0)
+                    transforms = self.save_generated_images(edited_image_idx, images, camera, transforms, True)
+                    transforms["original_indices"].append(edited_image_idx)
+                    edited_image_idx += 1
+                    t0 = self._tick("save_s", t0)
+                self.dataset.write_transforms(transforms)
+                self._tick("save_s", t0)
+            self.edited_reference_sheet, self.condition_reference_sheet = edited_sheet, condition_sheet  # (as left by the last view, :643-646)
+        finally:  # also when a diffuser call or a write raised: no worker threads or queued host copies left behind
+            self._views = {}
+            self.dataset.close()
+        self._finish(world, sync)
+
+    # -- end-of-dataset synchronisation --------------------------------------------------------------------------------------------
+    def _sync_group(self, world: int):
+        """The group the ranks meet in once the dataset is on disk.  Ranks other than 0 are idle for the whole serial stage -- the
+        sheet diffusion, one diffuser call per view (seconds each with a real Stable-Diffusion server, datasetgenerator.py:331-338),
+        PNG encoding, the merge loop -- which can exceed the default collective timeout (RCCL 10 min, gloo 30 min): a barrier on the
+        render group would have the watchdog abort the job before the dataset is written.  So the meeting point is a
+        dedicated gloo group (host-side, no GPU watchdog) with ``serial_stage_timeout_s`` (default 24 h), created here while all
+        ranks are together; ``finish_sync=False`` skips the meeting altogether (the other ranks return after the gather)."""
+        if world <= 1 or not self.finish_sync:
+            return None
+        import datetime as _dt
+
+        import torch.distributed as dist
+
+        ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
+        return dist.new_group(ranks=ranks, backend="gloo", timeout=_dt.timedelta(seconds=float(self.serial_stage_timeout_s)),
+                              use_local_synchronization=self.group is not None)
+
+    def _precompute_budget_bytes(self) -> int:
+        if self.precompute_budget_mb is not None:
+            return int(self.precompute_budget_mb) << 20
+        dev = torch.device(self.device)
+        if dev.type == "cuda" and torch.cuda.is_available():
+            return int(torch.cuda.get_device_properties(dev).total_memory // 4)   # a quarter of the 288 GB part: ~1 800 views at 800 x 800
+        return 8 << 30
+
+    def _finish(self, world: int, sync=None) -> None:
+        if world > 1 and sync is not None:  # every rank returns once the dataset is on disk
             import torch.distributed as dist
 
-            dist.barrier(group=self.group)
+            dist.barrier(group=sync)
+            dist.destroy_process_group(sync)

@@ -235,8 +235,119 @@ def test_merge_with_original_dataset(tmp_path, standins):
     assert np.array_equal(np.array(Image.open(root / "masks" / "mask_8.png")) > 0, (~m).squeeze(-1).numpy())
 
 
+class _ForeignCameras:
+    """`original_dataset.cameras` as a real run hands it over (datasetgenerator.py:274-275): a nerfstudio object, NOT this package's class --
+    attribute tensors, per-camera intrinsics, OPENCV distortion, integer indexing that yields 0-dim cameras, ``.to`` and ``.size``."""
+
+    def __init__(self, c2w, fx, sizes, dist):
+        self.camera_to_worlds, self.fx, self.fy = c2w, fx, fx * 1.02
+        self.width, self.height = sizes[:, :1].clone(), sizes[:, 1:].clone()
+        self.cx, self.cy = self.width.float() / 2, self.height.float() / 2
+        self.distortion_params, self.camera_type = dist, torch.ones(c2w.shape[0], 1, dtype=torch.int64)
+        self.times = self.metadata = None
+
+    size = property(lambda self: self.camera_to_worlds.shape[0])
+
+    def __len__(self):
+        return self.size
+
+    def __getitem__(self, i):
+        one = _ForeignCameras.__new__(_ForeignCameras)
+        for k in ("camera_to_worlds", "fx", "fy", "cx", "cy", "width", "height", "distortion_params", "camera_type"):
+            setattr(one, k, getattr(self, k)[i])
+        one.times = one.metadata = None
+        return one
+
+    def to(self, device):
+        return self
+
+
+def _original_dataset(tmp_path, n=6, second_size=None):
+    from PIL import Image
+
+    from signerf_amd import random_sphere_poses
+
+    torch.manual_seed(5)
+    c2w = random_sphere_poses(n, torch.device("cpu"), 0.6, (40.0, 100.0), (0.0, 360.0), [0.0, 0.0, 0.0], [0.0, 0.0, 0.0])[:, :3]
+    sizes = torch.full((n, 2), SIZE, dtype=torch.int64)
+    if second_size is not None:
+        sizes[n // 2:] = torch.tensor(second_size)
+    fx = torch.linspace(38.0, 44.0, n)[:, None]
+    dist = torch.tensor([0.05, -0.02, 0.0, 0.0, 0.001, -0.002]).expand(n, 6) * torch.linspace(0.5, 1.5, n)[:, None]
+    cams = _ForeignCameras(c2w, fx, sizes, dist)
+    files, photos = [], []
+    os.makedirs(tmp_path / "photos", exist_ok=True)
+    for i in range(n):
+        w, h = int(sizes[i, 0]), int(sizes[i, 1])
+        photo = (torch.rand(h, w, 3) * 255).to(torch.uint8)
+        f = tmp_path / "photos" / f"frame_{i}.png"
+        if not f.exists():
+            Image.fromarray(photo.numpy()).save(f)
+        files.append(f)
+        photos.append(photo.float() / 255)
+    return _Original(cams, files, photos)
+
+
+def test_original_cameras_mode_precomputes_foreign_distorted_cameras(tmp_path, standins):
+    """The reference's DEFAULT source of the generated views (`cameras = original_dataset.cameras`, :274-275; signerf_trainer.py:222) --
+    foreign camera objects with per-camera intrinsics and lens parameters: every view is pre-computed (r03 fell back to the serial
+    loop whenever a camera was not this package's class), each camera rendered once, intrinsics and lens carried through."""
+    ref, _ = _poses()
+    ds = _original_dataset(tmp_path)
+    gen = _generator(tmp_path, "exp")
+    seen = []
+    real = gen.precompute_views
+    gen.precompute_views = lambda graph, cams: (seen.append(len(cams)), real(graph, cams))[1]
+    gen.generate_dataset(_Graph(), ref, original_dataset=ds)
+    assert seen == [5 + 6] and gen.precompute_skipped == 0
+    assert len(RENDERED) == 11 and len(set(RENDERED)) == 11
+    t = json.load(open(tmp_path / "exp" / "transforms.json"))
+    assert t["is_synthetic"] is False and t["generated_indices"] == list(range(5, 11))
+    assert abs(t["frames"][5]["fl_x"] - 38.0) < 1e-6 and abs(t["frames"][10]["fl_x"] - 44.0) < 1e-5     # per-camera intrinsics survive the adoption
+    assert sorted(os.listdir(tmp_path / "exp" / "originals")) == sorted(f"image_{i}.png" for i in range(5, 11))  # the loaded photo replaces the render (:628-630)
+
+
+def test_mixed_image_sizes_and_memory_budget(tmp_path, standins):
+    """One gather per image size; views beyond the budget are rendered inside the serial loop -- the dataset is the same either way."""
+    ref, _ = _poses()
+    ds = _original_dataset(tmp_path, second_size=(SIZE + 8, SIZE - 8))
+    gen = _generator(tmp_path, "all")
+    sizes = []
+    real = gen.precompute_views
+    gen.precompute_views = lambda graph, cams: (sizes.append((len(cams), int(cams[0].width), int(cams[0].height))), real(graph, cams))[1]
+    gen.generate_dataset(_Graph(), ref, original_dataset=ds)
+    assert sizes == [(5 + 3, SIZE, SIZE), (3, SIZE + 8, SIZE - 8)]
+    RENDERED.clear()
+    tight = _generator(tmp_path, "tight", precompute_budget_mb=0)          # nothing fits: everything rendered in the loop
+    tight.generate_dataset(_Graph(), ref, original_dataset=ds)
+    assert tight.precompute_skipped == 11 and len(RENDERED) == 11
+    a, b = _tree(tmp_path / "all"), _tree(tmp_path / "tight")
+    a.pop("config.yml"), b.pop("config.yml")
+    assert a.keys() == b.keys() and all(a[k] == b[k] for k in a)
+
+
+def test_writer_threads_are_released(tmp_path, standins):
+    import threading
+
+    ref, syn = _poses(n_views=2)
+    before = threading.active_count()
+    for k in range(3):
+        gen = _generator(tmp_path, f"exp{k}", save_workers=4)
+        gen.generate_dataset(_Graph(), ref, synthetic_camera_to_worlds=syn)
+        assert gen.dataset._pool is None and not gen.dataset._pending
+    assert threading.active_count() <= before                              # r03 leaked one pool per generate_dataset call (ADVICE)
+
+    def broken(*a):
+        raise RuntimeError("diffuser down")
+
+    gen = _generator(tmp_path, "broken", diffuse=broken, save_workers=4)
+    with pytest.raises(RuntimeError, match="diffuser down"):
+        gen.generate_dataset(_Graph(), ref, synthetic_camera_to_worlds=syn)
+    assert gen.dataset._pool is None and threading.active_count() <= before
+
+
 # ---- world 2 over gloo: the written dataset equals the single-process one ----------------------------------------------------------
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode="synthetic"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -246,8 +357,14 @@ def _worker(rank, world, port, out_dir):
 
     me.install_cpu_standins()
     ref, syn = me._poses()
-    gen = me._generator(out_dir, "sharded")
-    gen.generate_dataset(me._Graph(), ref, synthetic_camera_to_worlds=syn)
+    import pathlib
+
+    if mode == "original":   # the reference's default camera source: a foreign camera batch, distorted, per-camera intrinsics
+        gen = me._generator(out_dir, "sharded", serial_stage_timeout_s=120.0)
+        gen.generate_dataset(me._Graph(), ref, original_dataset=me._original_dataset(pathlib.Path(out_dir)))
+    else:
+        gen = me._generator(out_dir, "sharded", finish_sync=(mode != "nosync"))
+        gen.generate_dataset(me._Graph(), ref, synthetic_camera_to_worlds=syn)
     json.dump({"rendered": me.RENDERED, "wrote": os.path.exists(os.path.join(out_dir, "sharded", "transforms.json"))},
               open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
     dist.destroy_process_group()
@@ -268,3 +385,25 @@ def test_generate_dataset_sharded_over_gloo_equals_single_process(tmp_path, stan
     counts = [len(p["rendered"]) for p in per_rank]
     assert sum(counts) == 12 and max(counts) - min(counts) <= 1                     # 5 + 7 cameras, camera i -> rank i mod N
     assert sorted(x for p in per_rank for x in p["rendered"]) == sorted(RENDERED)   # together: exactly the single-process renders
+
+
+@pytest.mark.parametrize("mode", ["original", "nosync"])
+def test_generate_dataset_sharded_other_modes(tmp_path, standins, mode):
+    """world 2: (original) the foreign, distorted dataset cameras still shard camera i -> rank i mod 2 -- r03 serialised them on rank 0;
+    (nosync) ranks other than 0 return right after the gather instead of waiting for the serial stage."""
+    if mode == "original":
+        _original_dataset(tmp_path)   # the photos exist before the ranks start
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), mode), nprocs=2, join=True)
+    ref, syn = _poses()
+    if mode == "original":
+        _generator(tmp_path, "single").generate_dataset(_Graph(), ref, original_dataset=_original_dataset(tmp_path))
+    else:
+        _generator(tmp_path, "single").generate_dataset(_Graph(), ref, synthetic_camera_to_worlds=syn)
+    a, b = _tree(tmp_path / "sharded"), _tree(tmp_path / "single")
+    a.pop("config.yml"), b.pop("config.yml")
+    assert a.keys() == b.keys() and all(a[k] == b[k] for k in a)
+    per_rank = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    n = 11 if mode == "original" else 12
+    counts = [len(p["rendered"]) for p in per_rank]
+    assert sum(counts) == n and max(counts) - min(counts) <= 1
+    assert per_rank[0]["wrote"] and (mode == "nosync" or per_rank[1]["wrote"])

@@ -65,6 +65,35 @@ def _render(model, c2w, W, H, focal, device, aabb=None):
     return keep
 
 
+# the lenses of tests/test_gpu_cameras.py: k1 k2 k3 k4 p1 p2
+DATASET_LENSES = {"phone": [0.05, -0.02, 0.0, 0.0, 0.001, -0.002], "barrel": [-0.28, 0.09, -0.01, 0.002, 0.0, 0.0],
+                  "tangential": [0.0, 0.0, 0.0, 0.0, 0.01, 0.02], "degenerate": [-1.5, 0.3, 0.0, 0.0, 0.05, 0.0], "zeros": [0.0] * 6}
+
+
+def _dataset_camera_rays(c2w, W, H):
+    """Ray bundles of DATASET cameras -- `cameras = original_dataset.cameras`, the reference's default source of the generated views
+    (datasetgenerator.py:274-275): OPENCV distortion parameters, per-camera intrinsics, PERSPECTIVE and FISHEYE.  Pins
+    oracle/nerfacto.py::radial_and_tangential_undistort / generate_rays (iteration count, eps rule, the zero-parameter short cut, the
+    fisheye mapping, whether fisheye coordinates are un-distorted)."""
+    from nerfstudio.cameras.cameras import Cameras, CameraType
+
+    fx = {}
+    for name, lens in DATASET_LENSES.items():
+        for ctype in (CameraType.PERSPECTIVE, CameraType.FISHEYE):
+            cams = Cameras(camera_to_worlds=c2w[None, :3, :4], fx=0.9 * W, fy=0.95 * W, cx=W / 2 + 0.25, cy=H / 2 - 0.5, width=W, height=H,
+                           distortion_params=torch.tensor(lens)[None], camera_type=ctype)
+            b = cams.generate_rays(camera_indices=0, keep_shape=True)
+            tag = f"rays.{name}.{ctype.name.lower()}"
+            fx[tag + ".directions"] = b.directions.detach().cpu().numpy()
+            fx[tag + ".pixel_area"] = b.pixel_area.detach().cpu().numpy()
+            fx[tag + ".directions_norm"] = b.metadata["directions_norm"].detach().cpu().numpy()
+    fx["rays.intrinsics"] = np.array([0.9 * W, 0.95 * W, W / 2 + 0.25, H / 2 - 0.5, W, H], dtype=np.float64)
+    fx["rays.c2w"] = c2w[:3, :4].numpy()
+    for name, lens in DATASET_LENSES.items():
+        fx[f"rays.lens.{name}"] = np.array(lens, dtype=np.float32)
+    return fx
+
+
 CV2_KSIZES = [(50, 50), (20, 20), (11, 11), (7, 7), (5, 5), (3, 3), (1, 1), (2, 2), (4, 6), (9, 5), (50, 30), (1, 7), (8, 1)]  # (width, height)
 
 
@@ -130,6 +159,7 @@ def main():
             fx[f"cam{cam}{'_aabb' if aabb else ''}.{k}"] = v
     for k, v in sd.items():
         fx["param." + k] = v.numpy()
+    fx.update(_dataset_camera_rays(c2w[1], 56, 40))
     np.savez_compressed(os.path.join(out_dir, "nerfstudio_nerfacto_torch.npz"), **fx)
     print("wrote nerfstudio_nerfacto_torch.npz:", sorted(k for k in fx if not k.startswith("param."))[:12], "...")
 
