@@ -241,6 +241,12 @@ int sn_hash_encode(SnHandle h, int32_t which, const float* q, int64_t n, float* 
  * rgb [n,3] (rows a9, a14, a15).  rgb/directions may be NULL. */
 int sn_field_forward(SnHandle h, int32_t which, const float* positions, const float* directions, int64_t n,
                      int32_t precision, float* density, float* rgb, SnStream stream);
+/* The same with the main field's 15 geometry features -- the second value of nerfstudio's `NerfactoField.get_density(ray_samples)`
+ * (`base_mlp_out`, which `Field.forward` hands to `get_outputs` as `density_embedding`): geo [n,15], nullable; which must be -1 when
+ * it is given.  Stands behind the Field objects' get_density / density_fn / get_outputs / forward (signerf/signerf.py:27 inherits them
+ * from NerfactoModel; nerfstudio's samplers and export tools call them). */
+int sn_field_forward_geo(SnHandle h, int32_t which, const float* positions, const float* directions, int64_t n,
+                         int32_t precision, float* density, float* rgb, float* geo, SnStream stream);
 /* Rows a10 + a17 on explicit per-sample inputs: euclid_bins [R,S+1], density [R,S], rgb_samples [R,S,3] ->
  * weights [R,S], rgb [R,3], depth [R], median_index [R] (int32), accumulation [R], expected_depth [R]
  * (clipped to the global [min,max] of the sample mid-points, i.e. one chunk). Outputs may be NULL. */

@@ -4,8 +4,8 @@ Hot path: ``Cameras.generate_rays`` -> ``NerfactoModel.get_outputs_for_camera_ra
 the C ABI in include/signerf_hip.h), plus the in-tree helpers either side of it.  See DESIGN.md.
 """
 
-from .cameras import Cameras, CameraType, OrientedBox, RayBundle, SceneBox  # noqa: F401
+from .cameras import Cameras, CameraType, Frustums, OrientedBox, RayBundle, RaySamples, SceneBox  # noqa: F401
 from .config import NerfactoModelConfig, SIGNeRFModelConfig  # noqa: F401
 from .intersection import intersect_with_aabb  # noqa: F401
-from .nerfacto import NerfactoModel, SIGNeRFModel  # noqa: F401
+from .nerfacto import FieldHeadNames, NerfactoModel, SIGNeRFModel  # noqa: F401
 from .poses import circle_poses, random_sphere_poses  # noqa: F401

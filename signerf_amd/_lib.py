@@ -146,6 +146,7 @@ SIGNATURES = {
     "sn_render_normals": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.POINTER(SnRenderOpts), _FP, _FP, C.c_void_p]),
     "sn_hash_encode": (C.c_int, [C.c_void_p, C.c_int32, _FP, C.c_int64, _FP, _FP, C.c_void_p]),
     "sn_field_forward": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, C.c_void_p]),
+    "sn_field_forward_geo": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, _FP, C.c_void_p]),
     "sn_composite": (C.c_int, [_FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
     "sn_pdf_sample": (C.c_int, [_FP, _FP, C.c_int64, C.c_int32, C.c_int32, _FP, C.c_float, _FP, _FP, C.c_void_p]),
     "sn_tensor_to_uint8": (C.c_int, [_FP, C.c_int64, _FP, C.c_void_p]),

@@ -83,6 +83,39 @@ class RayBundle:
         return self._map(lambda t: t.to(device))
 
 
+@dataclass
+class Frustums:
+    """nerfstudio's ``Frustums`` (``cameras.rays``): the geometry of ray samples.  The Field methods of this package read
+    ``get_positions()`` and ``directions`` -- of this class or of nerfstudio's own, which has the same two members."""
+
+    origins: Tensor      # [..., 3]
+    directions: Tensor   # [..., 3]
+    starts: Tensor       # [..., 1]
+    ends: Tensor         # [..., 1]
+    pixel_area: Optional[Tensor] = None
+
+    def get_positions(self) -> Tensor:
+        """Sample centres o + d (start + end) / 2."""
+        return self.origins + self.directions * ((self.starts + self.ends) / 2)
+
+    @property
+    def shape(self):
+        return self.origins.shape[:-1]
+
+
+@dataclass
+class RaySamples:
+    """nerfstudio's ``RaySamples`` as far as a Field reads it: ``frustums`` (+ ``camera_indices``, ``deltas``, unused in eval)."""
+
+    frustums: Frustums
+    camera_indices: Optional[Tensor] = None
+    deltas: Optional[Tensor] = None
+
+    @property
+    def shape(self):
+        return self.frustums.shape
+
+
 def _as_column(x: Union[float, int, Tensor], batch: int, dtype) -> Tensor:
     t = torch.as_tensor(x, dtype=dtype)
     if t.ndim == 0:

@@ -1730,7 +1730,13 @@ int sn_hash_encode(SnHandle h, int32_t which, const float* q, int64_t n, float* 
 
 int sn_field_forward(SnHandle h, int32_t which, const float* positions, const float* directions, int64_t n, int32_t precision,
                      float* density, float* rgb, SnStream stream) {
+    return sn_field_forward_geo(h, which, positions, directions, n, precision, density, rgb, nullptr, stream);
+}
+
+int sn_field_forward_geo(SnHandle h, int32_t which, const float* positions, const float* directions, int64_t n, int32_t precision,
+                         float* density, float* rgb, float* geo, SnStream stream) {
     if (!h) return SN_ERR_INVALID;
+    if (geo && which >= 0) return fail(h, SN_ERR_INVALID, "sn_field_forward_geo: only the main field (which = -1) has geometry features");
     if (!positions || !density || n < 0) return fail(h, SN_ERR_INVALID, "sn_field_forward: bad argument");
     if (which < -1 || which >= h->desc.num_proposals) return fail(h, SN_ERR_INVALID, "sn_field_forward: bad field selector");
     if (!h->finalized) return fail(h, SN_ERR_STATE, "sn_field_forward: weights not finalized");
@@ -1753,6 +1759,7 @@ int sn_field_forward(SnHandle h, int32_t which, const float* positions, const fl
         p.sh_remap = h->desc.sh_remap;
         p.density = density;
         p.rgb = rgb;
+        p.geo = geo;
         p.grid_mode = h->desc.main_field.grid_mode;
         p.grid = grid_levels(h->desc.main_field);
         if (precision == 0)

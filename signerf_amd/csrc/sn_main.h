@@ -82,7 +82,11 @@ struct SnShOps {
 
 // Full main-field evaluation of the wave's 64 samples.  feat[32]: this lane's own hash features.
 // Returns this lane's own pre-activation density h0 and post-sigmoid rgb.
-SN_DEV void sn_main_field_f32(const float* __restrict__ lds, float* feat, const SnShOps& sh, int lane, float& h0, float rgb[3]) {
+// GEO (stage kernel only): geo16[k] = layer-2 output k of the lane's own sample (k = 0: h0, k = 1..15: the geometry features nerfstudio
+// calls `base_mlp_out` / `density_embedding`), gathered from the accumulator layout with 8 half-wave swaps.
+template <bool GEO = false>
+SN_DEV void sn_main_field_f32(const float* __restrict__ lds, float* feat, const SnShOps& sh, int lane, float& h0, float rgb[3],
+                              float* geo16 = nullptr) {
     const bool upper = lane >= 32;
     // ---- layer 1: 32 -> 64, ReLU ---------------------------------------------------------
     float op0[32], op1[32];
@@ -108,6 +112,15 @@ SN_DEV void sn_main_field_f32(const float* __restrict__ lds, float* feat, const 
     f32x16 g0[1], g1[1];
     sn_mlp_layer_f32<1, 32>(lds + SnMainImg::W2, lds + SnMainImg::B2, op0, op1, g0, g1, lane);
     h0 = upper ? g1[0][8] : g0[0][0];
+    if (GEO) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float a = g0[0][r], b = g1[0][r];
+            sn_swap_halves(a, b);  // every lane: a = row rho(r), b = row rho(r) + 4 of its OWN sample
+            geo16[(r & 3) + 8 * (r >> 2)] = a;
+            geo16[(r & 3) + 8 * (r >> 2) + 4] = b;
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---- colour layer 1: (L2 rows 0..15 | SH16) -> 64, ReLU --------------------------------
 #pragma unroll
@@ -349,7 +362,9 @@ SN_DEV void sn_acc_to_ops(const f32x16& acc, bool relu, SnOpH& s0, SnOpH& s1) {
     s1.set(v + 8);
 }
 
-SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const SnShOpsH& sh, int lane, float& h0, float rgb[3]) {
+template <bool GEO = false>
+SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const SnShOpsH& sh, int lane, float& h0, float rgb[3],
+                            float* geo16 = nullptr) {
     const bool upper = lane >= 32;
     const float* tail = (const float*)(ldsb + SnMainImgH::FP32);
     SnOpH op0[4], op1[4];
@@ -381,6 +396,15 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
     // the layers run on power-of-two scaled activations (sn_api.hip plan_split_scales); the density row is scaled back here, the geo
     // rows carry their scale into colour layer 1, whose weights hold the inverse
     h0 = (upper ? g1[0][8] : g0[0][0]) * tail[SnMainImgH::B3 + 3];
+    if (GEO) {  // (as in sn_main_field_f32; the rows carry the layer's power-of-two output scale)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float a = g0[0][r], b = g1[0][r];
+            sn_swap_halves(a, b);
+            geo16[(r & 3) + 8 * (r >> 2)] = a * tail[SnMainImgH::B3 + 3];
+            geo16[(r & 3) + 8 * (r >> 2) + 4] = b * tail[SnMainImgH::B3 + 3];
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---- colour layer 1: k-step 0 <- layer-2 regs 0..7 (rows rho(e)+4h), k-step 1 <- SH ----
     {

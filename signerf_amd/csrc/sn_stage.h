@@ -273,6 +273,7 @@ struct SnFieldStageParams {
     int sh_remap;
     float* density;  // [n]
     float* rgb;      // [n,3] or null
+    float* geo;      // [n,15] or null: layer-2 outputs 1..15 (nerfstudio's `base_mlp_out`)
     int grid_mode;   // 1: tiny-cuda-nn grid semantics
     SnGridLevels grid;
     float feat_scale;  // power-of-two feature scale whose inverse the first layer's weights carry (both images)
@@ -307,10 +308,15 @@ __global__ __launch_bounds__(256, 2) void sn_main_field_stage_kernel(SnFieldStag
     else sn_hash_encode<16>(rsrc, p.scal, p.log2_t, q, feat);
 #pragma unroll
     for (int k = 0; k < 32; ++k) feat[k] *= p.feat_scale;
-    float h0, rgb[3];
-    if (PREC == 0) sn_main_field_f32(lds, feat, sh, lane, h0, rgb);
-    else sn_main_field_h((const char*)lds, feat, shh, lane, h0, rgb);
-    if ((q[0] != q[0]) | (q[1] != q[1]) | (q[2] != q[2])) h0 = rgb[0] = rgb[1] = rgb[2] = __builtin_nanf("");
+    float h0, rgb[3], geo16[16];
+    if (PREC == 0) sn_main_field_f32<true>(lds, feat, sh, lane, h0, rgb, geo16);
+    else sn_main_field_h<true>((const char*)lds, feat, shh, lane, h0, rgb, geo16);
+    const bool qnan = (q[0] != q[0]) | (q[1] != q[1]) | (q[2] != q[2]);
+    if (qnan) h0 = rgb[0] = rgb[1] = rgb[2] = __builtin_nanf("");
+    if (i < p.n && p.geo) {
+#pragma unroll
+        for (int k = 0; k < 15; ++k) p.geo[i * 15 + k] = qnan ? __builtin_nanf("") : geo16[1 + k];
+    }
     if (i < p.n) {
         p.density[i] = p.avg_density * expf(h0) * (sel ? 1.0f : 0.0f);
         if (p.rgb) {

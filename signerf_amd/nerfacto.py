@@ -25,7 +25,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib
-from .cameras import RayBundle, SceneBox
+from .cameras import Frustums, RaySamples, RayBundle, SceneBox  # noqa: F401
 from .config import NerfactoModelConfig, SIGNeRFModelConfig
 
 PRECISIONS = {"fp32": 0, "fp16x2": 1}
@@ -162,8 +162,100 @@ class CameraOptimizer(nn.Module):
             param_groups["camera_opt"] = params
 
 
-class NerfactoField(nn.Module):
-    """Parameters of nerfstudio's NerfactoField (A6-A9, A13-A15)."""
+try:  # inside a nerfstudio installation the Field outputs are keyed by ITS enum (members of different Enum classes never compare equal)
+    from nerfstudio.field_components.field_heads import FieldHeadNames  # type: ignore  # noqa: F401
+except Exception:  # pragma: no cover  (nerfstudio is not installed in the build container)
+    import enum
+
+    class FieldHeadNames(enum.Enum):
+        """nerfstudio's ``FieldHeadNames`` values [NS-RECALL, H] -- the keys of ``Field.forward`` / ``get_outputs``."""
+
+        RGB = "rgb"
+        SH = "sh"
+        DENSITY = "density"
+        NORMALS = "normals"
+        PRED_NORMALS = "pred_normals"
+        UNCERTAINTY = "uncertainty"
+        BACKGROUND_RGB = "background_rgb"
+        TRANSIENT_RGB = "transient_rgb"
+        TRANSIENT_DENSITY = "transient_density"
+        SEMANTICS = "semantics"
+        SDF = "sdf"
+        ALPHA = "alpha"
+        GRADIENT = "gradient"
+
+
+class _HipField(nn.Module):
+    """nerfstudio's ``Field`` call surface [NS-RECALL, H] as thin bindings over the stage entry point ``sn_field_forward_geo`` (the LITERAL
+    torch-path arithmetic, eval mode).  signerf/signerf.py:27 subclasses NerfactoModel and so inherits ``model.field`` /
+    ``model.proposal_networks[i]`` with these methods; nerfstudio's samplers (``density_fns``) and export tools call them.
+
+        density_fn(positions [...,3])                 -> density [...,1]
+        get_density(ray_samples)                      -> (density [...,1], base_mlp_out [...,15] | None)
+        get_outputs(ray_samples, density_embedding)   -> {FieldHeadNames.RGB: [...,3]}                      (main field)
+        forward(ray_samples, compute_normals=False)   -> {FieldHeadNames.DENSITY: ..., FieldHeadNames.RGB: ...}
+
+    The parameters live in the owning model's HIP handle, so a Field evaluates through its owner (set by ``populate_modules``); there
+    is no PyTorch forward and no CPU path."""
+
+    _which = -1  # -1: the main field; i >= 0: proposal network i
+
+    def _bind(self, owner, which: int) -> None:
+        import weakref
+
+        object.__setattr__(self, "_owner_ref", weakref.ref(owner))   # not a sub-module: no reference cycle, not in the state dict
+        object.__setattr__(self, "_which", which)
+
+    def _owner(self):
+        owner = getattr(self, "_owner_ref", lambda: None)()
+        if owner is None:
+            raise _lib.SignerfHipError("this Field is not attached to a model: its parameters are evaluated through the owning "
+                                       "NerfactoModel's HIP handle (there is no PyTorch forward)")
+        return owner
+
+    @torch.no_grad()
+    def _evaluate(self, positions: Tensor, directions: Optional[Tensor], want_geo: bool):
+        from . import ops
+
+        owner = self._owner()
+        if positions.shape[-1] != 3:
+            raise ValueError("positions must be [..., 3]")
+        shape = positions.shape[:-1]
+        dev = owner.device
+        pos = positions.reshape(-1, 3).to(device=dev, dtype=torch.float32)
+        d = None if directions is None else directions.reshape(-1, 3).to(device=dev, dtype=torch.float32)
+        if pos.shape[0] == 0:
+            z = lambda c: torch.empty((*shape, c), dtype=torch.float32, device=dev)  # noqa: E731
+            return z(1), (None if d is None or self._which >= 0 else z(3)), (z(15) if want_geo else None)
+        if want_geo:
+            density, rgb, geo = ops.field_forward(owner, pos, d, self._which, return_geo=True)
+        else:
+            (density, rgb), geo = ops.field_forward(owner, pos, d, self._which), None
+        return (density.view(*shape, 1), None if rgb is None else rgb.view(*shape, 3), None if geo is None else geo.view(*shape, 15))
+
+    def density_fn(self, positions: Tensor, times: Optional[Tensor] = None) -> Tensor:
+        """``Field.density_fn``: density at world positions (the scene contraction / normalisation is part of the field)."""
+        return self._evaluate(positions, None, False)[0]
+
+    def get_density(self, ray_samples):
+        positions = ray_samples.frustums.get_positions()
+        density, _, geo = self._evaluate(positions, None, self._which < 0)
+        return density, geo
+
+    def forward(self, ray_samples, compute_normals: bool = False) -> Dict:
+        if compute_normals:
+            raise NotImplementedError("per-sample normals are not exposed: the composited 'normals' / 'pred_normals' outputs of the model "
+                                      "are (NerfactoModel.get_outputs_for_camera_ray_bundle, csrc/sn_normals.h)")
+        fr = ray_samples.frustums
+        density, rgb, _ = self._evaluate(fr.get_positions(), fr.directions if self._which < 0 else None, False)
+        out = {FieldHeadNames.DENSITY: density}
+        if rgb is not None:
+            out[FieldHeadNames.RGB] = rgb
+        return out
+
+
+class NerfactoField(_HipField):
+    """Parameters of nerfstudio's NerfactoField (A6-A9, A13-A15) + its eval-mode call surface (``_HipField``)."""
 
     def __init__(self, config: NerfactoModelConfig, num_images: int):
         super().__init__()
@@ -177,9 +269,20 @@ class NerfactoField(nn.Module):
             self.mlp_pred_normals = MLP(12 + self.geo_feat_dim, 3, 64, 64)
             self.field_head_pred_normals = PredNormalsFieldHead(64)
 
+    def get_outputs(self, ray_samples, density_embedding: Optional[Tensor] = None) -> Dict:
+        """``NerfactoField.get_outputs``: {RGB: [...,3]} for the samples' positions and directions, eval mode (mean appearance embedding, A14).
+        ``density_embedding`` is a function of the positions; the kernel evaluates the whole field from them in one pass, so the
+        argument is only checked for its shape (``Field.forward`` always passes the value ``get_density`` returned for the same samples)."""
+        fr = ray_samples.frustums
+        if density_embedding is not None and tuple(density_embedding.shape) != (*fr.directions.shape[:-1], self.geo_feat_dim):
+            raise ValueError(f"density_embedding must be [..., {self.geo_feat_dim}] for these samples")
+        _, rgb, _ = self._evaluate(fr.get_positions(), fr.directions, False)
+        return {FieldHeadNames.RGB: rgb}
 
-class HashMLPDensityField(nn.Module):
-    """Parameters of a proposal network (row a9)."""
+
+class HashMLPDensityField(_HipField):
+    """Parameters of a proposal network (row a9) + ``density_fn`` / ``get_density`` (``_HipField``; ``get_density`` returns
+    ``(density, None)`` as nerfstudio's does)."""
 
     def __init__(self, hidden_dim=16, log2_hashmap_size=17, num_levels=5, max_res=128, base_res=16, features_per_level=2,
                  use_linear=False, implementation="torch", **_):
@@ -297,6 +400,10 @@ class NerfactoModel(nn.Module):
         for i in range(cfg.num_proposal_iterations):
             args = cfg.proposal_net_args_list[min(i, len(cfg.proposal_net_args_list) - 1)]
             self.proposal_networks.append(HashMLPDensityField(**args, implementation=cfg.implementation))
+        self.field._bind(self, -1)
+        for i, net in enumerate(self.proposal_networks):
+            net._bind(self, i)
+        self.density_fns = [net.density_fn for net in self.proposal_networks]   # nerfstudio's NerfactoModel attribute [NS-RECALL, H]
         self.camera_optimizer = CameraOptimizer(self.num_train_data, cfg.camera_optimizer_mode)
 
     @property

@@ -30,8 +30,9 @@ def hash_encode(model, q: Tensor, which: int = -1, return_indices: bool = False)
     return (feat, idx) if return_indices else feat
 
 
-def field_forward(model, positions: Tensor, directions: Optional[Tensor] = None, which: int = -1) -> Tuple[Tensor, Optional[Tensor]]:
-    """NerfactoField / HashMLPDensityField on explicit world positions (rows a9, a14, a15) -> density [n], rgb [n,3] | None."""
+def field_forward(model, positions: Tensor, directions: Optional[Tensor] = None, which: int = -1, return_geo: bool = False):
+    """NerfactoField / HashMLPDensityField on explicit world positions (rows a9, a14, a15) -> density [n], rgb [n,3] | None
+    (+ the main field's geometry features [n,15] with ``return_geo``: nerfstudio's ``base_mlp_out``)."""
     lib = model._ensure_engine()
     pos = _f32(positions)
     n = pos.shape[0]
@@ -39,11 +40,17 @@ def field_forward(model, positions: Tensor, directions: Optional[Tensor] = None,
     with torch.cuda.device(pos.device):
         density = torch.empty((n,), dtype=torch.float32, device=pos.device)
         rgb = torch.empty((n, 3), dtype=torch.float32, device=pos.device) if (which < 0 and d is not None) else None
+        geo = torch.empty((n, 15), dtype=torch.float32, device=pos.device) if return_geo else None
         from .nerfacto import PRECISIONS
 
-        _lib.check(lib.sn_field_forward(model._handle, which, _lib.ptr(pos), _lib.ptr(d), n, PRECISIONS[model.config.precision],
-                                        _lib.ptr(density), _lib.ptr(rgb), _lib.current_stream()), model._handle, "sn_field_forward")
-    return density, rgb
+        model._engine_rw.acquire_read()
+        try:
+            _lib.check(lib.sn_field_forward_geo(model._handle, which, _lib.ptr(pos), _lib.ptr(d), n, PRECISIONS[model.config.precision],
+                                                _lib.ptr(density), _lib.ptr(rgb), _lib.ptr(geo), _lib.current_stream()),
+                       model._handle, "sn_field_forward")
+        finally:
+            model._engine_rw.release_read()
+    return (density, rgb, geo) if return_geo else (density, rgb)
 
 
 def composite(euclid_bins: Tensor, density: Tensor, rgb_samples: Tensor):
