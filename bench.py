@@ -58,6 +58,107 @@ def measured_traffic(precision):
         return None, None
 
 
+def _json_line_of(cmd, timeout_s, env=None, cwd=None):
+    """Runs a child process and returns the last JSON object it printed on a line of its own (None + reason on any failure)."""
+    import subprocess
+
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd=cwd)
+    except Exception as e:  # noqa: BLE001
+        return None, repr(e)
+    for ln in reversed(r.stdout.splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                return json.loads(ln), None
+            except ValueError:
+                continue
+    # (tools/config5_bench.py pretty-prints one object)
+    try:
+        i = r.stdout.index("{")
+        return json.loads(r.stdout[i:]), None
+    except ValueError:
+        return None, "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])
+
+
+def other_configs(precision):
+    """BASELINE.json configs[3] and configs[4] in the driver's line: untimed legs AFTER the headline's timed region, each in
+    a child process of this interpreter so that the headline's handle, streams and allocator state are not disturbed.
+      configs[3]  `bench.py --workload nerfacto1080 --steps 12 --warmup 3`: 1920x1080, proposal nets 256 + 96 + 48 main samples
+      configs[4]  `tools/config5_bench.py --size 800 --only-nopng`: DatasetGenerator.generate_dataset, 8 reference + 50 views, PNG writes off"""
+    out = []
+    me = os.path.abspath(__file__)
+    base = [sys.executable, me, "--workload", "nerfacto1080", "--steps", "12", "--warmup", "3", "--precision", precision, "--no-cpu-baseline",
+            "--no-alt-precision", "--no-others", "--no-traffic"]
+    d, err = _json_line_of(base, 240)
+    if d is None:
+        out.append({"config": "BASELINE.json configs[3] (nerfacto1080)", "error": err})
+    else:
+        rf = d.get("roofline", {})
+        out.append({"config": d["config"]["workload"], "command": "bench.py --workload nerfacto1080 --steps 12 --warmup 3 (child process, after the headline)",
+                    "ms_per_frame": d["ms_per_step"], "frames": d["steps"], "frames_in_flight": d.get("frames_in_flight"),
+                    "kernel_ms_per_launch": d["kernel_ms"]["median"], "ray_samples_per_s": d["value"],
+                    "field_evaluations_per_s": d.get("field_evaluations_per_sec"), "rays_per_s": d.get("rays_per_sec"),
+                    "roofline": {k: rf.get(k) for k in ("bound", "frac", "frac_at_sustained_clock", "sustained_clock_ghz", "peak_clock_ghz", "unit")}})
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "config5_bench.py"), "--size", "800", "--reps", "1", "--only-nopng"]
+    d, err = _json_line_of(cmd, 240)
+    if d is None:
+        out.append({"config": "BASELINE.json configs[4] (generator loop)", "error": err})
+    else:
+        e = d.get("png_writes_off", {})
+        out.append({"config": "BASELINE.json configs[4]: DatasetGenerator.generate_dataset, " + d.get("workload", ""), "size": d.get("size"),
+                    "command": "tools/config5_bench.py --size 800 --reps 1 --only-nopng (child process; one warm-up repetition + one timed)",
+                    "png_writes": "off", "total_ms": e.get("total_ms"), "ms_per_view": e.get("ms_per_view"),
+                    "render_stage_ms": e.get("render_stage_ms"), "render_ms_per_view": e.get("render_ms_per_view"),
+                    "field_evaluations_per_s": e.get("field_evaluations_per_s"), "views": d.get("views"), "ranks": d.get("ranks")})
+    return out
+
+
+def inrun_traffic(precision, kernel_pattern="sn_render_main_kernel"):
+    """HBM-side bytes per launch of K1 from rocprofv3 PMC passes collected IN THIS RUN (MI355X_MICROARCH.md "HBM": the L2's memory-side
+    request counters, separate --pmc passes, never combined with a system trace): a child `bench.py --steps 3` per pass under
+    `rocprofv3 --kernel-trace --pmc ...`.  Reads = sum over size classes of TCC_EA0_RDREQ_{32,64,128}B x size (the size-classed counters need
+    no gfx950 halving correction: that applies to FETCH_SIZE, which tallies 128-B requests at 64 B); writes = WRITE_SIZE KiB (the guide calls
+    it uncalibrated; it is < 1 % of the total here).  Infinity-Cache hits are counted, so this is fabric traffic, an upper bound of DRAM bytes."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="sn_traffic_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    me = os.path.abspath(__file__)
+    child = [sys.executable, me, "--steps", "3", "--warmup", "1", "--frames-in-flight", "1", "--precision", precision, "--no-cpu-baseline",
+             "--no-alt-precision", "--no-others", "--no-traffic"]
+    acc = {}
+    try:
+        for name, counters in (("rd", ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]), ("wr", ["WRITE_SIZE"])):
+            import subprocess
+
+            d = os.path.join(tmp, name)
+            r = subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "--pmc", *counters, "-d", d, "--", *child],
+                               capture_output=True, text=True, timeout=240, env=env, cwd="/tmp")
+            rows = 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel_pattern in row.get("Kernel_Name", ""):
+                        acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                        rows += 1
+            if rows == 0:
+                return None, "pass %s: no counter rows (rc %d) %s" % (name, r.returncode, (r.stderr or "")[-200:])
+        a = {k: sum(v) / len(v) for k, v in acc.items()}
+        rd = 32 * a.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * a.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * a.get("TCC_EA0_RDREQ_128B_sum", 0)
+        wr = a.get("WRITE_SIZE", 0) * 1024
+        return {"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "launches_averaged": len(next(iter(acc.values())))}, None
+    except Exception as e:  # noqa: BLE001
+        return None, repr(e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def physical_cores():
     """(physical cores, logical CPUs) of the host."""
     pairs, phys, core = set(), None, None
@@ -168,6 +269,8 @@ def main():
                          "1 = one stream, every launch waits for the previous one to drain")
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the extra (untimed-region) run of the other precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the untimed legs of BASELINE.json configs[3] and configs[4] (`others` in the line)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed CPU-oracle renders of configs 2 and 1 (median reported; BASELINE.md §2: 5)")
     ap.add_argument("--cpu-runs-config4", type=int, default=1, help="timed CPU-oracle renders of the 240x135 config-4 crop (~45 s each)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -418,10 +521,11 @@ def main():
             "metric": "ray-samples/sec (%dx%d reference-sheet camera render)" % (W, H),
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else
-                     "f32 (MLP operands carried as fp16 hi+lo pairs on the matrix cores, f32 accumulate; every layer range-conditioned into "
-                     "fp16's [2^-3, 65504] by exact power-of-two scales at sn_finalize_weights, exact-fp32 MFMA fallback otherwise; validated "
-                     "against exact fp32 for tables x1..1e-5, weights x0.05 and activations > 65504: tests/test_gpu_precision.py)",
+            "dtype": "f32 (exact fp32 MFMA)" if args.precision == "fp32" else
+                     "fp16x2-split multiply (22-bit operand significands: every fp32 MLP operand carried as an fp16 hi+lo pair on the matrix "
+                     "cores, products hi.hi + hi.lo + lo.hi, lo.lo dropped), f32 accumulate; hash-grid blend, sampling and compositing in f32/f64.  "
+                     "Layers range-conditioned into fp16's [2^-3, 65504] by exact power-of-two scales at sn_finalize_weights, exact-fp32 MFMA "
+                     "fallback otherwise; error equals exact fp32's (tests/test_gpu_precision.py); the exact-fp32 figure is `alt_precision`",
             "data": "synthetic",
             "config": {"workload": (f"BASELINE.json configs[1]: {W}x{H} rays x {S} samples/ray, nerfacto hash grid L=16 T=2^19 F=2, "
                                     "no proposal nets, random-weight synthetic scene, one camera per GPU + tile all-gather")
@@ -467,13 +571,24 @@ def main():
         }
         achieved_gbps = (W * H * bytes_per_ray) / (k_med * 1e-3) / 1e9
         traffic, traffic_commit = measured_traffic(args.precision) if args.workload == "sheet64" else (None, None)
-        # HBM-side bytes per launch are NOT measured in this run (bench.py cannot run rocprofv3 on itself): `traffic` inside the roofline
-        # objects is null; the figure of the committed PMC passes is quoted here, labelled with the commit it was profiled at
+        # HBM-side bytes per launch: measured IN THIS RUN by two rocprofv3 --pmc child passes (inrun_traffic; N = 1, the headline workload);
+        # when that is skipped or fails `traffic` is null and `traffic_source` says so.  The figure of the committed PMC passes is quoted
+        # beside it, labelled with the commit it was profiled at.
         line["traffic_committed_profile"] = {"bytes_per_launch": traffic, "profiled_at": traffic_commit,
                                              "source": "profiles/traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ_* / TCC_EA0_WRREQ_*, tools/pmc_summary.py)"}
+        inrun, inrun_err = (None, "skipped (--no-traffic)" if args.no_traffic else "N > 1 or not the headline workload")
+        if world == 1 and args.workload == "sheet64" and not args.no_traffic:
+            inrun, inrun_err = inrun_traffic(args.precision)
+        traffic_now = inrun["bytes_per_launch"] if inrun else None
+        traffic_source = ("in-run rocprofv3 --pmc passes (child `bench.py --steps 3 --frames-in-flight 1`): TCC_EA0_RDREQ_{32,64,128}B_sum x size "
+                          "+ WRITE_SIZE KiB, averaged over the K1 dispatches") if inrun else "not measured in this run (%s); see traffic_committed_profile" % inrun_err
+        line["traffic_in_run"] = inrun
         line["roofline_hbm"] = {
             "bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved_gbps / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": traffic_now, "traffic_source": traffic_source,
+            "traffic_gbps": (traffic_now / (k_med * 1e-3) / 1e9) if traffic_now else None,
+            "traffic_frac_of_hbm_peak": (traffic_now / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic_now else None,
+            "traffic_over_algorithmic": (traffic_now / (W * H * bytes_per_ray)) if traffic_now else None,
             "kernel": ("sn_render_main_kernel<0,%d>" % (0 if args.precision == "fp32" else 1)) if args.workload == "sheet64"
             else "sn_proposal_kernel + sn_render_main_kernel<1,*> (whole render call)",
             "kernel_ms": k_med, "algorithmic_bytes_per_launch": W * H * bytes_per_ray,
@@ -506,36 +621,40 @@ def main():
                 }
                 for r in roofs.values():
                     r["achieved"] = r["per_wave_step"] * wave_steps / t_kernel / 1e9                  # G instructions / s, whole chip
-                    r["peak"] = r["units"] * clock / r["cycles_each"]                                # G instructions / s at the sustained clock
+                    # `frac` / `peak`: against the PART's peak (2.4 GHz), as a roofline fraction is quoted; the same roof priced at the
+                    # clock the chip sustains under this kernel (power-limited) is `frac_at_sustained_clock`
+                    r["peak"] = r["units"] * PEAK_CLOCK_GHZ / r["cycles_each"]                       # G instructions / s at the part's 2.4 GHz
                     r["frac"] = r["achieved"] / r["peak"]
-                    r["peak_at_peak_clock"] = r["units"] * PEAK_CLOCK_GHZ / r["cycles_each"]         # ... at the part's 2.4 GHz
-                    r["frac_at_peak_clock"] = r["achieved"] / r["peak_at_peak_clock"]
+                    r["peak_at_sustained_clock"] = r["units"] * clock / r["cycles_each"]             # ... at the sustained clock
+                    r["frac_at_sustained_clock"] = r["achieved"] / r["peak_at_sustained_clock"]
+                    r["peak_at_peak_clock"], r["frac_at_peak_clock"] = r["peak"], r["frac"]          # (r03's key names, kept)
                     r["roof_ms"] = r["per_wave_step"] * wave_steps * r["cycles_each"] / (r["units"] * clock * 1e9) * 1e3
-                bound = max(roofs, key=lambda k: roofs[k]["frac"])
+                bound = max(roofs, key=lambda k: roofs[k]["frac"])   # (the ranking is the same at either clock)
                 # Empirical issue model (NOT a roof): in the probes an f16 32x32x16 MFMA keeps the SIMD's vector issue port for ~12-17 cycles
                 # (its 24 source + 16 destination registers), not for one 4-cycle slot -- profiles/r02_overlap2_probe.txt, r02_mlp_probe.txt
                 model_cycles = cnt["valu"] * VALU_ISSUE_CYCLES + cnt["mfma"] * (MFMA_PORT_CYCLES if args.precision != "fp32" else MFMA_F32_CYCLES)
                 model_ms = model_cycles * wave_steps / (N_SIMDS * clock * 1e9) * 1e3
                 line["roofline"] = {
                     "bound": bound, "achieved": roofs[bound]["achieved"], "peak": roofs[bound]["peak"], "unit": "G wave-instructions/s",
-                    "frac": roofs[bound]["frac"], "traffic": None,
-                    "frac_at_peak_clock": roofs[bound]["frac_at_peak_clock"], "peak_at_peak_clock": roofs[bound]["peak_at_peak_clock"],
+                    "frac": roofs[bound]["frac"], "traffic": traffic_now, "traffic_source": traffic_source,
+                    "frac_at_sustained_clock": roofs[bound]["frac_at_sustained_clock"], "peak_at_sustained_clock": roofs[bound]["peak_at_sustained_clock"],
+                    "frac_at_peak_clock": roofs[bound]["frac"], "peak_at_peak_clock": roofs[bound]["peak"],
                     "peak_clock_ghz": PEAK_CLOCK_GHZ,
                     "kernel": cnt["kernel"], "kernel_ms": k_med, "sustained_clock_ghz": clock,
                     "instructions_per_wave_step": {k: cnt[k] for k in ("valu", "mfma", "vmem_load", "lds", "packed_f32") if k in cnt} | {"gather": n_gather},
                     "roofs": roofs,
-                    "empirical_issue_model": {"ms": model_ms, "frac": model_ms / k_med,
+                    "empirical_issue_model": {"ms": model_ms, "frac": model_ms / k_med, "priced_at": "sustained clock",
                                               "what": "VALU x 4 cycles + MFMA x %g cycles of vector-issue-port time per wave-step at the sustained clock "
                                                       "(measured port cost of an MFMA; the f32-input MFMA holds the port for its whole 64 cycles)"
                                                       % (MFMA_PORT_CYCLES if args.precision != "fp32" else MFMA_F32_CYCLES)},
-                    "note": "bound = the hardware resource with the largest busy fraction.  `frac` prices it at the clock the chip SUSTAINS "
-                            "under this kernel (measured in this run; power-limited), `frac_at_peak_clock` at the part's 2.4 GHz: the "
+                    "note": "bound = the hardware resource with the largest busy fraction.  `frac` prices it at the PART's 2.4 GHz peak clock, "
+                            "`frac_at_sustained_clock` at the clock the chip sustains under this kernel (measured in this run; package power limit): the "
                             "difference between the two is power, not scheduling.  The matrix pipe hides plain VALU issued beside it only in part "
                             "(profiles/r02_overlap2_probe.txt, r02_mlp_probe.txt), so the simd-issue and matrix-pipe fractions sum to more "
                             "than 1 and neither reaches it."}
             else:
                 line["roofline"] = {"bound": "simd-issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None,
-                                    "traffic": None, "error": cnt.get("error", "clock probe failed")}
+                                    "traffic": traffic_now, "traffic_source": traffic_source, "error": cnt.get("error", "clock probe failed")}
             # Secondary view (north_star: "MFMA utilisation against gfx950 peak"): matrix-core instructions issued per launch are
             # fixed by the kernel (per wave-step of 64 samples: 120 v_mfma_f32_32x32x16_f16 in split precision, 320
             # v_mfma_f32_32x32x2_f32 in exact fp32; rocprofv3 SQ_INSTS_MFMA agrees, profiles/) -- issued flops / kernel time
@@ -565,17 +684,18 @@ def main():
                 tiles = ((W + 7) // 8) * ((H + 7) // 8)
                 slots = sum(n * (c["valu"] + c["mfma"]) for n, c in zip(steps_k2, k2)) + S * (k1["valu"] + k1["mfma"])
                 achieved = slots * tiles / (k_med * 1e-3) / 1e9
-                peak = N_SIMDS * clock / VALU_ISSUE_CYCLES
+                peak = N_SIMDS * PEAK_CLOCK_GHZ / VALU_ISSUE_CYCLES
                 line["roofline"] = {
                     "bound": "simd-issue", "achieved": achieved, "peak": peak, "unit": "G wave-instructions/s", "frac": achieved / peak,
-                    "frac_at_peak_clock": achieved / (N_SIMDS * PEAK_CLOCK_GHZ / VALU_ISSUE_CYCLES), "peak_clock_ghz": PEAK_CLOCK_GHZ,
-                    "traffic": None, "kernel": "sn_proposal_kernel<0,5,4> + sn_render_main_kernel<1,*> (whole render call)", "kernel_ms": k_med,
+                    "frac_at_sustained_clock": achieved / (N_SIMDS * clock / VALU_ISSUE_CYCLES), "frac_at_peak_clock": achieved / peak,
+                    "peak_clock_ghz": PEAK_CLOCK_GHZ,
+                    "traffic": None, "traffic_source": "not measured for this workload", "kernel": "sn_proposal_kernel<0,5,4> + sn_render_main_kernel<1,*> (whole render call)", "kernel_ms": k_med,
                     "sustained_clock_ghz": clock,
                     "instructions_per_wave_step": {"K2 net %d (%d steps)" % (i, n): {k: c.get(k, 0) for k in ("valu", "mfma", "gather")}
                                                    for i, (n, c) in enumerate(zip(steps_k2, k2))} |
                                                   {"K1 bins mode (%d steps)" % S: {k: k1.get(k, 0) for k in ("valu", "mfma", "gather")}},
-                    "note": "VALU + MFMA instructions through the one vector issue port of a SIMD (4 cycles each) at the clock the chip "
-                            "sustains under this call; static counts (paths the workload does not take included, K2's resampling passes "
+                    "note": "VALU + MFMA instructions through the one vector issue port of a SIMD (4 cycles each); `frac` at the part's 2.4 GHz, "
+                            "`frac_at_sustained_clock` at the clock the chip sustains under this call; static counts (paths the workload does not take included, K2's resampling passes "
                             "excluded).  rocprofv3 PMC of K2 alone: VALU port 0.94 busy (profiles/r02_K2_960x540_pmc_summary.txt)."}
             except Exception as e:  # noqa: BLE001
                 line["roofline"] = {"bound": "simd-issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None,
@@ -588,6 +708,8 @@ def main():
             ms = kernel_ms_of(other)
             line["alt_precision"] = {"precision": other, "kernel_ms": ms, "ray_samples_per_s_per_gpu": W * H * S / (ms * 1e-3),
                                      "roofline_hbm_frac": (W * H * bytes_per_ray) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        if world == 1 and not args.no_others and args.workload == "sheet64":
+            line["others"] = other_configs(args.precision)
         if world == 1 and not args.no_cpu_baseline and args.workload == "sheet64":
             line["cpu_baseline"] = cpu_baseline(cfg, sd, W, H, S, args.cpu_runs, args.cpu_runs_config4)
         print(json.dumps(line), flush=True)

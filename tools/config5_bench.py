@@ -29,6 +29,7 @@ ap.add_argument("--size", type=int, default=800)
 ap.add_argument("--views", type=int, default=50)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+ap.add_argument("--only-nopng", action="store_true", help="only the PNG-writes-off leg (bench.py's `others`)")
 ap.add_argument("--save-workers", type=int, default=None, help="host threads for PNG encoding (default: min(32, cores / 2))")
 a = ap.parse_args()
 world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -74,7 +75,8 @@ def run(write_images: bool, tag: str, png_level=None):
 n = 8 + a.views
 out = {"views": n, "size": [S, S], "ranks": world, "backend": (dist.get_backend() if world > 1 else None),
        "workload": "8 reference + %d random_sphere_poses views, 256+96+48 samples, aabb +-0.1, dilation 50x50, downscale 2, identity diffuser" % a.views}
-for write, tag, level in ((False, "nopng", None), (True, "png", None), (True, "pngl1", 1)):
+legs = ((False, "nopng", None),) if a.only_nopng else ((False, "nopng", None), (True, "png", None), (True, "pngl1", 1))
+for write, tag, level in legs:
     dt, tm = run(write, tag, level)
     out["png_writes_" + (("on" if level is None else "on_compress_level_%d" % level) if write else "off")] = {
         "total_ms": dt * 1e3, "ms_per_view": dt * 1e3 / n,
@@ -86,10 +88,11 @@ if rank == 0:
     from PIL import Image
     import numpy as np
 
-    m = np.array(Image.open(os.path.join(tmp, "png1", "masks", "mask_10.png"))) > 0
-    out["mask_coverage_view_10"] = float(m.mean())
-    out["files_written"] = sum(len(f) for _, _, f in os.walk(os.path.join(tmp, "png1")))
-    print(json.dumps(out, indent=1))
+    if not a.only_nopng:
+        m = np.array(Image.open(os.path.join(tmp, "png1", "masks", "mask_10.png"))) > 0
+        out["mask_coverage_view_10"] = float(m.mean())
+        out["files_written"] = sum(len(f) for _, _, f in os.walk(os.path.join(tmp, "png1")))
+    print(json.dumps(out) if a.only_nopng else json.dumps(out, indent=1))
     shutil.rmtree(tmp, ignore_errors=True)
 if world > 1:
     dist.barrier()

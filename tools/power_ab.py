@@ -33,6 +33,7 @@ VARIANTS = {
     "group8": (("-DSN_HASH_GROUP=8",), {}, "fp16x2"),                          # 64 instead of 32 gathers in flight per wave
     "dense0": (None, {"SN_DENSE_LEVELS": "0"}, "fp16x2"),                      # every level hashed: 128 x 8-byte gathers instead of 84 (44 x 16 B + 40 x 8 B)
     "dense8": (None, {"SN_DENSE_LEVELS": "8"}, "fp16x2"),                      # 8 instead of 11 de-hashed levels
+    "wide4": (None, {"SN_K1_WIDE": "1"}, "fp16x2"),                            # r04: 8-wave workgroups, FOUR waves per SIMD (tile-sequential MLP, 127 VGPRs)
     "fp32": (None, {}, "fp32"),                                                # exact-fp32 MFMA (320 x 64-cycle MFMAs, no operand splits)
 }
 
@@ -136,6 +137,7 @@ def main():
     ap.add_argument("--one")
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--only", default=None, help="comma-separated variant names (default: all)")
     a = ap.parse_args()
     if a.build:
         return build()
@@ -144,6 +146,8 @@ def main():
     rows = {}
     for rnd in range(a.rounds):
         for name, (flags, env, _) in VARIANTS.items():
+            if a.only and name not in a.only.split(","):
+                continue
             e = dict(os.environ, **env)
             if flags:
                 if not os.path.exists(lib_path(name)):
@@ -163,7 +167,8 @@ def main():
         pass
     print("variant   ms/launch (2nd half of window)   probe GHz   socket W   W x ms (mJ per frame)   smi sclk MHz   what")
     what = {"base": "product library, fp16x2", "waves2": "2 waves per SIMD", "prio0": "no s_setprio around MFMA clusters", "group8": "64 gathers in flight",
-            "dense0": "no de-hashed copies: 128 hashed gathers", "dense8": "8 de-hashed levels", "fp32": "exact-fp32 MFMA"}
+            "dense0": "no de-hashed copies: 128 hashed gathers", "dense8": "8 de-hashed levels", "fp32": "exact-fp32 MFMA",
+            "wide4": "8-wave workgroups, 4 waves per SIMD, tile-sequential MLP (SN_K1_WIDE=1)"}
     for name, rs in rows.items():
         med = lambda k: statistics.median([r[k] for r in rs if r.get(k) is not None]) if any(r.get(k) is not None for r in rs) else float("nan")  # noqa: E731
         ms, ghz, w = med("ms_late"), med("probe_ghz"), med("power_w")
