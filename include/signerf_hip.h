@@ -98,6 +98,16 @@ typedef struct SnFieldDesc {
      * aabb[0]) with the model's scene box below (min xyz, max xyz).  The (0, 1) selector follows in both cases. */
     int32_t disable_scene_contraction;
     float aabb[6];
+    /* Memory budget of the DERIVED gather buffers sn_finalize_weights builds beside the uploaded tables (appended in r04; zero = the
+     * library defaults, so a zero-initialised descriptor behaves as before).  A viewer holding several models bounds them here instead of
+     * through the environment:
+     *   dense_levels        how many leading levels of the main grid get a de-hashed copy: 0 = default (11, 1.26 GB for nerfacto's
+     *                       grid), -1 = none (the kernels then read the uploaded table: ~14 % slower, no extra memory), 1..12 = that many;
+     *   dense_copy_cap_mb   per-level size cap of those copies in MB: 0 = default (600); a level above the cap ends the run of copies.
+     * The proposal nets' copies (90 + 81 MB) follow dense_levels with their own 100 MB cap.  SN_DENSE_LEVELS / SN_DENSE_CAP_MB in the
+     * environment still override both (diagnostics).  sn_debug_layout reports what a handle actually holds. */
+    int32_t dense_levels;
+    int32_t dense_copy_cap_mb;
 } SnFieldDesc;
 
 /* Per-call render options (NerfactoModelConfig values that shape one eval render). */
@@ -300,6 +310,8 @@ typedef struct SnDebugLayout {
     uint64_t pair_bytes;
     float feature_scale;               /* the copies / paired tables hold table rows TIMES this power of two (range conditioning of the
                                         * split-precision MLPs; the first layer's weights carry its inverse) */
+    uint64_t table_bytes;              /* (r04) the uploaded table of field `which` */
+    uint64_t handle_bytes;             /* (r04) every device buffer the HANDLE owns: tables, copies, paired tables, weight images */
 } SnDebugLayout;
 /* which: -1 main field, i >= 0 proposal net i. */
 int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out);

@@ -45,6 +45,8 @@ class SnFieldDesc(C.Structure):
         ("histogram_padding", C.c_float),
         ("disable_scene_contraction", C.c_int32),
         ("aabb", C.c_float * 6),
+        ("dense_levels", C.c_int32),
+        ("dense_copy_cap_mb", C.c_int32),
     ]
 
 
@@ -115,6 +117,8 @@ class SnDebugLayout(C.Structure):
         ("pair_base", C.c_uint32 * SN_MAX_LEVELS),
         ("pair_bytes", C.c_uint64),
         ("feature_scale", C.c_float),
+        ("table_bytes", C.c_uint64),
+        ("handle_bytes", C.c_uint64),
     ]
 
 

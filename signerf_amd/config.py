@@ -70,6 +70,13 @@ class NerfactoModelConfig(InstantiateConfig):
     num_train_data: int = 50
     """Rows of the appearance embedding table (the new dataset's size; signerf_pipeline.py:110-111 drops the
     trained table, so eval uses the mean of a freshly initialised one)."""
+    dense_levels: int = 0
+    """Memory budget of the derived gather buffers the HIP library builds beside the uploaded tables (``SnFieldDesc.dense_levels``):
+    0 = default (the 11 coarsest levels of the main grid get a de-hashed copy: 1.26 GB per model for nerfacto's grid, + 0.47 GB of x-paired
+    tables with proposal nets), -1 = none (~14 % slower renders, no extra memory), 1..12 = that many.  ``ops.debug_layout(model)``
+    reports the bytes a handle holds."""
+    dense_copy_cap_mb: int = 0
+    """Per-level size cap (MB) of those copies; 0 = default (600)."""
     precision: str = "fp16x2"
     """MFMA arithmetic of the tiny MLPs.  "fp16x2" (default): every fp32 operand is carried as an fp16 hi+lo pair and each
     product group is three fp16 MFMAs with fp32 accumulation -- measured error equals the exact path's (2.5e-6 relative on

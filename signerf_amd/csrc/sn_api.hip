@@ -1140,10 +1140,13 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
     }
     // torch grids: de-hashed copies of the coarse levels (SN_DENSE_LEVELS caps the count; 0 = off)
     {
+        // the budget comes from the descriptor (SnFieldDesc.dense_levels / dense_copy_cap_mb: 0 = default, -1 = no copies); the
+        // environment still overrides it (diagnostics, tools/dense_sweep.py)
         const char* e = getenv("SN_DENSE_LEVELS");
-        const int want = std::max(0, std::min(e ? atoi(e) : SN_DENSE_LEVELS_DEFAULT, 12));
-        const char* cap_env = getenv("SN_DENSE_CAP_MB");  // per-level size cap of the main grid's copies (experiments)
-        const uint64_t cap_main = cap_env ? (uint64_t)std::max(1, atoi(cap_env)) : 600;
+        const int asked = e ? atoi(e) : (d.dense_levels == 0 ? SN_DENSE_LEVELS_DEFAULT : std::max(0, d.dense_levels));
+        const int want = std::max(0, std::min(asked, 12));
+        const char* cap_env = getenv("SN_DENSE_CAP_MB");  // per-level size cap of the main grid's copies
+        const uint64_t cap_main = cap_env ? (uint64_t)std::max(1, atoi(cap_env)) : (d.dense_copy_cap_mb > 0 ? (uint64_t)d.dense_copy_cap_mb : 600);
         if (int rc = build_dense_copies(h, d.main_field, h->table_main, want, cap_main, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st,
                                         SN_BC_MAIN, h->feat_scale_main))
             return rc;
@@ -1604,6 +1607,12 @@ int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out) {
     const SnPairInfo& pi = which < 0 ? h->pinfo_main : h->pinfo_prop[which];
     for (int l = 0; l < SN_MAX_LEVELS; ++l) out->pair_base[l] = pi.base[l];
     out->pair_bytes = which < 0 ? h->pairs_main.bytes : h->pairs_prop[which].bytes;  // (main field: only for models with proposal nets)
+    out->table_bytes = which < 0 ? h->table_main.bytes : h->table_prop[which].bytes;
+    uint64_t total = h->table_main.bytes + h->wimg_main.bytes + h->wimg_main_h.bytes + h->wimg_normals.bytes + h->wimg_normals_h.bytes +
+                     h->pairs_main.bytes + h->dense_main.bytes;
+    for (int i = 0; i < SN_MAX_PROPOSALS; ++i)
+        total += h->table_prop[i].bytes + h->pairs_prop[i].bytes + h->wpack_prop[i].bytes + h->dense_prop[i].bytes;
+    out->handle_bytes = total;
     return SN_OK;
 }
 

@@ -468,6 +468,8 @@ class NerfactoModel(nn.Module):
         aabb = self.scene_box.aabb if self.scene_box is not None else torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
         for k, v in enumerate(aabb.detach().to(torch.float32).cpu().reshape(6).tolist()):
             d.aabb[k] = v
+        d.dense_levels = int(getattr(cfg, "dense_levels", 0))
+        d.dense_copy_cap_mb = int(getattr(cfg, "dense_copy_cap_mb", 0))
         return d
 
     @property

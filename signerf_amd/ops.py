@@ -182,7 +182,8 @@ def debug_layout(model, which: int = -1) -> dict:
     lay = _lib.SnDebugLayout()
     _lib.check(lib.sn_debug_layout(model._handle, which, C.byref(lay)), model._handle, "sn_debug_layout")
     return {"n_dense": lay.n_dense, "n_bc": lay.n_bc, "dense_res": list(lay.dense_res), "dense_off": list(lay.dense_off),
-            "dense_bytes": lay.dense_bytes, "pair_base": list(lay.pair_base), "pair_bytes": lay.pair_bytes, "feature_scale": lay.feature_scale}
+            "dense_bytes": lay.dense_bytes, "pair_base": list(lay.pair_base), "pair_bytes": lay.pair_bytes, "feature_scale": lay.feature_scale,
+            "table_bytes": lay.table_bytes, "handle_bytes": lay.handle_bytes}
 
 
 def debug_read(model, which: int, what: int) -> Tensor:

@@ -53,6 +53,8 @@ int main(void) {
          offsetof(SnRenderOpts, background_mode), offsetof(SnRenderOpts, background_rgb), offsetof(SnRenderOpts, spacing_mode));
   printf("%zu %zu %zu %zu %zu %zu\n", sizeof(SnDebugDump), offsetof(SnDebugDump, prop_q), offsetof(SnDebugDump, pdf_index),
          sizeof(SnDebugLayout), offsetof(SnDebugLayout, dense_bytes), offsetof(SnDebugLayout, pair_bytes));
+  printf("%zu %zu %zu %zu\n", offsetof(SnFieldDesc, dense_levels), offsetof(SnFieldDesc, dense_copy_cap_mb), offsetof(SnDebugLayout, table_bytes),
+         offsetof(SnDebugLayout, handle_bytes));
   printf("%zu %zu %zu %zu\n", sizeof(SnCameraDesc), offsetof(SnCameraDesc, height), offsetof(SnCameraDesc, camera_type),
          offsetof(SnCameraDesc, distortion));
   return 0;
@@ -71,6 +73,8 @@ int main(void) {
             _lib.SnRenderOpts.background_mode.offset, _lib.SnRenderOpts.background_rgb.offset, _lib.SnRenderOpts.spacing_mode.offset,
             C.sizeof(_lib.SnDebugDump), _lib.SnDebugDump.prop_q.offset, _lib.SnDebugDump.pdf_index.offset,
             C.sizeof(_lib.SnDebugLayout), _lib.SnDebugLayout.dense_bytes.offset, _lib.SnDebugLayout.pair_bytes.offset,
+            _lib.SnFieldDesc.dense_levels.offset, _lib.SnFieldDesc.dense_copy_cap_mb.offset, _lib.SnDebugLayout.table_bytes.offset,
+            _lib.SnDebugLayout.handle_bytes.offset,
             C.sizeof(_lib.SnCameraDesc), _lib.SnCameraDesc.height.offset, _lib.SnCameraDesc.camera_type.offset,
             _lib.SnCameraDesc.distortion.offset]
     assert got == want

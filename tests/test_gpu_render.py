@@ -392,6 +392,32 @@ def test_dehashed_and_plain_reads_agree(gpu, monkeypatch):
     assert lay["n_dense"] == 11 and lay["n_bc"] == 9
 
 
+def test_copy_budget_through_the_descriptor(gpu):
+    """SnFieldDesc.dense_levels / dense_copy_cap_mb (r04; r03 read the budget from the environment only): a viewer that holds several
+    models bounds the derived buffers per handle; sn_debug_layout reports what a handle holds.  Renders agree whatever the budget."""
+    from signerf_amd import ops
+
+    H = W = 64
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 64.0, 64.0, W / 2, H / 2, W, H).to(gpu)
+    b = cams[1].generate_rays(0)
+    held, ref = {}, None
+    for levels, cap, want in ((0, 0, 11), (-1, 0, 0), (6, 0, 6), (0, 100, 7)):   # (0, 100): level 7's copy (R = 156: 121 MB at 32 B per grid point) exceeds the cap
+        cfg = scene.benchmark_config(32)
+        cfg.dense_levels, cfg.dense_copy_cap_mb = levels, cap
+        model, _ = make_model(cfg, gpu)
+        out = model.get_outputs_for_camera_ray_bundle(b)
+        lay = ops.debug_layout(model, -1)
+        assert lay["n_dense"] == want, (levels, cap, lay["n_dense"])
+        assert lay["table_bytes"] == 16 * (1 << 19) * 8
+        assert lay["handle_bytes"] >= lay["table_bytes"] + lay["dense_bytes"] + lay["pair_bytes"]
+        held[(levels, cap)] = lay["handle_bytes"]
+        if ref is None:
+            ref = {k: out[k].clone() for k in ("rgb", "accumulation")}
+        else:
+            assert rmse(out["rgb"], ref["rgb"]) <= 2e-6 and rmse(out["accumulation"], ref["accumulation"]) <= 2e-6
+    assert held[(-1, 0)] < 70e6 < held[(6, 0)] < held[(0, 100)] < held[(0, 0)] and 1.2e9 < held[(0, 0)] < 1.5e9
+
+
 def test_proposal_coefficient_cache_is_bit_identical(gpu, monkeypatch):
     """K2 keeps the bilinear coefficients of its four coarsest levels in registers across the steps of the marching loop and re-fetches
     them only when a lane of the wave leaves its voxel.  SN_PROP_CACHE_OFF=1 re-fetches on every step (the plain path): every output of
