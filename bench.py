@@ -280,6 +280,9 @@ def main():
     ap.add_argument("--gather", default="all", choices=["all", "root"],
                     help="N > 1: all-gather the tiles (every rank holds the sheet; north_star's collective) or gather them to rank 0 "
                          "only (the rank that composes the sheet and talks to the diffuser; 1/N of the bytes)")
+    ap.add_argument("--gather-strategy", default="all_gather", choices=["all_gather", "p2p", "all_to_all"],
+                    help="N > 1: how the tiles travel (signerf_amd.sheet.gather_tiles_async): RCCL's all-gather / gather, direct point-to-point "
+                         "pushes (one per xGMI link), or the same pushes as one all_to_all_single; the line reports the exposed time of ALL three")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -383,7 +386,7 @@ def main():
             if world > 1:
                 # depth-1 pipeline: this frame's all-gather (RCCL's own stream, ordered behind this step's stream) overlaps the next
                 # frames' renders; every gather is waited for inside the timed region (drain() below)
-                handle = sheet.gather_tiles_async(tile, world, dst=dst)
+                handle = sheet.gather_tiles_async(tile, world, dst=dst, strategy=args.gather_strategy)
         issued[0] += 1
         if timed:
             render_ms.append((e0, e1))
@@ -417,7 +420,7 @@ def main():
         local = torch.stack(tiles) if tiles else torch.zeros((0, H, W, 4), dtype=torch.float32, device=dev)
         if world == 1:
             return local
-        handle = sheet.gather_tiles_async(local, n_sheet, dst=dst)
+        handle = sheet.gather_tiles_async(local, n_sheet, dst=dst, strategy=args.gather_strategy)
         done = pending[0].wait() if pending[0] is not None else None
         pending[0] = handle
         return done
@@ -428,7 +431,7 @@ def main():
             pending[0] = None
             return tiles
 
-    def exposed_gather_ms(n: int = 5):
+    def exposed_gather_ms(n: int = 5, strategy: str = "all_gather"):
         """The tile exchange on its own (N > 1): renders complete, then the gather is issued and waited for at once -- what every step
         would pay if the exchange were not overlapped with the next renders.  HIP events on the caller's stream."""
         ev = []
@@ -447,7 +450,7 @@ def main():
             dist.barrier()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            sheet.gather_tiles_async(local, n_items, dst=dst).wait()
+            sheet.gather_tiles_async(local, n_items, dst=dst, strategy=strategy).wait()
             b.record()
             ev.append((a, b))
         torch.cuda.synchronize()
@@ -504,11 +507,15 @@ def main():
         per_step = latency
     kernel_ms = sum(per_step) / max(len(per_step), 1)
     gather_ms = gather_err = None
+    gather_by_strategy = {}
     if world > 1:
-        try:  # a diagnostic leg after the timed region: it must never cost the line
-            gather_ms = exposed_gather_ms()
-        except Exception as e:  # noqa: BLE001
-            gather_err = repr(e)
+        for strat in sheet.GATHER_STRATEGIES:  # diagnostic legs after the timed region: they must never cost the line
+            try:
+                gather_by_strategy[strat] = exposed_gather_ms(strategy=strat)
+            except Exception as e:  # noqa: BLE001
+                gather_by_strategy[strat] = None
+                gather_err = repr(e)
+        gather_ms = gather_by_strategy.get(args.gather_strategy)
 
     if rank == 0:
         n_steps = len(per_step)
@@ -542,11 +549,15 @@ def main():
                        # what the process group itself reports (an N > 1 line must show the backend saw N ranks)
                        "dist_world_size": dist.get_world_size() if world > 1 else 1,
                        "dist_backend": dist.get_backend() if world > 1 else None,
-                       "cuda_device_count": n_dev, "gather": (args.gather if world > 1 else None)},
+                       "cuda_device_count": n_dev, "gather": (args.gather if world > 1 else None),
+                       "gather_strategy": (args.gather_strategy if world > 1 else None)},
             "ms_per_frame": elapsed / args.steps * 1e3 / (len(mine) if strong else 1) if (not strong or mine) else None,
             "ms_per_sheet": (elapsed / args.steps * 1e3) if strong else None,
             "gather_ms": ({"exposed": None, "error": gather_err} if gather_err else None) if gather_ms is None else {
-                "exposed": gather_ms, "in_timed_region": "overlapped with the next step's renders (depth-1 pipeline); every gather completes inside it",
+                "exposed": gather_ms, "strategy": args.gather_strategy, "exposed_by_strategy": gather_by_strategy,
+                "strategies": "all_gather = RCCL all_gather_into_tensor / gather (ring or tree, RCCL's choice); p2p = world - 1 direct isend / irecv "
+                              "pairs per rank (one per xGMI link); all_to_all = the same pushes as one all_to_all_single (signerf_amd/sheet.py)",
+                "in_timed_region": "overlapped with the next step's renders (depth-1 pipeline); every gather completes inside it",
                 "what": "HIP-event time on the caller's stream of issuing the tile gather and waiting for it with nothing to overlap "
                         "(median of 5, after a barrier), i.e. what each step would pay without the pipeline",
                 "bytes_sent_per_rank": (len(mine) if strong else 1) * H * W * 16},

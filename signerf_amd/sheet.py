@@ -54,18 +54,54 @@ class TileGather:
         return g.transpose(0, 1).reshape(world * per, *g.shape[2:])[: self._n_items].contiguous()
 
 
-def gather_tiles_async(local_tiles: Tensor, n_items: int, group=None, dst: Optional[int] = None) -> TileGather:
-    """Starts the all-gather of per-rank tiles and returns at once, so that the next camera's render overlaps the exchange
-    (the collective runs on RCCL's own stream; xGMI is point to point, a ring all-gather of 8 x 10 MB tiles is per-link bound
-    and would otherwise add ~1 ms to every 3 ms frame).  Keep ``local_tiles`` unmodified until ``wait()``.
+GATHER_STRATEGIES = ("all_gather", "p2p", "all_to_all")
 
-    ``dst``: gather to that rank only (``dist.gather``) -- in the generator loop only rank 0 composes the sheets and talks to the
+
+def default_strategy() -> str:
+    """SIGNERF_GATHER in the environment selects the exchange of the sheet / generator loops ("all_gather" when unset)."""
+    import os
+
+    s = os.environ.get("SIGNERF_GATHER", "all_gather")
+    if s not in GATHER_STRATEGIES:
+        raise ValueError(f"SIGNERF_GATHER={s!r}: one of {GATHER_STRATEGIES} expected")
+    return s
+
+
+class _Works:
+    """Several point-to-point work handles (and the buffers they read) waited for as one."""
+
+    def __init__(self, works, *keep):
+        self._works, self._keep = list(works), keep
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        self._works, self._keep = [], ()
+
+
+def gather_tiles_async(local_tiles: Tensor, n_items: int, group=None, dst: Optional[int] = None, strategy: str = "all_gather") -> TileGather:
+    """Starts the all-gather of per-rank tiles and returns at once, so that the next camera's render overlaps the exchange
+    (the collective runs on RCCL's own stream).  Keep ``local_tiles`` unmodified until ``wait()``.
+
+    ``dst``: gather to that rank only -- in the generator loop only rank 0 composes the sheets and talks to the
     diffuser (/root/reference/signerf/datasetgenerator/datasetgenerator.py:558), so the other ranks need no tiles: 1/world of the
-    bytes of the all-gather cross the links, and every sender uses its own xGMI link to the root."""
+    bytes of the all-gather cross the links, and every sender uses its own xGMI link to the root.
+
+    ``strategy`` -- how the bytes travel (xGMI is point to point, 7 links x ~153 GB/s per GPU, so a RING
+    all-gather of 8 tiles is bound by one link for 7 hops while 7 direct pushes use 7 links at once):
+      "all_gather"   ``all_gather_into_tensor`` / ``gather``: RCCL picks the algorithm (ring or tree over the xGMI mesh); one collective call
+      "p2p"          every rank SENDS its tile straight to each peer and RECEIVES each peer's tile (``batch_isend_irecv``: world - 1 sends
+                     and receives per rank, one per link); with ``dst`` only the sends to / receives at the root
+      "all_to_all"   ``all_to_all_single`` of the tile replicated per destination: the same direct pushes as one RCCL call
+                     (costs a world-fold staging copy of the tile)
+    The result is identical; `bench.py --gpus N` reports the exposed time of each so that the first multi-GPU run compares them."""
+    if strategy not in GATHER_STRATEGIES:
+        raise ValueError(f"gather strategy {strategy!r}: one of {GATHER_STRATEGIES} expected")
     if not (dist.is_available() and dist.is_initialized()):
         assert local_tiles.shape[0] == n_items
         return TileGather(None, local_tiles, n_items)
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     per = (n_items + world - 1) // world
     pad = per - local_tiles.shape[0]
     if pad > 0:
@@ -74,16 +110,39 @@ def gather_tiles_async(local_tiles: Tensor, n_items: int, group=None, dst: Optio
     device = None
     if _stage_through_host(local_tiles, group):
         device, local_tiles = local_tiles.device, local_tiles.cpu()
+    glob = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    tile_shape = local_tiles.shape[1:]
+    if strategy == "p2p":
+        if dst is None:
+            gathered = local_tiles.new_empty((world, per, *tile_shape))
+            gathered[rank].copy_(local_tiles)
+            ops = [dist.P2POp(dist.isend, local_tiles, glob(r), group) for r in range(world) if r != rank]
+            ops += [dist.P2POp(dist.irecv, gathered[r], glob(r), group) for r in range(world) if r != rank]
+            works = dist.batch_isend_irecv(ops) if ops else []
+            return TileGather(_Works(works, local_tiles), gathered, n_items, device)
+        if rank == dst:
+            gathered = local_tiles.new_empty((world, per, *tile_shape))
+            gathered[rank].copy_(local_tiles)
+            ops = [dist.P2POp(dist.irecv, gathered[r], glob(r), group) for r in range(world) if r != rank]
+            works = dist.batch_isend_irecv(ops) if ops else []
+            return TileGather(_Works(works), gathered, n_items, device)
+        works = dist.batch_isend_irecv([dist.P2POp(dist.isend, local_tiles, glob(dst), group)])
+        return TileGather(_Works(works, local_tiles), None, n_items, None)
+    if strategy == "all_to_all" and dst is None:
+        gathered = local_tiles.new_empty((world, per, *tile_shape))
+        send = local_tiles.unsqueeze(0).expand(world, per, *tile_shape).contiguous()   # the tile once per destination
+        work = dist.all_to_all_single(gathered.view(world * per, *tile_shape), send.view(world * per, *tile_shape), group=group, async_op=True)
+        return TileGather(_KeepAlive(work, send), gathered, n_items, device)
+    # "all_gather" (and "all_to_all" towards one root, which is a plain gather)
     if dst is None:
-        gathered = local_tiles.new_empty((world, per, *local_tiles.shape[1:]))
-        work = dist.all_gather_into_tensor(gathered.view(world * per, *local_tiles.shape[1:]), local_tiles, group=group, async_op=True)
+        gathered = local_tiles.new_empty((world, per, *tile_shape))
+        work = dist.all_gather_into_tensor(gathered.view(world * per, *tile_shape), local_tiles, group=group, async_op=True)
         return TileGather(work, gathered, n_items, device)
-    if dist.get_rank(group) == dst:
-        gathered = local_tiles.new_empty((world, per, *local_tiles.shape[1:]))
-        work = dist.gather(local_tiles, list(gathered.unbind(0)), dst=dist.get_global_rank(group, dst) if group is not None else dst,
-                           group=group, async_op=True)
+    if rank == dst:
+        gathered = local_tiles.new_empty((world, per, *tile_shape))
+        work = dist.gather(local_tiles, list(gathered.unbind(0)), dst=glob(dst), group=group, async_op=True)
         return TileGather(work, gathered, n_items, device)
-    work = dist.gather(local_tiles, None, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group, async_op=True)
+    work = dist.gather(local_tiles, None, dst=glob(dst), group=group, async_op=True)
     return TileGather(_KeepAlive(work, local_tiles), None, n_items, None)
 
 
@@ -98,13 +157,13 @@ class _KeepAlive:
         self._tensors = ()
 
 
-def gather_tiles(local_tiles: Tensor, n_items: int, group=None, dst: Optional[int] = None) -> Optional[Tensor]:
+def gather_tiles(local_tiles: Tensor, n_items: int, group=None, dst: Optional[int] = None, strategy: str = "all_gather") -> Optional[Tensor]:
     """All-gather per-rank tiles back into item order.
 
     local_tiles: [n_local, H, W, C] -- this rank's tiles for items rank, rank+world, ... (n_local may differ by one
     between ranks).  Returns [n_items, H, W, C] on every rank (``dst`` given: on that rank only, None elsewhere).
     """
-    return gather_tiles_async(local_tiles, n_items, group, dst).wait()
+    return gather_tiles_async(local_tiles, n_items, group, dst, strategy).wait()
 
 
 class FrameStreams:
@@ -164,7 +223,7 @@ class FrameStreams:
 
 
 def render_cameras_sharded(render_fn: Callable[[int], Tuple[Tensor, Tensor]], n_cameras: int, group=None, device=None,
-                           frames_in_flight: int = 2, dst: Optional[int] = None) -> Optional[Tensor]:
+                           frames_in_flight: int = 2, dst: Optional[int] = None, strategy: Optional[str] = None) -> Optional[Tensor]:
     """Renders cameras round-robin over the ranks and all-gathers the tiles.
 
     render_fn(i) -> (rgb [H,W,3], depth [H,W,1]) for camera i, on this rank's device.  ``device``: this rank's GPU -- its cameras are
@@ -192,7 +251,7 @@ def render_cameras_sharded(render_fn: Callable[[int], Tuple[Tensor, Tensor]], n_
         dist.broadcast(shape, src=0, group=group)
         if local is None:
             local = torch.zeros((0, *shape.tolist()), dtype=torch.float32, device=dev)
-    return gather_tiles(local, n_cameras, group, dst)
+    return gather_tiles(local, n_cameras, group, dst, strategy or default_strategy())
 
 
 def _default_device():

@@ -117,13 +117,16 @@ def test_bench_strong_scaling_dry_run(gpu, gather):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["cameras_per_step"] == 8 and d["config"]["gather"] == gather
     assert d["config"]["dist_world_size"] == 2 and d["config"]["dist_backend"] == "gloo" and d["config"]["cuda_device_count"] >= 1
     assert abs(d["ms_per_sheet"] - d["ms_per_step"]) < 1e-9 and d["gather_ms"]["exposed"] > 0
+    # every exchange strategy ran on the N > 1 path (ring all-gather vs direct pushes): the first RCCL run yields a comparison, not one point
+    assert set(d["gather_ms"]["exposed_by_strategy"]) == {"all_gather", "p2p", "all_to_all"}
+    assert all(v is not None and v > 0 for v in d["gather_ms"]["exposed_by_strategy"].values())
     assert abs(d["value"] - 8 * 160 * 160 * 64 * 3 / d["timed_region_s"]) / d["value"] < 1e-6      # total work fixed: 8 cameras per step
 
 
 def test_bench_strong_scaling_single_gpu(gpu):
     """The N = 1 point of the strong-scaling curve: all eight cameras on one GPU, no exchange."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--width", "160", "--height", "160",
-           "--no-cpu-baseline", "--no-alt-precision", "--scaling", "strong"]
+           "--no-cpu-baseline", "--no-alt-precision", "--no-others", "--no-traffic", "--scaling", "strong"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])

@@ -200,3 +200,54 @@ def test_frame_streams_degrade_to_in_order_execution_on_cpu():
     with fs.frame(0):
         pass
     fs.join()
+
+
+# ---- gather strategies: ring all-gather vs direct pushes, identical results -----------------------------------------
+def _strategy_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from signerf_amd import sheet
+
+    n_items = 2 * world - 1                       # ragged: the last rank holds one tile fewer
+    mine = sheet.shard_indices(n_items, world, rank)
+    local = torch.stack([torch.full((3, 4, 5), float(i)) + torch.arange(5.0) for i in mine])
+    got = {}
+    for strategy in sheet.GATHER_STRATEGIES:
+        for dst in (None, 0, world - 1):
+            h = sheet.gather_tiles_async(local, n_items, dst=dst, strategy=strategy)
+            t = h.wait()
+            got[f"{strategy}/{dst}"] = None if t is None else t.clone()
+    # two exchanges in flight at once, waited for out of order (the bench's depth-1 pipeline issues the next before waiting)
+    a = sheet.gather_tiles_async(local, n_items, strategy="p2p")
+    b = sheet.gather_tiles_async(local * 2, n_items, strategy="p2p")
+    got["pipelined"] = torch.stack([a.wait(), b.wait()])
+    torch.save(got, os.path.join(out_dir, f"strategy_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_strategies_deliver_the_same_tiles(tmp_path, world):
+    mp.spawn(_strategy_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    n_items = 2 * world - 1
+    want = torch.stack([torch.full((3, 4, 5), float(i)) + torch.arange(5.0) for i in range(n_items)])
+    for r in range(world):
+        got = torch.load(os.path.join(tmp_path, f"strategy_rank{r}.pt"))
+        for key, t in got.items():
+            if key == "pipelined":
+                assert torch.equal(t[0], want) and torch.equal(t[1], want * 2)
+                continue
+            strategy, dst = key.split("/")
+            if dst == "None" or int(dst) == r:
+                assert t is not None and torch.equal(t, want), f"rank {r}: {key}"
+            else:
+                assert t is None, f"rank {r} is not the root of {key}"
+
+
+def test_unknown_gather_strategy_raises():
+    from signerf_amd import sheet
+
+    with pytest.raises(ValueError, match="one of"):
+        sheet.gather_tiles_async(torch.zeros(1, 2, 2, 4), 1, strategy="broadcast")
