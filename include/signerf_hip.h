@@ -119,7 +119,11 @@ typedef struct SnRenderOpts {
     float far_plane;                               /* collider value used when fars == NULL (1000) */
     int32_t chunk_rays;                            /* eval_num_rays_per_chunk (signerf_config.py:32); only the
                                                       expected-depth clip bounds depend on it (A17) */
-    int32_t precision;                             /* 0: exact fp32 MFMA; 1: split-fp16 (hi+lo) MFMA, fp32 accumulate */
+    int32_t precision;                             /* 0: exact fp32 MFMA; 1: split-fp16 (hi+lo) MFMA, fp32 accumulate (fp32-grade, the default);
+                                                    * 2 (r04, OPT-IN, grid_mode 1 only): single fp16 operands, fp32 accumulate, fp16 activations
+                                                    *   between the layers -- the arithmetic tiny-cuda-nn checkpoints were trained in (README.md:
+                                                    *   146,170: `ns-train nerfacto` runs FullyFusedMLP in fp16); applies to the main field, the
+                                                    *   proposal nets and the normals kernel keep the split form.  NOT fp32-grade: ~1e-3. */
     void* workspace;                               /* device scratch, >= sn_workspace_bytes() */
     size_t workspace_bytes;
     /* Sampler grids, DEVICE pointers, computed by the host shim with the very torch ops nerfstudio uses so

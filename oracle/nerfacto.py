@@ -76,6 +76,10 @@ class NerfactoConfig:
     hidden_dim_color: int = 64
     sh_levels: int = 4
     sh_remap: str = "torch"
+    mlp_precision: str = "fp32"
+    """"fp16": emulate the roundings of the HIP library's opt-in single-fp16 mode for tiny-cuda-nn checkpoints (csrc/sn_main.h
+    sn_main_field_f16) in the MAIN field: fp16 (round-to-nearest-even) weights and layer inputs, fp32 accumulation inside a layer, every
+    layer output rounded to fp16; the appearance embedding folded into colour layer 1 in fp32.  The proposal nets stay fp32."""
     background_color: str = "last_sample"
     """RGBRenderer's background [NS]: "last_sample" (nerfacto's default; SIGNeRF does not override it), "black", "white", or "random" (a
     training device: in eval mode combine_rgb returns the composited colour as it is, i.e. a black background)."""
@@ -406,21 +410,40 @@ def hash_encode(q: Tensor, table: Tensor, scalings: Tensor, log2_hashmap_size: i
 # ----------------------------------------------------------------------------
 
 
-def mlp_forward(x: Tensor, params: Dict[str, Tensor], prefix: str, num_layers: int, out_activation: Optional[str] = None) -> Tensor:
-    """nn.Linear stack with bias, ReLU between layers (A8)."""
+def _f16(x: Tensor) -> Tensor:
+    """Round to the nearest fp16 (ties to even), back in fp32."""
+    return x.to(torch.float16).to(torch.float32)
+
+
+def mlp_forward(x: Tensor, params: Dict[str, Tensor], prefix: str, num_layers: int, out_activation: Optional[str] = None,
+                half: bool = False, fp32_tail: Optional[Tensor] = None) -> Tensor:
+    """nn.Linear stack with bias, ReLU between layers (A8).
+
+    half: the single-fp16 emulation (NerfactoConfig.mlp_precision): inputs and weights rounded to fp16, products summed in fp32, every
+    layer's output (after its ReLU) rounded to fp16.  fp32_tail: trailing input columns of the FIRST layer that stay fp32 with fp32 weights
+    (the eval-mode appearance embedding, which the library folds into that layer's bias on the host)."""
     for i in range(num_layers):
         w = params[f"{prefix}.layers.{i}.weight"]
         b = params[f"{prefix}.layers.{i}.bias"]
-        x = torch.nn.functional.linear(x, w, b)
+        if half:
+            if i == 0 and fp32_tail is not None:
+                n = x.shape[-1]
+                x = torch.nn.functional.linear(_f16(x), _f16(w[:, :n])) + (torch.nn.functional.linear(fp32_tail, w[:, n:]) + b)
+            else:
+                x = torch.nn.functional.linear(_f16(x), _f16(w), b)
+        else:
+            x = torch.nn.functional.linear(x, w, b)
         if i < num_layers - 1:
             x = torch.relu(x)
+        if half:
+            x = _f16(x)
     if out_activation == "sigmoid":
         x = torch.sigmoid(x)
     return x
 
 
 def density_field(params: Dict[str, Tensor], prefix: str, hcfg: HashMLPConfig, positions: Tensor, average_init_density: float,
-                  aabb: Optional[Tensor] = None):
+                  aabb: Optional[Tensor] = None, half: bool = False):
     """positions [R,N,3] (world) -> density [R,N,1], mlp_out [R,N,out_dim], q, selector  (A6-A9).  aabb: see scene_aabb()."""
     q, selector = normalized_positions(positions, aabb)
     if hcfg.grid == "tcnn":
@@ -431,7 +454,7 @@ def density_field(params: Dict[str, Tensor], prefix: str, hcfg: HashMLPConfig, p
     else:
         scalings = hash_scalings(hcfg.num_levels, hcfg.base_res, hcfg.max_res)
         enc = hash_encode(q.view(-1, 3), params[f"{prefix}.encoder.hash_table"], scalings, hcfg.log2_hashmap_size)
-    h = mlp_forward(enc, params, f"{prefix}.mlp", hcfg.num_layers).view(*positions.shape[:-1], -1)
+    h = mlp_forward(enc, params, f"{prefix}.mlp", hcfg.num_layers, half=half).view(*positions.shape[:-1], -1)
     density = average_init_density * torch.exp(h[..., 0:1])
     density = density * selector[..., None]
     return density, h, q, selector
@@ -535,6 +558,10 @@ def field_rgb(params: Dict[str, Tensor], cfg: NerfactoConfig, directions: Tensor
     geo = mlp_out[..., 1 : 1 + cfg.geo_feat_dim]
     app = params["field.embedding_appearance.embedding.weight"].mean(dim=0)
     app = torch.ones((R, N, cfg.appearance_embed_dim)) * app
+    if cfg.mlp_precision == "fp16":
+        h = torch.cat([d, geo], dim=-1).reshape(R * N, -1)
+        rgb = mlp_forward(h, params, "field.mlp_head", 3, out_activation="sigmoid", half=True, fp32_tail=app.reshape(R * N, -1))
+        return rgb.view(R, N, 3)
     h = torch.cat([d, geo, app], dim=-1).reshape(R * N, -1)
     rgb = mlp_forward(h, params, "field.mlp_head", 3, out_activation="sigmoid")
     return rgb.view(R, N, 3)
@@ -680,7 +707,8 @@ def get_outputs(params: Dict[str, Tensor], cfg: NerfactoConfig, origins: Tensor,
             d, _ = render_depth_median(weights, starts, ends)
             prop_depths.append(d)
     pos = sample_positions(origins, directions, starts, ends)
-    density, h, q, selector = density_field(params, "field.mlp_base", cfg.main, pos, cfg.average_init_density, scene_aabb(cfg))
+    density, h, q, selector = density_field(params, "field.mlp_base", cfg.main, pos, cfg.average_init_density, scene_aabb(cfg),
+                                            half=cfg.mlp_precision == "fp16")
     rgb_s = field_rgb(params, cfg, directions, h)
     weights = get_weights(ends - starts, density)
     rgb = render_rgb(rgb_s, weights, cfg.background_color)

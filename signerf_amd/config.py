@@ -80,7 +80,9 @@ class NerfactoModelConfig(InstantiateConfig):
     precision: str = "fp16x2"
     """MFMA arithmetic of the tiny MLPs.  "fp16x2" (default): every fp32 operand is carried as an fp16 hi+lo pair and each
     product group is three fp16 MFMAs with fp32 accumulation -- measured error equals the exact path's (2.5e-6 relative on
-    density, 3e-7 on colours) at 1.8x its speed; operands beyond +-65504 saturate.  "fp32": exact fp32 MFMA."""
+    density, 3e-7 on colours) at 1.8x its speed; operands beyond +-65504 saturate.  "fp32": exact fp32 MFMA.
+    "fp16" (opt-in, ``implementation="tcnn"`` only): single fp16 operands with fp16 activations between the layers, the arithmetic a
+    tiny-cuda-nn checkpoint was trained in (FullyFusedMLP) -- ~1e-3 from the fp32-grade render, 1.3x faster; never the default."""
 
 
 @dataclass

@@ -720,7 +720,9 @@ bool valid_opts(const SnFieldDesc& d, const SnRenderOpts& o, std::string& why) {
     if (o.num_proposal_iterations < 0 || o.num_proposal_iterations > d.num_proposals) why = "num_proposal_iterations exceeds the proposal nets of this handle";
     else if (o.num_nerf_samples < 1 || o.num_nerf_samples > 1024) why = "num_nerf_samples out of range [1,1024]";
     else if (o.chunk_rays < 1) why = "chunk_rays must be positive";
-    else if (o.precision != 0 && o.precision != 1) why = "precision must be 0 (fp32) or 1 (split fp16)";
+    else if (o.precision < 0 || o.precision > 2) why = "precision must be 0 (fp32), 1 (split fp16) or 2 (single fp16, tiny-cuda-nn grids)";
+    else if (o.precision == 2 && d.main_field.grid_mode != 1)
+        why = "precision 2 (single fp16) is the arithmetic of tiny-cuda-nn checkpoints: it needs main_field.grid_mode = 1";
     else if (o.background_mode != 0 && o.background_mode != 1) why = "background_mode must be 0 (last sample) or 1 (constant colour)";
     else if (o.spacing_mode != 0 && o.spacing_mode != 1) why = "spacing_mode must be 0 (piecewise) or 1 (uniform)";
     else {
@@ -942,6 +944,25 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
                                                 bc2s.data(), Wc3s.data(), t[9]->data(), app->data());
     img_s[SnMainImg::B3 + 3] = 1.0f / pl.s2;
     std::vector<float> imgh = build_main_image_h(d, W1s.data(), W2s.data(), Wc1s.data(), Wc2s.data(), img_s);
+    {
+        // single-fp16 mode (sn_main.h SnMainImgF16): colour layer 3 as an fp16 A operand behind the image -- rows 0..2 = the three output
+        // channels, k-slot (s, h, e) <-> hidden unit (s / 2) 32 + rho(8 (s % 2) + e) + 4 h (the operand order colour layer 2's output is
+        // converted into), lifted by the power of two s5 so that its largest entry sits in [128, 256) (the weights already carry 1 / s4)
+        imgh.resize(SnMainImgF16::TOTAL_FLOATS, 0.0f);
+        double m = 0.0;
+        for (float w : Wc3s) m = std::max(m, (double)std::fabs(w));
+        const float s5 = m > 0 && std::isfinite(m) ? pow2_floor(256.0 / m) : 1.0f;
+        uint16_t* hw = (uint16_t*)((char*)imgh.data() + SnMainImgF16::W3H);
+        for (int sk = 0; sk < 4; ++sk)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int row = lane & 31, hh = lane >> 5;
+                    const int hid = (sk / 2) * 32 + rho(8 * (sk % 2) + e) + 4 * hh;
+                    hw[((size_t)sk * 64 + lane) * 8 + e] = row < 3 ? f32_to_f16_rne((float)((double)Wc3s[row * 64 + hid] * s5)) : (uint16_t)0;
+                }
+        *(float*)((char*)imgh.data() + SnMainImgF16::TAILF) = 1.0f / s5;
+    }
+    if (h->wimg_main_h.ptr && h->wimg_main_h.bytes != imgh.size() * 4) h->wimg_main_h.release();
     if (!h->wimg_main_h.ptr) {
         SN_HIP(h, hipMalloc(&h->wimg_main_h.ptr, imgh.size() * 4));
         h->wimg_main_h.bytes = imgh.size() * 4;
@@ -1408,7 +1429,8 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     p.spacing_uniform = opts->spacing_mode;
     p.pm = h->pos_map;
     p.table = (const float*)h->table_main.ptr;
-    const bool split = opts->precision == 1 && h->split_ok;  // (a handle whose weights cannot be range-conditioned renders in exact fp32)
+    const bool split = opts->precision >= 1 && h->split_ok;  // (a handle whose weights cannot be range-conditioned renders in exact fp32)
+    const bool half1 = split && opts->precision == 2;       // single fp16 (sn_main.h sn_main_field_f16): tiny-cuda-nn grids only (valid_opts)
     p.wimg = (const float*)(split ? h->wimg_main_h.ptr : h->wimg_main.ptr);
     p.feat_scale = h->feat_scale_main;
     p.pairs = (const float*)h->pairs_main.ptr;
@@ -1453,10 +1475,10 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     p.sh_lds_off = 0;
     // weight image + (uniform sampler) the frame's S + 1 euclidean bins
     const size_t etab_bytes = nprop == 0 ? ((size_t)opts->num_nerf_samples + 1 + 3) / 4 * 16 : 0;
-    size_t lds_bytes = (size_t)SnMainImg::TOTAL * 4 + etab_bytes;
+    size_t lds_bytes = (half1 ? (size_t)SnMainImgF16::TOTAL_BYTES : (size_t)SnMainImg::TOTAL * 4) + etab_bytes;
     // split-depth tail (plan_tail): the workgroups of the last, partly filled round become n_seg segment jobs each
     const int ablate = h->sw.ablate.load(std::memory_order_relaxed);
-    const bool tail_split = !dump && ablate == 0 && !h->sw.tail_split_off.load(std::memory_order_relaxed) && wp.n_seg > 1;
+    const bool tail_split = !dump && !half1 && ablate == 0 && !h->sw.tail_split_off.load(std::memory_order_relaxed) && wp.n_seg > 1;
     p.seg_first_block = gbx * gby;
     p.n_seg = 1;
     p.seg_len = opts->num_nerf_samples;
@@ -1472,7 +1494,7 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     // The wide shape (SnK1Shape::W4: 8-wave workgroups of 4x2 tiles, four waves per SIMD, the waves' direction operands in LDS) for the
     // production split-precision kernel on frames that fill the chip at least twice over; small frames and frames whose tail is split
     // keep the 4-wave shape.  Instantiated for the default copy count only.
-    const bool wide = split && !dump && !alt && ablate == 0 && !tail_split && use_copies && h->nd_torch == 11 &&
+    const bool wide = split && !half1 && !dump && !alt && ablate == 0 && !tail_split && use_copies && h->nd_torch == 11 &&
                       h->sw.k1_wide.load(std::memory_order_relaxed) != 0 && g.tiles_x * g.tiles_y >= 2 * 16 * h->n_cus;
     if (wide) {
         p.wg_tx = 4;
@@ -1509,6 +1531,15 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     }
 #define SN_LAUNCH_MAIN_TORCH(MODE, PREC) SN_LAUNCH_MAIN_ND(MODE, PREC, 0)
 #define SN_LAUNCH_MAIN_TCNN(MODE, PREC) SN_LAUNCH_MAIN_ND(MODE, PREC, 1)
+    if (half1) {
+        // single-fp16 mode: the tiny-cuda-nn grid's kernels, with the de-hashed copies when the handle has the default 11 of them
+        if (dump || alt) return fail(h, SN_ERR_INVALID, "precision 2 (single fp16) has no instrumented / generic-sampler instantiation");
+        if (nprop > 0) {
+            if (nd_launch == 11) SN_LAUNCH_MAIN(1, 2, 0, 1, 11); else SN_LAUNCH_MAIN(1, 2, 0, 1, -1);
+        } else {
+            if (nd_launch == 11) SN_LAUNCH_MAIN(0, 2, 0, 1, 11); else SN_LAUNCH_MAIN(0, 2, 0, 1, -1);
+        }
+    } else
     if (dump) {
         // instrumented instantiations: the production variant (torch grid, 11 de-hashed levels), both samplers, both precisions
         if (tcnn || h->nd_torch != 11 || alt)
@@ -1584,9 +1615,13 @@ int sn_render_rays_debug(SnHandle h, const float* origins, const float* directio
 }
 
 int sn_effective_precision(SnHandle h, int32_t requested, int32_t kernel) {
-    if (!h || (requested != 0 && requested != 1) || (kernel != 0 && kernel != 1)) return -1;
+    if (!h || requested < 0 || requested > 2 || (kernel != 0 && kernel != 1)) return -1;
     if (!h->finalized) return -1;
     if (requested == 0) return 0;
+    if (requested == 2) {  // single fp16: the render / field kernels of a tiny-cuda-nn grid; the normals kernel keeps the split form
+        if (h->desc.main_field.grid_mode != 1) return -1;
+        if (kernel == 0) return h->split_ok ? 2 : 0;
+    }
     return (kernel == 0 ? h->split_ok : h->normals_split_ok) ? 1 : 0;
 }
 
@@ -1691,7 +1726,7 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
     p.spacing_uniform = opts->spacing_mode;
     p.pm = h->pos_map;
     p.table = (const float*)h->table_main.ptr;
-    const bool split = opts->precision == 1 && h->normals_split_ok;
+    const bool split = opts->precision >= 1 && h->normals_split_ok;  // (precision 2: the normals kernel keeps the split form)
     p.wimg = (const float*)(split ? h->wimg_normals_h.ptr : h->wimg_normals.ptr);
     p.normals = normals;
     p.pred_normals = pred_normals;
@@ -1788,7 +1823,9 @@ int sn_field_forward_geo(SnHandle h, int32_t which, const float* positions, cons
     if (!positions || !density || n < 0) return fail(h, SN_ERR_INVALID, "sn_field_forward: bad argument");
     if (which < -1 || which >= h->desc.num_proposals) return fail(h, SN_ERR_INVALID, "sn_field_forward: bad field selector");
     if (!h->finalized) return fail(h, SN_ERR_STATE, "sn_field_forward: weights not finalized");
-    if (precision != 0 && precision != 1) return fail(h, SN_ERR_INVALID, "sn_field_forward: precision must be 0 or 1");
+    if (precision < 0 || precision > 2) return fail(h, SN_ERR_INVALID, "sn_field_forward: precision must be 0, 1 or 2");
+    if (precision == 2 && h->desc.main_field.grid_mode != 1)
+        return fail(h, SN_ERR_INVALID, "precision 2 (single fp16) is the arithmetic of tiny-cuda-nn checkpoints: grid_mode 1 only");
     if (n == 0) return SN_OK;
     hipStream_t st = (hipStream_t)stream;
     if (which < 0) {
@@ -1798,7 +1835,7 @@ int sn_field_forward_geo(SnHandle h, int32_t which, const float* positions, cons
         p.directions = directions;
         p.n = n;
         p.table = (const float*)h->table_main.ptr;
-        if (precision == 1 && !h->split_ok) precision = 0;
+        if (precision >= 1 && !h->split_ok) precision = 0;
         p.wimg = (const float*)(precision == 0 ? h->wimg_main.ptr : h->wimg_main_h.ptr);
         p.feat_scale = h->feat_scale_main;
         for (int l = 0; l < 16; ++l) p.scal[l] = h->desc.main_field.scalings[l];
@@ -1812,6 +1849,8 @@ int sn_field_forward_geo(SnHandle h, int32_t which, const float* positions, cons
         p.grid = grid_levels(h->desc.main_field);
         if (precision == 0)
             hipLaunchKernelGGL(sn_main_field_stage_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)SnMainImg::TOTAL * 4, st, p);
+        else if (precision == 2)
+            hipLaunchKernelGGL(sn_main_field_stage_kernel<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)SnMainImgF16::TOTAL_BYTES, st, p);
         else
             hipLaunchKernelGGL(sn_main_field_stage_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)SnMainImg::TOTAL * 4, st, p);
     } else {

@@ -519,6 +519,198 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
 }
 
 // ==========================================================================================
+// Single-fp16 form (PREC 2, r04; opt-in `precision="fp16"` for tiny-cuda-nn checkpoints ONLY -- never the default, never the headline):
+// the arithmetic the library those checkpoints were trained with runs in (FullyFusedMLP: fp16 weights, fp16 activations between the
+// layers), as far as this hardware's MFMA allows -- fp16 operands, ONE v_mfma_f32_32x32x16_f16 per product group (no hi / lo split),
+// fp32 accumulation inside a layer, every layer's output rounded to fp16 (round-to-nearest-even, v_cvt_pk_f16_f32).  Weights are the hi
+// planes of the split-precision image (= RNE16 of the range-conditioned weights; a power-of-two scale commutes with the rounding).
+// Colour layer 3 (64 -> 3) runs on the matrix cores too (the library pads its output layer the same way): its fp16 A operand sits
+// behind the image (SnMainImgF16).  48 MFMAs and ~220 conversion VALU per wave-step instead of 120 and ~670.
+// oracle/tcnn_layout.py emulates exactly these roundings; what is NOT reproduced is the library's fp16 ACCUMULATION inside a layer.
+// ==========================================================================================
+struct SnMainImgF16 {
+    static constexpr int W3H = SnMainImg::TOTAL * 4;   // byte offset: A operand of colour layer 3, [s = 4][lane = 64][8 halves], rows 0..2 real
+    static constexpr int TAILF = W3H + 4096;           // float[4]: [0] = 1 / s5 (the power-of-two scale of that operand)
+    static constexpr int TOTAL_BYTES = TAILF + 16;
+    static constexpr int TOTAL_FLOATS = TOTAL_BYTES / 4;
+};
+
+SN_DEV uint32_t sn_pk_f16(float a, float b) {  // RNE (v_cvt_pkrtz_f16_f32 truncates)
+    uint32_t r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+SN_DEV uint32_t sn_pk_f16_relu(float a, float b) {
+    typedef _Float16 sn_h2 __attribute__((ext_vector_type(2)));
+    const sn_h2 zero = {(_Float16)0.0f, (_Float16)0.0f};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(sn_h2, sn_pk_f16(a, b)), zero));  // v_pk_max_f16
+}
+SN_DEV float sn_round_f16(float x) { return (float)(_Float16)x; }
+
+struct SnOpF {  // one B operand: 8 k-slots of one 32-sample tile, fp16
+    u32x4 v;
+    template <bool RELU>
+    SN_DEV void set(const float x[8]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = RELU ? sn_pk_f16_relu(x[2 * e], x[2 * e + 1]) : sn_pk_f16(x[2 * e], x[2 * e + 1]);
+    }
+};
+
+template <int RT, int KS>
+SN_DEV void sn_mlp_layer_f16(const char* __restrict__ wimg, const float* __restrict__ bimg, const SnOpF* op0, const SnOpF* op1, f32x16* acc0,
+                             f32x16* acc1, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        f32x16 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (bimg) {
+            const f32x4* b = (const f32x4*)(bimg + (rt * 2 + h) * 16);
+            f32x4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+            v = f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+        }
+        acc0[rt] = v;
+        acc1[rt] = v;
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        f16x8 a[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[rt] = __builtin_bit_cast(f16x8, *(const u32x4*)(wimg + (((rt * KS + s) * 2) * 64 + lane) * 16));  // the hi plane
+        const f16x8 b0 = __builtin_bit_cast(f16x8, op0[s].v), b1 = __builtin_bit_cast(f16x8, op1[s].v);
+#if SN_MFMA_PRIO
+        __builtin_amdgcn_s_setprio(SN_MFMA_PRIO);
+#endif
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            SN_MFMA_H(acc0[rt], a[rt], b0);
+            SN_MFMA_H(acc1[rt], a[rt], b1);
+        }
+#if SN_MFMA_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+}
+
+struct SnShOpsF {
+    SnOpF t0, t1;
+    SN_DEV void build(const float d[3], int remap) {
+        float c[16];
+        sn_direction_encoding(d, remap, c);
+        float v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = c[e], b = c[8 + e];
+            sn_swap_halves(a, b);
+            v0[e] = a;
+            v1[e] = b;
+        }
+        t0.set<false>(v0);
+        t1.set<false>(v1);
+    }
+};
+
+// one 32-row accumulator tile -> the two fp16 operands of the next layer (k-steps 2 rt, 2 rt + 1), ReLU applied
+SN_DEV void sn_acc_to_ops_f16(const f32x16& acc, SnOpF& s0, SnOpF& s1) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[r];
+    s0.set<true>(v);
+    s1.set<true>(v + 8);
+}
+
+template <bool GEO = false>
+SN_DEV void sn_main_field_f16(const char* __restrict__ ldsb, float* feat, const SnShOpsF& sh, int lane, float& h0, float rgb[3], float* geo16 = nullptr) {
+    const bool upper = lane >= 32;
+    const float* tail = (const float*)(ldsb + SnMainImgH::FP32);
+    SnOpF op0[4], op1[4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = feat[16 * s + e], b = feat[16 * s + 8 + e];
+            sn_swap_halves(a, b);
+            v0[e] = a;
+            v1[e] = b;
+        }
+        op0[s].set<false>(v0);   // the grid's features enter the network as fp16
+        op1[s].set<false>(v1);
+    }
+    f32x16 a0[2], a1[2];
+    sn_mlp_layer_f16<2, 2>(ldsb + SnMainImgH::W1, tail + SnMainImgH::B1, op0, op1, a0, a1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        sn_acc_to_ops_f16(a0[rt], op0[2 * rt], op0[2 * rt + 1]);
+        sn_acc_to_ops_f16(a1[rt], op1[2 * rt], op1[2 * rt + 1]);
+    }
+    f32x16 g0[1], g1[1];
+    sn_mlp_layer_f16<1, 4>(ldsb + SnMainImgH::W2, tail + SnMainImgH::B2, op0, op1, g0, g1, lane);
+    h0 = sn_round_f16(upper ? g1[0][8] : g0[0][0]) * tail[SnMainImgH::B3 + 3];
+    if (GEO) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float a = g0[0][r], b = g1[0][r];
+            sn_swap_halves(a, b);
+            geo16[(r & 3) + 8 * (r >> 2)] = sn_round_f16(a) * tail[SnMainImgH::B3 + 3];
+            geo16[(r & 3) + 8 * (r >> 2) + 4] = sn_round_f16(b) * tail[SnMainImgH::B3 + 3];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v0[e] = g0[0][e];
+            v1[e] = g1[0][e];
+        }
+        op0[0].set<false>(v0);
+        op1[0].set<false>(v1);
+        op0[1] = sh.t0;
+        op1[1] = sh.t1;
+    }
+    sn_mlp_layer_f16<2, 2>(ldsb + SnMainImgH::WC1, tail + SnMainImgH::BC1, op0, op1, a0, a1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        sn_acc_to_ops_f16(a0[rt], op0[2 * rt], op0[2 * rt + 1]);
+        sn_acc_to_ops_f16(a1[rt], op1[2 * rt], op1[2 * rt + 1]);
+    }
+    SnOpF q0[4], q1[4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        f32x16 c0[1], c1[1];
+        sn_mlp_layer_f16<1, 4>(ldsb + SnMainImgH::WC2 + rt * 8192, tail + SnMainImgH::BC2 + rt * 32, op0, op1, c0, c1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        sn_acc_to_ops_f16(c0[0], q0[2 * rt], q0[2 * rt + 1]);
+        sn_acc_to_ops_f16(c1[0], q1[2 * rt], q1[2 * rt + 1]);
+    }
+    // colour layer 3 on the matrix cores: rows 0..2 of a 32-row tile; lane j < 32 holds them in registers 0..2 (tile 0 = its own
+    // sample, tile 1 = the sample of lane j + 32, which one swap per channel hands over)
+    f32x16 r0, r1;
+    {
+        const char* w3 = ldsb + SnMainImgF16::W3H;
+        f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        r0 = z;
+        r1 = z;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f16x8 a = __builtin_bit_cast(f16x8, *(const u32x4*)(w3 + (s * 64 + lane) * 16));
+            SN_MFMA_H(r0, a, __builtin_bit_cast(f16x8, q0[s].v));
+            SN_MFMA_H(r1, a, __builtin_bit_cast(f16x8, q1[s].v));
+        }
+    }
+    const float inv_s5 = *(const float*)(ldsb + SnMainImgF16::TAILF);
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        float a = r0[n], b = r1[n];
+        sn_swap_halves(a, b);  // lower lanes keep tile 0's row n of their own sample; upper lanes receive tile 1's from their partner
+        const float x = sn_round_f16(fmaf(a, inv_s5, tail[SnMainImgH::B3 + n]));
+        rgb[n] = __builtin_amdgcn_rcpf(1.0f + sn_exp<true>(-x));
+    }
+}
+
+// ==========================================================================================
 // Tile-sequential form of the split-precision field (r04, the "4 waves per SIMD" variant: SN_K1_4W).
 // sn_main_field_h carries BOTH 32-sample column tiles of the wave through every layer together: 64 accumulator registers and 64 operand
 // registers are live at the layer boundaries, 161-168 VGPRs with the ray's state, three waves per SIMD.  Here one tile runs through the
@@ -915,11 +1107,12 @@ void sn_render_main_kernel(SnMainParams p) {
     const int su = ALT ? p.spacing_uniform : 0;          // (constants in the production instantiations: their code is what it was
     const SnPosMap* pm = ALT ? &p.pm : nullptr;          //  before the two options existed)
     // both weight images are SnMainImg::TOTAL floats (42 640 B)
-    for (int i = tid * 4; i < SnMainImg::TOTAL; i += NT * 4) *(f32x4*)(lds + i) = *(const f32x4*)(p.wimg + i);
+    constexpr int IMG_FLOATS = PREC == 2 ? SnMainImgF16::TOTAL_FLOATS : SnMainImg::TOTAL;   // (PREC 2: + colour layer 3's fp16 operand)
+    for (int i = tid * 4; i < IMG_FLOATS; i += NT * 4) *(f32x4*)(lds + i) = *(const f32x4*)(p.wimg + i);
     // Uniform sampler without per-ray nears / fars (the collider's constants): the S + 1 euclidean bins are the same for every ray
     // of the frame.  They are computed once per workgroup -- with the same strict arithmetic, so bit-identical -- and read back as
     // LDS broadcasts, instead of ~20 VALU instructions (an IEEE division among them) per lane and step.
-    float* etab = lds + SnMainImg::TOTAL;
+    float* etab = lds + IMG_FLOATS;
     const bool shared_bins = MODE == 0 && p.nears == nullptr;
     if (shared_bins) {
         const float sn = sn_spacing(p.near_plane, su), sf = sn_spacing(p.far_plane, su);
@@ -970,8 +1163,10 @@ void sn_render_main_kernel(SnMainParams p) {
     const float s_near = sn_spacing(near, su), s_far = sn_spacing(far, su);
     SnShOps sh;
     SnShOpsH shh;
+    SnShOpsF shf;
     char* shl = nullptr;  // W4: this wave's direction operands live in LDS, not in 16 registers
-    if (SHAPE::W4) {
+    if (PREC == 2) shf.build(d, p.sh_remap);
+    else if (SHAPE::W4) {
         shl = (char*)lds + p.sh_lds_off + wave * SnShLds::BYTES_PER_WAVE;
         SnShOpsH tmp;
         tmp.build(d, p.sh_remap);
@@ -1070,6 +1265,8 @@ void sn_render_main_kernel(SnMainParams p) {
             rgb[2] = 0.5f - 0.1f * a;
         } else if (PREC == 0) {
             sn_main_field_f32(lds, feat, sh, lane, h0, rgb);
+        } else if (PREC == 2) {
+            sn_main_field_f16((const char*)lds, feat, shf, lane, h0, rgb);
         } else if (SHAPE::W4) {
             sn_main_field_h4((const char*)lds, shl, feat, lane, h0, rgb);
         } else {

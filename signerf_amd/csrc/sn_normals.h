@@ -200,21 +200,32 @@ SN_DEV void sn_normals_field_h(const char* __restrict__ ldsb, const float* feat,
     f32x16 a0[2], a1[2];
     sn_mlp_layer_h<2, 2>(ldsb + SnMainImgH::W1, tail + SnMainImgH::B1, op0, op1, a0, a1, lane);
     __builtin_amdgcn_sched_barrier(0);
-    // ReLU mask of layer 1 as fp16 pairs (1.0h = 0x3c00), in the operand order of the next layer
+    // ReLU mask of layer 1 as fp16 pairs (1.0h = 0x3c00), in the operand order of the next layer.
+    // r04: by arithmetic, not selects -- m = clamp(a * inf) is exactly 1.0 for a > 0 (+inf clamps to 1) and 0.0 for a <= 0 or NaN (-inf, and
+    // 0 * inf = NaN, clamp to 0: compute kernels run with DX10_CLAMP), i.e. (a > 0) for every fp32 input; v_cvt_pkrtz packs the pair: 3
+    // instructions per pair instead of 2 compares + 2 VCC-form v_cndmask + 1 v_or (back-to-back VCC selects issue ~5x slower than plain
+    // VALU on gfx950, tools/probes/overlap2_probe.hip) -- 96 instead of 160 instructions per wave-step, none of them on VCC.
     u32x4 m0[4], m1[4];
+    {
+        const float big = __builtin_inff();
+        auto mask01 = [&](float a) {
+            float m;
+            asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(m) : "v"(a), "v"(big));
+            return m;
+        };
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t lo0 = a0[rt][2 * j] > 0.0f ? 0x3c00u : 0u, hi0 = a0[rt][2 * j + 1] > 0.0f ? 0x3c000000u : 0u;
-            const uint32_t lo1 = a1[rt][2 * j] > 0.0f ? 0x3c00u : 0u, hi1 = a1[rt][2 * j + 1] > 0.0f ? 0x3c000000u : 0u;
-            m0[2 * rt + j / 4][j % 4] = lo0 | hi0;
-            m1[2 * rt + j / 4][j % 4] = lo1 | hi1;
-        }
+            for (int j = 0; j < 8; ++j) {
+                m0[2 * rt + j / 4][j % 4] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(mask01(a0[rt][2 * j]), mask01(a0[rt][2 * j + 1])));
+                m1[2 * rt + j / 4][j % 4] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(mask01(a1[rt][2 * j]), mask01(a1[rt][2 * j + 1])));
+            }
+    }
+    // (the normals images are conditioned to the same 2^10 pre-activation bound as K1's, sn_api.hip: the ReLU folds into the split)
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-        sn_acc_to_ops(a0[rt], true, op0[2 * rt], op0[2 * rt + 1]);
-        sn_acc_to_ops(a1[rt], true, op1[2 * rt], op1[2 * rt + 1]);
+        sn_acc_to_ops<SN_RELU_FOLD != 0>(a0[rt], true, op0[2 * rt], op0[2 * rt + 1]);
+        sn_acc_to_ops<SN_RELU_FOLD != 0>(a1[rt], true, op1[2 * rt], op1[2 * rt + 1]);
     }
     f32x16 g0[1], g1[1];
     sn_mlp_layer_h<1, 4>(ldsb + SnMainImgH::W2, tail + SnMainImgH::B2, op0, op1, g0, g1, lane);
@@ -267,8 +278,8 @@ SN_DEV void sn_normals_field_h(const char* __restrict__ ldsb, const float* feat,
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-        sn_acc_to_ops(a0[rt], true, op0[2 * rt], op0[2 * rt + 1]);
-        sn_acc_to_ops(a1[rt], true, op1[2 * rt], op1[2 * rt + 1]);
+        sn_acc_to_ops<SN_RELU_FOLD != 0>(a0[rt], true, op0[2 * rt], op0[2 * rt + 1]);
+        sn_acc_to_ops<SN_RELU_FOLD != 0>(a1[rt], true, op1[2 * rt], op1[2 * rt + 1]);
     }
     const int h = lane >> 5;
     float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
@@ -312,126 +323,187 @@ SN_DEV float sn_nonzero01(float off) { return __builtin_amdgcn_fmed3f(off * 0x1p
 // ND > 0 (torch grid): levels [0, ND) come from the de-hashed copies, [0, NBC) of them in bilinear-coefficient form, where the slopes
 // are the coefficients themselves: per z slice d/d ox = B + oy D, d/d oy = C + ox D, and d/d oz = slice 1 - slice 0.  The copies hold
 // feature_scale x value; `inv_scale` (its exact inverse) rides in the per-level factor.
-template <int GRID, int ND = -1, int NBC = 0>
-SN_DEV void sn_hash_encode_grad(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], const float* gfeat,
-                                const SnGridLevels* grid, float g[3], const SnDenseCopy* dense = nullptr, float inv_scale = 1.0f) {
+// One level: the slopes d(feature pair)/d(in-voxel offset) -- and, from the SAME fetches, the feature pair itself (r04: K3 keeps the slopes of
+// its finest levels from the forward pass instead of gathering those levels a second time).  val / dx / dy / dz carry whatever scale the
+// fetched entries carry (the copies hold feature_scale x value); `sl` is the factor that turns a slope w.r.t. the offset into one w.r.t.
+// the normalised position and divides that scale out again.
+template <int GRID, int ND, int NBC>
+SN_DEV void sn_hash_level_slopes(int l, __amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], const SnGridLevels* grid,
+                                 const SnDenseCopy* dense, float inv_scale, float val[2], float dx[2], float dy[2], float dz[2], float off_out[3],
+                                 float& sl_out) {
     const uint32_t mask = (1u << log2_t) - 1u;
-    g[0] = g[1] = g[2] = 0.0f;
+    if (ND > 0 && l < NBC && l < 12) {
+        uint32_t R = dense->res[l];
+        asm volatile("" : "+s"(R));
+        const __amdgpu_buffer_rsrc_t drsrc = sn_table_rsrc(dense->base, dense->bytes);
+        uint32_t f[3];
+        float off[3];
 #pragma unroll
-    for (int l = 0; l < 16; ++l) {
-        if (l > 0 && (l % SN_GRAD_GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
-        if (ND > 0 && l < NBC && l < 12) {
-            uint32_t R = dense->res[l];
-            asm volatile("" : "+s"(R));
-            const __amdgpu_buffer_rsrc_t drsrc = sn_table_rsrc(dense->base, dense->bytes);
-            uint32_t f[3];
-            float off[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float x = q[a] * scal[l];
-                off[a] = __builtin_amdgcn_fractf(x);
-                f[a] = (uint32_t)(int)x;
-            }
-            const uint32_t R32 = R << 5, R2_32 = (R * R) << 5;
-            const uint32_t b = sn_mad24(f[2], R2_32, sn_mad24(f[1], R32, f[0] << 5));
-            const uint32_t o0 = dense->off[l], o1 = o0 + R2_32;
-            const f32x4 ab0 = sn_table_load_pair(drsrc, b, o0), cd0 = sn_table_load_pair(drsrc, b + 16u, o0);
-            const f32x4 ab1 = sn_table_load_pair(drsrc, b, o1), cd1 = sn_table_load_pair(drsrc, b + 16u, o1);
-            const float ox = off[0], oy = off[1], oz = off[2];
-            float dx[2], dy[2], dz[2];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const float e0 = fmaf(ox, cd0[2 + c], cd0[c]), e1 = fmaf(ox, cd1[2 + c], cd1[c]);   // d slice / d oy
-                const float z0 = fmaf(ox, ab0[2 + c], fmaf(oy, e0, ab0[c])), z1 = fmaf(ox, ab1[2 + c], fmaf(oy, e1, ab1[c]));
-                const float h0 = fmaf(oy, cd0[2 + c], ab0[2 + c]), h1 = fmaf(oy, cd1[2 + c], ab1[2 + c]);  // d slice / d ox
-                dx[c] = fmaf(h1 - h0, oz, h0);
-                dy[c] = fmaf(e1 - e0, oz, e0);
-                dz[c] = z1 - z0;
-            }
-            const float sl = scal[l] * inv_scale;
-            const float ga = gfeat[2 * l] * sl, gb = gfeat[2 * l + 1] * sl;
-            // an integer coordinate: torch's ceil == floor corner pair has no slope along that axis (see the hashed branch below)
-            g[0] = fmaf(fmaf(ga, dx[0], gb * dx[1]), sn_nonzero01(ox), g[0]);
-            g[1] = fmaf(fmaf(ga, dy[0], gb * dy[1]), sn_nonzero01(oy), g[1]);
-            g[2] = fmaf(fmaf(ga, dz[0], gb * dz[1]), sn_nonzero01(oz), g[2]);
-            continue;
+        for (int a = 0; a < 3; ++a) {
+            const float x = q[a] * scal[l];
+            off[a] = __builtin_amdgcn_fractf(x);
+            f[a] = (uint32_t)(int)x;
         }
-        f32x2 v[8];
-        float ox, oy, oz, sl = scal[l];
-        if (ND > 0 && l < ND && l < 12) {  // de-hashed copy in plain-row form: four 16-byte fetches (sn_hash_level_dense_copy)
-            uint32_t R = dense->res[l];
-            asm volatile("" : "+s"(R));
-            const __amdgpu_buffer_rsrc_t drsrc = sn_table_rsrc(dense->base, dense->bytes);
-            uint32_t f[3];
-            float off[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float x = q[a] * scal[l];
-                off[a] = __builtin_amdgcn_fractf(x);
-                f[a] = (uint32_t)(int)x;
-            }
-            const uint32_t R8 = R << 3, R28 = (R * R) << 3;
-            const uint32_t b_ff = sn_mad24(f[2], R28, sn_mad24(f[1], R8, f[0] << 3));
-            const uint32_t o_ff = dense->off[l], o_cf = o_ff + R8, o_fc = o_ff + R28, o_cc = o_ff + (R8 + R28);
-            const f32x4 p_cc = sn_table_load_pair(drsrc, b_ff, o_cc), p_fc = sn_table_load_pair(drsrc, b_ff, o_fc);
-            const f32x4 p_ff = sn_table_load_pair(drsrc, b_ff, o_ff), p_cf = sn_table_load_pair(drsrc, b_ff, o_cf);
-            v[3] = f32x2{p_cc.x, p_cc.y};
-            v[0] = f32x2{p_cc.z, p_cc.w};
-            v[2] = f32x2{p_fc.x, p_fc.y};
-            v[1] = f32x2{p_fc.z, p_fc.w};
-            v[6] = f32x2{p_ff.x, p_ff.y};
-            v[5] = f32x2{p_ff.z, p_ff.w};
-            v[7] = f32x2{p_cf.x, p_cf.y};
-            v[4] = f32x2{p_cf.z, p_cf.w};
-            ox = off[0];
-            oy = off[1];
-            oz = off[2];
-            sl *= inv_scale;
-        } else {
-            SnHashLevel hl;
-            if (GRID) sn_hash_corners_tcnn<-1>(q, scal[l], mask, sn_grid_dense_res(*grid, l), hl);
-            else sn_hash_corners_fast(q, scal[l], mask, hl);
-            const uint32_t lvl = ((uint32_t)l << log2_t) * 8u;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = sn_table_load(rsrc, hl.boff[k], lvl);
-            ox = hl.off[0];
-            oy = hl.off[1];
-            oz = hl.off[2];
-        }
-        // corner order 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf; the "c" corner of an axis has weight off.
-        // Plain fp32 instructions, lerps as a + w (b - a) (sn_hash_blend_fast explains both): the slopes are differences of lerps.
-        f32x2 dx, dy, dz;
+        const uint32_t R32 = R << 5, R2_32 = (R * R) << 5;
+        const uint32_t b = sn_mad24(f[2], R2_32, sn_mad24(f[1], R32, f[0] << 5));
+        const uint32_t o0 = dense->off[l], o1 = o0 + R2_32;
+        const f32x4 ab0 = sn_table_load_pair(drsrc, b, o0), cd0 = sn_table_load_pair(drsrc, b + 16u, o0);
+        const f32x4 ab1 = sn_table_load_pair(drsrc, b, o1), cd1 = sn_table_load_pair(drsrc, b + 16u, o1);
+        const float ox = off[0], oy = off[1], oz = off[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const float x03 = v[0][c] - v[3][c], x12 = v[1][c] - v[2][c], x47 = v[4][c] - v[7][c], x56 = v[5][c] - v[6][c];
-            const float xz1 = fmaf(x03 - x12, oy, x12), xz0 = fmaf(x47 - x56, oy, x56);   // d/d ox in the slices z + 1, z
-            dx[c] = fmaf(xz1 - xz0, oz, xz0);
-            const float f03 = fmaf(x03, ox, v[3][c]), f12 = fmaf(x12, ox, v[2][c]), f47 = fmaf(x47, ox, v[7][c]), f56 = fmaf(x56, ox, v[6][c]);
-            const float y1 = f03 - f12, y0 = f47 - f56;                                    // d/d oy in the slices z + 1, z
-            dy[c] = fmaf(y1 - y0, oz, y0);
-            dz[c] = fmaf(y1, oy, f12) - fmaf(y0, oy, f56);
+            const float e0 = fmaf(ox, cd0[2 + c], cd0[c]), e1 = fmaf(ox, cd1[2 + c], cd1[c]);   // d slice / d oy
+            const float z0 = fmaf(ox, ab0[2 + c], fmaf(oy, e0, ab0[c])), z1 = fmaf(ox, ab1[2 + c], fmaf(oy, e1, ab1[c]));
+            const float h0 = fmaf(oy, cd0[2 + c], ab0[2 + c]), h1 = fmaf(oy, cd1[2 + c], ab1[2 + c]);  // d slice / d ox
+            dx[c] = fmaf(h1 - h0, oz, h0);
+            dy[c] = fmaf(e1 - e0, oz, e0);
+            dz[c] = z1 - z0;
+            val[c] = fmaf(dz[c], oz, z0);
         }
+        off_out[0] = ox;
+        off_out[1] = oy;
+        off_out[2] = oz;
+        sl_out = scal[l] * inv_scale;
+        return;
+    }
+    f32x2 v[8];
+    float ox, oy, oz, sl = scal[l];
+    if (ND > 0 && l < ND && l < 12) {  // de-hashed copy in plain-row form: four 16-byte fetches (sn_hash_level_dense_copy)
+        uint32_t R = dense->res[l];
+        asm volatile("" : "+s"(R));
+        const __amdgpu_buffer_rsrc_t drsrc = sn_table_rsrc(dense->base, dense->bytes);
+        uint32_t f[3];
+        float off[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float x = q[a] * scal[l];
+            off[a] = __builtin_amdgcn_fractf(x);
+            f[a] = (uint32_t)(int)x;
+        }
+        const uint32_t R8 = R << 3, R28 = (R * R) << 3;
+        const uint32_t b_ff = sn_mad24(f[2], R28, sn_mad24(f[1], R8, f[0] << 3));
+        const uint32_t o_ff = dense->off[l], o_cf = o_ff + R8, o_fc = o_ff + R28, o_cc = o_ff + (R8 + R28);
+        const f32x4 p_cc = sn_table_load_pair(drsrc, b_ff, o_cc), p_fc = sn_table_load_pair(drsrc, b_ff, o_fc);
+        const f32x4 p_ff = sn_table_load_pair(drsrc, b_ff, o_ff), p_cf = sn_table_load_pair(drsrc, b_ff, o_cf);
+        v[3] = f32x2{p_cc.x, p_cc.y};
+        v[0] = f32x2{p_cc.z, p_cc.w};
+        v[2] = f32x2{p_fc.x, p_fc.y};
+        v[1] = f32x2{p_fc.z, p_fc.w};
+        v[6] = f32x2{p_ff.x, p_ff.y};
+        v[5] = f32x2{p_ff.z, p_ff.w};
+        v[7] = f32x2{p_cf.x, p_cf.y};
+        v[4] = f32x2{p_cf.z, p_cf.w};
+        ox = off[0];
+        oy = off[1];
+        oz = off[2];
+        sl *= inv_scale;
+    } else {
+        SnHashLevel hl;
+        if (GRID) sn_hash_corners_tcnn<-1>(q, scal[l], mask, sn_grid_dense_res(*grid, l), hl);
+        else sn_hash_corners_fast(q, scal[l], mask, hl);
+        const uint32_t lvl = ((uint32_t)l << log2_t) * 8u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = sn_table_load(rsrc, hl.boff[k], lvl);
+        ox = hl.off[0];
+        oy = hl.off[1];
+        oz = hl.off[2];
+    }
+    // corner order 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf; the "c" corner of an axis has weight off.
+    // Plain fp32 instructions, lerps as a + w (b - a) (sn_hash_blend_fast explains both): the slopes are differences of lerps.
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float x03 = v[0][c] - v[3][c], x12 = v[1][c] - v[2][c], x47 = v[4][c] - v[7][c], x56 = v[5][c] - v[6][c];
+        const float xz1 = fmaf(x03 - x12, oy, x12), xz0 = fmaf(x47 - x56, oy, x56);   // d/d ox in the slices z + 1, z
+        dx[c] = fmaf(xz1 - xz0, oz, xz0);
+        const float f03 = fmaf(x03, ox, v[3][c]), f12 = fmaf(x12, ox, v[2][c]), f47 = fmaf(x47, ox, v[7][c]), f56 = fmaf(x56, ox, v[6][c]);
+        const float y1 = f03 - f12, y0 = f47 - f56;                                    // d/d oy in the slices z + 1, z
+        dy[c] = fmaf(y1 - y0, oz, y0);
+        const float zc = fmaf(y1, oy, f12), zf = fmaf(y0, oy, f56);                    // the blend in the slices z + 1, z
+        dz[c] = zc - zf;
+        val[c] = fmaf(dz[c], oz, zf);
+    }
+    off_out[0] = ox;
+    off_out[1] = oy;
+    off_out[2] = oz;
+    sl_out = sl;
+}
+
+// torch path: where scale * q is an integer in fp32 (about 6e-4 of the samples: ulp(x) / 1 at the fine levels), ceil(x) == floor(x), both
+// corners of that axis are the SAME table row and autograd sees no slope along it; the kernels fetch floor + 1 (value-identical, weight 0),
+// so the slope is dropped explicitly -- as a 0 / 1 factor, not a select.  tiny-cuda-nn grids have no such points.
+template <int GRID, int ND = -1, int NBC = 0, int L0 = 0, int L1 = 16>
+SN_DEV void sn_hash_encode_grad(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], const float* gfeat,
+                                const SnGridLevels* grid, float g[3], const SnDenseCopy* dense = nullptr, float inv_scale = 1.0f) {
+    if (L0 == 0) g[0] = g[1] = g[2] = 0.0f;
+#pragma unroll
+    for (int l = L0; l < L1; ++l) {
+        if (l > L0 && (l % SN_GRAD_GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
+        float val[2], dx[2], dy[2], dz[2], off[3], sl;
+        sn_hash_level_slopes<GRID, ND, NBC>(l, rsrc, scal, log2_t, q, grid, dense, inv_scale, val, dx, dy, dz, off, sl);
         const float ga = gfeat[2 * l] * sl, gb = gfeat[2 * l + 1] * sl;
         if (!GRID) {
-            // torch path: where scale * q is an integer in fp32 (about 6e-4 of the samples: ulp(x) / 1 at the fine levels),
-            // ceil(x) == floor(x), both corners of that axis are the SAME table row and autograd sees no slope along it; the
-            // kernels fetch floor + 1 (value-identical, weight 0), so the slope is dropped explicitly -- as a 0 / 1 factor, not a select
-            g[0] = fmaf(fmaf(ga, dx.x, gb * dx.y), sn_nonzero01(ox), g[0]);
-            g[1] = fmaf(fmaf(ga, dy.x, gb * dy.y), sn_nonzero01(oy), g[1]);
-            g[2] = fmaf(fmaf(ga, dz.x, gb * dz.y), sn_nonzero01(oz), g[2]);
+            g[0] = fmaf(fmaf(ga, dx[0], gb * dx[1]), sn_nonzero01(off[0]), g[0]);
+            g[1] = fmaf(fmaf(ga, dy[0], gb * dy[1]), sn_nonzero01(off[1]), g[1]);
+            g[2] = fmaf(fmaf(ga, dz[0], gb * dz[1]), sn_nonzero01(off[2]), g[2]);
         } else {
-            g[0] = fmaf(ga, dx.x, fmaf(gb, dx.y, g[0]));
-            g[1] = fmaf(ga, dy.x, fmaf(gb, dy.y, g[1]));
-            g[2] = fmaf(ga, dz.x, fmaf(gb, dz.y, g[2]));
+            g[0] = fmaf(ga, dx[0], fmaf(gb, dx[1], g[0]));
+            g[1] = fmaf(ga, dy[0], fmaf(gb, dy[1], g[1]));
+            g[2] = fmaf(ga, dz[0], fmaf(gb, dz[1], g[2]));
         }
     }
 }
 
+// Forward pass of the levels [L0, 16) WITH their slopes (r04): the feature pairs go to feat[2l], feat[2l + 1] (times feat_mul: the hashed
+// levels take the feature scale the copies already carry, or the copies lose it, as the precision's weight image expects) and the six
+// position-slopes of every level -- already multiplied by the level's scale factor and the zero-offset 0 / 1 factors -- to keep[6 (l - L0) ..].
+// The second pass then contracts them with the back-propagated feature gradient (sn_kept_slopes_contract) without touching the tables.
+template <int GRID, int ND, int NBC, int L0>
+SN_DEV void sn_hash_encode_keep(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], float* feat, float* keep,
+                                const SnGridLevels* grid, const SnDenseCopy* dense, float inv_scale, float copy_mul, float plain_mul) {
+#pragma unroll
+    for (int l = L0; l < 16; ++l) {
+        if (l > L0 && ((l - L0) % 2) == 0) __builtin_amdgcn_sched_barrier(0);
+        float val[2], dx[2], dy[2], dz[2], off[3], sl;
+        sn_hash_level_slopes<GRID, ND, NBC>(l, rsrc, scal, log2_t, q, grid, dense, inv_scale, val, dx, dy, dz, off, sl);
+        const float fm = (ND > 0 && l < ND && l < 12) ? copy_mul : plain_mul;
+        feat[2 * l] = val[0] * fm;
+        feat[2 * l + 1] = val[1] * fm;
+        const float kx = GRID ? sl : sl * sn_nonzero01(off[0]), ky = GRID ? sl : sl * sn_nonzero01(off[1]), kz = GRID ? sl : sl * sn_nonzero01(off[2]);
+        float* k = keep + 6 * (l - L0);
+        k[0] = dx[0] * kx;
+        k[1] = dx[1] * kx;
+        k[2] = dy[0] * ky;
+        k[3] = dy[1] * ky;
+        k[4] = dz[0] * kz;
+        k[5] = dz[1] * kz;
+    }
+}
+
+template <int L0>
+SN_DEV void sn_kept_slopes_contract(const float* keep, const float* gfeat, float g[3]) {
+#pragma unroll
+    for (int l = L0; l < 16; ++l) {
+        const float* k = keep + 6 * (l - L0);
+        const float ga = gfeat[2 * l], gb = gfeat[2 * l + 1];
+        g[0] = fmaf(ga, k[0], fmaf(gb, k[1], g[0]));
+        g[1] = fmaf(ga, k[2], fmaf(gb, k[3], g[1]));
+        g[2] = fmaf(ga, k[4], fmaf(gb, k[5], g[2]));
+    }
+}
+
+// waves per SIMD the torch-grid kernels are compiled for (2: 197-210 VGPRs without spills; 3 caps them at 168)
+#ifndef SN_NORMALS_WAVES
+#define SN_NORMALS_WAVES 2
+#endif
+// first level whose slopes are kept from the forward pass (torch grid with de-hashed copies; 16 = none): 6 registers per kept level
+#ifndef SN_NORMALS_KEEP0
+#define SN_NORMALS_KEEP0 9
+#endif
 template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int GRID /*0 torch grid, 1 tiny-cuda-nn grid*/,
           int PREC /*0 exact fp32 MFMA, 1 fp16 hi+lo split MFMA*/, int ND = -1 /*torch grid: leading levels read from the de-hashed copies*/,
           bool ALT = false /*the non-default sampler / position map (SnNormalsParams::spacing_uniform, pm)*/>
 // (the run-time dense / hashed branch of the tiny-cuda-nn grid needs more registers than 2 waves per SIMD leave: 1 wave there)
-__global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormalsParams p) {
+__global__ __launch_bounds__(256, GRID ? 1 : SN_NORMALS_WAVES) void sn_normals_kernel(SnNormalsParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int su = ALT ? p.spacing_uniform : 0;
@@ -482,14 +554,26 @@ __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormals
         const bool sel = sn_sample_q(o, d, t0, t1, q, pm);
         float feat[32];
         constexpr int NBC = ND > SN_BC_MAIN ? SN_BC_MAIN : (ND > 0 ? ND : 0);
+        // r04: the finest levels [KEEP0, 16) are fetched ONCE -- value and slopes from the same gathers (sn_hash_encode_keep), the slopes
+        // (6 registers per level) waiting across the MLPs -- instead of twice; the kernel sat at 0.94 of the gather-issue roof with 168
+        // gathers per wave-step (DESIGN K3) and has registers to spare at two waves per SIMD
+        constexpr int KEEP0 = (ND > 0 && !GRID) ? SN_NORMALS_KEEP0 : 16;
+        float keep[KEEP0 < 16 ? 6 * (16 - KEEP0) : 1];
         if (ND > 0) {
             // values of the copies are the table's own times the feature scale t0 (an exact power of two).  Split precision: the
             // conditioned image expects t0 x feature, so the copies' values go in as they are and the hashed levels are multiplied
             // (sn_hash_encode's plain_scale); exact fp32: divided out again here
-            sn_hash_encode<16, 4, 1, ND, false, NBC>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, nullptr, PREC ? p.feat_scale : 1.0f);
+            if (KEEP0 > 0)
+                sn_hash_encode<(KEEP0 < 16 ? (KEEP0 > 0 ? KEEP0 : 1) : 16), 4, 1, ND, false, NBC>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, nullptr,
+                                                                                                  PREC ? p.feat_scale : 1.0f);
             if (!PREC) {
 #pragma unroll
-                for (int k = 0; k < 2 * (ND > 0 ? ND : 0); ++k) feat[k] *= p.inv_feat_scale;
+                for (int k = 0; k < 2 * ((ND > 0 ? ND : 0) < KEEP0 ? (ND > 0 ? ND : 0) : KEEP0); ++k) feat[k] *= p.inv_feat_scale;
+            }
+            if (KEEP0 < 16) {
+                __builtin_amdgcn_sched_barrier(0);
+                sn_hash_encode_keep<GRID, ND, NBC, KEEP0>(rsrc, p.scal, p.log2_t, q, feat, keep, &p.grid, &p.dense, p.inv_feat_scale,
+                                                          PREC ? 1.0f : p.inv_feat_scale, PREC ? p.feat_scale : 1.0f);
             }
         } else {
             sn_hash_encode<16, 4, (GRID ? 2 : 1), -1>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, nullptr, nullptr, PREC ? p.feat_scale : 1.0f);
@@ -509,7 +593,8 @@ __global__ __launch_bounds__(256, GRID ? 1 : 2) void sn_normals_kernel(SnNormals
         // opaque copies of q: otherwise the compiler keeps the first pass's 128 corner offsets alive across the MLPs to reuse
         // them here (~120 spilled registers) instead of recomputing them
         asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]));
-        sn_hash_encode_grad<GRID, ND, NBC>(rsrc, p.scal, p.log2_t, q, gfeat, &p.grid, g, &p.dense, p.inv_feat_scale);
+        sn_hash_encode_grad<GRID, ND, NBC, 0, KEEP0>(rsrc, p.scal, p.log2_t, q, gfeat, &p.grid, g, &p.dense, p.inv_feat_scale);
+        if (KEEP0 < 16) sn_kept_slopes_contract<KEEP0>(keep, gfeat, g);
         __builtin_amdgcn_sched_barrier(0);
         // Field.get_normals: -F.normalize(grad) = -grad / max(|grad|, 1e-12)
         const float gl = fmaxf(sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), PREC ? 1e-12f * p.grad_scale : 1e-12f);  // (g carries grad_scale)

@@ -284,7 +284,7 @@ template <int PREC>
 __global__ __launch_bounds__(256, 2) void sn_main_field_stage_kernel(SnFieldStageParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    for (int i = tid * 4; i < SnMainImg::TOTAL; i += 256 * 4) *(f32x4*)(lds + i) = *(const f32x4*)(p.wimg + i);
+    for (int i = tid * 4; i < (PREC == 2 ? SnMainImgF16::TOTAL_FLOATS : SnMainImg::TOTAL); i += 256 * 4) *(f32x4*)(lds + i) = *(const f32x4*)(p.wimg + i);
     __syncthreads();
     const int lane = tid & 63;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + tid;
@@ -298,7 +298,9 @@ __global__ __launch_bounds__(256, 2) void sn_main_field_stage_kernel(SnFieldStag
     }
     SnShOps sh;
     SnShOpsH shh;
+    SnShOpsF shf;
     if (PREC == 0) sh.build(d, p.sh_remap);
+    else if (PREC == 2) shf.build(d, p.sh_remap);
     else shh.build(d, p.sh_remap);
     float q[3];
     const bool sel = sn_position_q(pos, q, &p.pm);
@@ -310,6 +312,7 @@ __global__ __launch_bounds__(256, 2) void sn_main_field_stage_kernel(SnFieldStag
     for (int k = 0; k < 32; ++k) feat[k] *= p.feat_scale;
     float h0, rgb[3], geo16[16];
     if (PREC == 0) sn_main_field_f32<true>(lds, feat, sh, lane, h0, rgb, geo16);
+    else if (PREC == 2) sn_main_field_f16<true>((const char*)lds, feat, shf, lane, h0, rgb, geo16);
     else sn_main_field_h<true>((const char*)lds, feat, shh, lane, h0, rgb, geo16);
     const bool qnan = (q[0] != q[0]) | (q[1] != q[1]) | (q[2] != q[2]);
     if (qnan) h0 = rgb[0] = rgb[1] = rgb[2] = __builtin_nanf("");

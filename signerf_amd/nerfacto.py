@@ -28,7 +28,7 @@ from . import _lib
 from .cameras import Frustums, RaySamples, RayBundle, SceneBox  # noqa: F401
 from .config import NerfactoModelConfig, SIGNeRFModelConfig
 
-PRECISIONS = {"fp32": 0, "fp16x2": 1}
+PRECISIONS = {"fp32": 0, "fp16x2": 1, "fp16": 2}   # "fp16": opt-in, implementation="tcnn" only (config.py)
 # RGBRenderer's background in EVAL mode [NS]: "last_sample" (nerfacto's default, what SIGNeRF runs), a named constant colour, or "random" --
 # a training device: combine_rgb returns the composited colour without a background, i.e. black
 BACKGROUNDS = {"last_sample": None, "black": (0.0, 0.0, 0.0), "white": (1.0, 1.0, 1.0), "random": (0.0, 0.0, 0.0)}
@@ -393,6 +393,11 @@ class NerfactoModel(nn.Module):
         # the kernels implement the values SIGNeRF runs with (nerfacto's defaults); anything else must not render silently wrong
         if cfg.background_color not in BACKGROUNDS:
             raise NotImplementedError(f"background_color={cfg.background_color!r}: one of {sorted(BACKGROUNDS)} expected")
+        if cfg.precision not in PRECISIONS:
+            raise NotImplementedError(f"precision={cfg.precision!r}: one of {sorted(PRECISIONS)} expected")
+        if cfg.precision == "fp16" and cfg.implementation != "tcnn":
+            raise NotImplementedError('precision="fp16" (single fp16 operands, fp16 activations between layers) is the arithmetic of '
+                                      'tiny-cuda-nn checkpoints: it needs implementation="tcnn"; the torch-path parity target runs "fp16x2" / "fp32"')
         if cfg.proposal_initial_sampler not in INITIAL_SAMPLERS:
             raise NotImplementedError(f"proposal_initial_sampler={cfg.proposal_initial_sampler!r}: one of {sorted(INITIAL_SAMPLERS)} expected")
         self.field = NerfactoField(cfg, self.num_train_data)
@@ -483,7 +488,7 @@ class NerfactoModel(nn.Module):
             eff = _lib.load().sn_effective_precision(self._handle, PRECISIONS[self.config.precision], 0)
         finally:
             self._engine_rw.release_read()
-        return {0: "fp32", 1: "fp16x2"}.get(eff, self.config.precision)
+        return {0: "fp32", 1: "fp16x2", 2: "fp16"}.get(eff, self.config.precision)
 
     def _ensure_engine(self):
         lib = _lib.load()

@@ -31,6 +31,7 @@ def oracle_config(cfg: NerfactoModelConfig, scene_aabb=None) -> onf.NerfactoConf
         appearance_embed_dim=cfg.appearance_embed_dim,
         hidden_dim_color=cfg.hidden_dim_color,
         sh_remap="torch" if cfg.implementation == "torch" else "tcnn",
+        mlp_precision="fp16" if getattr(cfg, "precision", "") == "fp16" else "fp32",
         background_color=cfg.background_color,
         proposal_initial_sampler=cfg.proposal_initial_sampler,
         disable_scene_contraction=cfg.disable_scene_contraction,
