@@ -103,7 +103,8 @@ typedef struct SnFieldDesc {
      * through the environment:
      *   dense_levels        how many leading levels of the main grid get a de-hashed copy: 0 = default (11, 1.26 GB for nerfacto's
      *                       grid), -1 = none (the kernels then read the uploaded table: ~14 % slower, no extra memory), 1..12 = that many;
-     *   dense_copy_cap_mb   per-level size cap of those copies in MB: 0 = default (600); a level above the cap ends the run of copies.
+     *   dense_copy_cap_mb   per-level size cap of those copies in MB, measured on the plain-row form (R^3 x 8 bytes; the coefficient form of
+     *                       the first nine levels takes 4x that): 0 = default (600); the first level above the cap ends the run of copies.
      * The proposal nets' copies (90 + 81 MB) follow dense_levels with their own 100 MB cap.  SN_DENSE_LEVELS / SN_DENSE_CAP_MB in the
      * environment still override both (diagnostics).  sn_debug_layout reports what a handle actually holds. */
     int32_t dense_levels;

@@ -535,10 +535,14 @@ struct SnMainImgF16 {
     static constexpr int TOTAL_FLOATS = TOTAL_BYTES / 4;
 };
 
-SN_DEV uint32_t sn_pk_f16(float a, float b) {  // RNE (v_cvt_pkrtz_f16_f32 truncates)
-    uint32_t r;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+// RNE (v_cvt_pkrtz_f16_f32 truncates): hipcc selects v_cvt_pk_f16_f32 for the vector conversion.  NOT inline asm: its operands are MFMA
+// results, and the compiler inserts the wait states an MFMA write -> VALU read needs only in front of instructions it knows (found on
+// hardware, r04: with an asm conversion the geometry rows came back as garbage that changed with unrelated code further down).
+SN_DEV uint32_t sn_pk_f16(float a, float b) {
+    typedef float sn_f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 sn_h2v __attribute__((ext_vector_type(2)));
+    const sn_f2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sn_h2v));
 }
 SN_DEV uint32_t sn_pk_f16_relu(float a, float b) {
     typedef _Float16 sn_h2 __attribute__((ext_vector_type(2)));
@@ -701,6 +705,32 @@ SN_DEV void sn_main_field_f16(const char* __restrict__ ldsb, float* feat, const 
         }
     }
     const float inv_s5 = *(const float*)(ldsb + SnMainImgF16::TAILF);
+#ifdef SN_F16_L3_VALU  // debugging aid: colour layer 3 from the same fp16 activations on the vector ALU (fp32 weights of the image's tail)
+    {
+        const int hh = lane >> 5;
+        float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const _Float16 x0 = __builtin_bit_cast(f16x8, q0[s].v)[e], x1 = __builtin_bit_cast(f16x8, q1[s].v)[e];
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    const float w = tail[SnMainImgH::W3 + (n * 2 + hh) * 32 + (s / 2) * 16 + 8 * (s % 2) + e];
+                    p0[n] = fmaf(w, (float)x0, p0[n]);
+                    p1[n] = fmaf(w, (float)x1, p1[n]);
+                }
+            }
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            float a = p0[n], b = p1[n];
+            sn_swap_halves(a, b);
+            const float x = sn_round_f16(a + b + tail[SnMainImgH::B3 + n]);
+            rgb[n] = __builtin_amdgcn_rcpf(1.0f + sn_exp<true>(-x));
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
         float a = r0[n], b = r1[n];

@@ -201,24 +201,23 @@ SN_DEV void sn_normals_field_h(const char* __restrict__ ldsb, const float* feat,
     sn_mlp_layer_h<2, 2>(ldsb + SnMainImgH::W1, tail + SnMainImgH::B1, op0, op1, a0, a1, lane);
     __builtin_amdgcn_sched_barrier(0);
     // ReLU mask of layer 1 as fp16 pairs (1.0h = 0x3c00), in the operand order of the next layer.
-    // r04: by arithmetic, not selects -- m = clamp(a * inf) is exactly 1.0 for a > 0 (+inf clamps to 1) and 0.0 for a <= 0 or NaN (-inf, and
-    // 0 * inf = NaN, clamp to 0: compute kernels run with DX10_CLAMP), i.e. (a > 0) for every fp32 input; v_cvt_pkrtz packs the pair: 3
-    // instructions per pair instead of 2 compares + 2 VCC-form v_cndmask + 1 v_or (back-to-back VCC selects issue ~5x slower than plain
-    // VALU on gfx950, tools/probes/overlap2_probe.hip) -- 96 instead of 160 instructions per wave-step, none of them on VCC.
+    // r04: by integer arithmetic, not selects -- a > 0 <=> the float's bit pattern is a positive int32, so clamp(bits, 0, 1) (v_med3_i32)
+    // is the 0 / 1 mask, and (m1 << 16 | m0) * 0x3c00 the fp16 pair: 4 instructions per pair instead of 2 compares + 2 VCC-form v_cndmask
+    // + 1 v_or (back-to-back VCC selects issue ~5x slower than plain VALU on gfx950, tools/probes/overlap2_probe.hip).  Compiler builtins
+    // only: these are the first readers of the layer's MFMA results, and hipcc inserts the MFMA-write -> VALU-read wait states in front
+    // of instructions it knows, not in front of inline asm (sn_main.h sn_pk_f16 met exactly that).
     u32x4 m0[4], m1[4];
     {
-        const float big = __builtin_inff();
-        auto mask01 = [&](float a) {
-            float m;
-            asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(m) : "v"(a), "v"(big));
-            return m;
+        auto pair = [](float lo, float hi) {
+            const int a = min(max(__float_as_int(lo), 0), 1), b = min(max(__float_as_int(hi), 0), 1);
+            return (uint32_t)((b << 16) | a) * 0x3c00u;
         };
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                m0[2 * rt + j / 4][j % 4] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(mask01(a0[rt][2 * j]), mask01(a0[rt][2 * j + 1])));
-                m1[2 * rt + j / 4][j % 4] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(mask01(a1[rt][2 * j]), mask01(a1[rt][2 * j + 1])));
+                m0[2 * rt + j / 4][j % 4] = pair(a0[rt][2 * j], a0[rt][2 * j + 1]);
+                m1[2 * rt + j / 4][j % 4] = pair(a1[rt][2 * j], a1[rt][2 * j + 1]);
             }
     }
     // (the normals images are conditioned to the same 2^10 pre-activation bound as K1's, sn_api.hip: the ReLU folds into the split)
@@ -495,9 +494,12 @@ SN_DEV void sn_kept_slopes_contract(const float* keep, const float* gfeat, float
 #ifndef SN_NORMALS_WAVES
 #define SN_NORMALS_WAVES 2
 #endif
-// first level whose slopes are kept from the forward pass (torch grid with de-hashed copies; 16 = none): 6 registers per kept level
+// first level whose slopes are kept from the forward pass (torch grid with de-hashed copies; 16 = none): 6 registers per kept level.
+// Measured r04, same box, 800x800x64, tables x 1e-3 (profiles/r04_normals_keep_ab.txt): none 4.95 ms (168 gathers per wave-step, 200 VGPRs);
+// levels 11-15: 4.37 (128 gathers, 228 VGPRs); 9-15: 4.30 (120, 240); 7-15: 4.12 (112, 252 -- the last level that fits two waves per SIMD
+// without spills).  Three waves per SIMD (168 VGPRs, 31 spilled, nothing kept): 5.4 ms.
 #ifndef SN_NORMALS_KEEP0
-#define SN_NORMALS_KEEP0 9
+#define SN_NORMALS_KEEP0 7
 #endif
 template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int GRID /*0 torch grid, 1 tiny-cuda-nn grid*/,
           int PREC /*0 exact fp32 MFMA, 1 fp16 hi+lo split MFMA*/, int ND = -1 /*torch grid: leading levels read from the de-hashed copies*/,

@@ -132,4 +132,6 @@ def test_bench_strong_scaling_single_gpu(gpu):
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["gather_ms"] is None and d["config"]["dist_world_size"] == 1
     assert abs(d["value"] - 8 * 160 * 160 * 64 * 3 / d["timed_region_s"]) / d["value"] < 1e-6
-    assert d["roofline"]["frac_at_peak_clock"] < d["roofline"]["frac"] <= 1.0 and d["roofline"]["traffic"] is None
+    # `frac` is priced at the part's 2.4 GHz peak clock (r04), the sustained-clock figure sits beside it; no PMC child pass was asked for
+    assert d["roofline"]["frac"] == d["roofline"]["frac_at_peak_clock"] <= d["roofline"]["frac_at_sustained_clock"] * 1.02 and d["roofline"]["frac"] <= 1.0
+    assert d["roofline"]["traffic"] is None and "not measured" in d["roofline"]["traffic_source"]
