@@ -21,6 +21,13 @@
 #pragma once
 #include "sn_device.h"
 
+// EXPERIMENT (r03, measured and NOT adopted; profiles/r03_l3_mfma_ab.txt): colour layer 3 of the split-precision kernel as 64 x
+// v_mfma_f32_4x4x1_16b_f32 instead of 192 v_fmac (sn_main_field_h).  1428 -> 1236 VALU per wave-step, bit-identical with 2 accumulator
+// chains -- and 6 % SLOWER (2.83 -> 2.99-3.08 ms; 4 chains spill: 3.29 ms): the fp32-input MFMA holds the vector port like the 32x32x2
+// form does (r02), and every one of them waits for a v_max (its ReLU'd operand) and for its predecessor's accumulator.
+#ifndef SN_L3_MFMA
+#define SN_L3_MFMA 0
+#endif
 // LDS weight image of the main field, float offsets.  Built on the host by sn_api.hip
 // (build_main_image) -- keep the two in sync.
 struct SnMainImg {
@@ -32,9 +39,10 @@ struct SnMainImg {
     static constexpr int B2 = 10304;    // [1][2][16]
     static constexpr int BC1 = 10336;   // [2][2][16]
     static constexpr int BC2 = 10400;   // [2][2][16]
-    static constexpr int W3 = 10464;    // [n=4][h=2][32]; n = 3 is a row of zeros (the A operand of the 4x4x1 MFMAs of colour layer 3 reads row lane & 3)
-    static constexpr int B3 = 10720;    // [4]: the 3 biases; [3] = 1 / (output scale of layer 2) of the split-precision image (h0 = row 0 * that)
-    static constexpr int TOTAL = 10724; // floats (multiple of 4)
+    static constexpr int W3 = 10464;    // [n][h=2][32], n = 3 channels (SN_L3_MFMA: + a row of zeros, which the A operand of its 4x4x1 MFMAs reads as row lane & 3)
+    static constexpr int W3_ROWS = SN_L3_MFMA ? 4 : 3;
+    static constexpr int B3 = W3 + W3_ROWS * 64;  // [4]: the 3 biases; [3] = 1 / (output scale of layer 2) of the split-precision image (h0 = row 0 * that)
+    static constexpr int TOTAL = B3 + 4;  // 10 660 floats = 42 640 bytes (10 724 / 42 896 with SN_L3_MFMA); a multiple of 4
 };
 
 // acc[rt] (tile 0) / acc[rt] (tile 1) <- bias + W . op     (exact fp32 MFMA)
@@ -263,13 +271,6 @@ struct SnOpH {  // one B operand (8 k-slots of one 32-sample tile), hi and lo pa
 #ifndef SN_MFMA_PRIO
 #define SN_MFMA_PRIO 1
 #endif
-// EXPERIMENT (r03, measured and NOT adopted; profiles/r03_l3_mfma_ab.txt): colour layer 3 of the split-precision kernel as 64 x
-// v_mfma_f32_4x4x1_16b_f32 instead of 192 v_fmac (sn_main_field_h).  1428 -> 1236 VALU per wave-step, bit-identical with 2 accumulator
-// chains -- and 6 % SLOWER (2.83 -> 2.99-3.08 ms; 4 chains spill: 3.29 ms): the fp32-input MFMA holds the vector port like the 32x32x2
-// form does (r02), and every one of them waits for a v_max (its ReLU'd operand) and for its predecessor's accumulator.
-#ifndef SN_L3_MFMA
-#define SN_L3_MFMA 0
-#endif
 #ifndef SN_L3_CHAINS
 #define SN_L3_CHAINS 2
 #endif
@@ -486,13 +487,6 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
             r0[j] = sn_relu(c0[0][j]);
             r1[j] = sn_relu(c1[0][j]);
         }
-#if defined(SN_EXP_NO_L3)  // experiment (wrong images): the ceiling of moving colour layer 3 off the vector port
-        for (int n = 0; n < 3; ++n) {
-            p0[n] += r0[n] + r0[4 + n] + r0[8 + n] + r0[12 + n];
-            p1[n] += r1[n] + r1[4 + n] + r1[8 + n] + r1[12 + n];
-        }
-        if (false)
-#endif
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             const f32x4* w = (const f32x4*)(tail + SnMainImgH::W3 + (n * 2 + h) * 32);
@@ -1136,7 +1130,7 @@ void sn_render_main_kernel(SnMainParams p) {
     const int tid = threadIdx.x;
     const int su = ALT ? p.spacing_uniform : 0;          // (constants in the production instantiations: their code is what it was
     const SnPosMap* pm = ALT ? &p.pm : nullptr;          //  before the two options existed)
-    // both weight images are SnMainImg::TOTAL floats (42 640 B)
+    // both weight images are SnMainImg::TOTAL floats (42 640 B; the single-fp16 mode appends colour layer 3's fp16 operand)
     constexpr int IMG_FLOATS = PREC == 2 ? SnMainImgF16::TOTAL_FLOATS : SnMainImg::TOTAL;   // (PREC 2: + colour layer 3's fp16 operand)
     for (int i = tid * 4; i < IMG_FLOATS; i += NT * 4) *(f32x4*)(lds + i) = *(const f32x4*)(p.wimg + i);
     // Uniform sampler without per-ray nears / fars (the collider's constants): the S + 1 euclidean bins are the same for every ray
@@ -1315,11 +1309,7 @@ void sn_render_main_kernel(SnMainParams p) {
         r = rgb[0] + nan_term;
         g = rgb[1] + nan_term;
         b = rgb[2] + nan_term;
-#if defined(SN_EXP_NO_SEG_STORE)  // experiment (wrong images): what does the per-sample store cost the segment jobs?
-        if (seg_out) { if (density == 12345.678f) seg_out[(int64_t)i * 64] = f32x4{density, r, g, b}; }
-#else
         if (seg_out) seg_out[(int64_t)i * 64] = f32x4{density, r, g, b};  // (wave-uniform branch) composited later, in sample order
-#endif
         else comp.step_fused(t0, t1, density, r, g, b);
         t0 = t1;
     }

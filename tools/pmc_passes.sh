@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 run_pass() {
   name=$1; shift
   timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d "$OUT/$name" -- \
-      python "$ROOT/bench.py" --frames-in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline --no-alt-precision ${BENCH_ARGS:-} > "$OUT/$name.log" 2>&1
+      python "$ROOT/bench.py" --frames-in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline --no-alt-precision --no-others --no-traffic ${BENCH_ARGS:-} > "$OUT/$name.log" 2>&1
   echo "pass $name rc=$?"
 }
 run_pass tcc_fetch   FETCH_SIZE

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 run_pass() {
   name=$1; shift
   timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d "$OUT/$name" -- \
-      python "$ROOT/bench.py" --frames-in-flight 1 --workload nerfacto1080 --width 960 --height 540 --steps 2 --warmup 1 --no-cpu-baseline --no-alt-precision > "$OUT/$name.log" 2>&1
+      python "$ROOT/bench.py" --frames-in-flight 1 --workload nerfacto1080 --width 960 --height 540 --steps 2 --warmup 1 --no-cpu-baseline --no-alt-precision --no-others --no-traffic > "$OUT/$name.log" 2>&1
   echo "pass $name rc=$?"
 }
 run_pass sq_a   SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY

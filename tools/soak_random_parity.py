@@ -25,7 +25,7 @@ from signerf_amd import Cameras, SceneBox, scene  # noqa: E402
 from test_gpu_random_parity import _look_at, _random_c2w  # noqa: E402
 
 
-def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False):
+def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False, lenses=False):
     g = torch.Generator().manual_seed(910000 + seed)
 
     def ri(lo, hi):
@@ -93,7 +93,15 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
 
             obb = OrientedBox(R=_random_c2w(g)[:, :3].contiguous(), T=(torch.rand(3, generator=g) - 0.5) * 0.3, S=torch.rand(3, generator=g) * 0.5 + 0.08)
             c2w = _look_at(pos, obb.T)
-    cams = Cameras(c2w[None], focal, focal * ru(0.8, 1.25), W / 2 + ru(-2, 2), H / 2 + ru(-2, 2), W, H).to(gpu)
+    fy_, cx_, cy_ = focal * ru(0.8, 1.25), W / 2 + ru(-2, 2), H / 2 + ru(-2, 2)
+    lens, ctype = None, 1
+    if lenses:   # r04: the cameras of the original dataset (datasetgenerator.py:274-275): OPENCV distortion, PERSPECTIVE / FISHEYE
+        ctype = 2 if ri(0, 3) == 0 else 1
+        if ri(0, 4) > 0:
+            lens = torch.tensor([ru(-0.3, 0.3), ru(-0.1, 0.1), ru(-0.02, 0.02), ru(-0.005, 0.005), ru(-0.01, 0.01), ru(-0.01, 0.01)])
+            if ri(0, 5) == 0:
+                lens = lens * 6.0    # a lens whose Jacobian degenerates inside the frame: the eps rule of the Newton step
+    cams = Cameras(c2w[None], focal, fy_, cx_, cy_, W, H, distortion_params=lens, camera_type=ctype).to(gpu)
     model.render_aabb = box
     if obb is not None:
         bundle = cams[0].generate_rays(camera_indices=0, obb_box=obb)
@@ -107,6 +115,19 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
     tag = (f"seed {seed}: {H}x{W}, samples {props}+{S}, far {far:.3g}, {sampler}, box-normalised {no_contract}, {background}, {precision}, "
            f"camera kind {kind}, render box {box is not None}, crop box {obb is not None}")
     problems, msgs = [], []
+    if lenses:   # the bundle itself against the oracle's restatement of nerfstudio's ray generation
+        rr = onf.generate_rays(c2w[:3], focal, fy_, cx_, cy_, H, W, distortion_params=lens, camera_type=ctype)
+        gd, wd = bundle.directions.cpu(), rr["directions"]
+        fin = torch.isfinite(wd).all(-1)
+        if not torch.equal(torch.isfinite(gd).all(-1), fin):
+            problems.append("rays: the non-finite directions differ")
+        elif bool(fin.any()):
+            e = float((gd[fin] - wd[fin]).abs().max())
+            msgs.append(f"rays (type {ctype}, lens {'none' if lens is None else 'yes'}) {e:.1e}")
+            # a degenerate lens amplifies the last bit of an early Newton step (chaotic region: |det J| near the 1e-3 rule): counted, not gated by value
+            offp = int(((gd - wd).abs().amax(-1)[fin] > (2e-6 if ctype == 2 else 5e-7)).sum())
+            if offp > max(1, int(fin.sum()) // 100):
+                problems.append(f"rays: {offp} of {int(fin.sum())} directions beyond tolerance (max {e:.2e})")
     if obb is not None:   # the bounds themselves against the oracle's restatement of nerfstudio's intersect_obb
         o, d = bundle.origins.cpu().reshape(-1, 3), bundle.directions.cpu().reshape(-1, 3)
         t0, t1 = onf.intersect_obb(o, d, obb.R, obb.T, obb.S)
@@ -186,12 +207,13 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--full-tables", action="store_true", help="nerfacto's table sizes (2^19 / 2^17) instead of the small ones")
     ap.add_argument("--tcnn", action="store_true", help="tiny-cuda-nn grid semantics and checkpoint import")
+    ap.add_argument("--lenses", action="store_true", help="random OPENCV distortion parameters and PERSPECTIVE / FISHEYE cameras; the bundle is checked too")
     ap.add_argument("--normals", action="store_true", help="uniform-sampler scenarios only, with the normals kernel's two outputs checked as well")
     ap.add_argument("--inspect", type=int, nargs="*", default=[], help="print the worst pixels of these seeds instead of running the sweep")
     a = ap.parse_args()
     gpu = torch.device("cuda", 0)
     for seed in a.inspect:
-        tag, msgs, problems = scenario(seed, gpu, inspect=("expected_depth", "depth", "rgb") + (("normals", "pred_normals") if a.normals else ()), normals=a.normals, full_tables=a.full_tables, tcnn=a.tcnn)
+        tag, msgs, problems = scenario(seed, gpu, inspect=("expected_depth", "depth", "rgb") + (("normals", "pred_normals") if a.normals else ()), normals=a.normals, full_tables=a.full_tables, tcnn=a.tcnn, lenses=a.lenses)
         print(tag, "|", "; ".join(problems), "|", ", ".join(msgs))
     if a.inspect:
         return
@@ -199,7 +221,7 @@ def main():
     bad = 0
     for seed in range(a.first, a.first + a.n):
         try:
-            tag, msgs, problems = scenario(seed, gpu, normals=a.normals, full_tables=a.full_tables, tcnn=a.tcnn)
+            tag, msgs, problems = scenario(seed, gpu, normals=a.normals, full_tables=a.full_tables, tcnn=a.tcnn, lenses=a.lenses)
         except Exception as e:  # noqa: BLE001
             tag, msgs, problems = f"seed {seed}", [], [f"EXCEPTION {type(e).__name__}: {str(e)[:300]}"]
         if problems:
