@@ -90,7 +90,7 @@ struct SnContext {
     // diagnostic / test switches of the environment, read when the handle is created, when its weights are finalized and by
     // sn_debug_reload_env -- not by every render call (getenv on the render path of several threads)
     struct Switches {
-        std::atomic<int> render_chain{0}, prop_cache_off{0}, pdf_ieee{0}, pdf_fast{0}, ablate{0}, hash_plain{0}, tail_split_off{0}, k1_wide{SN_K1_WIDE_DEFAULT};
+        std::atomic<int> render_chain{0}, prop_cache_off{0}, pdf_ieee{0}, pdf_fast{0}, ablate{0}, hash_plain{0}, tail_split_off{0}, k1_wide{SN_K1_WIDE_DEFAULT}, early_term{1};
     } sw;
 };
 
@@ -132,6 +132,10 @@ void load_switches(SnHandle h) {
     {
         const char* e = getenv("SN_TAIL_SPLIT");                  // test / A-B switch: SN_TAIL_SPLIT=0 renders the last round of workgroups whole
         h->sw.tail_split_off = e && atoi(e) == 0;
+    }
+    {
+        const char* e = getenv("SN_EARLY_TERM");   // 0: every sample of every ray is evaluated (bit-identical outputs; A/B and test switch)
+        h->sw.early_term = e ? (atoi(e) != 0) : 1;
     }
     {
         const char* e = getenv("SN_K1_WIDE");
@@ -1308,6 +1312,7 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     pp.ebins_out = d_ebins;
     pp.scratch = (float*)(ws + wp.off_prop_scratch);
     pp.cache_off = h->sw.prop_cache_off.load(std::memory_order_relaxed);
+    pp.early_term = h->sw.early_term.load(std::memory_order_relaxed);
     pp.spacing_uniform = opts->spacing_mode;
     pp.pm = h->pos_map;
     pp.pdf_ieee = h->sw.pdf_ieee.load(std::memory_order_relaxed);
@@ -1457,6 +1462,7 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     p.sh_remap = d.sh_remap;
     p.chunk_rays = opts->chunk_rays;
     p.bg_mode = opts->background_mode;
+    p.early_term = h->sw.early_term.load(std::memory_order_relaxed);
     for (int c = 0; c < 3; ++c) p.bg[c] = opts->background_rgb[c];
     const bool tcnn = d.main_field.grid_mode == 1;
     // de-hashed copies are used when they cover every level tiny-cuda-nn indexes densely (always true for torch grids and for nerfacto's

@@ -797,6 +797,7 @@ struct SnComposite {
         median_idx = 0;
         found = false;
         below = 0.f;
+        last_trans = 1.0f;
     }
 
     // One sample.  Returns the weight.
@@ -838,6 +839,7 @@ struct SnComposite {
     // steps with cum_w < 0.5; `below` accumulates clamp(2^100 (0.5 - cum_w), 0, 1), which is exactly 1 or 0 (|0.5 - cum_w| is 0 or
     // >= 2^-25).  The caller turns the count into the index and re-reads that bin (median_index(), sn_main.h).
     float below;
+    float last_trans;  // transmittance in front of the sample step_fused composited last (exact early termination, sn_main.h)
     SN_DEV void step_fused(float start, float end, float density, float r, float g, float b) {
         float w, mid;
         {
@@ -846,6 +848,7 @@ struct SnComposite {
             const float tau = delta * density;
             const float alpha = 1.0f - sn_exp<true>(-tau);
             const float trans = sn_exp<true>(-(float)cum_tau);
+            last_trans = trans;
             w = fmaxf(alpha * trans, 0.0f);
             cum_tau += (double)tau;
             mid = (start + end) / 2.0f;

@@ -1018,6 +1018,7 @@ struct SnMainParams {
     // sample order with the same arithmetic (bit-identical outputs).  n_seg <= 1: no segment jobs.
     int seg_first_block, n_seg, seg_len;
     f32x4* seg_scratch;
+    int early_term;   // exact early termination of saturated waves (below); 0 = off (SN_EARLY_TERM=0: the A/B and bit-identity switch)
     int bg_mode;      // RGBRenderer background: 0 = the ray's last sample, 1 = the constant colour bg
     float bg[3];
     int spacing_uniform;  // SnRenderOpts.spacing_mode: the initial sampler's s(x) is the identity (sn_spacing)
@@ -1312,6 +1313,18 @@ void sn_render_main_kernel(SnMainParams p) {
         if (seg_out) seg_out[(int64_t)i * 64] = f32x4{density, r, g, b};  // (wave-uniform branch) composited later, in sample order
         else comp.step_fused(t0, t1, density, r, g, b);
         t0 = t1;
+        // EXACT early termination (r04).  Once the transmittance in front of a sample is exactly 0 in fp32 -- exp(-cumsum(tau)) underflows
+        // beyond tau ~ 88: a few samples behind any trained surface -- every later weight of that ray is exactly +0 whatever the field
+        // returns (alpha * 0, NaN -> 0 by nan_to_num; cumsum(tau) only grows, and a NaN sum gives a NaN transmittance whose weight
+        // nan_to_num zeroes as well), so the sums, the median count and the expected depth cannot change any more.  When that holds for
+        // ALL 64 rays of the wave the march jumps to the last sample, whose colour is the 'last_sample' background (rgb += c_last (1 -
+        // sum w)).  Outputs are bit-identical (tests/test_gpu_early_term.py); the synthetic benchmark scene never saturates (its
+        // densities are O(1): max cumsum(tau) < 88), so the check costs it one v_cmp and one branch per step.  Segment jobs store every
+        // sample and the DUMP instantiations record every fetch: not for them.
+        if (!DUMP && ABLATE == 0 && p.early_term && !seg_out && i < i_hi - 2 && __all(comp.last_trans == 0.0f)) {
+            i = i_hi - 2;
+            t0 = bin(i_hi - 1);
+        }
     }
     if (seg_out) return;
     sn_main_epilogue<DUMP>(p, comp, r, g, b, bin, S, valid, px, py, lane);

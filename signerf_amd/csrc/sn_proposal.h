@@ -335,6 +335,7 @@ struct SnPropParams {
     int height, width, tile_w_log2, tile_h_log2, tiles_x, tiles_y;
     float near_plane, far_plane, avg_density, hist_pad;
     int pdf_ieee;   // test switch (SN_PDF_IEEE=1): the resampler divides with the plain IEEE sequence instead of sn_pdf_lane's RECIP form
+    int early_term; // exact early termination of saturated waves (sn_prop_level); 0 = off (SN_EARLY_TERM=0)
     int cache_off;  // test switch: the coefficient cache re-fetches on every step (tests/test_gpu_render.py compares the two bit for bit)
     int spacing_uniform;  // SnRenderOpts.spacing_mode (sn_spacing)
     SnPosMap pm;          // SnFieldDesc.disable_scene_contraction (sn_sample_q_fast)
@@ -409,11 +410,12 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
         const float h0 = sn_prop_h0<GRID, ND, DUMP, NCACHE>(rsrc, pi, scal, log2_t, wp, q, &p.grid[LV], plain, &p.dense[LV], rec, p.feat_scale[LV], cache,
                                                             &nanq);
         const float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
-        float wt;
+        float wt, trans;
         {
 #pragma clang fp contract(off)
             const float tau = (e1 - e0) * density;
-            wt = fmaxf((1.0f - sn_exp<true>(-tau)) * sn_exp<true>(-(float)cum_tau), 0.0f);  // nan_to_num: tau >= 0 or NaN, so wt >= 0 or NaN
+            trans = sn_exp<true>(-(float)cum_tau);
+            wt = fmaxf((1.0f - sn_exp<true>(-tau)) * trans, 0.0f);  // nan_to_num: tau >= 0 or NaN, so wt >= 0 or NaN
             cum_tau += (double)tau;
             cum_w += (double)wt;
             swp += (double)(wt + p.hist_pad);
@@ -421,6 +423,17 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
         below += __builtin_amdgcn_fmed3f(fmaf((float)cum_w, -0x1p100f, 0x1p99f), 0.0f, 1.0f);
         w[(int64_t)i * 64] = wt;
         e0 = e1;
+        // EXACT early termination (r04; sn_main.h explains why it is exact): the transmittance in front of this sample was exactly 0 for
+        // every ray of the wave, so every later weight is exactly +0 -- written as such, and added to the padded sum one by one as the
+        // full march does (fp64 additions of the same constant, the same roundings); cumsum(w) and the median count stay what they are.
+        if (!DUMP && p.early_term && __all(trans == 0.0f)) {
+            for (int k = i + 1; k < N; ++k) {
+#pragma clang fp contract(off)
+                swp += (double)(0.0f + p.hist_pad);
+                w[(int64_t)k * 64] = 0.0f;
+            }
+            break;
+        }
     }
     sum_wp = swp;
     {
