@@ -90,7 +90,7 @@ def other_configs(precision):
     me = os.path.abspath(__file__)
     base = [sys.executable, me, "--workload", "nerfacto1080", "--steps", "12", "--warmup", "3", "--precision", precision, "--no-cpu-baseline",
             "--no-alt-precision", "--no-others", "--no-traffic"]
-    d, err = _json_line_of(base, 240)
+    d, err = _json_line_of(base, 200)
     if d is None:
         out.append({"config": "BASELINE.json configs[3] (nerfacto1080)", "error": err})
     else:
@@ -101,7 +101,7 @@ def other_configs(precision):
                     "field_evaluations_per_s": d.get("field_evaluations_per_sec"), "rays_per_s": d.get("rays_per_sec"),
                     "roofline": {k: rf.get(k) for k in ("bound", "frac", "frac_at_sustained_clock", "sustained_clock_ghz", "peak_clock_ghz", "unit")}})
     cmd = [sys.executable, os.path.join(ROOT, "tools", "config5_bench.py"), "--size", "800", "--reps", "1", "--only-nopng"]
-    d, err = _json_line_of(cmd, 240)
+    d, err = _json_line_of(cmd, 200)
     if d is None:
         out.append({"config": "BASELINE.json configs[4] (generator loop)", "error": err})
     else:
@@ -140,7 +140,7 @@ def inrun_traffic(precision, kernel_pattern="sn_render_main_kernel"):
 
             d = os.path.join(tmp, name)
             r = subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "--pmc", *counters, "-d", d, "--", *child],
-                               capture_output=True, text=True, timeout=240, env=env, cwd="/tmp")
+                               capture_output=True, text=True, timeout=150, env=env, cwd="/tmp")
             rows = 0
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):

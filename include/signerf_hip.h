@@ -184,13 +184,15 @@ int sn_generate_rays(const float* c2w, float fx, float fy, float cx, float cy, i
  * points (pixel centre, +1 px in x, +1 px in y) with 10 fixed Newton steps of the radial-tangential model (step 0 where
  * |det J| <= 1e-3), then forms the pin-hole direction (u, v, -1) or the fisheye one (u sin t / t, v sin t / t, -cos t), t = |(u, v)|
  * clipped to [0, pi].  With has_distortion = 0 and camera_type = SN_CAMERA_PERSPECTIVE the result is bit-identical to
- * sn_generate_rays.
+ * sn_generate_rays.  camera_type = SN_CAMERA_EQUIRECTANGULAR: the spherical mapping below, no un-distortion.
  *   cam     HOST struct.
  *   coords  optional DEVICE [n_coords, 2] image coordinates as (y, x) -- `generate_rays(coords=...)`; NULL = every pixel centre
  *           (row, col) + 0.5 of the height x width image in row-major order (then n_coords is ignored and the outputs are [H,W,.]).
  * Outputs as sn_generate_rays; with coords they are [n_coords, .].  Other camera types return SN_ERR_INVALID. */
 #define SN_CAMERA_PERSPECTIVE 1   /* nerfstudio CameraType.PERSPECTIVE.value */
 #define SN_CAMERA_FISHEYE 2       /* nerfstudio CameraType.FISHEYE.value */
+#define SN_CAMERA_EQUIRECTANGULAR 3 /* nerfstudio CameraType.EQUIRECTANGULAR.value: the viewer's preview camera (signerf/interface/viewer.py:307-319);
+                                     * theta = -pi u, phi = pi (1/2 - v), d = (-sin theta sin phi, cos phi, -cos theta sin phi); never un-distorted */
 typedef struct SnCameraDesc {
     float c2w[12];           /* 3x4 row-major camera-to-world */
     float fx, fy, cx, cy;

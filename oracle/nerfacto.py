@@ -143,7 +143,7 @@ def radial_and_tangential_undistort(coords: Tensor, distortion_params: Tensor, e
     return torch.stack([x, y], dim=-1)
 
 
-CAMERA_PERSPECTIVE, CAMERA_FISHEYE = 1, 2  # nerfstudio CameraType values
+CAMERA_PERSPECTIVE, CAMERA_FISHEYE, CAMERA_EQUIRECTANGULAR = 1, 2, 3  # nerfstudio CameraType values
 
 
 def generate_rays(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, height: int, width: int,
@@ -175,7 +175,7 @@ def generate_rays(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, heigh
     coord_x = torch.stack([(x - cx_t + 1) / fx_t, -(y - cy_t) / fy_t], -1)
     coord_y = torch.stack([(x - cx_t) / fx_t, -(y - cy_t + 1) / fy_t], -1)
     coord_stack = torch.stack([coord, coord_x, coord_y], dim=0)  # [3,...,2]
-    if distortion_params is not None and bool((distortion_params != 0).any()):
+    if distortion_params is not None and bool((distortion_params != 0).any()) and camera_type != CAMERA_EQUIRECTANGULAR:
         coord_stack = radial_and_tangential_undistort(coord_stack, distortion_params.to(torch.float32).reshape(6))
     dirs = torch.empty((3, *shape, 3), dtype=torch.float32)
     if camera_type == CAMERA_PERSPECTIVE:
@@ -189,6 +189,13 @@ def generate_rays(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, heigh
         dirs[..., 0] = coord_stack[..., 0] * sin_theta / theta
         dirs[..., 1] = coord_stack[..., 1] * sin_theta / theta
         dirs[..., 2] = -torch.cos(theta)
+    elif camera_type == CAMERA_EQUIRECTANGULAR:
+        # [NS-RECALL] M: for equirectangular images fx = fy = height = width / 2, so coord x spans (-1, 1) and y (-1/2, 1/2)
+        theta = -torch.pi * coord_stack[..., 0]          # minus sign for a right-handed frame
+        phi = torch.pi * (0.5 - coord_stack[..., 1])
+        dirs[..., 0] = -torch.sin(theta) * torch.sin(phi)
+        dirs[..., 1] = torch.cos(phi)
+        dirs[..., 2] = -torch.cos(theta) * torch.sin(phi)
     else:
         raise ValueError(f"camera_type {camera_type} is not restated")
     rotation = c2w[:3, :3]

@@ -127,7 +127,8 @@ def _as_column(x: Union[float, int, Tensor], batch: int, dtype) -> Tensor:
 
 class CameraType(enum.Enum):
     """nerfstudio's ``CameraType`` values (``nerfstudio.cameras.cameras``, [NS-RECALL] H): what a dataparser stores in
-    ``Cameras.camera_type``.  The HIP ray generation implements PERSPECTIVE and FISHEYE; the others are rejected loudly."""
+    ``Cameras.camera_type``.  The HIP ray generation implements PERSPECTIVE, FISHEYE and EQUIRECTANGULAR (the three the viewer can preview,
+    signerf/interface/viewer.py:307-319); the others are rejected loudly."""
 
     PERSPECTIVE = 1
     FISHEYE = 2
@@ -140,7 +141,7 @@ class CameraType(enum.Enum):
     FISHEYE624 = 9
 
 
-_SUPPORTED_TYPES = (CameraType.PERSPECTIVE.value, CameraType.FISHEYE.value)
+_SUPPORTED_TYPES = (CameraType.PERSPECTIVE.value, CameraType.FISHEYE.value, CameraType.EQUIRECTANGULAR.value)
 # columns of the host mirror
 _H_FX, _H_FY, _H_CX, _H_CY, _H_W, _H_H, _H_TYPE, _H_HASDIST, _H_DIST, _H_COLS = 12, 13, 14, 15, 16, 17, 18, 19, 20, 26
 
@@ -335,7 +336,7 @@ class Cameras:
         ctype = int(host[_H_TYPE])
         if ctype not in _SUPPORTED_TYPES:
             name = CameraType(ctype).name if ctype in [t.value for t in CameraType] else str(ctype)
-            raise NotImplementedError(f"camera_type {name} is not supported by the HIP ray generation (PERSPECTIVE and FISHEYE are)")
+            raise NotImplementedError(f"camera_type {name} is not supported by the HIP ray generation (PERSPECTIVE, FISHEYE and EQUIRECTANGULAR are)")
         desc = _lib.SnCameraDesc()
         desc.c2w[:] = host[:12]
         desc.fx, desc.fy, desc.cx, desc.cy = host[_H_FX], host[_H_FY], host[_H_CX], host[_H_CY]

@@ -1204,9 +1204,9 @@ int sn_generate_rays_camera(const SnCameraDesc* cam, const float* coords, int64_
                             float* pixel_area, float* directions_norm, const float* aabb, float* nears, float* fars, SnStream stream) {
     if (!cam || cam->height <= 0 || cam->width <= 0 || (coords && n_coords < 0))
         return fail(nullptr, SN_ERR_INVALID, "sn_generate_rays_camera: bad argument");
-    if (cam->camera_type != SN_CAMERA_PERSPECTIVE && cam->camera_type != SN_CAMERA_FISHEYE)
+    if (cam->camera_type != SN_CAMERA_PERSPECTIVE && cam->camera_type != SN_CAMERA_FISHEYE && cam->camera_type != SN_CAMERA_EQUIRECTANGULAR)
         return fail(nullptr, SN_ERR_INVALID, "sn_generate_rays_camera: camera_type " + std::to_string(cam->camera_type) +
-                                                 " is not supported (1 = PERSPECTIVE, 2 = FISHEYE)");
+                                                 " is not supported (1 = PERSPECTIVE, 2 = FISHEYE, 3 = EQUIRECTANGULAR)");
     SnRayGenParams p;
     memcpy(p.c2w, cam->c2w, sizeof(p.c2w));
     p.fx = cam->fx;
@@ -1216,7 +1216,7 @@ int sn_generate_rays_camera(const SnCameraDesc* cam, const float* coords, int64_
     p.height = cam->height;
     p.width = cam->width;
     p.camera_type = cam->camera_type;
-    p.has_distortion = cam->has_distortion != 0;
+    p.has_distortion = cam->has_distortion != 0 && cam->camera_type != SN_CAMERA_EQUIRECTANGULAR;  // (nerfstudio never un-distorts equirectangular images)
     memcpy(p.dist, cam->distortion, sizeof(p.dist));
     p.coords = coords;
     p.n = coords ? n_coords : (int64_t)cam->height * cam->width;
@@ -1232,10 +1232,11 @@ int sn_generate_rays_camera(const SnCameraDesc* cam, const float* coords, int64_
     if (p.n == 0) return SN_OK;
     const dim3 grid((unsigned)((p.n + 255) / 256)), block(256);
     const bool fish = cam->camera_type == SN_CAMERA_FISHEYE;
-    if (fish && p.has_distortion) hipLaunchKernelGGL((sn_generate_rays_kernel<true, true>), grid, block, 0, (hipStream_t)stream, p);
-    else if (fish) hipLaunchKernelGGL((sn_generate_rays_kernel<true, false>), grid, block, 0, (hipStream_t)stream, p);
-    else if (p.has_distortion) hipLaunchKernelGGL((sn_generate_rays_kernel<false, true>), grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((sn_generate_rays_kernel<false, false>), grid, block, 0, (hipStream_t)stream, p);
+    if (cam->camera_type == SN_CAMERA_EQUIRECTANGULAR) hipLaunchKernelGGL((sn_generate_rays_kernel<3, false>), grid, block, 0, (hipStream_t)stream, p);
+    else if (fish && p.has_distortion) hipLaunchKernelGGL((sn_generate_rays_kernel<2, true>), grid, block, 0, (hipStream_t)stream, p);
+    else if (fish) hipLaunchKernelGGL((sn_generate_rays_kernel<2, false>), grid, block, 0, (hipStream_t)stream, p);
+    else if (p.has_distortion) hipLaunchKernelGGL((sn_generate_rays_kernel<1, true>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((sn_generate_rays_kernel<1, false>), grid, block, 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_generate_rays launch: ") + hipGetErrorString(e));
     return SN_OK;

@@ -56,18 +56,27 @@ SN_DEV void sn_undistort(const float* kk, float xd, float yd, float& xo, float& 
     yo = y;
 }
 
-// image-plane point -> camera-frame direction -> world direction (d_world = R . d_cam), normalised
-template <bool FISHEYE>
+// image-plane point -> camera-frame direction -> world direction (d_world = R . d_cam), normalised.
+// TYPE: nerfstudio CameraType value -- 1 PERSPECTIVE (u, v, -1); 2 FISHEYE (equidistant: the image-plane radius is the angle from the axis);
+// 3 EQUIRECTANGULAR (the viewer's preview, signerf/interface/viewer.py:307-319; [NS-RECALL] M: theta = -pi u, phi = pi (1/2 - v),
+// d = (-sin theta sin phi, cos phi, -cos theta sin phi))
+template <int TYPE>
 SN_DEV void sn_cam_dir(const float* c2w, float u, float v, float out[3], float& norm) {
 #pragma clang fp contract(off)
     float a = u, b = v, c = -1.0f;
-    if (FISHEYE) {
+    if (TYPE == 2) {
         float th = sqrtf(u * u + v * v);
         th = fminf(fmaxf(th, 0.0f), 3.14159265358979323846f);
         const float st = sinf(th);
         a = (u * st) / th;
         b = (v * st) / th;
         c = -cosf(th);
+    } else if (TYPE == 3) {
+        const float theta = -3.14159265358979323846f * u, phi = 3.14159265358979323846f * (0.5f - v);
+        const float sp = sinf(phi);
+        a = -sinf(theta) * sp;
+        b = cosf(phi);
+        c = -cosf(theta) * sp;
     }
     float w[3];
 #pragma unroll
@@ -79,7 +88,7 @@ SN_DEV void sn_cam_dir(const float* c2w, float u, float v, float out[3], float& 
     norm = n;
 }
 
-template <bool FISHEYE, bool DISTORT>
+template <int TYPE, bool DISTORT>
 __global__ void sn_generate_rays_kernel(SnRayGenParams p) {
 #pragma clang fp contract(off)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,9 +112,9 @@ __global__ void sn_generate_rays_kernel(SnRayGenParams p) {
         sn_undistort(p.dist, u0, vy, uy, vy);
     }
     float d[3], dx[3], dy[3], nrm, n1, n2;
-    sn_cam_dir<FISHEYE>(p.c2w, u, v, d, nrm);
-    sn_cam_dir<FISHEYE>(p.c2w, ux, vx, dx, n1);
-    sn_cam_dir<FISHEYE>(p.c2w, uy, vy, dy, n2);
+    sn_cam_dir<TYPE>(p.c2w, u, v, d, nrm);
+    sn_cam_dir<TYPE>(p.c2w, ux, vx, dx, n1);
+    sn_cam_dir<TYPE>(p.c2w, uy, vy, dy, n2);
     float o[3] = {p.c2w[3], p.c2w[7], p.c2w[11]};
     if (p.origins) {
         p.origins[i * 3 + 0] = o[0];

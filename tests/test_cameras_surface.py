@@ -120,3 +120,14 @@ def test_fisheye_direction_closed_form():
     d = out["directions"][0]
     theta = 20.0 / 40.0
     assert torch.allclose(d, torch.tensor([math.sin(theta), 0.0, -math.cos(theta)]), atol=1e-6)
+
+
+def test_equirectangular_direction_closed_form():
+    """Image centre looks down -z; a quarter of the width to the right looks down +x; the top row looks up (+y)."""
+    eye = torch.eye(4)[:3]
+    H, W = 32, 64
+    coords = torch.tensor([[H / 2, W / 2], [H / 2, 3 * W / 4], [0.0, W / 2]])
+    d = onf.generate_rays(eye, float(H), float(H), W / 2, H / 2, H, W, camera_type=onf.CAMERA_EQUIRECTANGULAR, coords=coords)["directions"]
+    assert torch.allclose(d[0], torch.tensor([0.0, 0.0, -1.0]), atol=1e-6)
+    assert torch.allclose(d[1], torch.tensor([1.0, 0.0, 0.0]), atol=1e-6)
+    assert torch.allclose(d[2], torch.tensor([0.0, 1.0, 0.0]), atol=1e-6)

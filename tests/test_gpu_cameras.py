@@ -84,6 +84,22 @@ def test_fisheye_matches_oracle(gpu, dist):
     assert float(((b.pixel_area.cpu() - ref["pixel_area"]).abs() / ref["pixel_area"]).max()) <= 5e-3
 
 
+def test_equirectangular_matches_oracle(gpu):
+    """The viewer's third preview camera type (signerf/interface/viewer.py:307-319): fx = fy = H = W / 2, cx = W / 2, cy = H / 2."""
+    H, W = 32, 64
+    c2w = scene.benchmark_cameras(8)
+    cam = Cameras(c2w[:, :3], float(H), float(H), W / 2, H / 2, W, H, camera_type=CameraType.EQUIRECTANGULAR,
+                  distortion_params=torch.tensor(DISTORTIONS[0])).to(gpu)[4]        # (lens parameters are ignored for this type)
+    b = cam.generate_rays(0)
+    ref = onf.generate_rays(c2w[4, :3], float(H), float(H), W / 2, H / 2, H, W, camera_type=onf.CAMERA_EQUIRECTANGULAR)
+    assert float((b.directions.cpu() - ref["directions"]).abs().max()) <= 1e-6
+    d = b.directions.cpu()
+    assert float((d.norm(dim=-1) - 1).abs().max()) <= 1e-6
+    # the full sphere: every hemisphere of the camera frame is seen
+    local = d @ c2w[4, :3, :3]
+    assert float(local[..., 2].max()) > 0.9 and float(local[..., 2].min()) < -0.9 and float(local[..., 1].max()) > 0.9
+
+
 def test_explicit_coords_and_keep_shape(gpu):
     cam, args = _cam(gpu, 40, 56, dist=DISTORTIONS[0])
     g = torch.Generator().manual_seed(0)
@@ -124,9 +140,9 @@ def test_unsupported_requests_raise(gpu):
         cam.generate_rays(camera_indices=0, not_an_argument=1)          # r03 swallowed unknown keywords
     with pytest.raises(NotImplementedError):
         cam.generate_rays(camera_indices=0, camera_opt_to_camera=torch.eye(4)[:3])
-    equi, _ = _cam(gpu, 16, 16, ctype=CameraType.EQUIRECTANGULAR)
-    with pytest.raises(NotImplementedError, match="EQUIRECTANGULAR"):
-        equi.generate_rays(0)
+    ortho, _ = _cam(gpu, 16, 16, ctype=CameraType.ORTHOPHOTO)
+    with pytest.raises(NotImplementedError, match="ORTHOPHOTO"):
+        ortho.generate_rays(0)
     with pytest.raises(IndexError):
         cam.generate_rays(camera_indices=1)
 
