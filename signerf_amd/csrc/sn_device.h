@@ -325,9 +325,21 @@ SN_DEV __amdgpu_buffer_rsrc_t sn_table_rsrc(const float* table, uint32_t bytes) 
     return __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, (int)bytes, 0x00020000);
 }
 
+// Cache policy of the three kinds of gather (the builtin's `aux` operand: 1 = sc0, 2 = nt, 16 = sc1; MI355X_MICROARCH.md: sc1 / nt loads are
+// served by the L2 without allocating in the CU's L1).  Compile-time experiment knobs; 0 = default policy.
+#ifndef SN_AUX_ROW
+#define SN_AUX_ROW 0     // 8-byte rows of a hashed level
+#endif
+#ifndef SN_AUX_DENSE
+#define SN_AUX_DENSE 0   // 16-byte fetches of the de-hashed copies
+#endif
+#ifndef SN_AUX_PAIR
+#define SN_AUX_PAIR 0    // 16-byte fetches of the x-paired tables (K2)
+#endif
+
 SN_DEV f32x2 sn_table_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, uint32_t level_off_bytes) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)byte_off, (int)level_off_bytes, 0);
+    u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)byte_off, (int)level_off_bytes, SN_AUX_ROW);
     f32x2 o;
     o.x = __uint_as_float(r.x);
     o.y = __uint_as_float(r.y);
@@ -340,7 +352,7 @@ SN_DEV f32x2 sn_table_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, uint3
 // one 16-byte gather (two adjacent rows, or half a bilinear-coefficient entry)
 SN_DEV f32x4 sn_table_load_pair(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, uint32_t level_off_bytes) {
     typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
-    u32x4_ r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, (int)level_off_bytes, 0);
+    u32x4_ r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, (int)level_off_bytes, SN_AUX_DENSE);
     return f32x4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
 }
 
@@ -639,7 +651,7 @@ struct SnPairInfo {
 
 SN_DEV f32x4 sn_pair_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t entry) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(entry * 16u), 0, 0);
+    u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(entry * 16u), 0, SN_AUX_PAIR);
     f32x4 o;
     o.x = __uint_as_float(r.x);
     o.y = __uint_as_float(r.y);
