@@ -27,6 +27,7 @@ import json
 import os
 import statistics
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -280,6 +281,8 @@ def main():
     ap.add_argument("--gather", default="all", choices=["all", "root"],
                     help="N > 1: all-gather the tiles (every rank holds the sheet; north_star's collective) or gather them to rank 0 "
                          "only (the rank that composes the sheet and talks to the diffuser; 1/N of the bytes)")
+    ap.add_argument("--diagnostics-timeout", type=float, default=120.0,
+                    help="N > 1: seconds the per-strategy exposed-gather legs (after the timed region) may take before the line is printed without them")
     ap.add_argument("--gather-strategy", default="all_gather", choices=["all_gather", "p2p", "all_to_all"],
                     help="N > 1: how the tiles travel (signerf_amd.sheet.gather_tiles_async): RCCL's all-gather / gather, direct point-to-point "
                          "pushes (one per xGMI link), or the same pushes as one all_to_all_single; the line reports the exposed time of ALL three")
@@ -508,15 +511,36 @@ def main():
     kernel_ms = sum(per_step) / max(len(per_step), 1)
     gather_ms = gather_err = None
     gather_by_strategy = {}
-    if world > 1:
-        for strat in sheet.GATHER_STRATEGIES:  # diagnostic legs after the timed region: they must never cost the line
-            try:
-                gather_by_strategy[strat] = exposed_gather_ms(strategy=strat)
-            except Exception as e:  # noqa: BLE001
-                gather_by_strategy[strat] = None
-                gather_err = repr(e)
-        gather_ms = gather_by_strategy.get(args.gather_strategy)
 
+    def gather_diagnostics(line=None):
+        """The exposed cost of the tile gather, per strategy: diagnostic legs AFTER the timed region.  They must never cost the line -- an
+        exception is recorded per strategy, and a collective that HANGS (p2p / all_to_all have only ever run on gloo and on one-rank RCCL) is cut
+        by a watchdog: rank 0 prints the line it has (gather_ms: error) and every rank leaves with status 0, the measurement being complete."""
+        by, err, done = {}, None, threading.Event()
+
+        def bail():
+            if done.is_set():
+                return
+            if line is not None:
+                line["gather_ms"] = {"exposed": None, "error": "the diagnostic gather legs did not finish within their time limit", "exposed_by_strategy": by}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.diagnostics_timeout if rank == 0 else args.diagnostics_timeout + 240.0, bail)   # (rank 0 builds its line first)
+        dog.daemon = True
+        dog.start()
+        for strat in sheet.GATHER_STRATEGIES:
+            try:
+                by[strat] = exposed_gather_ms(strategy=strat)
+            except Exception as e:  # noqa: BLE001
+                by[strat] = None
+                err = repr(e)
+        done.set()
+        dog.cancel()
+        return by, err
+
+    if world > 1 and rank != 0:
+        gather_diagnostics()
     if rank == 0:
         n_steps = len(per_step)
         pct = lambda q: per_step[min(n_steps - 1, int(q * n_steps))]  # noqa: E731
@@ -553,14 +577,7 @@ def main():
                        "gather_strategy": (args.gather_strategy if world > 1 else None)},
             "ms_per_frame": elapsed / args.steps * 1e3 / (len(mine) if strong else 1) if (not strong or mine) else None,
             "ms_per_sheet": (elapsed / args.steps * 1e3) if strong else None,
-            "gather_ms": ({"exposed": None, "error": gather_err} if gather_err else None) if gather_ms is None else {
-                "exposed": gather_ms, "strategy": args.gather_strategy, "exposed_by_strategy": gather_by_strategy,
-                "strategies": "all_gather = RCCL all_gather_into_tensor / gather (ring or tree, RCCL's choice); p2p = world - 1 direct isend / irecv "
-                              "pairs per rank (one per xGMI link); all_to_all = the same pushes as one all_to_all_single (signerf_amd/sheet.py)",
-                "in_timed_region": "overlapped with the next step's renders (depth-1 pipeline); every gather completes inside it",
-                "what": "HIP-event time on the caller's stream of issuing the tile gather and waiting for it with nothing to overlap "
-                        "(median of 5, after a barrier), i.e. what each step would pay without the pipeline",
-                "bytes_sent_per_rank": (len(mine) if strong else 1) * H * W * 16},
+            "gather_ms": None,   # (world > 1: filled in below, after the line's own measurements)
             "timed_region_s": elapsed,
             "frames_in_flight": max(1, args.frames_in_flight),
             # for comparison with one-launch-at-a-time figures (r01's lines, rocprofv3): samples of one frame over the per-launch time
@@ -723,6 +740,17 @@ def main():
             line["others"] = other_configs(args.precision)
         if world == 1 and not args.no_cpu_baseline and args.workload == "sheet64":
             line["cpu_baseline"] = cpu_baseline(cfg, sd, W, H, S, args.cpu_runs, args.cpu_runs_config4)
+        if world > 1:
+            gather_by_strategy, gather_err = gather_diagnostics(line)
+            gather_ms = gather_by_strategy.get(args.gather_strategy)
+            line["gather_ms"] = {"exposed": None, "error": gather_err, "exposed_by_strategy": gather_by_strategy} if gather_ms is None else {
+                "exposed": gather_ms, "strategy": args.gather_strategy, "exposed_by_strategy": gather_by_strategy,
+                "strategies": "all_gather = RCCL all_gather_into_tensor / gather (ring or tree, RCCL's choice); p2p = world - 1 direct isend / irecv "
+                              "pairs per rank (one per xGMI link); all_to_all = the same pushes as one all_to_all_single (signerf_amd/sheet.py)",
+                "in_timed_region": "overlapped with the next step's renders (depth-1 pipeline); every gather completes inside it",
+                "what": "HIP-event time on the caller's stream of issuing the tile gather and waiting for it with nothing to overlap "
+                        "(median of 5, after a barrier), i.e. what each step would pay without the pipeline",
+                "bytes_sent_per_rank": (len(mine) if strong else 1) * H * W * 16}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
