@@ -112,6 +112,11 @@ typedef struct SnFieldDesc {
      * environment still override both (diagnostics).  sn_debug_layout reports what a handle actually holds. */
     int32_t dense_levels;
     int32_t dense_copy_cap_mb;
+    /*   half_grid           1 = also keep the main grid in fp16 STORAGE for SnRenderOpts.precision = 2 (tiny-cuda-nn grids only, ignored
+     *                       otherwise): 16-byte quads of the de-hashed levels (2 gathers per level instead of 4) + 4-byte rows of the hashed
+     *                       ones, ~1.9 GB for nerfacto's grid.  Without it a precision-2 render reads the uploaded fp32 table (same values:
+     *                       every row rounded through fp16 on the fly; ~2x slower).  0 = not built (default). */
+    int32_t half_grid;
 } SnFieldDesc;
 
 /* Per-call render options (NerfactoModelConfig values that shape one eval render). */
@@ -322,6 +327,7 @@ typedef struct SnDebugLayout {
                                         * split-precision MLPs; the first layer's weights carry its inverse) */
     uint64_t table_bytes;              /* (r04) the uploaded table of field `which` */
     uint64_t handle_bytes;             /* (r04) every device buffer the HANDLE owns: tables, copies, paired tables, weight images */
+    uint64_t half_grid_bytes;          /* (r04) the main grid's fp16 storage (SnFieldDesc.half_grid), 0 when not built */
 } SnDebugLayout;
 /* which: -1 main field, i >= 0 proposal net i. */
 int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out);

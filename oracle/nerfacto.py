@@ -427,7 +427,7 @@ def mlp_forward(x: Tensor, params: Dict[str, Tensor], prefix: str, num_layers: i
     """nn.Linear stack with bias, ReLU between layers (A8).
 
     half: the single-fp16 emulation (NerfactoConfig.mlp_precision): inputs and weights rounded to fp16, products summed in fp32, every
-    layer's output (after its ReLU) rounded to fp16.  fp32_tail: trailing input columns of the FIRST layer that stay fp32 with fp32 weights
+    layer's output (after its ReLU) rounded to fp16 (and density_field rounds the grid's table values to fp16 before the fp32 blend).  fp32_tail: trailing input columns of the FIRST layer that stay fp32 with fp32 weights
     (the eval-mode appearance embedding, which the library folds into that layer's bias on the host)."""
     for i in range(num_layers):
         w = params[f"{prefix}.layers.{i}.weight"]
@@ -457,7 +457,9 @@ def density_field(params: Dict[str, Tensor], prefix: str, hcfg: HashMLPConfig, p
         from . import tcnn_layout
 
         meta = tcnn_layout.grid_meta(hcfg.num_levels, hcfg.base_res, hcfg.max_res, hcfg.log2_hashmap_size, hcfg.features_per_level)
-        enc = tcnn_layout.grid_encode(q.view(-1, 3), params[f"{prefix}.encoder.tcnn_grid"], meta)
+        # single-fp16 emulation: tiny-cuda-nn evaluates the grid on an fp16 copy of its parameters (`params.to(half)`); the blend stays fp32
+        grid = params[f"{prefix}.encoder.tcnn_grid"]
+        enc = tcnn_layout.grid_encode(q.view(-1, 3), _f16(grid) if half else grid, meta)
     else:
         scalings = hash_scalings(hcfg.num_levels, hcfg.base_res, hcfg.max_res)
         enc = hash_encode(q.view(-1, 3), params[f"{prefix}.encoder.hash_table"], scalings, hcfg.log2_hashmap_size)

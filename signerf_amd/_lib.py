@@ -47,6 +47,7 @@ class SnFieldDesc(C.Structure):
         ("aabb", C.c_float * 6),
         ("dense_levels", C.c_int32),
         ("dense_copy_cap_mb", C.c_int32),
+        ("half_grid", C.c_int32),
     ]
 
 
@@ -119,6 +120,7 @@ class SnDebugLayout(C.Structure):
         ("feature_scale", C.c_float),
         ("table_bytes", C.c_uint64),
         ("handle_bytes", C.c_uint64),
+        ("half_grid_bytes", C.c_uint64),
     ]
 
 

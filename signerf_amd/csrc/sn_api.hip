@@ -66,6 +66,9 @@ struct SnContext {
     SnDenseCopy dense_info{};
     SnGridLevels dense_res{};     // their resolutions R = scale + 2, packed like a tcnn level table
     int nd_torch = 0;             // number of copied levels
+    DevBuf hquads_main, hrows_main;   // SnFieldDesc.half_grid: fp16 storage of a tiny-cuda-nn main grid (sn_device.h "fp16 STORAGE")
+    SnDenseCopy hquads_info{};        // (quads of the levels [0, nd_torch); hrows_main: rows of the levels [nd_torch, L))
+    float table_absmax_main = 0.0f;   // max |value| of the uploaded main table (sn_finalize_weights)
     DevBuf dense_prop[SN_MAX_PROPOSALS];
     SnDenseCopy dense_info_prop[SN_MAX_PROPOSALS]{};
     SnGridLevels dense_res_prop[SN_MAX_PROPOSALS]{};
@@ -300,6 +303,60 @@ int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, 
     info.bytes = (uint32_t)bytes;
     info.n_bc = (uint32_t)std::min(nd, std::max(bc_levels, 0));
     nd_out = nd;
+    return SN_OK;
+}
+
+// fp16 storage of a tiny-cuda-nn grid for the single-fp16 mode (SnFieldDesc.half_grid; sn_device.h "fp16 STORAGE"): quads of the `nd` levels
+// that have a de-hashed copy (same R), 4-byte rows of the others.  `absmax` = max |table value| (finite, checked by the caller).
+int build_half_grid(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, const SnDenseCopy& copies, int nd, DevBuf& quads, SnDenseCopy& qinfo,
+                    DevBuf& rows, hipStream_t st, float scale, float absmax) {
+    memset(&qinfo, 0, sizeof(qinfo));
+    if (nd <= 0 || nd > 12 || !table.ptr) {
+        quads.release();
+        rows.release();
+        return SN_OK;
+    }
+    if (!((double)absmax * scale <= 65504.0))
+        return fail(h, SN_ERR_INVALID, "half_grid: the scaled table values leave fp16's range (max |value| " + std::to_string(absmax) + " x feature scale " +
+                                           std::to_string(scale) + ")");
+    const SnGridLevels tcnn_dense = grid_levels(d);
+    uint64_t bytes = 0;
+    for (int l = 0; l < nd; ++l) {
+        const uint64_t r = copies.res[l];
+        if (r >= 1024) return fail(h, SN_ERR_INVALID, "half_grid: a copied level is wider than 1023 grid points");
+        qinfo.off[l] = (uint32_t)bytes;
+        qinfo.res[l] = (uint32_t)r;
+        bytes += r * r * r * 16;
+        bytes = (bytes + 255) & ~255ull;
+    }
+    if (bytes >= 0xf0000000ull) return fail(h, SN_ERR_INVALID, "half_grid: the quads exceed the 32-bit buffer-offset range");
+    if (quads.bytes != bytes) {
+        quads.release();
+        SN_HIP(h, hipMalloc(&quads.ptr, bytes));
+        quads.bytes = bytes;
+    }
+    for (int l = 0; l < nd; ++l) {
+        const uint32_t n = qinfo.res[l] * qinfo.res[l] * qinfo.res[l];
+        const uint32_t dres = (tcnn_dense.packed[l >> 2] >> ((l & 3) * 8)) & 0xffu;
+        hipLaunchKernelGGL(sn_build_quad_h16_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)table.ptr,
+                           (uint32_t*)((char*)quads.ptr + qinfo.off[l]), l, d.log2_hashmap_size, qinfo.res[l], scale, dres);
+    }
+    qinfo.base = (const float*)quads.ptr;
+    qinfo.bytes = (uint32_t)bytes;
+    qinfo.n_bc = 0;
+    const int rest = d.num_levels - nd;
+    const uint64_t rbytes = std::max<uint64_t>(((uint64_t)std::max(rest, 0) << d.log2_hashmap_size) * 4, 256);
+    if (rows.bytes != rbytes) {
+        rows.release();
+        SN_HIP(h, hipMalloc(&rows.ptr, rbytes));
+        rows.bytes = rbytes;
+    }
+    if (rest > 0) {
+        const uint64_t n = (uint64_t)rest << d.log2_hashmap_size;
+        hipLaunchKernelGGL(sn_build_rows_h16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)table.ptr, (uint32_t*)rows.ptr, nd, rest,
+                           d.log2_hashmap_size, scale);
+    }
+    SN_HIP(h, hipGetLastError());
     return SN_OK;
 }
 
@@ -800,6 +857,8 @@ int sn_destroy(SnHandle h) {
     if (h->weights_ev) (void)hipEventDestroy(h->weights_ev);
     h->table_main.release();
     h->dense_main.release();
+    h->hquads_main.release();
+    h->hrows_main.release();
     h->pairs_main.release();
     h->wimg_main.release();
     h->wimg_main_h.release();
@@ -908,6 +967,7 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         (void)hipFree(d_m);
         if (e != hipSuccess) return fail(h, SN_ERR_HIP, std::string("sn_finalize_weights: table scan: ") + hipGetErrorString(e));
         memcpy(&absmax_main, &bits[0], 4);
+        h->table_absmax_main = absmax_main;
         for (int i = 0; i < SN_MAX_PROPOSALS; ++i) memcpy(&absmax_prop[i], &bits[1 + i], 4);
     }
     const MainSplitPlan pl = plan_split_scales(d, absmax_main, true, t[0]->data(), t[1]->data(), t[2]->data(), t[3]->data(), t[4]->data(),
@@ -1179,6 +1239,18 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
             if (int rc = build_dense_copies(h, d.proposals[i], h->table_prop[i], want, 100, h->dense_prop[i], h->dense_info_prop[i],
                                             h->dense_res_prop[i], h->nd_prop[i], st, SN_BC_PROP, h->feat_scale_prop[i]))
                 return rc;
+        // single-fp16 mode: the main grid once more in fp16 storage (tiny-cuda-nn grids whose copies cover the densely indexed levels)
+        const char* hg = getenv("SN_HALF_GRID");   // (diagnostics: 0 forces the fp32-table path of the mode)
+        const int td = d.main_field.grid_mode == 1 ? leading_dense(d.main_field) : -1;
+        if (d.half_grid == 1 && !(hg && atoi(hg) == 0) && d.main_field.grid_mode == 1 && h->split_ok && h->nd_torch > 0 && td >= 0 && td <= h->nd_torch) {
+            if (int rc = build_half_grid(h, d.main_field, h->table_main, h->dense_info, h->nd_torch, h->hquads_main, h->hquads_info, h->hrows_main, st,
+                                         h->feat_scale_main, h->table_absmax_main))
+                return rc;
+        } else {
+            h->hquads_main.release();
+            h->hrows_main.release();
+            memset(&h->hquads_info, 0, sizeof(h->hquads_info));
+        }
     }
 #if SN_MAIN_PAIRS
     // main grid, torch semantics: the levels beyond the de-hashed ones from x-paired tables (4 gathers per level instead of 8)
@@ -1439,6 +1511,9 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     const bool half1 = split && opts->precision == 2;       // single fp16 (sn_main.h sn_main_field_f16): tiny-cuda-nn grids only (valid_opts)
     p.wimg = (const float*)(split ? h->wimg_main_h.ptr : h->wimg_main.ptr);
     p.feat_scale = h->feat_scale_main;
+    p.hquads = h->hquads_info;
+    p.hrows = (const float*)h->hrows_main.ptr;
+    p.hrows_bytes = (uint32_t)h->hrows_main.bytes;
     p.pairs = (const float*)h->pairs_main.ptr;
     p.pairs_bytes = (uint32_t)h->pairs_main.bytes;
     p.pinfo = h->pinfo_main;
@@ -1541,10 +1616,14 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     if (half1) {
         // single-fp16 mode: the tiny-cuda-nn grid's kernels, with the de-hashed copies when the handle has the default 11 of them
         if (dump || alt) return fail(h, SN_ERR_INVALID, "precision 2 (single fp16) has no instrumented / generic-sampler instantiation");
+        // ND = 11: the grid from its fp16 storage (SnFieldDesc.half_grid); otherwise the run-time variant on the uploaded fp32 table with every
+        // row rounded through fp16 on the fly -- the same values
+        const bool hgrid = nd_launch == 11 && h->hquads_main.ptr && h->hrows_main.ptr;
+        if (!hgrid) p.grid = grid_levels(d.main_field);
         if (nprop > 0) {
-            if (nd_launch == 11) SN_LAUNCH_MAIN(1, 2, 0, 1, 11); else SN_LAUNCH_MAIN(1, 2, 0, 1, -1);
+            if (hgrid) SN_LAUNCH_MAIN(1, 2, 0, 1, 11); else SN_LAUNCH_MAIN(1, 2, 0, 1, -1);
         } else {
-            if (nd_launch == 11) SN_LAUNCH_MAIN(0, 2, 0, 1, 11); else SN_LAUNCH_MAIN(0, 2, 0, 1, -1);
+            if (hgrid) SN_LAUNCH_MAIN(0, 2, 0, 1, 11); else SN_LAUNCH_MAIN(0, 2, 0, 1, -1);
         }
     } else
     if (dump) {
@@ -1651,7 +1730,8 @@ int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out) {
     out->pair_bytes = which < 0 ? h->pairs_main.bytes : h->pairs_prop[which].bytes;  // (main field: only for models with proposal nets)
     out->table_bytes = which < 0 ? h->table_main.bytes : h->table_prop[which].bytes;
     uint64_t total = h->table_main.bytes + h->wimg_main.bytes + h->wimg_main_h.bytes + h->wimg_normals.bytes + h->wimg_normals_h.bytes +
-                     h->pairs_main.bytes + h->dense_main.bytes;
+                     h->pairs_main.bytes + h->dense_main.bytes + h->hquads_main.bytes + h->hrows_main.bytes;
+    out->half_grid_bytes = which < 0 ? h->hquads_main.bytes + h->hrows_main.bytes : 0;
     for (int i = 0; i < SN_MAX_PROPOSALS; ++i)
         total += h->table_prop[i].bytes + h->pairs_prop[i].bytes + h->wpack_prop[i].bytes + h->dense_prop[i].bytes;
     out->handle_bytes = total;

@@ -566,6 +566,148 @@ __global__ void sn_build_dense_copy_kernel(const float* __restrict__ table, floa
     ((f32x2*)dense)[i] = f32x2{v.x * scale, v.y * scale};
 }
 
+// ------------------------------------------------------------------------------------------
+// fp16 STORAGE of a tiny-cuda-nn grid (r04; the single-fp16 mode of the main field only, sn_main.h "single-fp16 mode")
+//
+// tiny-cuda-nn evaluates its grids on an fp16 copy of the parameters (`params.to(half)`); the single-fp16 mode does the same: every table
+// value is rounded to fp16 ONCE (round to nearest even, subnormals kept -- torch's `.half()`), the blend itself stays fp32.  Stored as
+// fp16 a row is 4 bytes, so
+//   * a de-hashed level keeps QUADS: entry (x, y, z) = { v(x,y,z), v(x+1,y,z), v(x,y+1,z), v(x+1,y+1,z) }, 16 bytes -- the four corners of
+//     a z slice in ONE gather, a level in TWO instead of four;
+//   * a hashed level keeps its rows as they are, 4 bytes each (eight 4-byte gathers; same count as before, half the bytes).
+// 62 gathers per sample instead of 84 -- the mode's MLP is cheap enough (48 MFMAs, no operand splits) that the gather path was what bound it.
+// Values carry the feature scale (an exact power of two): stored = half(float(half(raw)) * scale), exact while in fp16's range (the host checks).
+// ------------------------------------------------------------------------------------------
+SN_DEV uint32_t sn_pack_h2_scaled(f32x2 v, float scale) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    const _Float16 a = (_Float16)v.x, b = (_Float16)v.y;                       // the rounding of the mode (RNE, subnormals kept)
+    const h2v r = {(_Float16)((float)a * scale), (_Float16)((float)b * scale)}; // exact: a power-of-two scale inside fp16's range
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+// one thread per quad entry i <-> grid point (x, y, z) = (i % R, i / R % R, i / R^2) of a copied level
+__global__ void sn_build_quad_h16_kernel(const float* __restrict__ table, uint32_t* __restrict__ quads, int level, int log2_t, uint32_t R, float scale,
+                                         uint32_t dense_res) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * R * R) return;
+    const uint32_t x = i % R, y = (i / R) % R, z = i / (R * R);
+    const uint32_t mask = (1u << log2_t) - 1u;
+    const f32x2* lv = (const f32x2*)table + ((uint64_t)level << log2_t);
+    typedef uint32_t u32x4q __attribute__((ext_vector_type(4)));
+    const u32x4q e = {sn_pack_h2_scaled(lv[sn_grid_row(x, y, z, mask, dense_res)], scale), sn_pack_h2_scaled(lv[sn_grid_row(x + 1u, y, z, mask, dense_res)], scale),
+                      sn_pack_h2_scaled(lv[sn_grid_row(x, y + 1u, z, mask, dense_res)], scale),
+                      sn_pack_h2_scaled(lv[sn_grid_row(x + 1u, y + 1u, z, mask, dense_res)], scale)};
+    ((u32x4q*)quads)[i] = e;
+}
+
+// the rows of the levels [level0, level0 + n_levels) as they are, 4 bytes each
+__global__ void sn_build_rows_h16_kernel(const float* __restrict__ table, uint32_t* __restrict__ rows, int level0, int n_levels, int log2_t, float scale) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((uint64_t)n_levels << log2_t)) return;
+    rows[i] = sn_pack_h2_scaled(((const f32x2*)table)[((uint64_t)level0 << log2_t) + i], scale);
+}
+
+// b + (a - b) w with a, b the fp16 halves C of two packed registers: two v_fma_mix_f32 (full rate; the fp16 operands are read in place,
+// no conversions).  hipcc forms cvt, cvt, sub for the difference, hence the asm; its inputs come from buffer loads (s_waitcnt is the
+// compiler's, which tracks asm operands -- the MFMA-result hazard of DESIGN.md "third hazard" does not apply to loads).
+template <int C>
+SN_DEV float sn_lerp_hh(uint32_t ra, uint32_t rb, float w) {
+    float d, x;
+    if (C == 0) {
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(ra), "v"(rb));
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,0,1]" : "=v"(x) : "v"(d), "v"(w), "v"(rb));
+    } else {
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(ra), "v"(rb));
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(x) : "v"(d), "v"(w), "v"(rb));
+    }
+    return x;
+}
+
+// a de-hashed level from its quads: two 16-byte gathers (z, z + 1), the blend of sn_hash_blend_fast (x, then y, then z) on the fp16 corners
+SN_DEV f32x2 sn_hash_level_quad_h16(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_off_bytes, const float q[3], float scale, uint32_t R) {
+    typedef uint32_t u32x4q __attribute__((ext_vector_type(4)));
+    uint32_t f[3];
+    float off[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = fmaf(scale, q[a], 0.5f);
+        off[a] = __builtin_amdgcn_fractf(x);
+        f[a] = (uint32_t)(int)x;
+    }
+    const uint32_t R16 = R << 4, R2_16 = (R * R) << 4;   // R < 1024: 16 R^2 and both products stay inside 24 bits
+    const uint32_t b = sn_mad24(f[2], R2_16, sn_mad24(f[1], R16, f[0] << 4));
+    const uint32_t o_z1 = level_off_bytes + R2_16;       // the z + 1 slice: a wave-uniform stride in the scalar offset
+    const u32x4q e0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)b, (int)level_off_bytes, SN_AUX_DENSE);
+    const u32x4q e1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)b, (int)o_z1, SN_AUX_DENSE);
+    const float ox = off[0], oy = off[1], oz = off[2];
+    f32x2 out;
+    {
+        const float x0 = sn_lerp_hh<0>(e0.y, e0.x, ox), x1 = sn_lerp_hh<0>(e0.w, e0.z, ox), x2 = sn_lerp_hh<0>(e1.y, e1.x, ox), x3 = sn_lerp_hh<0>(e1.w, e1.z, ox);
+        const float y0 = fmaf(x1 - x0, oy, x0), y1 = fmaf(x3 - x2, oy, x2);
+        out.x = fmaf(y1 - y0, oz, y0);
+    }
+    {
+        const float x0 = sn_lerp_hh<1>(e0.y, e0.x, ox), x1 = sn_lerp_hh<1>(e0.w, e0.z, ox), x2 = sn_lerp_hh<1>(e1.y, e1.x, ox), x3 = sn_lerp_hh<1>(e1.w, e1.z, ox);
+        const float y0 = fmaf(x1 - x0, oy, x0), y1 = fmaf(x3 - x2, oy, x2);
+        out.y = fmaf(y1 - y0, oz, y0);
+    }
+    return out;
+}
+
+// a hashed level from its 4-byte rows: tiny-cuda-nn's positions and xor hash (sn_hash_corners_tcnn<0>), byte offsets row * 4
+SN_DEV f32x2 sn_hash_level_rows_h16(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_off_bytes, const float q[3], float scale, uint32_t mask) {
+    uint32_t f[3];
+    float off[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = fmaf(scale, q[a], 0.5f);
+        off[a] = __builtin_amdgcn_fractf(x);
+        f[a] = (uint32_t)(int)x;
+    }
+    const uint32_t P1 = (2654435761u & mask) << 2, P2 = (805459861u & mask) << 2, m4 = mask << 2;
+    const uint32_t yf = __umul24(f[1], P1), zf = __umul24(f[2], P2), xf = f[0] << 2;
+    const uint32_t yc = yf + P1, zc = zf + P2, xc = xf + 4u;
+    auto row = [&](uint32_t boff) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(boff & m4), (int)level_off_bytes, SN_AUX_ROW); };
+    // (x, y, z + 1) ... in the pairing of the x lerps: [x+1 | x] at (y, z), (y+1, z), (y, z+1), (y+1, z+1)
+    const uint32_t a_ff = row(xc ^ yf ^ zf), b_ff = row(xf ^ yf ^ zf), a_cf = row(xc ^ yc ^ zf), b_cf = row(xf ^ yc ^ zf);
+    const uint32_t a_fc = row(xc ^ yf ^ zc), b_fc = row(xf ^ yf ^ zc), a_cc = row(xc ^ yc ^ zc), b_cc = row(xf ^ yc ^ zc);
+    const float ox = off[0], oy = off[1], oz = off[2];
+    f32x2 out;
+    {
+        const float x0 = sn_lerp_hh<0>(a_ff, b_ff, ox), x1 = sn_lerp_hh<0>(a_cf, b_cf, ox), x2 = sn_lerp_hh<0>(a_fc, b_fc, ox), x3 = sn_lerp_hh<0>(a_cc, b_cc, ox);
+        const float y0 = fmaf(x1 - x0, oy, x0), y1 = fmaf(x3 - x2, oy, x2);
+        out.x = fmaf(y1 - y0, oz, y0);
+    }
+    {
+        const float x0 = sn_lerp_hh<1>(a_ff, b_ff, ox), x1 = sn_lerp_hh<1>(a_cf, b_cf, ox), x2 = sn_lerp_hh<1>(a_fc, b_fc, ox), x3 = sn_lerp_hh<1>(a_cc, b_cc, ox);
+        const float y0 = fmaf(x1 - x0, oy, x0), y1 = fmaf(x3 - x2, oy, x2);
+        out.y = fmaf(y1 - y0, oz, y0);
+    }
+    return out;
+}
+
+// all L levels of a tiny-cuda-nn grid from its fp16 storage: levels [0, ND) from the quads (`quads`: SnDenseCopy with n_bc = 0 and 16-byte
+// entries), the rest from the 4-byte rows (`rows_rsrc`, the levels [ND, L) back to back)
+template <int L, int ND, int GROUP>
+SN_DEV void sn_hash_encode_h16(const SnDenseCopy* quads, __amdgpu_buffer_rsrc_t rows_rsrc, const float* scal, int log2_t, const float q[3], float* feat) {
+    const uint32_t mask = (1u << log2_t) - 1u;
+    const __amdgpu_buffer_rsrc_t qrsrc = sn_table_rsrc(quads->base, quads->bytes);
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        if (GROUP > 0 && l > 0 && (l % GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
+        f32x2 e;
+        if (l < ND) {
+            uint32_t R = quads->res[l < 12 ? l : 0];
+            asm volatile("" : "+s"(R));
+            e = sn_hash_level_quad_h16(qrsrc, quads->off[l < 12 ? l : 0], q, scal[l], R);
+        } else {
+            e = sn_hash_level_rows_h16(rows_rsrc, ((uint32_t)(l - ND) << log2_t) * 4u, q, scal[l], mask);
+        }
+        feat[2 * l] = e.x;
+        feat[2 * l + 1] = e.y;
+    }
+}
+
 // max |x| over a buffer (bit pattern of the non-negative float, which orders like the value; NaN sorts above inf and so shows)
 __global__ void sn_absmax_kernel(const float* __restrict__ x, size_t n, uint32_t* out) {
     uint32_t m = 0u;
@@ -587,7 +729,9 @@ __global__ void sn_absmax_kernel(const float* __restrict__ x, size_t n, uint32_t
 // (32 bytes each), word 4 = 0xB0000000.  Taken from the very registers that feed the loads.
 // NBC (ARITH 1, ND > 0): levels [0, NBC) of the de-hashed copies are in bilinear-coefficient form (SnDenseCopy::n_bc).
 // NCACHE: levels [0, NCACHE) (all of them in bilinear-coefficient form) keep their fetches across calls in cache[] (SnBcCache above).
-template <int L, int GROUP = 0, int ARITH = 0, int ND = -1, bool DUMP = false, int NBC = 0, int NCACHE = 0>
+// R16 (the single-fp16 mode on a path that reads the uploaded fp32 table): every fetched row is rounded through fp16 first -- the same values as
+// the fp16 storage above (sn_pack_h2_scaled without the scale, which these paths apply to the blended feature).
+template <int L, int GROUP = 0, int ARITH = 0, int ND = -1, bool DUMP = false, int NBC = 0, int NCACHE = 0, bool R16 = false>
 SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int log2_t, const float q[3], float* feat,
                            const SnGridLevels* grid = nullptr, const SnDenseCopy* dense = nullptr, uint32_t* rec = nullptr,
                            float plain_scale = 1.0f, SnBcCache* cache = nullptr) {
@@ -622,6 +766,10 @@ SN_DEV void sn_hash_encode(__amdgpu_buffer_rsrc_t rsrc, const float* scal, int l
         f32x2 v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = sn_table_load(rsrc, hl.boff[k], lvl);
+        if (R16) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = f32x2{(float)(_Float16)v[k].x, (float)(_Float16)v[k].y};
+        }
         if (DUMP && rec) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) rec[8 * l + k] = hl.boff[k];

@@ -1007,6 +1007,9 @@ struct SnMainParams {
     int sh_remap;
     int chunk_rays;
     float feat_scale;   // torch grid: power-of-two scale of the hash features (carried by the de-hashed copies; applied here to the other levels)
+    SnDenseCopy hquads;  // single-fp16 mode (PREC 2, tiny-cuda-nn grid, ND > 0): the fp16 storage of the grid (sn_device.h "fp16 STORAGE") ...
+    const float* hrows;  // ... its 4-byte rows of the levels [ND, 16)
+    uint32_t hrows_bytes;
     const float* pairs;  // SN_MAIN_PAIRS: x-paired tables of the levels >= ND (pre-scaled by feat_scale), or null
     uint32_t pairs_bytes;
     SnPairInfo pinfo;
@@ -1259,7 +1262,12 @@ void sn_render_main_kernel(SnMainParams p) {
             // from the uploaded table with the dense / hashed decision per level at run time (ND = -1: shapes the copies do not cover)
             constexpr int AR = GRID ? (ND > 0 ? 3 : 2) : (SN_FAST_HASH ? 1 : 0);
             constexpr int NBC = ND > SN_BC_MAIN ? SN_BC_MAIN : (ND > 0 ? ND : 0);
-            if (SN_MAIN_PAIRS && MODE == 1 && ND > 0 && ND < 16) {
+            if (PREC == 2 && GRID == 1 && ND > 0) {
+                // single-fp16 mode: the tiny-cuda-nn grid from its fp16 storage (quads of the de-hashed levels, 4-byte rows of the hashed ones)
+                sn_hash_encode_h16<16, (ND > 0 ? ND : 1), SHAPE::HASH_GROUP>(&p.hquads, sn_table_rsrc(p.hrows, p.hrows_bytes), p.scal, p.log2_t, q, feat);
+            } else if (PREC == 2) {
+                sn_hash_encode<16, SHAPE::HASH_GROUP, AR, ND, DUMP, NBC, 0, true>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
+            } else if (SN_MAIN_PAIRS && MODE == 1 && ND > 0 && ND < 16) {
                 // de-hashed levels [0, ND), then the hashed levels [ND, 16) from the x-paired tables
                 sn_hash_encode<(ND > 0 ? ND : 1), SHAPE::HASH_GROUP, AR, ND, DUMP, NBC>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
                 __builtin_amdgcn_sched_barrier(0);

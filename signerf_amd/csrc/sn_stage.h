@@ -315,7 +315,8 @@ __global__ __launch_bounds__(256, 2) void sn_main_field_stage_kernel(SnFieldStag
     const bool sel = sn_position_q(pos, q, &p.pm);
     const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table, (16u << p.log2_t) * 8u);
     float feat[32];
-    if (p.grid_mode) sn_hash_encode<16, 0, 2>(rsrc, p.scal, p.log2_t, q, feat, &p.grid);
+    if (p.grid_mode && PREC == 2) sn_hash_encode<16, 0, 2, -1, false, 0, 0, true>(rsrc, p.scal, p.log2_t, q, feat, &p.grid);  // fp16 grid values (sn_device.h "fp16 STORAGE")
+    else if (p.grid_mode) sn_hash_encode<16, 0, 2>(rsrc, p.scal, p.log2_t, q, feat, &p.grid);
     else sn_hash_encode<16>(rsrc, p.scal, p.log2_t, q, feat);
 #pragma unroll
     for (int k = 0; k < 32; ++k) feat[k] *= p.feat_scale;

@@ -380,6 +380,7 @@ class NerfactoModel(nn.Module):
         self.device_indicator_param = nn.Parameter(torch.empty(0))
         self._handle = C.c_void_p(None)
         self._handle_device = None
+        self._handle_half_grid = False   # whether the handle holds the grid's fp16 storage (SnFieldDesc.half_grid)
         self._weights_dirty = True
         self._weights_lock = threading.Lock()
         self._engine_rw = _RWLock()
@@ -475,6 +476,8 @@ class NerfactoModel(nn.Module):
             d.aabb[k] = v
         d.dense_levels = int(getattr(cfg, "dense_levels", 0))
         d.dense_copy_cap_mb = int(getattr(cfg, "dense_copy_cap_mb", 0))
+        # the single-fp16 mode keeps the tiny-cuda-nn grid in fp16 storage as well (half the gather bytes; include/signerf_hip.h half_grid)
+        d.half_grid = 1 if (cfg.precision == "fp16" and cfg.implementation == "tcnn") else 0
         return d
 
     @property
@@ -495,11 +498,14 @@ class NerfactoModel(nn.Module):
         if self.device.type != "cuda":
             raise _lib.SignerfHipError("NerfactoModel renders on the GPU only: move it with .to('cuda') (no CPU fallback)")
         with self._weights_lock:
-            if (self._handle and self._handle_device != self.device) or not self._handle or self._weights_dirty:
+            # precision="fp16" set on a model whose handle was created without the grid's fp16 storage: start over with it (once)
+            want_half = self.config.precision == "fp16" and self.config.implementation == "tcnn"
+            stale_half = bool(self._handle) and want_half and not self._handle_half_grid
+            if (self._handle and self._handle_device != self.device) or not self._handle or self._weights_dirty or stale_half:
                 # the handle is replaced / its weights rewritten: no render CALL of another thread may hold or take the handle meanwhile
                 self._engine_rw.acquire_write()
                 try:
-                    if self._handle and self._handle_device != self.device:
+                    if self._handle and (self._handle_device != self.device or stale_half):
                         # model.to("cuda:N") after the first render: the handle and all its buffers live on the old GPU -- start over
                         lib.sn_destroy(self._handle)
                         self._handle = C.c_void_p(None)
@@ -510,6 +516,7 @@ class NerfactoModel(nn.Module):
                         with torch.cuda.device(self.device):
                             _lib.check(lib.sn_create(C.byref(desc), C.byref(self._handle)), None, "sn_create")
                         self._handle_device = self.device
+                        self._handle_half_grid = bool(desc.half_grid)
                     if self._weights_dirty:
                         self._upload(lib)
                         self._weights_dirty = False

@@ -183,7 +183,7 @@ def debug_layout(model, which: int = -1) -> dict:
     _lib.check(lib.sn_debug_layout(model._handle, which, C.byref(lay)), model._handle, "sn_debug_layout")
     return {"n_dense": lay.n_dense, "n_bc": lay.n_bc, "dense_res": list(lay.dense_res), "dense_off": list(lay.dense_off),
             "dense_bytes": lay.dense_bytes, "pair_base": list(lay.pair_base), "pair_bytes": lay.pair_bytes, "feature_scale": lay.feature_scale,
-            "table_bytes": lay.table_bytes, "handle_bytes": lay.handle_bytes}
+            "table_bytes": lay.table_bytes, "handle_bytes": lay.handle_bytes, "half_grid_bytes": lay.half_grid_bytes}
 
 
 def debug_read(model, which: int, what: int) -> Tensor:

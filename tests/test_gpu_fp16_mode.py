@@ -44,7 +44,10 @@ def test_fp16_field_matches_the_emulated_roundings(gpu):
     assert float(rel.quantile(0.99)) <= 2e-3 and float(rel.median()) <= 1e-5
     assert rmse(rgb, o_rgb) <= 2e-4 and float((rgb.cpu() - o_rgb).abs().max()) <= 5e-3
     # the geometry features leave the density MLP as fp16 values
-    assert torch.equal(geo, geo.to(torch.float16).to(torch.float32))
+    # (the kernel rounds the layer's SCALED output -- an exact power of two, undone afterwards -- so a value that lands in fp16's subnormal range
+    #  after un-scaling carries more bits than an unscaled fp16 would: exempt)
+    not_h = geo != geo.to(torch.float16).to(torch.float32)
+    assert not bool((not_h & (geo.abs() >= 2.0 ** -14)).any()), f"{int((not_h & (geo.abs() >= 2.0 ** -14)).sum())} normal-range geo values are not fp16 values"
     assert float(((geo.cpu() - h[:, 0, 1:]).abs() > 1e-6 * h[:, 0, 1:].abs().clamp_min(1.0)).float().mean()) <= 2e-2
     # and the mode is NOT fp32-grade: it differs from the fp32 evaluation of the same checkpoint at the 1e-3 level
     f_d, fh, _, _ = onf.density_field(params, "field.mlp_base", ocfg.main, pos[:, None, :], ocfg.average_init_density)
@@ -72,6 +75,33 @@ def test_fp16_render_vs_emulation_and_vs_fp32_grade(gpu, props):
     assert e["rgb"] <= 3e-4 and e["accumulation"] <= 3e-4 and e["depth"] <= 1e-2     # (a median-depth flip is a whole bin)
     assert 1e-6 <= moved["rgb"] <= 1e-2                                               # a different arithmetic, at the 1e-3 level
     assert float(ref["rgb"].std()) > 0.05
+
+
+def test_fp16_storage_of_the_grid_equals_rounding_on_the_fly(gpu, monkeypatch):
+    """The mode's grid values are the table rounded through fp16 once (what tiny-cuda-nn's `params.to(half)` holds).  Two ways to read them: the
+    fp16 STORAGE (SnFieldDesc.half_grid: 16-byte quads of the de-hashed levels, 4-byte rows of the hashed ones -- 62 gathers per sample instead
+    of 84) and the uploaded fp32 table with every row rounded on the fly (a handle without the storage).  Same values, same blend: bit-identical."""
+    kw = dict(num_proposal_iterations=0, num_nerf_samples_per_ray=24, precision="fp16")
+    full = dict(log2_hashmap_size=19)       # nerfacto's table size: 5 densely indexed levels + 6 more de-hashed ones, 5 hashed
+    H, W = 48, 40
+    outs, layouts = [], []
+    for env in (None, "0"):
+        if env is None:
+            monkeypatch.delenv("SN_HALF_GRID", raising=False)
+        else:
+            monkeypatch.setenv("SN_HALF_GRID", env)
+        cfg, sd, model = _tcnn_model(gpu, seed=5, **kw, **full)
+        b = Cameras(scene.benchmark_cameras(8)[:, :3], 55.0, 55.0, W / 2, H / 2, W, H).to(gpu)[1].generate_rays(0)
+        outs.append({k: v.clone() for k, v in model.get_outputs_for_camera_ray_bundle(b).items() if k in ("rgb", "depth", "accumulation", "expected_depth")})
+        layouts.append(ops.debug_layout(model))
+        assert model.effective_precision == "fp16"
+    assert layouts[0]["half_grid_bytes"] > 0 and layouts[1]["half_grid_bytes"] == 0
+    assert layouts[0]["n_dense"] == 11
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    # and the storage is what the layout says: 16 bytes per grid point of the copied levels + 4 bytes per row of the others
+    want = sum((r ** 3 * 16 + 255) // 256 * 256 for r in layouts[0]["dense_res"][:11]) + (16 - 11) * (1 << 19) * 4
+    assert layouts[0]["half_grid_bytes"] == want
 
 
 def test_fp16_mode_is_for_tcnn_checkpoints_only(gpu):

@@ -27,6 +27,7 @@ dev = torch.device("cuda", 0)
 def run(cfg, W, H, focal, tag):
     cfg.implementation = "tcnn"
     cfg.average_init_density = 3.0
+    cfg.precision = "fp16"   # (the handle is created with the grid's fp16 storage; the other modes ignore it)
     sd = synthetic_tcnn_checkpoint(cfg, seed=2)
     model = cfg.setup()
     model.load_state_dict(sd, strict=False)
@@ -49,6 +50,10 @@ def run(cfg, W, H, focal, tag):
             torch.cuda.synchronize()
             times[m].append(e0.elapsed_time(e1))
     med = {m: statistics.median(t) for m, t in times.items()}
+    from signerf_amd import ops
+    lay = ops.debug_layout(model)
+    print(f"    handle: {lay['handle_bytes'] / 1e9:.2f} GB on the device, of which the grid's fp16 storage {lay['half_grid_bytes'] / 1e9:.2f} GB, "
+          f"fp32 de-hashed copies {lay['dense_bytes'] / 1e9:.2f} GB")
     print(f"{tag}: render call ms (median of {a.rounds}, interleaved): " + ", ".join(f"{m} {med[m]:.3f}" for m in modes) +
           f"  -> fp16 / fp16x2 = {med['fp16'] / med['fp16x2']:.3f}")
     for ref in ("fp16x2", "fp32"):

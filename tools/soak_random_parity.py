@@ -25,7 +25,7 @@ from signerf_amd import Cameras, SceneBox, scene  # noqa: E402
 from test_gpu_random_parity import _look_at, _random_c2w  # noqa: E402
 
 
-def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False, lenses=False):
+def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False, lenses=False, fp16=False):
     g = torch.Generator().manual_seed(910000 + seed)
 
     def ri(lo, hi):
@@ -42,6 +42,10 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
     background = ["last_sample", "last_sample", "white", "black", "random"][ri(0, 4)]
     far = [1000.0, 1000.0, ru(2.0, 60.0), ru(3.0, 8.0)][ri(0, 3)] if sampler == "piecewise" else ru(3.0, 9.0)
     precision = "fp32" if ri(0, 2) == 0 else "fp16x2"
+    if fp16:   # r04: the opt-in single-fp16 mode (tiny-cuda-nn checkpoints only) against the oracle's emulation of its roundings (mlp_forward(half=True))
+        precision, tcnn = "fp16", True
+        if sampler != "piecewise" or no_contract:   # the mode has the default sampler / contraction instantiations only (sn_render_rays says so)
+            sampler, no_contract, far = "piecewise", False, (far if far > 9.0 else 1000.0)
     kw = dict(num_nerf_samples_per_ray=S, far_plane=far, proposal_initial_sampler=sampler, disable_scene_contraction=no_contract,
               background_color=background, precision=precision)
     if full_tables:   # nerfacto's own table sizes (T = 2^19 main, 2^17 proposal nets): the shapes the production instantiations are specialised for
@@ -96,7 +100,7 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
     fy_, cx_, cy_ = focal * ru(0.8, 1.25), W / 2 + ru(-2, 2), H / 2 + ru(-2, 2)
     lens, ctype = None, 1
     if lenses:   # r04: the cameras of the original dataset (datasetgenerator.py:274-275): OPENCV distortion, PERSPECTIVE / FISHEYE
-        ctype = 2 if ri(0, 3) == 0 else 1
+        ctype = [1, 1, 2, 3][ri(0, 3)]   # PERSPECTIVE / FISHEYE / EQUIRECTANGULAR (the viewer's three preview types)
         if ri(0, 4) > 0:
             lens = torch.tensor([ru(-0.3, 0.3), ru(-0.1, 0.1), ru(-0.02, 0.02), ru(-0.005, 0.005), ru(-0.01, 0.01), ru(-0.01, 0.01)])
             if ri(0, 5) == 0:
@@ -161,7 +165,9 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
         if "depth" in k:
             rel = d.abs() / want[ok].double().abs().clamp_min(1e-6)
             flips = rel > 1e-3
-            if k != "expected_depth" and int(flips.sum()) > max(1, int(ok.sum()) // 300):
+            # (single-fp16 mode: kernel and emulation sum a layer in different orders, a pre-rounding value next to an fp16 boundary lands on the
+            #  neighbouring fp16 in one of them -- 2^-11 of one activation -- so whole-bin median flips are ten times as frequent; still counted)
+            if k != "expected_depth" and int(flips.sum()) > max(1, int(ok.sum()) // (30 if fp16 else 300)):
                 problems.append(f"{k}: {int(flips.sum())} flips of {int(ok.sum())}")
             d = (d / want[ok].double().abs().clamp_min(1.0))[~flips] if k != "expected_depth" else d / want[ok].double().abs().clamp_min(1.0)
         if k in ("normals", "pred_normals"):
@@ -207,13 +213,14 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--full-tables", action="store_true", help="nerfacto's table sizes (2^19 / 2^17) instead of the small ones")
     ap.add_argument("--tcnn", action="store_true", help="tiny-cuda-nn grid semantics and checkpoint import")
-    ap.add_argument("--lenses", action="store_true", help="random OPENCV distortion parameters and PERSPECTIVE / FISHEYE cameras; the bundle is checked too")
+    ap.add_argument("--lenses", action="store_true", help="random OPENCV distortion parameters and PERSPECTIVE / FISHEYE / EQUIRECTANGULAR cameras; the bundle is checked too")
+    ap.add_argument("--fp16", action="store_true", help="the opt-in single-fp16 mode on tiny-cuda-nn checkpoints against the oracle's emulation of its roundings")
     ap.add_argument("--normals", action="store_true", help="uniform-sampler scenarios only, with the normals kernel's two outputs checked as well")
     ap.add_argument("--inspect", type=int, nargs="*", default=[], help="print the worst pixels of these seeds instead of running the sweep")
     a = ap.parse_args()
     gpu = torch.device("cuda", 0)
     for seed in a.inspect:
-        tag, msgs, problems = scenario(seed, gpu, inspect=("expected_depth", "depth", "rgb") + (("normals", "pred_normals") if a.normals else ()), normals=a.normals, full_tables=a.full_tables, tcnn=a.tcnn, lenses=a.lenses)
+        tag, msgs, problems = scenario(seed, gpu, inspect=("expected_depth", "depth", "rgb") + (("normals", "pred_normals") if a.normals else ()), normals=a.normals, full_tables=a.full_tables, tcnn=a.tcnn, lenses=a.lenses, fp16=a.fp16)
         print(tag, "|", "; ".join(problems), "|", ", ".join(msgs))
     if a.inspect:
         return
@@ -221,7 +228,7 @@ def main():
     bad = 0
     for seed in range(a.first, a.first + a.n):
         try:
-            tag, msgs, problems = scenario(seed, gpu, normals=a.normals, full_tables=a.full_tables, tcnn=a.tcnn, lenses=a.lenses)
+            tag, msgs, problems = scenario(seed, gpu, normals=a.normals, full_tables=a.full_tables, tcnn=a.tcnn, lenses=a.lenses, fp16=a.fp16)
         except Exception as e:  # noqa: BLE001
             tag, msgs, problems = f"seed {seed}", [], [f"EXCEPTION {type(e).__name__}: {str(e)[:300]}"]
         if problems:
