@@ -67,7 +67,8 @@ struct SnContext {
     SnGridLevels dense_res{};     // their resolutions R = scale + 2, packed like a tcnn level table
     int nd_torch = 0;             // number of copied levels
     DevBuf hquads_main, hrows_main;   // SnFieldDesc.half_grid: fp16 storage of a tiny-cuda-nn main grid (sn_device.h "fp16 STORAGE")
-    SnDenseCopy hquads_info{};        // (quads of the levels [0, nd_torch); hrows_main: rows of the levels [nd_torch, L))
+    SnDenseCopy hquads_info{};        // (quads of the levels [0, nd_torch); hrows_main: x-pairs / rows of the levels [nd_torch, L))
+    SnPairInfo hpinfo_main{};
     float table_absmax_main = 0.0f;   // max |value| of the uploaded main table (sn_finalize_weights)
     DevBuf dense_prop[SN_MAX_PROPOSALS];
     SnDenseCopy dense_info_prop[SN_MAX_PROPOSALS]{};
@@ -309,8 +310,9 @@ int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, 
 // fp16 storage of a tiny-cuda-nn grid for the single-fp16 mode (SnFieldDesc.half_grid; sn_device.h "fp16 STORAGE"): quads of the `nd` levels
 // that have a de-hashed copy (same R), 4-byte rows of the others.  `absmax` = max |table value| (finite, checked by the caller).
 int build_half_grid(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, const SnDenseCopy& copies, int nd, DevBuf& quads, SnDenseCopy& qinfo,
-                    DevBuf& rows, hipStream_t st, float scale, float absmax) {
+                    DevBuf& rows, SnPairInfo& pinfo, hipStream_t st, float scale, float absmax) {
     memset(&qinfo, 0, sizeof(qinfo));
+    memset(&pinfo, 0, sizeof(pinfo));
     if (nd <= 0 || nd > 12 || !table.ptr) {
         quads.release();
         rows.release();
@@ -345,17 +347,41 @@ int build_half_grid(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, con
     qinfo.bytes = (uint32_t)bytes;
     qinfo.n_bc = 0;
     const int rest = d.num_levels - nd;
+#if SN_H16_PAIRS
+    // the hashed levels as x-pairs: per level one table per count t of trailing one bits of the floor-x coordinate (build_pairs), 8-byte entries
+    const uint32_t T = 1u << d.log2_hashmap_size;
+    uint64_t entries = 0;
+    int n_t[SN_MAX_LEVELS] = {};
+    for (int l = nd; l < d.num_levels; ++l) {
+        int bits = 0;
+        for (uint32_t s = (uint32_t)ceilf(d.scalings[l]) + 1u; s; s >>= 1) ++bits;
+        n_t[l] = bits + 1;
+        pinfo.base[l] = (uint32_t)entries;
+        entries += (uint64_t)n_t[l] * T;
+    }
+    const uint64_t rbytes = std::max<uint64_t>(entries * 8, 256);
+    if (rbytes >= (1ull << 32)) return fail(h, SN_ERR_INVALID, "half_grid: the paired fp16 tables exceed the 4 GiB buffer-descriptor range");
+#else
     const uint64_t rbytes = std::max<uint64_t>(((uint64_t)std::max(rest, 0) << d.log2_hashmap_size) * 4, 256);
+#endif
     if (rows.bytes != rbytes) {
         rows.release();
         SN_HIP(h, hipMalloc(&rows.ptr, rbytes));
         rows.bytes = rbytes;
     }
+#if SN_H16_PAIRS
+    for (int l = nd; l < d.num_levels; ++l) {
+        const uint64_t n = (uint64_t)n_t[l] * T;
+        hipLaunchKernelGGL(sn_build_pairs_h16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)table.ptr, (uint32_t*)rows.ptr, l,
+                           d.log2_hashmap_size, pinfo.base[l], n_t[l], scale);
+    }
+#else
     if (rest > 0) {
         const uint64_t n = (uint64_t)rest << d.log2_hashmap_size;
         hipLaunchKernelGGL(sn_build_rows_h16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)table.ptr, (uint32_t*)rows.ptr, nd, rest,
                            d.log2_hashmap_size, scale);
     }
+#endif
     SN_HIP(h, hipGetLastError());
     return SN_OK;
 }
@@ -1243,8 +1269,8 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         const char* hg = getenv("SN_HALF_GRID");   // (diagnostics: 0 forces the fp32-table path of the mode)
         const int td = d.main_field.grid_mode == 1 ? leading_dense(d.main_field) : -1;
         if (d.half_grid == 1 && !(hg && atoi(hg) == 0) && d.main_field.grid_mode == 1 && h->split_ok && h->nd_torch > 0 && td >= 0 && td <= h->nd_torch) {
-            if (int rc = build_half_grid(h, d.main_field, h->table_main, h->dense_info, h->nd_torch, h->hquads_main, h->hquads_info, h->hrows_main, st,
-                                         h->feat_scale_main, h->table_absmax_main))
+            if (int rc = build_half_grid(h, d.main_field, h->table_main, h->dense_info, h->nd_torch, h->hquads_main, h->hquads_info, h->hrows_main, h->hpinfo_main,
+                                         st, h->feat_scale_main, h->table_absmax_main))
                 return rc;
         } else {
             h->hquads_main.release();
@@ -1514,6 +1540,7 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     p.hquads = h->hquads_info;
     p.hrows = (const float*)h->hrows_main.ptr;
     p.hrows_bytes = (uint32_t)h->hrows_main.bytes;
+    p.hpinfo = h->hpinfo_main;
     p.pairs = (const float*)h->pairs_main.ptr;
     p.pairs_bytes = (uint32_t)h->pairs_main.bytes;
     p.pinfo = h->pinfo_main;

@@ -686,28 +686,6 @@ SN_DEV f32x2 sn_hash_level_rows_h16(__amdgpu_buffer_rsrc_t rsrc, uint32_t level_
     return out;
 }
 
-// all L levels of a tiny-cuda-nn grid from its fp16 storage: levels [0, ND) from the quads (`quads`: SnDenseCopy with n_bc = 0 and 16-byte
-// entries), the rest from the 4-byte rows (`rows_rsrc`, the levels [ND, L) back to back)
-template <int L, int ND, int GROUP>
-SN_DEV void sn_hash_encode_h16(const SnDenseCopy* quads, __amdgpu_buffer_rsrc_t rows_rsrc, const float* scal, int log2_t, const float q[3], float* feat) {
-    const uint32_t mask = (1u << log2_t) - 1u;
-    const __amdgpu_buffer_rsrc_t qrsrc = sn_table_rsrc(quads->base, quads->bytes);
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        if (GROUP > 0 && l > 0 && (l % GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
-        f32x2 e;
-        if (l < ND) {
-            uint32_t R = quads->res[l < 12 ? l : 0];
-            asm volatile("" : "+s"(R));
-            e = sn_hash_level_quad_h16(qrsrc, quads->off[l < 12 ? l : 0], q, scal[l], R);
-        } else {
-            e = sn_hash_level_rows_h16(rows_rsrc, ((uint32_t)(l - ND) << log2_t) * 4u, q, scal[l], mask);
-        }
-        feat[2 * l] = e.x;
-        feat[2 * l + 1] = e.y;
-    }
-}
-
 // max |x| over a buffer (bit pattern of the non-negative float, which orders like the value; NaN sorts above inf and so shows)
 __global__ void sn_absmax_kernel(const float* __restrict__ x, size_t n, uint32_t* out) {
     uint32_t m = 0u;
@@ -890,6 +868,79 @@ __global__ void sn_build_pairs_kernel(const float* __restrict__ table, float* __
     const f32x2* lv = (const f32x2*)table + ((uint64_t)level << log2_t);
     const f32x2 a = lv[r], b = lv[r ^ m];
     ((f32x4*)pairs)[(uint64_t)base + i] = f32x4{a.x * scale, a.y * scale, b.x * scale, b.y * scale};
+}
+
+// fp16 storage, hashed levels as x-PAIRS (r04): P16[l][t][r] = { half2 table[l][r], half2 table[l][r ^ m_t] }, 8 bytes -- the x-paired
+// tables above on the fp16 rows of sn_pack_h2_scaled: one 8-byte gather per corner pair, four per level instead of eight.
+__global__ void sn_build_pairs_h16_kernel(const float* __restrict__ table, uint32_t* __restrict__ pairs, int level, int log2_t, uint32_t base,
+                                          int n_t, float scale) {
+    const uint32_t T = 1u << log2_t;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)T * n_t) return;
+    const uint32_t t = (uint32_t)(i >> log2_t), r = (uint32_t)i & (T - 1u);
+    const uint32_t m = ((2u << t) - 1u) & (T - 1u);
+    const f32x2* lv = (const f32x2*)table + ((uint64_t)level << log2_t);
+    typedef uint32_t u32x2p __attribute__((ext_vector_type(2)));
+    ((u32x2p*)pairs)[(uint64_t)base + i] = u32x2p{sn_pack_h2_scaled(lv[r], scale), sn_pack_h2_scaled(lv[r ^ m], scale)};
+}
+
+// a hashed level of a tiny-cuda-nn grid from its fp16 x-pairs: entry numbers as in sn_hash_encode_pairs (8-byte entries), the blend of
+// sn_hash_level_rows_h16
+SN_DEV f32x2 sn_hash_level_pairs_h16(__amdgpu_buffer_rsrc_t prsrc, uint32_t base_entry, const float q[3], float scale, uint32_t mask, int log2_t) {
+    typedef uint32_t u32x2p __attribute__((ext_vector_type(2)));
+    uint32_t f[3];
+    float off[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = fmaf(scale, q[a], 0.5f);
+        off[a] = __builtin_amdgcn_fractf(x);
+        f[a] = (uint32_t)(int)x;
+    }
+    const uint32_t P1 = 2654435761u & mask, P2 = 805459861u & mask;
+    const uint32_t yf = __umul24(f[1], P1), zf = __umul24(f[2], P2), yc = yf + P1, zc = zf + P2;
+    const uint32_t t = (uint32_t)__builtin_ctz(~f[0]);  // trailing ones of xf
+    const uint32_t base = base_entry + (t << log2_t);
+    auto pair = [&](uint32_t h) { return (u32x2p)__builtin_amdgcn_raw_buffer_load_b64(prsrc, (int)((base + ((f[0] ^ h) & mask)) << 3), 0, SN_AUX_PAIR); };
+    const u32x2p p_ff = pair(yf ^ zf), p_cf = pair(yc ^ zf), p_fc = pair(yf ^ zc), p_cc = pair(yc ^ zc);   // .x = floor-x corner, .y = ceil-x corner
+    const float ox = off[0], oy = off[1], oz = off[2];
+    f32x2 out;
+    {
+        const float x0 = sn_lerp_hh<0>(p_ff.y, p_ff.x, ox), x1 = sn_lerp_hh<0>(p_cf.y, p_cf.x, ox), x2 = sn_lerp_hh<0>(p_fc.y, p_fc.x, ox), x3 = sn_lerp_hh<0>(p_cc.y, p_cc.x, ox);
+        const float y0 = fmaf(x1 - x0, oy, x0), y1 = fmaf(x3 - x2, oy, x2);
+        out.x = fmaf(y1 - y0, oz, y0);
+    }
+    {
+        const float x0 = sn_lerp_hh<1>(p_ff.y, p_ff.x, ox), x1 = sn_lerp_hh<1>(p_cf.y, p_cf.x, ox), x2 = sn_lerp_hh<1>(p_fc.y, p_fc.x, ox), x3 = sn_lerp_hh<1>(p_cc.y, p_cc.x, ox);
+        const float y0 = fmaf(x1 - x0, oy, x0), y1 = fmaf(x3 - x2, oy, x2);
+        out.y = fmaf(y1 - y0, oz, y0);
+    }
+    return out;
+}
+
+// all L levels of a tiny-cuda-nn grid from its fp16 storage: levels [0, ND) from the quads (`quads`: SnDenseCopy with n_bc = 0 and 16-byte
+// entries), the rest from their x-pairs (PAIRS: `rows_rsrc` = the paired tables, `pi.base[l]` = first 8-byte entry of level l) or from the
+// 4-byte rows (`rows_rsrc` = the levels [ND, L) back to back)
+template <int L, int ND, int GROUP, bool PAIRS>
+SN_DEV void sn_hash_encode_h16(const SnDenseCopy* quads, __amdgpu_buffer_rsrc_t rows_rsrc, const SnPairInfo& pi, const float* scal, int log2_t,
+                               const float q[3], float* feat) {
+    const uint32_t mask = (1u << log2_t) - 1u;
+    const __amdgpu_buffer_rsrc_t qrsrc = sn_table_rsrc(quads->base, quads->bytes);
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        if (GROUP > 0 && l > 0 && (l % GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
+        f32x2 e;
+        if (l < ND) {
+            uint32_t R = quads->res[l < 12 ? l : 0];
+            asm volatile("" : "+s"(R));
+            e = sn_hash_level_quad_h16(qrsrc, quads->off[l < 12 ? l : 0], q, scal[l], R);
+        } else if (PAIRS) {
+            e = sn_hash_level_pairs_h16(rows_rsrc, pi.base[l], q, scal[l], mask, log2_t);
+        } else {
+            e = sn_hash_level_rows_h16(rows_rsrc, ((uint32_t)(l - ND) << log2_t) * 4u, q, scal[l], mask);
+        }
+        feat[2 * l] = e.x;
+        feat[2 * l + 1] = e.y;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

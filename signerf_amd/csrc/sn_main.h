@@ -961,6 +961,10 @@ SN_DEV void sn_main_field_h4(const char* __restrict__ ldsb, const char* __restri
 #ifndef SN_MAIN_PAIRS
 #define SN_MAIN_PAIRS 1
 #endif
+// single-fp16 mode: the hashed levels of the grid's fp16 storage as x-pairs (four 8-byte gathers per level) instead of 4-byte rows (eight)
+#ifndef SN_H16_PAIRS
+#define SN_H16_PAIRS 1
+#endif
 #ifndef SN_STRIP_W
 #define SN_STRIP_W 8  // r02 same-box A/B over widths 0 / 4 / 8 / 12 / 16: 2.826 / 2.803 / 2.805 / 2.817 / 2.823 ms (camera 0)
 #endif
@@ -1008,8 +1012,9 @@ struct SnMainParams {
     int chunk_rays;
     float feat_scale;   // torch grid: power-of-two scale of the hash features (carried by the de-hashed copies; applied here to the other levels)
     SnDenseCopy hquads;  // single-fp16 mode (PREC 2, tiny-cuda-nn grid, ND > 0): the fp16 storage of the grid (sn_device.h "fp16 STORAGE") ...
-    const float* hrows;  // ... its 4-byte rows of the levels [ND, 16)
+    const float* hrows;  // ... its hashed levels [ND, 16): fp16 x-pairs (SN_H16_PAIRS, entry numbers in hpinfo) or 4-byte rows
     uint32_t hrows_bytes;
+    SnPairInfo hpinfo;
     const float* pairs;  // SN_MAIN_PAIRS: x-paired tables of the levels >= ND (pre-scaled by feat_scale), or null
     uint32_t pairs_bytes;
     SnPairInfo pinfo;
@@ -1264,7 +1269,8 @@ void sn_render_main_kernel(SnMainParams p) {
             constexpr int NBC = ND > SN_BC_MAIN ? SN_BC_MAIN : (ND > 0 ? ND : 0);
             if (PREC == 2 && GRID == 1 && ND > 0) {
                 // single-fp16 mode: the tiny-cuda-nn grid from its fp16 storage (quads of the de-hashed levels, 4-byte rows of the hashed ones)
-                sn_hash_encode_h16<16, (ND > 0 ? ND : 1), SHAPE::HASH_GROUP>(&p.hquads, sn_table_rsrc(p.hrows, p.hrows_bytes), p.scal, p.log2_t, q, feat);
+                sn_hash_encode_h16<16, (ND > 0 ? ND : 1), SHAPE::HASH_GROUP, SN_H16_PAIRS != 0>(&p.hquads, sn_table_rsrc(p.hrows, p.hrows_bytes), p.hpinfo, p.scal, p.log2_t,
+                                                                                              q, feat);
             } else if (PREC == 2) {
                 sn_hash_encode<16, SHAPE::HASH_GROUP, AR, ND, DUMP, NBC, 0, true>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
             } else if (SN_MAIN_PAIRS && MODE == 1 && ND > 0 && ND < 16) {
