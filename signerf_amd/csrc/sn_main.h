@@ -941,6 +941,9 @@ SN_DEV void sn_main_field_h4(const char* __restrict__ ldsb, const char* __restri
 #ifndef SN_HASH_GROUP
 #define SN_HASH_GROUP 4
 #endif
+#ifndef SN_MAIN_NCACHE
+#define SN_MAIN_NCACHE 0   // (measured r04, tools/ab_libs.sh: see DESIGN.md K1 "r04")
+#endif
 #ifndef SN_MAIN_WAVES_PER_SIMD
 #define SN_MAIN_WAVES_PER_SIMD 3
 #endif
@@ -1220,6 +1223,10 @@ void sn_render_main_kernel(SnMainParams p) {
     };
     float t0 = bin(i_lo);
     float r = 0.f, g = 0.f, b = 0.f;
+    // experiment knob (r04): the coarsest SN_MAIN_NCACHE levels keep their four fetches across the steps of the march (SnBcCache, as K2 does)
+    SnBcCache bc_cache[SN_MAIN_NCACHE > 0 ? SN_MAIN_NCACHE : 1];
+#pragma unroll
+    for (int c = 0; c < (SN_MAIN_NCACHE > 0 ? SN_MAIN_NCACHE : 1); ++c) bc_cache[c].reset();
 #pragma unroll 1
     for (int i = i_lo; i < i_hi; ++i) {
         // The LDS weight reads are loop-invariant; LICM would hoist them all (368 VGPRs) and spill.  A compiler-only
@@ -1275,12 +1282,14 @@ void sn_render_main_kernel(SnMainParams p) {
                 sn_hash_encode<16, SHAPE::HASH_GROUP, AR, ND, DUMP, NBC, 0, true>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
             } else if (SN_MAIN_PAIRS && MODE == 1 && ND > 0 && ND < 16) {
                 // de-hashed levels [0, ND), then the hashed levels [ND, 16) from the x-paired tables
-                sn_hash_encode<(ND > 0 ? ND : 1), SHAPE::HASH_GROUP, AR, ND, DUMP, NBC>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
+                sn_hash_encode<(ND > 0 ? ND : 1), SHAPE::HASH_GROUP, AR, ND, DUMP, NBC, (NBC >= SN_MAIN_NCACHE && !DUMP ? SN_MAIN_NCACHE : 0)>(
+                    rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale, bc_cache);
                 __builtin_amdgcn_sched_barrier(0);
                 sn_hash_encode_pairs<16, SHAPE::HASH_GROUP, true, (ND > 0 && ND < 16 ? ND : 0), GRID == 1, DUMP>(sn_table_rsrc(p.pairs, p.pairs_bytes), p.pinfo,
                                                                                                            p.scal, p.log2_t, q, feat, rec);
             } else {
-                sn_hash_encode<16, SHAPE::HASH_GROUP, AR, ND, DUMP, NBC>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
+                sn_hash_encode<16, SHAPE::HASH_GROUP, AR, ND, DUMP, NBC, (NBC >= SN_MAIN_NCACHE && !DUMP ? SN_MAIN_NCACHE : 0)>(rsrc, p.scal, p.log2_t, q, feat, &p.grid,
+                                                                                                                    &p.dense, rec, p.feat_scale, bc_cache);
             }
 #if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 3
             __builtin_amdgcn_s_setprio(0);
