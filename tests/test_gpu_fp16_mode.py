@@ -105,6 +105,24 @@ def test_fp16_storage_of_the_grid_equals_rounding_on_the_fly(gpu, monkeypatch):
     assert quads + 5 * 10 * (1 << 19) * 8 <= layouts[0]["half_grid_bytes"] <= quads + 5 * 14 * (1 << 19) * 8
 
 
+def test_switching_the_precision_on_later_rebuilds_the_handle_with_the_storage(gpu):
+    """`model.config.precision = "fp16"` on a model that has already rendered at fp32 grade: the handle is re-created once with the grid's
+    fp16 storage (the fast path), and the render equals that of a model configured so from the start."""
+    kw = dict(num_proposal_iterations=0, num_nerf_samples_per_ray=16)
+    cfg, sd, model = _tcnn_model(gpu, seed=1, precision="fp16x2", **kw)
+    b = Cameras(scene.benchmark_cameras(8)[:, :3], 50.0, 50.0, 16.0, 12.0, 32, 24).to(gpu)[3].generate_rays(0)
+    model.get_outputs_for_camera_ray_bundle(b)
+    assert ops.debug_layout(model)["half_grid_bytes"] == 0
+    model.config.precision = "fp16"
+    late = model.get_outputs_for_camera_ray_bundle(b)["rgb"].clone()
+    assert ops.debug_layout(model)["half_grid_bytes"] > 0 and model.effective_precision == "fp16"
+    _, _, ref = _tcnn_model(gpu, seed=1, precision="fp16", **kw)
+    assert torch.equal(late, ref.get_outputs_for_camera_ray_bundle(b)["rgb"])
+    model.config.precision = "fp16x2"                      # ... and back: the same handle, the storage simply stays
+    model.get_outputs_for_camera_ray_bundle(b)
+    assert ops.debug_layout(model)["half_grid_bytes"] > 0
+
+
 def test_fp16_mode_is_for_tcnn_checkpoints_only(gpu):
     with pytest.raises(NotImplementedError, match="tcnn"):
         small_config(precision="fp16").setup()                                        # implementation="torch": the parity target stays fp32-grade
