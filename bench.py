@@ -86,7 +86,8 @@ def other_configs(precision):
     """BASELINE.json configs[3] and configs[4] in the driver's line: untimed legs AFTER the headline's timed region, each in
     a child process of this interpreter so that the headline's handle, streams and allocator state are not disturbed.
       configs[3]  `bench.py --workload nerfacto1080 --steps 12 --warmup 3`: 1920x1080, proposal nets 256 + 96 + 48 main samples
-      configs[4]  `tools/config5_bench.py --size 800 --only-nopng`: DatasetGenerator.generate_dataset, 8 reference + 50 views, PNG writes off"""
+      configs[4]  `tools/config5_bench.py --size 800 --only-nopng`: DatasetGenerator.generate_dataset, 8 reference + 50 views, PNG writes off
+      + (r04) `tools/tcnn_modes_bench.py`: the headline frame on a tiny-cuda-nn grid, fp32-grade default vs the opt-in single-fp16 mode"""
     out = []
     me = os.path.abspath(__file__)
     base = [sys.executable, me, "--workload", "nerfacto1080", "--steps", "12", "--warmup", "3", "--precision", precision, "--no-cpu-baseline",
@@ -112,6 +113,11 @@ def other_configs(precision):
                     "png_writes": "off", "total_ms": e.get("total_ms"), "ms_per_view": e.get("ms_per_view"),
                     "render_stage_ms": e.get("render_stage_ms"), "render_ms_per_view": e.get("render_ms_per_view"),
                     "field_evaluations_per_s": e.get("field_evaluations_per_s"), "views": d.get("views"), "ranks": d.get("ranks")})
+    # the same frame on a tiny-cuda-nn grid, fp32-grade default and the opt-in single-fp16 mode (what the library itself computes with): timing only
+    d, err = _json_line_of([sys.executable, os.path.join(ROOT, "tools", "tcnn_modes_bench.py"), "--rounds", "12"], 150)
+    out.append({"config": "tiny-cuda-nn grid (SURVEY 8(f) row 2), 800x800x64: fp32-grade default vs the opt-in single-fp16 mode", "error": err} if d is None else
+               dict({"config": "tiny-cuda-nn grid (SURVEY 8(f) row 2), 800x800x64: fp32-grade default vs the opt-in single-fp16 mode (NOT fp32-grade, never the headline)",
+                     "command": "tools/tcnn_modes_bench.py --rounds 12 (child process)"}, **d))
     return out
 
 
