@@ -190,6 +190,23 @@ def physical_cores():
     return min(n, logical), logical
 
 
+def cpu_quota():
+    """CPUs the container may actually use: the cgroup CPU quota (v2 cpu.max, v1 cfs_quota / cfs_period), None when unlimited.  A GPU box of
+    this pool shows 256 logical CPUs and grants 16 (measured r04: host threads stop scaling there, tools/png_scaling_probe.py)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+            q, per = float(f.read()), float(g.read())
+            return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(main_cfg, main_sd, width, height, samples, runs=3, runs_config4=1):
     """The CPU oracle (kind "port": nerfstudio itself cannot be installed here) timed on the bounded samples BASELINE.md §2 names
     (SURVEY §8(d)): a centred 200x200 crop of the headline frame (config 2), config 1 in full, a centred 240x135 crop of config 4;
@@ -202,6 +219,10 @@ def cpu_baseline(main_cfg, main_sd, width, height, samples, runs=3, runs_config4
     from signerf_amd import scene
 
     cores, logical = physical_cores()
+    quota = cpu_quota()
+    physical = cores
+    if quota is not None:   # more threads than granted CPUs only get throttled
+        cores = max(1, min(cores, int(quota + 0.5)))
     old_threads = torch.get_num_threads()
     torch.set_num_threads(cores)
     cpu = "unknown CPU"
@@ -229,7 +250,8 @@ def cpu_baseline(main_cfg, main_sd, width, height, samples, runs=3, runs_config4
 
     crop = 200
     dt2, all2 = timed(main_cfg, main_sd, width, height, float(width), crop, crop, runs)
-    out = {"value": crop * crop * samples / dt2, "unit": "ray-samples/s", "cores": cores, "threads": cores, "logical_cpus": logical,
+    out = {"value": crop * crop * samples / dt2, "unit": "ray-samples/s", "cores": cores, "threads": cores, "logical_cpus": logical, "physical_cores_of_the_host": physical,
+           "cgroup_cpu_quota": quota,
            "kind": "port", "host_cpu": cpu, "timer": "time.perf_counter around the render, 1 warm-up + median of the timed renders",
            "sample": f"config 2: centred {crop}x{crop} crop of the {width}x{height}x{samples} frame, median of {len(all2)} renders = {dt2:.1f} s, "
                      "torch CPU fp32 oracle",

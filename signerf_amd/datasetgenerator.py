@@ -270,8 +270,9 @@ class DatasetGenerator:
                  diffuse: Optional[Callable[[Tensor, Tensor, Tensor, Tensor], Tensor]] = None, group=None, write_images: bool = True,
                  save_workers: Optional[int] = None, precompute: bool = True, profile: bool = False,
                  png_compress_level: Optional[int] = None, finish_sync: bool = True, serial_stage_timeout_s: float = 24 * 3600.0,
-                 precompute_budget_mb: Optional[int] = None) -> None:
+                 precompute_budget_mb: Optional[int] = None, png_encoder: str = "native") -> None:
         self.config = config
+        self.png_encoder = png_encoder   # "native": dataset_io.encode_png (same pixels, parallel on the pool); "pil": the reference's Image.save
         self.finish_sync, self.serial_stage_timeout_s = finish_sync, serial_stage_timeout_s
         self.precompute_budget_mb, self.precompute_skipped = precompute_budget_mb, 0
         self.png_compress_level = png_compress_level   # None: PIL's default, the files the reference writes (dataset_io.GeneratedDataset)
@@ -290,10 +291,17 @@ class DatasetGenerator:
         self.mask_dialation, self.additional_depth_radius, self.manual_depth = config.mask_dialation, config.additional_depth_radius, config.manual_depth
         self.diffuse = diffuse or identity_diffuse
         self.group = group
-        if save_workers is None:  # PNG encoding (PIL, zlib: releases the GIL) is the slowest stage of the loop by 10x: spread it over the host's cores
+        if save_workers is None:  # PNG encoding is the slowest stage of the loop: spread it over the host's cores (dataset_io.encode_png releases the GIL)
             import os
 
             save_workers = max(1, min(32, (os.cpu_count() or 8) // 2))
+            try:   # a container's CPU quota, not the host's CPU count, is what the threads get (cgroup v2)
+                with open("/sys/fs/cgroup/cpu.max") as f:
+                    q, per = f.read().split()[:2]
+                if q != "max":
+                    save_workers = max(1, min(save_workers, int(float(q) / float(per) + 0.5)))
+            except (OSError, ValueError):
+                pass
         self.write_images, self.save_workers = write_images, save_workers
         self.precompute, self.profile = precompute, profile
         self.is_synthetic = False
@@ -322,7 +330,7 @@ class DatasetGenerator:
         from .dataset_io import GeneratedDataset
 
         self.dataset = GeneratedDataset(self.config.path, self.dataset_name, self.downscale_factor, write_images=self.write_images,
-                                        save_workers=self.save_workers, png_compress_level=self.png_compress_level)
+                                        save_workers=self.save_workers, png_compress_level=self.png_compress_level, png_encoder=self.png_encoder)
         self.dataset.init_directory()
         self.dataset_path, self.transforms_path = self.dataset.dataset_path, self.dataset.transforms_path
         for key, d in self.dataset.dirs.items():  # images_path, masks_scaled_path, ... as attributes, like the reference's

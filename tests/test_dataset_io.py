@@ -89,3 +89,43 @@ def test_png_compress_level_changes_bytes_not_pixels(gpu, tmp_path):
         assert np.array_equal(a, b)
     assert out["fast"][0][1] != out["default"][0][1]
     assert np.array_equal(out["default"][0][0], (x.cpu().numpy() * 255).astype(np.uint8))
+
+
+def test_native_png_encoder_round_trips_through_pillow(tmp_path):
+    """dataset_io.encode_png (the GIL-free encoder of the generator's PNG pool): Pillow decodes exactly the pixels that went in -- RGB and
+    greyscale, one-row / one-column images, every compression level the generator exposes."""
+    import numpy as np
+    from PIL import Image
+
+    from signerf_amd.dataset_io import encode_png
+
+    rng = np.random.default_rng(0)
+    for shape in ((37, 53, 3), (64, 64, 1), (1, 17, 3), (23, 1, 1), (2, 2, 3)):
+        smooth = (np.add.outer(np.arange(shape[0]), np.arange(shape[1]))[..., None] * 3 + rng.integers(0, 9, shape)).astype(np.uint8)
+        for img in (smooth, rng.integers(0, 256, shape, dtype=np.uint8), np.zeros(shape, np.uint8), np.full(shape, 255, np.uint8)):
+            for level in (1, 6):
+                p = tmp_path / "x.png"
+                p.write_bytes(encode_png(img, level))
+                back = np.array(Image.open(p))
+                assert back.dtype == np.uint8 and np.array_equal(back.reshape(shape), img)
+                assert Image.open(p).mode == ("L" if shape[2] == 1 else "RGB")
+
+
+@pytest.mark.gpu
+def test_generated_dataset_writes_the_same_pixels_with_both_encoders(tmp_path, gpu):
+    import numpy as np
+    from PIL import Image
+
+    t = torch.rand(20, 24, 3, device=gpu)
+    m = (torch.rand(20, 24, 1, device=gpu) > 0.5).float()
+    out = {}
+    for enc in ("native", "pil"):
+        ds = dataset_io.GeneratedDataset(tmp_path, enc, save_workers=2, png_encoder=enc)
+        ds.init_directory()
+        ds.save_image(t, ds.dirs["images"] / "a.png")
+        ds.save_image(m, ds.dirs["masks"] / "m.png")
+        ds.close()
+        out[enc] = (np.array(Image.open(ds.dirs["images"] / "a.png")), np.array(Image.open(ds.dirs["masks"] / "m.png")))
+    assert np.array_equal(out["native"][0], out["pil"][0]) and np.array_equal(out["native"][1], out["pil"][1])
+    with pytest.raises(ValueError):
+        dataset_io.GeneratedDataset(tmp_path, "x", png_encoder="fast")

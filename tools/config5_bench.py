@@ -53,13 +53,13 @@ if world > 1:
     tmp = box[0]
 
 
-def run(write_images: bool, tag: str, png_level=None):
+def run(write_images: bool, tag: str, png_level=None, encoder="native"):
     best = None
     for rep in range(a.reps + 1):   # the first repetition warms the handle, the streams and the allocator
         gcfg = DatasetGeneratorConfig(path=tmp, dataset_name=f"{tag}{rep}", fx=1.2 * S, fy=1.2 * S, cx=S / 2, cy=S / 2, width=S, height=S,
                                       rows=3, cols=3)   # aabb +-0.1, dilation (50, 50), downscale 2: the reference's defaults
         gen = DatasetGenerator(gcfg, torch.eye(4)[:3], 1.0, None, device=dev, write_images=write_images, save_workers=a.save_workers, profile=True,
-                               png_compress_level=png_level)
+                               png_compress_level=png_level, png_encoder=encoder)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -75,10 +75,11 @@ def run(write_images: bool, tag: str, png_level=None):
 n = 8 + a.views
 out = {"views": n, "size": [S, S], "ranks": world, "backend": (dist.get_backend() if world > 1 else None),
        "workload": "8 reference + %d random_sphere_poses views, 256+96+48 samples, aabb +-0.1, dilation 50x50, downscale 2, identity diffuser" % a.views}
-legs = ((False, "nopng", None),) if a.only_nopng else ((False, "nopng", None), (True, "png", None), (True, "pngl1", 1))
-for write, tag, level in legs:
-    dt, tm = run(write, tag, level)
-    out["png_writes_" + (("on" if level is None else "on_compress_level_%d" % level) if write else "off")] = {
+legs = ((False, "nopng", None, "native"),) if a.only_nopng else ((False, "nopng", None, "native"), (True, "png", None, "native"), (True, "pngl1", 1, "native"),
+                                                                  (True, "pngpil", None, "pil"))
+for write, tag, level, enc in legs:
+    dt, tm = run(write, tag, level, enc)
+    out["png_writes_" + ((("on" if level is None else "on_compress_level_%d" % level) + ("_pil_encoder" if enc == "pil" else "")) if write else "off")] = {
         "total_ms": dt * 1e3, "ms_per_view": dt * 1e3 / n,
         "render_stage_ms": tm.get("render_s", 0) * 1e3, "render_ms_per_view": tm.get("render_s", 0) * 1e3 / n,
         "field_evaluations_per_s": n * S * S * 400 / max(tm.get("render_s", 0), 1e-9),
@@ -92,6 +93,12 @@ if rank == 0:
         m = np.array(Image.open(os.path.join(tmp, "png1", "masks", "mask_10.png"))) > 0
         out["mask_coverage_view_10"] = float(m.mean())
         out["files_written"] = sum(len(f) for _, _, f in os.walk(os.path.join(tmp, "png1")))
+        # same pixels from both encoders, and what the files weigh
+        size = lambda d: sum(os.path.getsize(os.path.join(r, f)) for r, _, fs in os.walk(os.path.join(tmp, d)) for f in fs if f.endswith(".png"))  # noqa: E731
+        out["png_bytes"] = {"native_level_6": size("png1"), "native_level_1": size("pngl11"), "pil_level_6": size("pngpil1")}
+        same = all(np.array_equal(np.array(Image.open(os.path.join(tmp, "png1", d, f))), np.array(Image.open(os.path.join(tmp, "pngpil1", d, f))))
+                   for d in ("images", "masks", "conditions", "rendered", "images_2") for f in sorted(os.listdir(os.path.join(tmp, "png1", d)))[:6])
+        out["native_and_pil_files_decode_to_the_same_pixels"] = bool(same)
     print(json.dumps(out) if a.only_nopng else json.dumps(out, indent=1))
     shutil.rmtree(tmp, ignore_errors=True)
 if world > 1:
