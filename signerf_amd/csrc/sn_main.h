@@ -965,6 +965,9 @@ SN_DEV void sn_main_field_h4(const char* __restrict__ ldsb, const char* __restri
 #define SN_MAIN_PAIRS 1
 #endif
 // single-fp16 mode: the hashed levels of the grid's fp16 storage as x-pairs (four 8-byte gathers per level) instead of 4-byte rows (eight)
+#ifndef SN_H16_GROUP
+#define SN_H16_GROUP SN_HASH_GROUP   // levels per scheduler fence in the single-fp16 mode; measured r04 (tools/ab_libs.sh, tcnn fp16): 2 / 4 / 8 / 16 = 1.99 / 1.85 / 1.95 / 2.03 ms
+#endif
 #ifndef SN_H16_PAIRS
 #define SN_H16_PAIRS 1
 #endif
@@ -985,7 +988,7 @@ struct SnK1Shape {
     static constexpr int TX = W4 ? 4 : 2, TY = 2;             // tiles per workgroup
     static constexpr int THREADS = WG_WAVES * 64;
     static constexpr int WAVES_PER_SIMD = W4 ? 4 : SN_MAIN_WAVES_PER_SIMD;
-    static constexpr int HASH_GROUP = W4 ? SN_K1_4W_GROUP : SN_HASH_GROUP;
+    static constexpr int HASH_GROUP = W4 ? SN_K1_4W_GROUP : (PREC == 2 ? SN_H16_GROUP : SN_HASH_GROUP);
 };
 
 struct SnMainParams {
