@@ -134,7 +134,9 @@ typedef struct SnRenderOpts {
                                                     * 2 (r04, OPT-IN, grid_mode 1 only): single fp16 operands, fp32 accumulate, fp16 activations
                                                     *   between the layers -- the arithmetic tiny-cuda-nn checkpoints were trained in (README.md:
                                                     *   146,170: `ns-train nerfacto` runs FullyFusedMLP in fp16); applies to the main field, the
-                                                    *   proposal nets and the normals kernel keep the split form.  NOT fp32-grade: ~1e-3. */
+                                                    *   proposal nets and the normals kernel keep the split form.  The main grid's table values are
+                                                    *   rounded through fp16 once, as the library's inference copy of the parameters is (blend in
+                                                    *   fp32); SnFieldDesc.half_grid keeps them in fp16 storage.  NOT fp32-grade: ~1e-3. */
     void* workspace;                               /* device scratch, >= sn_workspace_bytes() */
     size_t workspace_bytes;
     /* Sampler grids, DEVICE pointers, computed by the host shim with the very torch ops nerfstudio uses so
