@@ -190,6 +190,25 @@ def physical_cores():
     return min(n, logical), logical
 
 
+def run_with_watchdog(fn, timeout_s, on_timeout):
+    """fn() with a watchdog: if it has not returned after timeout_s seconds, on_timeout() runs on a timer thread (it is expected to end the
+    process -- a hung collective cannot be cancelled).  A call that returns in time never sees on_timeout."""
+    done = threading.Event()
+
+    def fire():
+        if not done.is_set():
+            on_timeout()
+
+    dog = threading.Timer(timeout_s, fire)
+    dog.daemon = True
+    dog.start()
+    try:
+        return fn()
+    finally:
+        done.set()
+        dog.cancel()
+
+
 def cpu_quota():
     """CPUs the container may actually use: the cgroup CPU quota (v2 cpu.max, v1 cfs_quota / cfs_period), None when unlimited.  A GPU box of
     this pool shows 256 logical CPUs and grants 16 (measured r04: host threads stop scaling there, tools/png_scaling_probe.py)."""
@@ -544,28 +563,24 @@ def main():
         """The exposed cost of the tile gather, per strategy: diagnostic legs AFTER the timed region.  They must never cost the line -- an
         exception is recorded per strategy, and a collective that HANGS (p2p / all_to_all have only ever run on gloo and on one-rank RCCL) is cut
         by a watchdog: rank 0 prints the line it has (gather_ms: error) and every rank leaves with status 0, the measurement being complete."""
-        by, err, done = {}, None, threading.Event()
+        by, err = {}, [None]
 
         def bail():
-            if done.is_set():
-                return
             if line is not None:
                 line["gather_ms"] = {"exposed": None, "error": "the diagnostic gather legs did not finish within their time limit", "exposed_by_strategy": by}
                 print(json.dumps(line), flush=True)
             os._exit(0)
 
-        dog = threading.Timer(args.diagnostics_timeout if rank == 0 else args.diagnostics_timeout + 240.0, bail)   # (rank 0 builds its line first)
-        dog.daemon = True
-        dog.start()
-        for strat in sheet.GATHER_STRATEGIES:
-            try:
-                by[strat] = exposed_gather_ms(strategy=strat)
-            except Exception as e:  # noqa: BLE001
-                by[strat] = None
-                err = repr(e)
-        done.set()
-        dog.cancel()
-        return by, err
+        def legs():
+            for strat in sheet.GATHER_STRATEGIES:
+                try:
+                    by[strat] = exposed_gather_ms(strategy=strat)
+                except Exception as e:  # noqa: BLE001
+                    by[strat] = None
+                    err[0] = repr(e)
+
+        run_with_watchdog(legs, args.diagnostics_timeout if rank == 0 else args.diagnostics_timeout + 240.0, bail)   # (rank 0 builds its line first)
+        return by, err[0]
 
     if world > 1 and rank != 0:
         gather_diagnostics()
