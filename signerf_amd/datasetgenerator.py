@@ -507,8 +507,12 @@ class DatasetGenerator:
             self.edited_reference_sheet, self.condition_reference_sheet = edited_sheet, condition_sheet  # (as left by the last view, :643-646)
         finally:  # also when a diffuser call or a write raised: no worker threads or queued host copies left behind
             self._views = {}
-            self.dataset.close()
-        self._finish(world, sync)
+            try:
+                self.dataset.close()
+            finally:
+                # ... and the idle ranks are released either way: they wait in `_finish` with a 24 h timeout, and a rank 0 that
+                # leaves through an exception without meeting them would park them there (outside torchrun nothing kills them)
+                self._finish(world, sync)
 
     # -- end-of-dataset synchronisation --------------------------------------------------------------------------------------------
     def _sync_group(self, world: int):

@@ -7,6 +7,7 @@ import json
 import os
 import socket
 import sys
+import time
 
 import pytest
 import torch
@@ -362,6 +363,19 @@ def _worker(rank, world, port, out_dir, mode="synthetic"):
     if mode == "original":   # the reference's default camera source: a foreign camera batch, distorted, per-camera intrinsics
         gen = me._generator(out_dir, "sharded", serial_stage_timeout_s=120.0)
         gen.generate_dataset(me._Graph(), ref, original_dataset=me._original_dataset(pathlib.Path(out_dir)))
+    elif mode == "diffuser_raises":   # rank 0 leaves the serial stage through an exception: the idle ranks must not stay parked
+        def broken(*a, **k):
+            raise ConnectionError("diffuser down")
+
+        gen = me._generator(out_dir, "sharded", diffuse=broken, serial_stage_timeout_s=600.0)
+        t0, raised = time.perf_counter(), None
+        try:
+            gen.generate_dataset(me._Graph(), ref, synthetic_camera_to_worlds=syn)
+        except ConnectionError as e:
+            raised = str(e)
+        json.dump({"raised": raised, "seconds": time.perf_counter() - t0}, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
+        dist.destroy_process_group()
+        return
     else:
         gen = me._generator(out_dir, "sharded", finish_sync=(mode != "nosync"))
         gen.generate_dataset(me._Graph(), ref, synthetic_camera_to_worlds=syn)
@@ -407,3 +421,12 @@ def test_generate_dataset_sharded_other_modes(tmp_path, standins, mode):
     counts = [len(p["rendered"]) for p in per_rank]
     assert sum(counts) == n and max(counts) - min(counts) <= 1
     assert per_rank[0]["wrote"] and (mode == "nosync" or per_rank[1]["wrote"])
+
+
+def test_rank0_exception_releases_the_idle_ranks(tmp_path, standins):
+    """world 2, the diffuser raises on rank 0 inside the serial stage: rank 0 re-raises AFTER meeting rank 1 in the closing barrier, so
+    rank 1 returns at once instead of waiting out `serial_stage_timeout_s` (600 s here)."""
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "diffuser_raises"), nprocs=2, join=True)
+    r0, r1 = (json.load(open(tmp_path / f"rank{r}.json")) for r in range(2))
+    assert r0["raised"] == "diffuser down" and r1["raised"] is None
+    assert r1["seconds"] < 60.0
