@@ -518,6 +518,35 @@ def test_4k_frame_indexing(gpu, props):
             assert torch.equal(band[k], full[k][r0:r0 + 8]), (r0, k)
 
 
+@pytest.mark.parametrize("workload", ["sheet64", "nerfacto"])
+def test_maximum_size_8192x8192_crosses_2_to_32_samples(gpu, workload):
+    """Maximum sizes: an 8192 x 8192 frame (2^26 rays; 1 048 576 tiles) of BOTH BASELINE field configurations at their real sample counts
+    and table sizes -- 64 main samples per ray = 2^32 samples per launch, and 256 + 96 + 48 = 2.7e10 field evaluations with a 13 GB
+    K2 -> K1 bin hand-over ([tile][49][64] floats, offsets beyond 2^32 bytes).  Size-independent properties: finite and in range everywhere;
+    32 x 32 crops at the first tile, in the middle and at the LAST tile (largest ray / tile / bin offsets) re-rendered as their own
+    bundles are bit-identical to the frame (rays are independent); the last-tile crop matches the oracle within the 1e-3 gate."""
+    cfg = scene.benchmark_config(64) if workload == "sheet64" else scene.proposal_config()
+    model, sd = make_model(cfg, gpu)
+    W = H = 8192
+    b = Cameras(scene.benchmark_cameras(8)[:, :3], 1.1 * W, 1.1 * W, W / 2, H / 2, W, H).to(gpu)[2].generate_rays(0)
+    full = model.get_outputs_for_camera_ray_bundle(b)
+    keys = ("rgb", "depth", "accumulation") + (("prop_depth_0", "prop_depth_1") if workload == "nerfacto" else ())
+    for k in keys:
+        assert full[k].shape[:2] == (H, W) and bool(torch.isfinite(full[k]).all()), k
+    assert float(full["rgb"].min()) >= 0 and float(full["rgb"].max()) <= 1 and float(full["rgb"].std()) > 0.05
+    last = None
+    for y0, x0 in ((0, 0), (4088, 4104), (H - 32, W - 32)):
+        crop = b._map(lambda t: t[y0:y0 + 32, x0:x0 + 32].contiguous())
+        last = model.get_outputs_for_camera_ray_bundle(crop)
+        for k in keys:
+            assert torch.equal(last[k], full[k][y0:y0 + 32, x0:x0 + 32]), (y0, x0, k)
+    ref = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg), crop.origins.cpu(), crop.directions.cpu())
+    assert rmse(last["rgb"], ref["rgb"]) <= RMSE_TOL and rmse(last["depth"], ref["depth"]) <= RMSE_TOL
+    assert rmse(last["accumulation"], ref["accumulation"]) <= RMSE_TOL
+    del full, b
+    torch.cuda.empty_cache()
+
+
 def test_unsupported_options_fail_loudly(gpu):
     """Error behaviour of the boundary: int status + sn_last_error text -> SignerfHipError, never a silent fallback."""
     from signerf_amd import _lib
