@@ -213,6 +213,41 @@ def test_config4_depth_error_is_scale_free(gpu, density_bias):
     assert rmse(out["rgb"], ref["rgb"]) <= RMSE_TOL and rmse(out["accumulation"], ref["accumulation"]) <= RMSE_TOL
 
 
+@pytest.mark.parametrize("workload", ["sheet64", "nerfacto"])
+@pytest.mark.parametrize("density_bias", [-2.0, -3.0])
+def test_thin_media_keep_accumulation_in_the_informative_range(gpu, workload, density_bias):
+    """SURVEY 8(d) asks for `0.05 < accumulation.mean() < 0.95` lest the accumulation gate be vacuous; the benchmark scene (density bias +4,
+    far plane 1000) is opaque by the far plane -- accumulation 1.000 in every pixel of both BASELINE frames (profiles/r04_full_frame_parity.txt).
+    The same fields with sigma = 0.01 exp(h0 + bias), bias -2 / -3: mean accumulation 0.77 / 0.42 (64 uniform-in-s samples) and 0.68 / 0.31
+    (behind the proposal sampler), so that (1 - accumulation) x last-sample colour is a real part of every pixel.  Gates: rgb / accumulation
+    RMSE <= 1e-3; the depths live at 10^2 .. 10^3 ray units here, so they are gated in the sampler's own coordinate s (two ulp RMSE; an absolute or a
+    relative gate on d measures the scene's scale, test_config4_depth_error_is_scale_free)."""
+    cfg = scene.benchmark_config(64) if workload == "sheet64" else scene.proposal_config()
+    model, sd = make_model(cfg, gpu, density_bias=density_bias)
+    out, ref = _render_pair(cfg, model, sd, gpu, 72, 128, cam=5, focal=150.0)
+    acc = float(ref["accumulation"].mean())
+    print(f"{workload}, bias {density_bias:+.0f}: mean accumulation {acc:.3f}, rgb rmse {rmse(out['rgb'], ref['rgb']):.2e}, "
+          f"accumulation rmse {rmse(out['accumulation'], ref['accumulation']):.2e}")
+    assert 0.05 < acc < 0.95 and float(ref["rgb"].std()) > 0.05
+    assert rmse(out["rgb"], ref["rgb"]) <= RMSE_TOL and rmse(out["accumulation"], ref["accumulation"]) <= RMSE_TOL
+    n = ref["depth"].numel()
+
+    def spacing(d):   # the sampler's own coordinate, s = 1 - 1 / (2 d) beyond d = 1: one fp32 ulp of s is 2 d^2 x 6e-8 of depth
+        return torch.where(d < 1, d / 2, 1 - 1 / (2 * d))
+
+    for k in ("depth", "expected_depth"):
+        g, w = out[k].double().cpu().reshape(-1), ref[k].double().reshape(-1)
+        rel = (g - w).abs() / w.abs().clamp_min(1e-30)
+        flips = rel > 1e-3
+        r = depth_error_report(out[k].reshape(-1)[~flips], ref[k].reshape(-1)[~flips])
+        print(fmt_report(f"{k} ({int(flips.sum())} median flips excluded)", r))
+        assert int(flips.sum()) <= max(2, n // 2000) and (k != "expected_depth" or int(flips.sum()) == 0), (k, int(flips.sum()))
+        es = (spacing(g[~flips]) - spacing(w[~flips])).abs()
+        print(f"   in the sampler's s coordinate: rmse {float(torch.sqrt(torch.mean(es * es))):.2e}, max {float(es.max()):.2e} (fp32 ulp of s: 6e-8)")
+        gate = 1.2e-7 if k == "depth" else 1e-6   # a bin midpoint (strict bins: ~ulp of s) / a weighted mean of 48 or 64 of them
+        assert float(torch.sqrt(torch.mean(es * es))) <= gate and float(es.max()) <= 20 * gate and r["rel_max"] <= 1e-3, (k, r)
+
+
 def test_state_dict_boundary(gpu):
     """The pipeline's load path (signerf_pipeline.py:93-132): keys filtered, strict=False, appearance table dropped; and
     re-loading different weights changes the render (weights are re-uploaded)."""

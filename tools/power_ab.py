@@ -35,6 +35,12 @@ VARIANTS = {
     "dense8": (None, {"SN_DENSE_LEVELS": "8"}, "fp16x2"),                      # 8 instead of 11 de-hashed levels
     "wide4": (None, {"SN_K1_WIDE": "1"}, "fp16x2"),                            # r04: 8-wave workgroups, FOUR waves per SIMD (tile-sequential MLP, 127 VGPRs)
     "fp32": (None, {}, "fp32"),                                                # exact-fp32 MFMA (320 x 64-cycle MFMAs, no operand splits)
+    # DATA variants of the product binary (r04): the same instruction stream on operands that do not toggle -- which part of the package
+    # power is data activity, and where?  (early termination off in all four, so that every wave marches all 64 samples)
+    "data_base": (None, {"SN_EARLY_TERM": "0"}, "fp16x2"),
+    "zero_weights": (None, {"SN_EARLY_TERM": "0", "SN_POWER_SCENE": "zero_weights"}, "fp16x2"),   # MLP matrices 0 (biases kept): A operands of every MFMA are 0
+    "zero_table": (None, {"SN_EARLY_TERM": "0", "SN_POWER_SCENE": "zero_table"}, "fp16x2"),       # hash table = one constant: every gather returns the same bits
+    "zero_both": (None, {"SN_EARLY_TERM": "0", "SN_POWER_SCENE": "zero_both"}, "fp16x2"),
 }
 
 
@@ -80,7 +86,17 @@ def one(name, seconds):
     cfg = scene.benchmark_config(64)
     cfg.precision = precision
     model = cfg.setup()
-    model.load_state_dict(scene.synthetic_state_dict(cfg, seed=0), strict=False)
+    sd = scene.synthetic_state_dict(cfg, seed=0)
+    tweak = os.environ.get("SN_POWER_SCENE", "")
+    if tweak in ("zero_weights", "zero_both"):
+        for k in sd:
+            if k.endswith(".weight") and ".layers." in k:
+                sd[k] = torch.zeros_like(sd[k])
+    if tweak in ("zero_table", "zero_both"):
+        for k in sd:
+            if k.endswith("hash_table"):
+                sd[k] = torch.full_like(sd[k], 0.5)   # (a constant: nothing toggles on the return path; 0 would defeat the range conditioning)
+    model.load_state_dict(sd, strict=False)
     model = model.to(dev).eval()
     cam = Cameras(scene.benchmark_cameras(8)[:, :3], 800.0, 800.0, 400.0, 400.0, 800, 800).to(dev)[0]
     b = cam.generate_rays(0)
@@ -125,7 +141,7 @@ def one(name, seconds):
     ms = sorted(a.elapsed_time(c) for a, c in ev)
     pw = [p for p, _ in samples if p]
     ck = [c for _, c in samples if c]
-    print(json.dumps({"name": name, "ms_median": statistics.median(ms), "ms_p05": ms[int(0.05 * len(ms))], "launches": len(ms), "ms_late": statistics.median(late),
+    print(json.dumps({"name": name, "effective_precision": model.effective_precision, "ms_median": statistics.median(ms), "ms_p05": ms[int(0.05 * len(ms))], "launches": len(ms), "ms_late": statistics.median(late),
                       "probe_ghz": cyc / (ticks / rate) / 1e9 if ticks > 0 and rate > 0 else None,
                       "power_w": statistics.median(pw) if pw else None, "power_w_max": max(pw) if pw else None,
                       "smi_sclk_mhz": statistics.median(ck) if ck else None, "smi_samples": len(samples)}))
@@ -168,11 +184,13 @@ def main():
     print("variant   ms/launch (2nd half of window)   probe GHz   socket W   W x ms (mJ per frame)   smi sclk MHz   what")
     what = {"base": "product library, fp16x2", "waves2": "2 waves per SIMD", "prio0": "no s_setprio around MFMA clusters", "group8": "64 gathers in flight",
             "dense0": "no de-hashed copies: 128 hashed gathers", "dense8": "8 de-hashed levels", "fp32": "exact-fp32 MFMA",
-            "wide4": "8-wave workgroups, 4 waves per SIMD, tile-sequential MLP (SN_K1_WIDE=1)"}
+            "wide4": "8-wave workgroups, 4 waves per SIMD, tile-sequential MLP (SN_K1_WIDE=1)",
+            "data_base": "product library, early termination off", "zero_weights": "same binary, MLP matrices = 0 (MFMA A operands do not toggle)",
+            "zero_table": "same binary, hash table = one constant (gathers return the same bits)", "zero_both": "same binary, matrices 0 and table constant"}
     for name, rs in rows.items():
         med = lambda k: statistics.median([r[k] for r in rs if r.get(k) is not None]) if any(r.get(k) is not None for r in rs) else float("nan")  # noqa: E731
         ms, ghz, w = med("ms_late"), med("probe_ghz"), med("power_w")
-        print(f"{name:8s}  {ms:7.3f}                        {ghz:6.3f}     {w:7.1f}    {w * ms:8.1f}                {med('smi_sclk_mhz'):7.0f}        {what.get(name, '')}")
+        print(f"{name:8s}  {ms:7.3f}                        {ghz:6.3f}     {w:7.1f}    {w * ms:8.1f}                {med('smi_sclk_mhz'):7.0f}        {what.get(name, '')} [{rs[0].get('effective_precision')}]")
 
 
 if __name__ == "__main__":
