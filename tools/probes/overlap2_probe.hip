@@ -15,6 +15,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define DEV __device__ __forceinline__
 
@@ -75,6 +76,12 @@ DEV void mfma(f32x16& acc, const f16x8& a, const f16x8& b, float fa, float fb) {
     if (MK == 2) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(fa), "v"(fb));
 }
 
+// r04: the 16x16x32 tile (K = 32 per instruction, a FOUR-register accumulator, 16 cycles of matrix pipe): the same MACs as one 32x32x16
+// in two instructions, half of the accumulator read-modify-write traffic
+DEV void mfma_small(f32x4& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
 DEV uint64_t memtime() {
     uint64_t t;
     asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t));
@@ -90,6 +97,7 @@ struct State {
     float x[8];
     f32x2 xp[8];
     f32x16 acc[4];
+    f32x4 acc4[8];
     f16x8 a, b;
     float c1, c2, fa, fb;
     f32x2 cp;
@@ -101,6 +109,7 @@ struct State {
         }
         for (int i = 0; i < 4; ++i)
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int i = 0; i < 8; ++i) acc4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int e = 0; e < 8; ++e) {
             a[e] = (_Float16)(s * 0.01f);
             b[e] = (_Float16)0.5f;
@@ -116,6 +125,7 @@ struct State {
         float r = 0.f;
         for (int i = 0; i < 8; ++i) r += x[i] + xp[i].x + xp[i].y;
         for (int i = 0; i < 4; ++i) r += acc[i][0] + acc[i][15];
+        for (int i = 0; i < 8; ++i) r += acc4[i][0] + acc4[i][3];
         return r;
     }
 };
@@ -256,7 +266,7 @@ static void run_two(int n_m, int n_v, int prio_m, int prio_v, uint64_t* cyc, uin
 }
 
 // ---- C: phases, W waves per SIMD all running {NA fillers ; NB MFMAs [+ NI fillers each]} ---------------------------------
-template <int VK, int NA, int NB, int NI, int WAVES /*per workgroup*/>
+template <int VK, int NA, int NB, int NI, int WAVES /*per workgroup*/, bool SMALL = false>
 __global__ __launch_bounds__(WAVES * 64) void phases(int mode, int n, uint64_t* cyc, float* out) {
     extern __shared__ float pad[];
     State s;
@@ -271,7 +281,8 @@ __global__ __launch_bounds__(WAVES * 64) void phases(int mode, int n, uint64_t* 
         if (mode & 2) {
 #pragma unroll
             for (int m = 0; m < NB; ++m) {
-                mfma<1>(s.acc[m & 3], s.a, s.b, s.fa, s.fb);
+                if (SMALL) mfma_small(s.acc4[m & 7], s.a, s.b);
+                else mfma<1>(s.acc[m & 3], s.a, s.b, s.fa, s.fb);
 #pragma unroll
                 for (int f = 0; f < NI; ++f) filler<VK>(s.x[(m * NI + f) & 7], s.xp[(m * NI + f) & 7], s.c1, s.c2, s.cp);
             }
@@ -283,9 +294,9 @@ __global__ __launch_bounds__(WAVES * 64) void phases(int mode, int n, uint64_t* 
     if (r == 123.456f) out[0] = r + pad[0];
 }
 
-template <int VK, int NA, int NB, int NI, int WAVES>
+template <int VK, int NA, int NB, int NI, int WAVES, bool SMALL = false>
 static void run_phases(int n, uint64_t* cyc, float* out) {
-    auto k = phases<VK, NA, NB, NI, WAVES>;
+    auto k = phases<VK, NA, NB, NI, WAVES, SMALL>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -304,8 +315,8 @@ static void run_phases(int n, uint64_t* cyc, float* out) {
         }
         ms[mode] = best;
     }
-    printf("C phases     %-14s %d waves/SIMD, per iteration %d fillers then %d MFMA(f16) with %d fillers each | ms: A %.3f  B %.3f  both %.3f (sum %.3f max %.3f)\n",
-           kind_name[VK], WAVES / 4, NA, NB, NI, ms[1], ms[2], ms[3], ms[1] + ms[2], std::max(ms[1], ms[2]));
+    printf("C phases     %-14s %d waves/SIMD, per iteration %d fillers then %d MFMA(%s) with %d fillers each | ms: A %.3f  B %.3f  both %.3f (sum %.3f max %.3f)\n",
+           kind_name[VK], WAVES / 4, NA, NB, SMALL ? "16x16x32 f16" : "32x32x16 f16", NI, ms[1], ms[2], ms[3], ms[1] + ms[2], std::max(ms[1], ms[2]));
 }
 
 int main(int argc, char** argv) {
@@ -328,6 +339,18 @@ int main(int argc, char** argv) {
         run_phases<F_FMA, 232, 6, 0, 12>(2000, cyc, out);
         run_phases<F_FMA, 512, 120, 0, 12>(1000, cyc, out);    // K1-shaped, for the same box
         run_phases<F_PKFMA, 512, 120, 0, 12>(1000, cyc, out);
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'm') {
+        // r04: K1's wave-step {~900 VALU of hash phase and compositing ; 120 MFMAs with the ~480 MLP VALU between them} with the MLPs' products as
+        // 32x32x16 tiles (today) and as twice as many 16x16x32 tiles (the candidate of DESIGN.md 9 item 2a): the same MACs, half the accumulator traffic
+        for (int rep = 0; rep < 2; ++rep) {
+            run_phases<F_FMA, 900, 120, 4, 12>(1000, cyc, out);
+            run_phases<F_FMA, 900, 240, 2, 12, true>(1000, cyc, out);
+            run_phases<F_FMA, 964, 216, 2, 12, true>(1000, cyc, out);   // ... density layer 2 without its zero rows (-24), 32 more half-rate swaps as 64 fillers
+            run_phases<F_FMA, 0, 120, 0, 12>(1000, cyc, out);          // the MFMAs alone
+            run_phases<F_FMA, 0, 240, 0, 12, true>(1000, cyc, out);
+        }
         return 0;
     }
     // A: fillers alone (issue cost of each kind), then beside the f16 MFMA and the f32 MFMA
