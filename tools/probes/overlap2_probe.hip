@@ -348,6 +348,11 @@ int main(int argc, char** argv) {
             run_phases<F_FMA, 900, 120, 4, 12>(1000, cyc, out);
             run_phases<F_FMA, 900, 240, 2, 12, true>(1000, cyc, out);
             run_phases<F_FMA, 964, 216, 2, 12, true>(1000, cyc, out);   // ... density layer 2 without its zero rows (-24), 32 more half-rate swaps as 64 fillers
+            // the same 1380 VALU + 120 MFMAs with the hash-phase VALU spread BETWEEN the MFMAs (what a software-pipelined K1 would issue: sample i + 1's
+            // hash arithmetic inside sample i's MLP), at 3 and at 2 waves per SIMD (the pipelined kernel needs ~80 more registers: 2 waves)
+            run_phases<F_FMA, 60, 120, 11, 12>(1000, cyc, out);
+            run_phases<F_FMA, 900, 120, 4, 8>(1000, cyc, out);
+            run_phases<F_FMA, 60, 120, 11, 8>(1000, cyc, out);
             run_phases<F_FMA, 0, 120, 0, 12>(1000, cyc, out);          // the MFMAs alone
             run_phases<F_FMA, 0, 240, 0, 12, true>(1000, cyc, out);
         }
