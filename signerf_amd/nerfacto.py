@@ -15,6 +15,8 @@ The modules below hold the parameters under nerfstudio's torch-path state-dict n
 
 from __future__ import annotations
 
+import re
+
 import ctypes as C
 import threading
 import warnings
@@ -435,13 +437,43 @@ class NerfactoModel(nn.Module):
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> dict:
         raise NotImplementedError("training losses are outside the render path (SURVEY.md §2 row 8)")
 
+    # nerfstudio's MLPWithHashEncoding may register its torch-path pair as `model = nn.Sequential(encoder, mlp)` [NS-RECALL, M] -- a checkpoint then
+    # holds `<...>.mlp_base.model.0.hash_table` / `<...>.mlp_base.model.1.layers.N.{weight,bias}` instead of (or beside) the `encoder.` / `mlp.` names
+    # this package uses.  Both spellings load: an alias is renamed when its canonical key is absent and dropped when it is present (same tensor).
+    _KEY_ALIASES = ((re.compile(r"^(.*\.mlp_base)\.model\.0\.(hash_table)$"), r"\1.encoder.\2"),
+                    (re.compile(r"^(.*\.mlp_base)\.model\.1\.(layers\.\d+\.(?:weight|bias))$"), r"\1.mlp.\2"))
+
+    @classmethod
+    def _canonical_keys(cls, state_dict):
+        out = {}
+        for k, v in state_dict.items():
+            for pat, rep in cls._KEY_ALIASES:
+                if pat.match(k):
+                    canon = pat.sub(rep, k)
+                    if canon not in state_dict:
+                        out[canon] = v
+                    break
+            else:
+                out[k] = v
+        return out
+
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         if any(k.endswith(".params") for k in state_dict):  # a tiny-cuda-nn checkpoint (flat parameter vectors)
             from .tcnn_import import convert_tcnn_state_dict
 
             state_dict = convert_tcnn_state_dict(state_dict, self.config)
+        state_dict = self._canonical_keys(state_dict)
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         self._weights_dirty = True
+        # strict=False is how the reference loads (signerf_pipeline.py:131): a FIELD parameter that is not in the checkpoint keeps its random
+        # initialisation without a word from torch, and the render is noise.  The keys the reference strips on purpose (the appearance table,
+        # the camera optimiser; the proposal nets only before retraining, :126-129) are not field weights of the render and are not reported.
+        lost = [k for k in out.missing_keys if k.startswith(("field.mlp_base.", "field.mlp_head.", "proposal_networks."))]
+        if lost:
+            mods = sorted({".".join(k.split(".")[:3 if k.startswith("proposal") else 2]) for k in lost})
+            warnings.warn(f"load_state_dict: {len(lost)} render parameters are not in the state dict and keep their random initialisation "
+                          f"({', '.join(mods)}; e.g. {lost[0]!r}) -- renders through these modules are meaningless until they are loaded",
+                          RuntimeWarning, stacklevel=2)
         return out
 
     def _apply(self, fn, *a, **kw):

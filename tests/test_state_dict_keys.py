@@ -1,0 +1,56 @@
+"""`NerfactoModel.load_state_dict` at the drop-in boundary (signerf_pipeline.py:93-132 loads with strict=False): both spellings of the
+torch-path MLPWithHashEncoding keys load, and render parameters that a checkpoint does not hold are REPORTED -- torch's strict=False would
+leave them at their random initialisation without a word.  CPU only: no render is made."""
+import warnings
+
+import pytest
+import torch
+
+from helpers import small_config
+from signerf_amd import scene
+
+
+def _model_and_sd(**kw):
+    cfg = small_config(**kw)
+    return cfg, cfg.setup(), scene.synthetic_state_dict(cfg, seed=3)
+
+
+def test_canonical_keys_load_silently_and_the_stripped_keys_are_not_reported():
+    cfg, model, sd = _model_and_sd()
+    sd = dict(sd)
+    del sd["field.embedding_appearance.embedding.weight"]      # signerf_pipeline.py:110-111
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        res = model.load_state_dict(sd, strict=False)
+    assert "field.embedding_appearance.embedding.weight" in res.missing_keys and not res.unexpected_keys
+    assert torch.equal(model.field.mlp_base.encoder.hash_table.detach(), sd["field.mlp_base.encoder.hash_table"])
+
+
+def test_sequential_spelling_of_the_hash_mlp_keys_is_accepted():
+    cfg, model, sd = _model_and_sd()
+    alias = {}
+    for k, v in sd.items():
+        k = k.replace(".mlp_base.encoder.hash_table", ".mlp_base.model.0.hash_table").replace(".mlp_base.mlp.layers.", ".mlp_base.model.1.layers.")
+        alias[k] = v
+    assert not any(".mlp_base.encoder." in k or ".mlp_base.mlp." in k for k in alias)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        res = model.load_state_dict(alias, strict=False)
+    assert not res.unexpected_keys and not [k for k in res.missing_keys if "mlp" in k or "hash_table" in k], res
+    assert torch.equal(model.field.mlp_base.mlp.layers[1].weight.detach(), sd["field.mlp_base.mlp.layers.1.weight"])
+    assert torch.equal(model.proposal_networks[1].mlp_base.encoder.hash_table.detach(), sd["proposal_networks.1.mlp_base.encoder.hash_table"])
+    # both spellings at once (a module that registers encoder, mlp AND the Sequential): the duplicates are the same tensors and are dropped
+    both = dict(sd)
+    both.update(alias)
+    res = model.load_state_dict(both, strict=False)
+    assert not res.unexpected_keys and not [k for k in res.missing_keys if "mlp" in k or "hash_table" in k], res
+
+
+def test_missing_render_parameters_are_reported():
+    cfg, model, sd = _model_and_sd()
+    partial = {k: v for k, v in sd.items() if not k.startswith("proposal") and "mlp_head.layers.2" not in k}   # :126-129 strips `proposal*`
+    with pytest.warns(RuntimeWarning, match=r"render parameters are not in the state dict.*field\.mlp_head.*proposal_networks\.0\.mlp_base"):
+        res = model.load_state_dict(partial, strict=False)
+    assert any(k.startswith("proposal_networks.1") for k in res.missing_keys)
+    with pytest.raises(RuntimeError):     # strict=True stays torch's error
+        model.load_state_dict(partial, strict=True)
