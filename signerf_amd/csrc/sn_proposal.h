@@ -479,8 +479,23 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
     float* __restrict__ B1 = sc + SN_PROP_SCRATCH_B1;
     const int tw = 1 << p.tile_w_log2;
 
+#ifndef SN_PROP_XCD
+#define SN_PROP_XCD 0   // experiment (r04, tools/ab_k2.sh): XCD-banded tile order, see below
+#endif
+    // Default: wave w of the grid walks tiles w, w + n_waves, ...  SN_PROP_XCD: the dispatcher places block b on XCD b % 8 -- every XCD gets a
+    // contiguous band of tiles and its waves walk the band together, so that the tiles in flight on one XCD are neighbours and share its L2 (the
+    // main kernel's sn_xcd_remap, for persistent waves).  A bijection of [0, n_tiles) whenever the grid is a multiple of 8 blocks.
+    int t_first = wave_global, t_stride = n_waves, t_base = 0, t_len = n_tiles;
+    if (SN_PROP_XCD && ((int)gridDim.x & 7) == 0) {
+        const int xcd = (int)blockIdx.x & 7, qn = n_tiles >> 3, rn = n_tiles & 7;
+        t_first = ((int)blockIdx.x >> 3) * SN_PROP_WAVES + wave;
+        t_stride = ((int)gridDim.x >> 3) * SN_PROP_WAVES;
+        t_base = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
+        t_len = qn + (xcd < rn ? 1 : 0);
+    }
 #pragma unroll 1
-    for (int tile = wave_global; tile < n_tiles; tile += n_waves) {
+    for (int t_it = t_first; t_it < t_len; t_it += t_stride) {
+        const int tile = t_base + t_it;
         const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
         const int px = (tx << p.tile_w_log2) + (lane & (tw - 1));
         const int py = (ty << p.tile_h_log2) + (lane >> p.tile_w_log2);
