@@ -343,9 +343,10 @@ int sn_debug_read(SnHandle h, int32_t which, int32_t what, void* dst, size_t byt
 int sn_debug_reload_env(SnHandle h);
 
 /* ---- measurement aid (bench.py's issue roofs need the clock the chip actually sustains under the render) ------------------
- * Enqueues a ONE-WAVE kernel that idles for `seconds` (<= 1) of the device's constant-rate wall clock and reports how many shader
- * cycles passed meanwhile: out[0] = shader cycles (s_memtime), out[1] = wall-clock ticks (s_memrealtime), out[2] = wall-clock
- * rate in Hz.  out: 3 x uint64 in DEVICE memory.  Launch it on a side stream just before the renders to be clocked. */
+ * Enqueues eight ONE-WAVE workgroups (one per XCD: the dies of one part run at different clocks under load) that idle for `seconds` (<= 1)
+ * of the device's constant-rate wall clock and report how many shader cycles passed meanwhile: out[0] = shader cycles (s_memtime) and
+ * out[1] = wall-clock ticks (s_memrealtime), both SUMMED over the eight, out[2] = wall-clock rate in Hz -- out[0] / out[1] * out[2] is the
+ * mean shader clock.  out: 3 x uint64 in DEVICE memory (zeroed by the call).  Launch it on a side stream just before the renders to be clocked. */
 int sn_clock_probe(uint64_t* out, double seconds, SnStream stream);
 
 /* ---- the mask + condition step after the render, "aabb" masking mode ------------------

@@ -1778,7 +1778,10 @@ int sn_debug_read(SnHandle h, int32_t which, int32_t what, void* dst, size_t byt
     return SN_OK;
 }
 
-// one wave: shader-clock cycles (s_memtime) elapsed while the constant-rate wall clock (s_memrealtime) advances by `ticks`
+// one wave per workgroup: shader-clock cycles (s_memtime) elapsed while the constant-rate wall clock (s_memrealtime) advances by `ticks`.
+// EIGHT workgroups, one per XCD (the dispatcher places block b on XCD b % 8): the XCDs of one part do not run at one clock under load
+// (measured r04, profiles/r04_power_data_activity.txt: 1.84 .. 1.99 GHz side by side, persistently), so a single wave reports whichever die it
+// lands on; the sums over the eight give the mean.
 __global__ void sn_clock_probe_kernel(unsigned long long* out, unsigned long long ticks) {
     const unsigned long long r0 = wall_clock64();
     const unsigned long long c0 = __builtin_readcyclecounter();
@@ -1786,8 +1789,8 @@ __global__ void sn_clock_probe_kernel(unsigned long long* out, unsigned long lon
     const unsigned long long c1 = __builtin_readcyclecounter();
     const unsigned long long r1 = wall_clock64();
     if (threadIdx.x == 0) {
-        out[0] = c1 - c0;
-        out[1] = r1 - r0;
+        atomicAdd(&out[0], c1 - c0);
+        atomicAdd(&out[1], r1 - r0);
     }
 }
 
@@ -1798,8 +1801,11 @@ int sn_clock_probe(uint64_t* out, double seconds, SnStream stream) {
         return fail(nullptr, SN_ERR_HIP, "sn_clock_probe: cannot read the wall-clock rate of the device");
     const unsigned long long rate = (unsigned long long)khz * 1000ull;
     const unsigned long long ticks = (unsigned long long)(seconds * (double)rate);
-    hipLaunchKernelGGL(sn_clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out, ticks);
-    hipError_t e = hipGetLastError();
+    hipError_t e = hipMemsetAsync(out, 0, 16, (hipStream_t)stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(sn_clock_probe_kernel, dim3(8), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out, ticks);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(out + 2, &rate, 8, hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_clock_probe: ") + hipGetErrorString(e));
     return SN_OK;
