@@ -1,5 +1,6 @@
 #!/bin/bash
 # Experiment (r04): does it pay to split K1's tiles between the XCDs in proportion to the clock each die sustains under load, instead of 1/8 each?
+# Needs the kernel-side knob: `patch -p0 < tools/patches/xcd_weights_experiment.patch && python -m signerf_amd.build --force` (r04: measured, no gain, not kept in the library).
 #   1. per-XCD clocks under the back-to-back bench frame (amd-smi, mean of 8 samples)   2. bench.py with SN_XCD_WEIGHTS = those clocks, = equal, = the
 #   inverse (sanity: must be slower), interleaved.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
