@@ -404,7 +404,7 @@ def main():
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
     def sustained_clock_ghz(frames: int = 12) -> float:
-        """Shader clock the chip sustains under this render: sn_clock_probe's one wave on a side stream counts shader cycles against
+        """Shader clock the chip sustains under this render: sn_clock_probe's eight waves (one per XCD) on a side stream count shader cycles against
         the constant-rate wall clock while `frames` renders run on the main stream."""
         lib = _lib.load()
         ms = statistics.median(a.elapsed_time(b) for a, b in render_ms) if render_ms else 5.0
