@@ -56,14 +56,14 @@ def compare(name, got, ref, depth_like):
     return row
 
 
-def run(workload, dev):
+def run(workload, dev, camera=0):
     if workload == "sheet64":
         cfg, W, H, focal = scene.benchmark_config(64), 800, 800, 800.0
     else:
         cfg, W, H = scene.proposal_config(), 1920, 1080
         focal = 1.2 * H
     model, sd = make_model(cfg, dev)
-    cam = Cameras(scene.benchmark_cameras(8)[:, :3], focal, focal, W / 2, H / 2, W, H).to(dev)[0]
+    cam = Cameras(scene.benchmark_cameras(8)[:, :3], focal, focal, W / 2, H / 2, W, H).to(dev)[camera]
     b = cam.generate_rays(camera_indices=0, aabb_box=model.render_aabb)
     out = model.get_outputs_for_camera_ray_bundle(b)
     torch.cuda.synchronize()
@@ -73,7 +73,7 @@ def run(workload, dev):
     keys = [("rgb", False), ("accumulation", False), ("depth", True), ("expected_depth", True)]
     keys += [(f"prop_depth_{i}", True) for i in range(cfg.num_proposal_iterations)]
     rows = [compare(k, out[k], ref[k], dl) for k, dl in keys]
-    return {"workload": workload, "frame": [W, H], "rays": W * H, "oracle_seconds": secs, "oracle_threads": torch.get_num_threads(),
+    return {"workload": workload, "camera": camera, "frame": [W, H], "rays": W * H, "oracle_seconds": secs, "oracle_threads": torch.get_num_threads(),
             "oracle_chunk_rays": cfg.eval_num_rays_per_chunk, "precision": cfg.precision, "outputs": rows,
             "rgb_std": float(ref["rgb"].std()), "accumulation_mean": float(ref["accumulation"].mean())}
 
@@ -81,17 +81,18 @@ def run(workload, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None, choices=["sheet64", "nerfacto1080"])
+    ap.add_argument("--cameras", default="0", help="comma-separated cameras of the 8-camera reference sheet (BASELINE configs[2]: the eight circle_poses views)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "full_frame_parity.txt"))
     a = ap.parse_args()
     torch.set_num_threads(granted_cpus())
     dev = torch.device("cuda", 0)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
-        for w in ([a.only] if a.only else ["sheet64", "nerfacto1080"]):
-            r = run(w, dev)
+        for w, c in [(w, int(c)) for w in ([a.only] if a.only else ["sheet64", "nerfacto1080"]) for c in a.cameras.split(",")]:
+            r = run(w, dev, c)
             f.write(json.dumps(r) + "\n")
             f.flush()
-            print(f"== {w}: {r['frame'][0]} x {r['frame'][1]}, oracle {r['oracle_seconds']:.0f} s on {r['oracle_threads']} threads "
+            print(f"== {w}, camera {c}: {r['frame'][0]} x {r['frame'][1]}, oracle {r['oracle_seconds']:.0f} s on {r['oracle_threads']} threads "
                   f"(rgb std {r['rgb_std']:.3f}, mean accumulation {r['accumulation_mean']:.3f})")
             for row in r["outputs"]:
                 extra = (f" | bin jumps {row['bin_jumps']}, rel rmse {row['rel_rmse_without_jumps']:.2e}, rel max {row['rel_max_without_jumps']:.2e}"
