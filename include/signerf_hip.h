@@ -153,6 +153,13 @@ typedef struct SnRenderOpts {
      * UniformLinDispPiecewiseSampler (s(x) = x / 2 below 1, 1 - 1 / (2 x) above); 1 = "uniform", UniformSampler (s(x) = x).  Every
      * spacing bin of the proposal chain maps to a distance through it: t = s^-1(b s(far) + (1 - b) s(near)). */
     int32_t spacing_mode;
+    /* March statistics (appended in r05; NULL = none): DEVICE pointer to 3 uint64 counters the render ADDS to (the caller zeroes them):
+     * the wave-steps (one sample of each of the 64 rays of an 8x8 tile) that the exact early termination of saturated waves
+     * (SN_EARLY_TERM) SKIPPED in [0] the main kernel, [1] proposal level 0, [2] proposal level 1.  A full march is tiles x samples of
+     * the level wave-steps (tiles = ceil(W / 8) x ceil(H / 8); H < 8: ceil(W / 64) x H).  One atomic where a wave stops, nothing on
+     * the path of a wave that does not.  Diagnostics: bench.py's `trained` leg and tests/test_gpu_trained.py report the skipped
+     * fraction with it. */
+    uint64_t* march_stats;
 } SnRenderOpts;
 
 /* ---- lifetime -------------------------------------------------------------------------- */

@@ -358,7 +358,7 @@ def hash_scalings(num_levels: int, base_res: int, max_res: int) -> Tensor:
 
 def hash_fn(coords: Tensor, table_size: int, level_offsets: Tensor) -> Tensor:
     """coords [...,L,3] int32 -> table row [...,L] int64 (products in int64)."""
-    c = coords * torch.tensor(HASH_PRIMES, dtype=torch.int64)
+    c = coords * torch.tensor(HASH_PRIMES, dtype=torch.int64, device=coords.device)
     x = torch.bitwise_xor(c[..., 0], c[..., 1])
     x = torch.bitwise_xor(x, c[..., 2])
     x = x % table_size
@@ -374,8 +374,8 @@ def hash_corner_indices(q: Tensor, scalings: Tensor, log2_hashmap_size: int):
     """
     table_size = 2**log2_hashmap_size
     num_levels = scalings.shape[0]
-    level_offsets = torch.arange(num_levels) * table_size
-    scaled = q[..., None, :] * scalings.view(-1, 1)
+    level_offsets = torch.arange(num_levels, device=q.device) * table_size
+    scaled = q[..., None, :] * scalings.to(q.device).view(-1, 1)   # (the device: tools/make_trained_scene.py fits this function with autograd on a GPU)
     sc = torch.ceil(scaled).type(torch.int32)
     sf = torch.floor(scaled).type(torch.int32)
     offset = scaled - sf
@@ -528,7 +528,7 @@ def pdf_sample(existing_bins: Tensor, weights: Tensor, num_samples: int, histogr
 def sh_components(directions: Tensor, levels: int = 4) -> Tensor:
     """Real SH basis up to ``levels`` (A13), evaluated on whatever it is handed."""
     n = levels**2
-    comp = torch.zeros((*directions.shape[:-1], n), dtype=directions.dtype)
+    comp = torch.zeros((*directions.shape[:-1], n), dtype=directions.dtype, device=directions.device)
     x, y, z = directions[..., 0], directions[..., 1], directions[..., 2]
     xx, yy, zz = x**2, y**2, z**2
     comp[..., 0] = 0.28209479177387814
@@ -566,7 +566,7 @@ def field_rgb(params: Dict[str, Tensor], cfg: NerfactoConfig, directions: Tensor
     d = direction_encoding(directions, cfg)[:, None, :].expand(R, N, -1)
     geo = mlp_out[..., 1 : 1 + cfg.geo_feat_dim]
     app = params["field.embedding_appearance.embedding.weight"].mean(dim=0)
-    app = torch.ones((R, N, cfg.appearance_embed_dim)) * app
+    app = torch.ones((R, N, cfg.appearance_embed_dim), device=app.device) * app
     if cfg.mlp_precision == "fp16":
         h = torch.cat([d, geo], dim=-1).reshape(R * N, -1)
         rgb = mlp_forward(h, params, "field.mlp_head", 3, out_activation="sigmoid", half=True, fp32_tail=app.reshape(R * N, -1))

@@ -67,6 +67,7 @@ class SnRenderOpts(C.Structure):
         ("background_mode", C.c_int32),
         ("background_rgb", C.c_float * 3),
         ("spacing_mode", C.c_int32),
+        ("march_stats", C.c_void_p),
     ]
 
 

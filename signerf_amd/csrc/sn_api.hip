@@ -1412,6 +1412,7 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     pp.scratch = (float*)(ws + wp.off_prop_scratch);
     pp.cache_off = h->sw.prop_cache_off.load(std::memory_order_relaxed);
     pp.early_term = h->sw.early_term.load(std::memory_order_relaxed);
+    pp.march_stats = (unsigned long long*)opts->march_stats;
     pp.spacing_uniform = opts->spacing_mode;
     pp.pm = h->pos_map;
     pp.pdf_ieee = h->sw.pdf_ieee.load(std::memory_order_relaxed);
@@ -1566,6 +1567,7 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     p.chunk_rays = opts->chunk_rays;
     p.bg_mode = opts->background_mode;
     p.early_term = h->sw.early_term.load(std::memory_order_relaxed);
+    p.march_stats = (unsigned long long*)opts->march_stats;
     for (int c = 0; c < 3; ++c) p.bg[c] = opts->background_rgb[c];
     const bool tcnn = d.main_field.grid_mode == 1;
     // de-hashed copies are used when they cover every level tiny-cuda-nn indexes densely (always true for torch grids and for nerfacto's

@@ -1033,6 +1033,7 @@ struct SnMainParams {
     int seg_first_block, n_seg, seg_len;
     f32x4* seg_scratch;
     int early_term;   // exact early termination of saturated waves (below); 0 = off (SN_EARLY_TERM=0: the A/B and bit-identity switch)
+    unsigned long long* march_stats;  // SnRenderOpts.march_stats ([0]: wave-steps this kernel's early termination skipped) or null
     int bg_mode;      // RGBRenderer background: 0 = the ray's last sample, 1 = the constant colour bg
     float bg[3];
     int spacing_uniform;  // SnRenderOpts.spacing_mode: the initial sampler's s(x) is the identity (sn_spacing)
@@ -1348,6 +1349,7 @@ void sn_render_main_kernel(SnMainParams p) {
         // densities are O(1): max cumsum(tau) < 88), so the check costs it one v_cmp and one branch per step.  Segment jobs store every
         // sample and the DUMP instantiations record every fetch: not for them.
         if (!DUMP && ABLATE == 0 && p.early_term && !seg_out && i < i_hi - 2 && __all(comp.last_trans == 0.0f)) {
+            if (p.march_stats && lane == 0) atomicAdd(&p.march_stats[0], (unsigned long long)(i_hi - 2 - i));  // (here, not behind the loop: no state carried)
             i = i_hi - 2;
             t0 = bin(i_hi - 1);
         }

@@ -336,6 +336,7 @@ struct SnPropParams {
     float near_plane, far_plane, avg_density, hist_pad;
     int pdf_ieee;   // test switch (SN_PDF_IEEE=1): the resampler divides with the plain IEEE sequence instead of sn_pdf_lane's RECIP form
     int early_term; // exact early termination of saturated waves (sn_prop_level); 0 = off (SN_EARLY_TERM=0)
+    unsigned long long* march_stats;  // SnRenderOpts.march_stats ([1 + LV]: wave-steps the early termination of level LV skipped) or null
     int cache_off;  // test switch: the coefficient cache re-fetches on every step (tests/test_gpu_render.py compares the two bit for bit)
     int spacing_uniform;  // SnRenderOpts.spacing_mode (sn_spacing)
     SnPosMap pm;          // SnFieldDesc.disable_scene_contraction (sn_sample_q_fast)
@@ -427,6 +428,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
         // every ray of the wave, so every later weight is exactly +0 -- written as such, and added to the padded sum one by one as the
         // full march does (fp64 additions of the same constant, the same roundings); cumsum(w) and the median count stay what they are.
         if (!DUMP && p.early_term && __all(trans == 0.0f)) {
+            if (p.march_stats && (threadIdx.x & 63) == 0) atomicAdd(&p.march_stats[1 + LV], (unsigned long long)(N - 1 - i));
             for (int k = i + 1; k < N; ++k) {
 #pragma clang fp contract(off)
                 swp += (double)(0.0f + p.hist_pad);

@@ -625,6 +625,8 @@ class NerfactoModel(nn.Module):
         bg = BACKGROUNDS[cfg.background_color]
         o.background_mode = 0 if bg is None else 1
         o.spacing_mode = INITIAL_SAMPLERS[cfg.proposal_initial_sampler]
+        stats = getattr(self, "_march_stats", None)   # diagnostics (ops.render_with_march_stats): 6 int64 counters the kernels add to
+        o.march_stats = stats.data_ptr() if stats is not None else None
         for c in range(3):
             o.background_rgb[c] = 0.0 if bg is None else bg[c]
         bins0, us = self._grids(n_levels)

@@ -203,3 +203,26 @@ def reload_env(model) -> None:
     sn_finalize_weights only) -- for tests that flip one between two renders of the same model."""
     lib = model._ensure_engine()
     _lib.check(lib.sn_debug_reload_env(model._handle), model._handle, "sn_debug_reload_env")
+
+
+def render_with_march_stats(model, ray_bundle):
+    """``Model.get_outputs_for_camera_ray_bundle`` with ``SnRenderOpts.march_stats`` set: returns (outputs, {kernel: (wave-steps executed,
+    wave-steps of the full march)}) for "K1" and, with proposal nets, "K2 level 0" / "K2 level 1".  executed < full only through the exact
+    early termination of saturated waves.  A diagnostic: not thread-safe against other renders of the same model."""
+    stats = torch.zeros(3, dtype=torch.int64, device=model.device)
+    model._march_stats = stats
+    try:
+        out = model.get_outputs_for_camera_ray_bundle(ray_bundle)
+        torch.cuda.synchronize(model.device)
+    finally:
+        model._march_stats = None
+    skipped = [int(x) for x in stats.tolist()]
+    H, W = ray_bundle.origins.shape[:2]
+    tiles = ((W + 7) // 8) * ((H + 7) // 8) if H >= 8 else ((W + 63) // 64) * H   # the kernels' tile geometry (csrc/sn_api.hip tile_geometry)
+    cfg = model.config
+    full = tiles * cfg.num_nerf_samples_per_ray
+    res = {"K1": (full - skipped[0], full)}
+    for lv in range(cfg.num_proposal_iterations):
+        full = tiles * cfg.num_proposal_samples_per_ray[lv]
+        res[f"K2 level {lv}"] = (full - skipped[1 + lv], full)
+    return out, res
