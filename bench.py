@@ -118,10 +118,54 @@ def other_configs(precision):
     out.append({"config": "tiny-cuda-nn grid (SURVEY 8(f) row 2), 800x800x64: fp32-grade default vs the opt-in single-fp16 mode", "error": err} if d is None else
                dict({"config": "tiny-cuda-nn grid (SURVEY 8(f) row 2), 800x800x64: fp32-grade default vs the opt-in single-fp16 mode (NOT fp32-grade, never the headline)",
                      "command": "tools/tcnn_modes_bench.py --rounds 12 (child process)"}, **d))
+    out.append(trained_leg())
+    out.append(big_table_leg(precision))
     return out
 
 
-def inrun_traffic(precision, kernel_pattern="sn_render_main_kernel"):
+def trained_leg():
+    """r05: the TRAINED scene (tools/make_trained_scene.py: the torch-path field + proposal nets fitted to an analytic scene with surfaces and
+    empty space -- the regime every real SIGNeRF render is in, README.md:146,170).  `tools/trained_bench.py` in a child process: ms per frame
+    with the exact early termination on / off (interleaved), the fraction of wave-steps it skips per kernel (SnRenderOpts.march_stats)."""
+    d, err = _json_line_of([sys.executable, os.path.join(ROOT, "tools", "trained_bench.py"), "--rounds", "6", "--frames", "5"], 420)
+    if d is None:
+        return {"config": "trained scene (tools/make_trained_scene.py)", "error": err}
+    return dict({"config": "trained scene (tools/make_trained_scene.py): HIP render with the exact early termination on / off",
+                 "command": "tools/trained_bench.py --rounds 6 --frames 5 (child process; fits the scene with torch on the GPU first, untimed)"}, **d)
+
+
+def big_table_leg(precision, log2_t=21):
+    """r05: the headline frame with a 2^21-row table per level -- the library's stated limit (include/signerf_hip.h):
+    256 MiB of table + its de-hashed copies no longer fit the 256 MiB Infinity Cache, so SURVEY 8(d)'s NAMED roof (HBM) can bind and the
+    128-byte request for an 8-byte row becomes visible.  A child `bench.py --log2-hashmap-size 21` for the timing + three in-run rocprofv3
+    PMC passes (TCC_EA0_RDREQ_*, WRITE_SIZE, TCC_HIT / TCC_MISS) of the same command."""
+    me = os.path.abspath(__file__)
+    extra = ["--log2-hashmap-size", str(log2_t)]
+    d, err = _json_line_of([sys.executable, me, "--steps", "12", "--warmup", "3", "--precision", precision, "--no-cpu-baseline", "--no-alt-precision",
+                            "--no-others", "--no-traffic", *extra], 200)
+    name = f"BASELINE configs[1] frame with T = 2^{log2_t} rows per level ({(16 << log2_t) * 8 >> 20} MiB table)"
+    if d is None:
+        return {"config": name, "error": err}
+    k_ms = d["kernel_ms"]["median"]
+    alg = d["roofline_hbm"]["algorithmic_bytes_per_launch"]
+    tr, terr = inrun_traffic(precision, extra_args=extra, with_l2=True)
+    rf = d.get("roofline", {})
+    leg = {"config": name, "command": "bench.py --log2-hashmap-size %d --steps 12 --warmup 3 (child) + rocprofv3 --pmc passes of the same" % log2_t,
+           "ms_per_frame": d["ms_per_step"], "kernel_ms_per_launch": k_ms, "ray_samples_per_s": d["value"],
+           "simd_issue_frac": rf.get("frac"), "simd_issue_frac_at_sustained_clock": rf.get("frac_at_sustained_clock"), "sustained_clock_ghz": rf.get("sustained_clock_ghz"),
+           "algorithmic_bytes_per_launch": alg, "traffic": tr, "traffic_error": terr}
+    if tr:
+        gbps = tr["bytes_per_launch"] / (k_ms * 1e-3) / 1e9
+        leg.update({"traffic_bytes_per_launch": tr["bytes_per_launch"], "traffic_gbps": gbps, "traffic_frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
+                    "traffic_over_algorithmic": tr["bytes_per_launch"] / alg, "l2_hit_rate": tr.get("l2_hit_rate")})
+        hbm, issue = gbps / HBM_PEAK_GBPS, rf.get("frac") or 0.0
+        leg["binding_roof"] = "hbm" if hbm > issue else "simd-issue"
+        leg["note"] = ("fabric bytes (Infinity-Cache hits included: an upper bound of DRAM bytes) over the 8 TB/s HBM peak vs the vector issue port's "
+                       "busy fraction at the 2.4 GHz peak clock; the larger one binds")
+    return leg
+
+
+def inrun_traffic(precision, kernel_pattern="sn_render_main_kernel", extra_args=(), with_l2=False):
     """HBM-side bytes per launch of K1 from rocprofv3 PMC passes collected IN THIS RUN (MI355X_MICROARCH.md "HBM": the L2's memory-side
     request counters, separate --pmc passes, never combined with a system trace): a child `bench.py --steps 3` per pass under
     `rocprofv3 --kernel-trace --pmc ...`.  Reads = sum over size classes of TCC_EA0_RDREQ_{32,64,128}B x size (the size-classed counters need
@@ -139,10 +183,13 @@ def inrun_traffic(precision, kernel_pattern="sn_render_main_kernel"):
     env = dict(os.environ, TMPDIR="/tmp")
     me = os.path.abspath(__file__)
     child = [sys.executable, me, "--steps", "3", "--warmup", "1", "--frames-in-flight", "1", "--precision", precision, "--no-cpu-baseline",
-             "--no-alt-precision", "--no-others", "--no-traffic"]
+             "--no-alt-precision", "--no-others", "--no-traffic", *extra_args]
     acc = {}
+    passes = [("rd", ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]), ("wr", ["WRITE_SIZE"])]
+    if with_l2:   # L2 hit rate of the same dispatches (its own pass, as the guide prescribes)
+        passes.append(("l2", ["TCC_HIT_sum", "TCC_MISS_sum"]))
     try:
-        for name, counters in (("rd", ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]), ("wr", ["WRITE_SIZE"])):
+        for name, counters in passes:
             import subprocess
 
             d = os.path.join(tmp, name)
@@ -159,7 +206,11 @@ def inrun_traffic(precision, kernel_pattern="sn_render_main_kernel"):
         a = {k: sum(v) / len(v) for k, v in acc.items()}
         rd = 32 * a.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * a.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * a.get("TCC_EA0_RDREQ_128B_sum", 0)
         wr = a.get("WRITE_SIZE", 0) * 1024
-        return {"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "launches_averaged": len(next(iter(acc.values())))}, None
+        out = {"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "launches_averaged": len(next(iter(acc.values()))),
+               "read_requests": {k: a[k] for k in sorted(a) if k.startswith("TCC_EA0_RDREQ")}}
+        if with_l2 and a.get("TCC_HIT_sum", 0) + a.get("TCC_MISS_sum", 0) > 0:
+            out["l2_hit_rate"] = a["TCC_HIT_sum"] / (a["TCC_HIT_sum"] + a["TCC_MISS_sum"])
+        return out, None
     except Exception as e:  # noqa: BLE001
         return None, repr(e)
     finally:
@@ -273,7 +324,7 @@ def cpu_baseline(main_cfg, main_sd, width, height, samples, runs=3, runs_config4
            "cgroup_cpu_quota": quota,
            "kind": "port", "host_cpu": cpu, "timer": "time.perf_counter around the render, 1 warm-up + median of the timed renders",
            "sample": f"config 2: centred {crop}x{crop} crop of the {width}x{height}x{samples} frame, median of {len(all2)} renders = {dt2:.1f} s, "
-                     "torch CPU fp32 oracle",
+                     "torch CPU fp32 oracle (BASELINE.md plans the median of 5: `--cpu-runs 5 --cpu-runs-config4 5`); SAMPLE_OTHERS",
            "runs": len(all2), "seconds_each": all2,
            "rays_per_s": crop * crop / dt2,
            "ms_per_frame_extrapolated": dt2 * 1e3 * (width * height) / (crop * crop), "others": []}
@@ -290,6 +341,9 @@ def cpu_baseline(main_cfg, main_sd, width, height, samples, runs=3, runs_config4
                           "runs": len(all4), "seconds": dt4, "seconds_each": all4, "rays_per_s": n4 / dt4,
                           "ray_samples_per_s": n4 * 48 / dt4, "field_evaluations_per_s": n4 * 400 / dt4,
                           "ms_per_frame_extrapolated": dt4 * 1e3 * (1920 * 1080) / n4})
+    out["sample"] = out["sample"].replace("SAMPLE_OTHERS", f"also timed: config 1 in full (64x64x32), median of {len(all1)} renders = {dt1:.2f} s; "
+                                          f"config 4: centred {cw}x{ch} crop of the 1920x1080 frame (256 + 96 + 48 samples), "
+                                          f"{'median of ' + str(len(all4)) + ' renders' if len(all4) > 1 else 'ONE render'} = {dt4:.1f} s (`others`)")
     torch.set_num_threads(old_threads)
     return out
 
@@ -305,6 +359,8 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--samples", type=int, default=None)
+    ap.add_argument("--log2-hashmap-size", type=int, default=None,
+                    help="rows per level of the main hash table (default: nerfacto's 19; 21 = the library's limit, a 256 MiB table that leaves the Infinity Cache)")
     ap.add_argument("--precision", default="fp16x2", choices=["fp32", "fp16x2"],
                     help="MFMA arithmetic of the tiny MLPs: fp16x2 = fp32 operands split into fp16 hi+lo, fp32 accumulate "
                          "(error equals exact fp32 MFMA inside the validated operand range, tests/test_gpu_precision.py); fp32 = exact fp32 MFMA")
@@ -376,6 +432,8 @@ def main():
         focal = 1.2 * args.height
         bytes_per_ray = sum(cfg.num_proposal_samples_per_ray) * 320.0 + args.samples * BYTES_PER_MAIN_SAMPLE  # 161.8 kB
     cfg.precision = args.precision
+    if args.log2_hashmap_size:
+        cfg.log2_hashmap_size = args.log2_hashmap_size
     sd = scene.synthetic_state_dict(cfg, seed=0)
     model = cfg.setup()
     model.load_state_dict(sd, strict=False)
@@ -601,7 +659,7 @@ def main():
                      "Layers range-conditioned into fp16's [2^-3, 65504] by exact power-of-two scales at sn_finalize_weights, exact-fp32 MFMA "
                      "fallback otherwise; error equals exact fp32's (tests/test_gpu_precision.py); the exact-fp32 figure is `alt_precision`",
             "data": "synthetic",
-            "config": {"workload": (f"BASELINE.json configs[1]: {W}x{H} rays x {S} samples/ray, nerfacto hash grid L=16 T=2^19 F=2, "
+            "config": {"workload": (f"BASELINE.json configs[1]: {W}x{H} rays x {S} samples/ray, nerfacto hash grid L=16 T=2^{cfg.log2_hashmap_size} F=2, "
                                     "no proposal nets, random-weight synthetic scene, one camera per GPU + tile all-gather")
                        if args.workload == "sheet64" else
                        (f"BASELINE.json configs[3]: {W}x{H} rays, proposal nets 256 + 96 samples (L=5, T=2^17) + {S} main samples "
@@ -649,7 +707,8 @@ def main():
                                              "source": "profiles/traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ_* / TCC_EA0_WRREQ_*, tools/pmc_summary.py)"}
         inrun, inrun_err = (None, "skipped (--no-traffic)" if args.no_traffic else "N > 1 or not the headline workload")
         if world == 1 and args.workload == "sheet64" and not args.no_traffic:
-            inrun, inrun_err = inrun_traffic(args.precision)
+            inrun, inrun_err = inrun_traffic(args.precision, extra_args=(["--log2-hashmap-size", str(args.log2_hashmap_size)] if args.log2_hashmap_size else []),
+                                             with_l2=True)
         traffic_now = inrun["bytes_per_launch"] if inrun else None
         traffic_source = ("in-run rocprofv3 --pmc passes (child `bench.py --steps 3 --frames-in-flight 1`): TCC_EA0_RDREQ_{32,64,128}B_sum x size "
                           "+ WRITE_SIZE KiB, averaged over the K1 dispatches") if inrun else "not measured in this run (%s); see traffic_committed_profile" % inrun_err
@@ -783,6 +842,47 @@ def main():
             line["others"] = other_configs(args.precision)
         if world == 1 and not args.no_cpu_baseline and args.workload == "sheet64":
             line["cpu_baseline"] = cpu_baseline(cfg, sd, W, H, S, args.cpu_runs, args.cpu_runs_config4)
+        # r05: the driver's record keeps `config`, `roofline` and `cpu_baseline` whole and only the NAMES of every other
+        # key -- so the figures a reader needs beside `value` are repeated, compactly, inside `roofline`
+        rf = line["roofline"]
+        rf["one_launch_ms"] = k_med
+        rf["one_launch_ray_samples_per_s"] = W * H * S / (k_med * 1e-3)
+        rf["frames_in_flight"] = max(1, args.frames_in_flight)
+        rf["value_is"] = ("whole-job rate over the timed steps with %d frames in flight on alternating streams; one launch at a time: one_launch_*"
+                          % max(1, args.frames_in_flight))
+        if inrun and inrun.get("l2_hit_rate") is not None:
+            rf["l2_hit_rate"] = inrun["l2_hit_rate"]
+        if traffic_now:
+            rf["traffic_over_algorithmic"] = traffic_now / (W * H * bytes_per_ray)
+            rf["traffic_frac_of_hbm_peak"] = traffic_now / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        alt = line.get("alt_precision")
+        if alt:
+            key = "exact_fp32" if alt["precision"] == "fp32" else "split_fp16x2"
+            rf[key] = {"kernel_ms": alt["kernel_ms"], "ray_samples_per_s": alt["ray_samples_per_s_per_gpu"],
+                       "what": "the same frame in the other MFMA arithmetic, one launch at a time, after the timed region (HIP events, mean of 10)"}
+        if "others" in line:
+            oc = {}
+            for leg in line["others"]:
+                c = leg.get("config", "")
+                if "error" in leg:
+                    oc.setdefault("errors", []).append({"config": c, "error": leg["error"]})
+                elif c.startswith("BASELINE.json configs[3]"):
+                    oc["configs3"] = {"what": "1920x1080, proposal nets 256 + 96 + 48 main samples, random-weight scene", "ms_per_frame": leg["ms_per_frame"],
+                                      "kernel_ms_per_launch": leg["kernel_ms_per_launch"], "field_evaluations_per_s": leg["field_evaluations_per_s"],
+                                      "frac": (leg.get("roofline") or {}).get("frac"), "frac_at_sustained_clock": (leg.get("roofline") or {}).get("frac_at_sustained_clock")}
+                elif c.startswith("BASELINE.json configs[4]"):
+                    oc["configs4"] = {"what": "DatasetGenerator.generate_dataset, 8 reference + 50 views at 800x800, PNG writes off, 1 GPU", "total_ms": leg["total_ms"],
+                                      "ms_per_view": leg["ms_per_view"], "render_ms_per_view": leg.get("render_ms_per_view")}
+                elif c.startswith("trained scene"):
+                    oc["trained"] = {"scene_fit_s": (leg.get("scene") or {}).get("seconds"),
+                                     "legs": [{"frame": x["frame"], "ms_early_term_off": x["ms_per_frame"]["early_term_off"], "ms_early_term_on": x["ms_per_frame"]["early_term_on"],
+                                               "speedup": x["ms_per_frame"]["speedup"], "bit_identical": x["bit_identical_on_vs_off"],
+                                               "skipped_wave_step_fraction": {k: v["skipped_fraction"] for k, v in x["wave_steps"].items()},
+                                               "accumulation_above_0.99": x["picture"]["accumulation_above_0.99"]} for x in leg.get("legs", [])]}
+                elif c.startswith("BASELINE configs[1] frame with T = 2^"):
+                    oc["T21"] = {k: leg.get(k) for k in ("ms_per_frame", "kernel_ms_per_launch", "traffic_bytes_per_launch", "traffic_over_algorithmic",
+                                                         "traffic_frac_of_hbm_peak", "l2_hit_rate", "simd_issue_frac", "binding_roof")}
+            rf["other_configs"] = oc
         if world > 1:
             gather_by_strategy, gather_err = gather_diagnostics(line)
             gather_ms = gather_by_strategy.get(args.gather_strategy)

@@ -302,8 +302,11 @@ class Cameras:
         self._height = (self._height * s).to(torch.int64)
         host = self._host.clone()
         host[:, _H_FX:_H_CY + 1] = host[:, _H_FX:_H_CY + 1] * s
-        host[:, _H_W] = torch.floor(host[:, _H_W].double() * s).float()
-        host[:, _H_H] = torch.floor(host[:, _H_H].double() * s).float()
+        # the SAME arithmetic as the device tensors above -- nerfstudio's `(width * scaling_factor).to(torch.int64)`: an int64 tensor times a
+        # Python float is an fp32 product, truncated -- so that the bundle generate_rays builds from the mirror has the camera's own
+        # width / height (floor(double(W) * s) differs for viewer-style factors, e.g. W = 800, s = 0.0725: 57 vs 58)
+        host[:, _H_W] = (host[:, _H_W].to(torch.int64) * s).to(torch.int64).float()
+        host[:, _H_H] = (host[:, _H_H].to(torch.int64) * s).to(torch.int64).float()
         self._host = host
 
     # -- row a5 ------------------------------------------------------------------------------------------
@@ -360,6 +363,11 @@ class Cameras:
                 shape = tuple(coords.shape[:-1])
                 cflat = coords.to(device=dev, dtype=torch.float32).reshape(-1, 2).contiguous()
                 n = cflat.shape[0]
+                if n == 0:   # (an empty tensor has a NULL data pointer, which the C ABI reads as "coords == NULL: the full image")
+                    z = lambda c, dt=torch.float32: torch.empty((*shape, c), dtype=dt, device=dev)  # noqa: E731
+                    box = aabb_box is not None or obb_box is not None
+                    return RayBundle(origins=z(3), directions=z(3), pixel_area=z(1), camera_indices=z(1, torch.int64), nears=z(1) if box else None,
+                                     fars=z(1) if box else None, metadata={"directions_norm": z(1)}, times=None if self._times is None else z(1))
             else:
                 shape, cflat, n = (H, W), None, H * W
             if keep_shape is False:

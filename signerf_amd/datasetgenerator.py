@@ -422,34 +422,37 @@ class DatasetGenerator:
         cameras = cameras.to(self.device)
 
         sync = self._sync_group(world)   # created while every rank is here: the serial stage below may take hours
-        if rank == 0:
-            self.init_directory()        # before the expensive stage: a missing dependency or an unwritable path fails now
-
-        # Stage 1 (every rank): all NeRF renders, one gather per image size (an original dataset may hold several).  Views beyond the
-        # memory budget are rendered inside the serial loop instead (rank 0 alone): correct, just not sharded.
-        self._views = {}
-        if self.precompute:
-            todo = [reference_cameras[i] for i in range(len(reference_cameras))] + [cameras[i] for i in range(len(cameras))]
-            if merge_with_original_dataset:
-                merged = original_cameras.to(graph.device)
-                todo += [merged[i] for i in range(len(merged))]
-            groups: Dict[Tuple[int, int], List] = {}
-            for c in todo:
-                groups.setdefault((int(c._host[0, 16]), int(c._host[0, 17])), []).append(c)
-            budget = self._precompute_budget_bytes()
-            for (w, h), cams in groups.items():
-                per_view = 3 * 5 * 4 * w * h   # the [n,H,W,5] fp32 tiles + the gather buffer + the reorder copy at their peak
-                fit = int(min(len(cams), budget // per_view))
-                if fit < len(cams):
-                    self.precompute_skipped += len(cams) - fit
-                if fit > 0:
-                    self.precompute_views(graph, cams[:fit])
-                    budget -= fit * per_view
-        if rank != 0:  # the serial stage belongs to the rank that talks to the diffuser and the disk
-            self._finish(world, sync)
-            return
-
+        # From here on EVERY exit path of EVERY rank goes through `_finish`: the idle ranks wait there with a 24 h timeout, so a
+        # rank 0 that raised in init_directory() or in stage 1 -- before the old try block began -- would have parked them.
         try:
+            if rank == 0:
+                self.init_directory()        # before the expensive stage: a missing dependency or an unwritable path fails now
+
+            # Stage 1 (every rank): all NeRF renders, one gather per image size (an original dataset may hold several).  Views beyond the
+            # memory budget are rendered inside the serial loop instead (rank 0 alone): correct, just not sharded.
+            self._views = {}
+            if self.precompute:
+                todo = [reference_cameras[i] for i in range(len(reference_cameras))] + [cameras[i] for i in range(len(cameras))]
+                if merge_with_original_dataset:
+                    merged = original_cameras.to(graph.device)
+                    todo += [merged[i] for i in range(len(merged))]
+                groups: Dict[Tuple[int, int], List] = {}
+                for c in todo:
+                    groups.setdefault((int(c._host[0, 16]), int(c._host[0, 17])), []).append(c)
+                # the number of views per gather must be the SAME on every rank or the per-group collectives desynchronise: the ranks
+                # agree on the smallest budget (total_memory // 4 per device: equal on a homogeneous node, not assumed)
+                budget = self._agreed_budget_bytes(world)
+                for (w, h), cams in groups.items():
+                    per_view = 3 * 5 * 4 * w * h   # the [n,H,W,5] fp32 tiles + the gather buffer + the reorder copy at their peak
+                    fit = int(min(len(cams), budget // per_view))
+                    if fit < len(cams):
+                        self.precompute_skipped += len(cams) - fit
+                    if fit > 0:
+                        self.precompute_views(graph, cams[:fit])
+                        budget -= fit * per_view
+            if rank != 0:  # the serial stage belongs to the rank that talks to the diffuser and the disk
+                return     # (through the finally below: `_finish`)
+
             # Stage 2 (rank 0): the reference's sequence
             transforms = self.dataset.new_transforms(self.original_transform_matrix, self.original_scale_factor, self.is_synthetic,
                                                      merge_with_original_dataset)
@@ -508,7 +511,8 @@ class DatasetGenerator:
         finally:  # also when a diffuser call or a write raised: no worker threads or queued host copies left behind
             self._views = {}
             try:
-                self.dataset.close()
+                if rank == 0 and self.dataset is not None:
+                    self.dataset.close()
             finally:
                 # ... and the idle ranks are released either way: they wait in `_finish` with a 24 h timeout, and a rank 0 that
                 # leaves through an exception without meeting them would park them there (outside torchrun nothing kills them)
@@ -531,6 +535,18 @@ class DatasetGenerator:
         ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
         return dist.new_group(ranks=ranks, backend="gloo", timeout=_dt.timedelta(seconds=float(self.serial_stage_timeout_s)),
                               use_local_synchronization=self.group is not None)
+
+    def _agreed_budget_bytes(self, world: int) -> int:
+        """``_precompute_budget_bytes`` reduced to the minimum over the ranks (one tiny collective per dataset)."""
+        budget = self._precompute_budget_bytes()
+        if world > 1:
+            import torch.distributed as dist
+
+            on_host = dist.get_backend(self.group) == "gloo"
+            t = torch.tensor([budget], dtype=torch.int64, device="cpu" if on_host else torch.device(self.device))
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            budget = int(t.item())
+        return budget
 
     def _precompute_budget_bytes(self) -> int:
         if self.precompute_budget_mb is not None:

@@ -79,6 +79,27 @@ def test_rescale_output_resolution():
     assert cams._host[0, 12] == 25.0 and cams._host[0, 16] == 24 and cams._host[0, 17] == 16
 
 
+def test_rescale_keeps_the_host_mirror_equal_to_the_camera_size():
+    """the size generate_rays uses (the host mirror) must be the camera's own width / height for EVERY factor -- nerfstudio's
+    `(width * s).to(int64)` is an fp32 product, truncated (W = 800, s = 0.0725 -> 58; floor(double(800) * 0.0725) is 57).  Sweep of the
+    viewer-style factors k / W and a grid of plain ones."""
+    bad = []
+    for W, H in ((800, 800), (1920, 1080), (1297, 840)):
+        factors = [k / W for k in range(1, W, 7)] + [i / 997.0 for i in range(1, 997, 5)] + [0.0725, 0.1, 0.3, 1.0 / 3.0, 0.7]
+        for s in factors:
+            cams = Cameras(torch.eye(4)[None, :3], 500.0, 500.0, W / 2, H / 2, W, H)
+            cams.rescale_output_resolution(s)
+            want = ((torch.tensor([W], dtype=torch.int64) * s).to(torch.int64).item(), (torch.tensor([H], dtype=torch.int64) * s).to(torch.int64).item())
+            got_dev = (int(cams.width[0].item()), int(cams.height[0].item()))
+            got_host = (int(cams._host[0, 16]), int(cams._host[0, 17]))
+            if not (got_dev == want == got_host):
+                bad.append((W, H, s, want, got_dev, got_host))
+    assert not bad, bad[:5]
+    cams = Cameras(torch.eye(4)[None, :3], 500.0, 500.0, 400.0, 400.0, 800, 800)
+    cams.rescale_output_resolution(0.0725)
+    assert int(cams.width[0].item()) == int(cams._host[0, 16]) == 58
+
+
 # ---- known-answer tests of the un-distortion restatement (the oracle is unpinned: these anchor it analytically) ---------------------
 def _distort(p, k):
     """The forward OPENCV model the Newton iteration inverts (double precision)."""

@@ -376,6 +376,22 @@ def _worker(rank, world, port, out_dir, mode="synthetic"):
         json.dump({"raised": raised, "seconds": time.perf_counter() - t0}, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
         dist.destroy_process_group()
         return
+    elif mode == "init_raises":   # rank 0 fails BEFORE the serial stage (an unwritable path); nothing is pre-computed, so the
+        # other ranks go straight to the closing barrier and must be met there
+        gen = me._generator(out_dir, "sharded", precompute=False, serial_stage_timeout_s=600.0)
+        if rank == 0:
+            def broken_init():
+                raise PermissionError("cannot create the dataset directory")
+
+            gen.init_directory = broken_init
+        t0, raised = time.perf_counter(), None
+        try:
+            gen.generate_dataset(me._Graph(), ref, synthetic_camera_to_worlds=syn)
+        except PermissionError as e:
+            raised = str(e)
+        json.dump({"raised": raised, "seconds": time.perf_counter() - t0}, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
+        dist.destroy_process_group()
+        return
     else:
         gen = me._generator(out_dir, "sharded", finish_sync=(mode != "nosync"))
         gen.generate_dataset(me._Graph(), ref, synthetic_camera_to_worlds=syn)
@@ -384,7 +400,7 @@ def _worker(rank, world, port, out_dir, mode="synthetic"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_generate_dataset_sharded_over_gloo_equals_single_process(tmp_path, standins, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     ref, syn = _poses()
@@ -430,3 +446,12 @@ def test_rank0_exception_releases_the_idle_ranks(tmp_path, standins):
     r0, r1 = (json.load(open(tmp_path / f"rank{r}.json")) for r in range(2))
     assert r0["raised"] == "diffuser down" and r1["raised"] is None
     assert r1["seconds"] < 60.0
+
+
+def test_rank0_failure_before_the_serial_stage_releases_the_idle_ranks(tmp_path, standins):
+    """world 2, `init_directory` raises on rank 0 (it used to run before the try block that guarantees `_finish`), nothing
+    pre-computed: rank 1 is already in the closing barrier (600 s timeout here) and must be released at once."""
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "init_raises"), nprocs=2, join=True)
+    r0, r1 = (json.load(open(tmp_path / f"rank{r}.json")) for r in range(2))
+    assert r0["raised"] == "cannot create the dataset directory" and r1["raised"] is None
+    assert r0["seconds"] < 60.0 and r1["seconds"] < 60.0

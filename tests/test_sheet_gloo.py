@@ -1,4 +1,4 @@
-"""Multi-rank path on CPU: world_size 2 and 3 over gloo.  The render itself is replaced by a deterministic
+"""Multi-rank path on CPU: world_size 2, 3 and -- r05, the rank count BASELINE configs[2] / [4] name -- 8 over gloo.  The render itself is replaced by a deterministic
 per-camera stand-in (the oracle on a tiny frame for camera 0, a cheap closed form for the rest) -- what is under test is the
 sharding, padding, all-gather and re-ordering logic in signerf_amd/sheet.py, which is identical under RCCL."""
 import os
@@ -47,7 +47,7 @@ def _worker(rank, world, port, n_cameras, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_cameras", [(2, 8), (2, 5), (3, 8), (2, 1)])
+@pytest.mark.parametrize("world,n_cameras", [(2, 8), (2, 5), (3, 8), (2, 1), (8, 8), (8, 58), (8, 5)])   # 8 x 8: one camera per rank (configs[2]); 58 = 8 + 50 views (configs[4]): 7 x 8 + 2, ragged; 5: ranks without a camera
 def test_sharded_sheet_matches_single_rank(tmp_path, world, n_cameras):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n_cameras, str(tmp_path)), nprocs=world, join=True)
@@ -131,7 +131,7 @@ def _row_worker(rank, world, port, H, W, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,H,W", [(2, 40, 12), (3, 50, 7), (2, 7, 5), (3, 8, 4)])
+@pytest.mark.parametrize("world,H,W", [(2, 40, 12), (3, 50, 7), (2, 7, 5), (3, 8, 4), (8, 100, 6), (8, 24, 4)])
 def test_row_sharded_frame_matches_single_rank(tmp_path, world, H, W):
     from signerf_amd import sheet
 
@@ -203,14 +203,14 @@ def test_frame_streams_degrade_to_in_order_execution_on_cpu():
 
 
 # ---- gather strategies: ring all-gather vs direct pushes, identical results -----------------------------------------
-def _strategy_worker(rank, world, port, out_dir):
+def _strategy_worker(rank, world, port, out_dir, n_items=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
     from signerf_amd import sheet
 
-    n_items = 2 * world - 1                       # ragged: the last rank holds one tile fewer
+    n_items = n_items or 2 * world - 1            # ragged: the last rank holds one tile fewer
     mine = sheet.shard_indices(n_items, world, rank)
     local = torch.stack([torch.full((3, 4, 5), float(i)) + torch.arange(5.0) for i in mine])
     got = {}
@@ -228,10 +228,9 @@ def _strategy_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gather_strategies_deliver_the_same_tiles(tmp_path, world):
-    mp.spawn(_strategy_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    n_items = 2 * world - 1
+@pytest.mark.parametrize("world,n_items", [(2, 3), (3, 5), (8, 58), (8, 8)])
+def test_gather_strategies_deliver_the_same_tiles(tmp_path, world, n_items):
+    mp.spawn(_strategy_worker, args=(world, _free_port(), str(tmp_path), n_items), nprocs=world, join=True)
     want = torch.stack([torch.full((3, 4, 5), float(i)) + torch.arange(5.0) for i in range(n_items)])
     for r in range(world):
         got = torch.load(os.path.join(tmp_path, f"strategy_rank{r}.pt"))
