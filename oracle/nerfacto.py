@@ -400,7 +400,9 @@ def hash_corner_indices(q: Tensor, scalings: Tensor, log2_hashmap_size: int):
 def hash_encode(q: Tensor, table: Tensor, scalings: Tensor, log2_hashmap_size: int) -> Tensor:
     """q [P,3] in [0,1) -> [P, L*F] level-major (A7)."""
     _, _, idx, offset = hash_corner_indices(q, scalings, log2_hashmap_size)
-    f = [table[idx[..., k]] for k in range(8)]  # each [P,L,F]
+    # each [P,L,F]; index_select returns the rows table[idx] does -- its BACKWARD is an atomic index_add on a GPU, where advanced indexing
+    # sorts the 8 x L x P indices (tools/make_trained_scene.py fits this function with autograd; forward values are identical)
+    f = [table.index_select(0, idx[..., k].reshape(-1)).view(*idx.shape[:-1], table.shape[-1]) for k in range(8)]
     ox, oy, oz = offset[..., 0:1], offset[..., 1:2], offset[..., 2:3]
     f_03 = f[0] * ox + f[3] * (1 - ox)
     f_12 = f[1] * ox + f[2] * (1 - ox)

@@ -21,8 +21,8 @@ around the analytic hit distance) plus volume and near-surface points.  sigma = 
 (solid), transmittance underflows to an exact 0 a few samples behind every surface, proposal weights are near one-hot: the regime the
 early-termination logic, the PDF merge and the median search of the kernels see in production.
 
-Full-size shapes (L=16, T=2^19; proposal nets T=2^17): the state dict is ~75 MB and is regenerated where it is needed (~20 s on an
-MI355X through torch, minutes on a CPU), cached under $SIGNERF_TRAINED_CACHE (default /tmp).  GPU fits are not bit-reproducible
+Full-size shapes (L=16, T=2^19; proposal nets T=2^17): the state dict is ~75 MB and is regenerated where it is needed (well under a minute
+on an MI355X through torch, ~8 minutes on 8 CPU cores), cached under $SIGNERF_TRAINED_CACHE (default /tmp).  GPU fits are not bit-reproducible
 (atomic scatter-adds), so what is committed is a FINGERPRINT with tolerances (tests/golden/trained_scene_fingerprint.json) and the
 64x64 oracle render of the CPU fit made in the build container (tests/golden/trained_scene_64.npz): a regenerated scene must render
 the same picture (PSNR, silhouette IoU, depth vs the analytic depth), not the same bits.
@@ -47,6 +47,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 SCENE_VERSION = 3
+STEPS, POINTS = 300, 1 << 17      # Adam steps x points per step of the default fit (r05: 400 x 2^18 renders the same picture, 2.5x the time)
 H_IN, H_OUT = 13.0, -9.0          # pre-activation density inside / outside (sigma = average_init_density * exp(h))
 BETA0 = 0.0015                    # surface thickness in world units inside the unit box (finest grid cell: 4 / 2048 = 0.002)
 SPHERES = (((-0.06, 0.02, -0.02), 0.07), ((0.07, -0.04, -0.045), 0.045))
@@ -204,7 +205,7 @@ def initial_state_dict(cfg, seed: int):
     return sd
 
 
-def fit(cfg, device: str = "cpu", steps: int = 400, points: int = 1 << 18, seed: int = 0, lr: float = 1e-2, log=None):
+def fit(cfg, device: str = "cpu", steps: int = STEPS, points: int = POINTS, seed: int = 0, lr: float = 1e-2, log=None):
     from helpers import oracle_config
     from oracle import nerfacto as onf
 
@@ -258,7 +259,7 @@ def scene_key(cfg, steps: int, points: int, seed: int) -> str:
     return hashlib.sha1(sig.encode()).hexdigest()[:12]
 
 
-def trained_state_dict(cfg, device: str = None, steps: int = 400, points: int = 1 << 18, seed: int = 0, cache: bool = True, log=None):
+def trained_state_dict(cfg, device: str = None, steps: int = STEPS, points: int = POINTS, seed: int = 0, cache: bool = True, log=None):
     """The fitted state dict (CPU fp32, nerfstudio's torch-path names) + meta; cached on disk per (shapes, steps, points, seed)."""
     device = device or ("cuda" if torch.cuda.is_available() else "cpu")
     path = os.path.join(os.environ.get("SIGNERF_TRAINED_CACHE", "/tmp"), f"signerf_trained_{scene_key(cfg, steps, points, seed)}.pt")
@@ -312,8 +313,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None, help="write {state_dict, meta} here (torch.save)")
     ap.add_argument("--device", default=None)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--points", type=int, default=1 << 18)
+    ap.add_argument("--steps", type=int, default=STEPS)
+    ap.add_argument("--points", type=int, default=POINTS)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--small", action="store_true", help="tests/helpers.small_config tables (T=2^14 / 2^12): a quick CPU check of the fit")
     ap.add_argument("--no-normals", action="store_true")
