@@ -39,7 +39,6 @@
  *     SN_HASH_PLAIN=1 (sn_hash_encode ignores the copies), SN_ABLATE=k (profiling only: WRONG images),
  *     SN_EARLY_TERM=0 (r04: every sample of every ray is evaluated; by default a wave whose 64 rays all have an exactly-zero transmittance
  *     skips the samples that can no longer change any output -- bit-identical results, tests/test_gpu_early_term.py),
- *     SN_K1_WIDE=1 (r04: the main kernel as 8-wave workgroups at four waves per SIMD for large frames; bit-identical, measured slower),
  *     SN_HALF_GRID=0 (r04, read by sn_finalize_weights: SnFieldDesc.half_grid is ignored -- a precision-2 render then rounds the rows of
  *     the uploaded table on the fly; bit-identical to the fp16 storage, tests/test_gpu_fp16_mode.py).
  *   - architecture limits (sn_create returns SN_ERR_INVALID otherwise -- the kernels are written

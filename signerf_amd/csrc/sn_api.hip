@@ -38,11 +38,6 @@ struct DevBuf {
 
 }  // namespace
 
-// K1's launch shape for large frames (sn_main.h SnK1Shape): 1 = 8-wave workgroups at four waves per SIMD; SN_K1_WIDE=0/1 in the
-// environment overrides it per handle (A/B in one library)
-#ifndef SN_K1_WIDE_DEFAULT
-#define SN_K1_WIDE_DEFAULT 0
-#endif
 struct SnContext {
     SnFieldDesc desc;
     int device = 0;
@@ -94,7 +89,7 @@ struct SnContext {
     // diagnostic / test switches of the environment, read when the handle is created, when its weights are finalized and by
     // sn_debug_reload_env -- not by every render call (getenv on the render path of several threads)
     struct Switches {
-        std::atomic<int> render_chain{0}, prop_cache_off{0}, pdf_ieee{0}, pdf_fast{0}, ablate{0}, hash_plain{0}, tail_split_off{0}, k1_wide{SN_K1_WIDE_DEFAULT}, early_term{1};
+        std::atomic<int> render_chain{0}, prop_cache_off{0}, pdf_ieee{0}, pdf_fast{0}, ablate{0}, hash_plain{0}, tail_split_off{0}, early_term{1};
     } sw;
 };
 
@@ -140,10 +135,6 @@ void load_switches(SnHandle h) {
     {
         const char* e = getenv("SN_EARLY_TERM");   // 0: every sample of every ray is evaluated (bit-identical outputs; A/B and test switch)
         h->sw.early_term = e ? (atoi(e) != 0) : 1;
-    }
-    {
-        const char* e = getenv("SN_K1_WIDE");
-        h->sw.k1_wide = e ? (atoi(e) != 0) : SN_K1_WIDE_DEFAULT;
     }
 }
 
@@ -1580,13 +1571,10 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
         p.grid = h->dense_res;
         p.dense = h->dense_info;
     }
-    int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
-    p.wg_tx = 2;
-    p.wg_ty = 2;
-    p.sh_lds_off = 0;
+    const int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
     // weight image + (uniform sampler) the frame's S + 1 euclidean bins
     const size_t etab_bytes = nprop == 0 ? ((size_t)opts->num_nerf_samples + 1 + 3) / 4 * 16 : 0;
-    size_t lds_bytes = (half1 ? (size_t)SnMainImgF16::TOTAL_BYTES : (size_t)SnMainImg::TOTAL * 4) + etab_bytes;
+    const size_t lds_bytes = (half1 ? (size_t)SnMainImgF16::TOTAL_BYTES : (size_t)SnMainImg::TOTAL * 4) + etab_bytes;
     // split-depth tail (plan_tail): the workgroups of the last, partly filled round become n_seg segment jobs each
     const int ablate = h->sw.ablate.load(std::memory_order_relaxed);
     const bool tail_split = !dump && !half1 && ablate == 0 && !h->sw.tail_split_off.load(std::memory_order_relaxed) && wp.n_seg > 1;
@@ -1601,30 +1589,7 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
         p.seg_len = wp.seg_len;
         p.seg_scratch = (f32x4*)(ws + wp.off_seg);
     }
-    dim3 grid((unsigned)(gbx * gby - n_tail + ((n_tail + 7) / 8 * 8) * p.n_seg)), block(256);  // (segment jobs: the tail padded to whole XCD rows)
-    // The wide shape (SnK1Shape::W4: 8-wave workgroups of 4x2 tiles, four waves per SIMD, the waves' direction operands in LDS) for the
-    // production split-precision kernel on frames that fill the chip at least twice over; small frames and frames whose tail is split
-    // keep the 4-wave shape.  Instantiated for the default copy count only.
-    const bool wide = split && !half1 && !dump && !alt && ablate == 0 && !tail_split && use_copies && h->nd_torch == 11 &&
-                      h->sw.k1_wide.load(std::memory_order_relaxed) != 0 && g.tiles_x * g.tiles_y >= 2 * 16 * h->n_cus;
-    if (wide) {
-        p.wg_tx = 4;
-        gbx = (g.tiles_x + 3) / 4;
-        p.seg_first_block = gbx * gby;
-        p.sh_lds_off = (int)lds_bytes;
-        lds_bytes += 8 * SnShLds::BYTES_PER_WAVE;
-        grid = dim3((unsigned)(gbx * gby));
-        block = dim3(512);
-    }
-#define SN_LAUNCH_MAIN_WIDE(MODE, GRID)                                                                                        \
-    {                                                                                                                          \
-        static std::once_flag once;                                                                                            \
-        std::call_once(once, [&] {                                                                                             \
-            (void)hipFuncSetAttribute((const void*)sn_render_main_kernel<MODE, 1, 0, GRID, 11, false, false, true>,                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                       \
-        });                                                                                                                    \
-        hipLaunchKernelGGL((sn_render_main_kernel<MODE, 1, 0, GRID, 11, false, false, true>), grid, block, lds_bytes, st, p); \
-    }
+    const dim3 grid((unsigned)(gbx * gby - n_tail + ((n_tail + 7) / 8 * 8) * p.n_seg)), block(256);  // (segment jobs: the tail padded to whole XCD rows)
 #define SN_LAUNCH_MAIN(MODE, PREC, ABL, GRID, ND) \
     hipLaunchKernelGGL((sn_render_main_kernel<MODE, PREC, ABL, GRID, ND>), grid, block, lds_bytes, st, p)
     const int nd_launch = use_copies ? h->nd_torch : -1;
@@ -1679,9 +1644,6 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
             else { if (tcnn) SN_LAUNCH_MAIN_ALT(0, 0, 1); else SN_LAUNCH_MAIN_ALT(0, 0, 0); }
         }
 #undef SN_LAUNCH_MAIN_ALT
-    } else if (wide) {
-        if (nprop > 0) { if (tcnn) SN_LAUNCH_MAIN_WIDE(1, 1) else SN_LAUNCH_MAIN_WIDE(1, 0) }
-        else { if (tcnn) SN_LAUNCH_MAIN_WIDE(0, 1) else SN_LAUNCH_MAIN_WIDE(0, 0) }
     } else
     if (ablate == 12 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 1, 2, 0, 11);        // fp16x2 kernel: hash phase (11 de-hashed levels) only
     else if (ablate == 14 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 1, 4, 0, -1);   // fp16x2 kernel: MLP phase only
@@ -1695,7 +1657,6 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
         if (split) { if (tcnn) { SN_LAUNCH_MAIN_TCNN(0, 1) } else { SN_LAUNCH_MAIN_TORCH(0, 1) } }
         else { if (tcnn) { SN_LAUNCH_MAIN_TCNN(0, 0) } else { SN_LAUNCH_MAIN_TORCH(0, 0) } }
     }
-#undef SN_LAUNCH_MAIN_WIDE
 #undef SN_LAUNCH_MAIN_TCNN
 #undef SN_LAUNCH_MAIN_TORCH
 #undef SN_LAUNCH_MAIN_ND
