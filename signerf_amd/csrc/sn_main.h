@@ -21,13 +21,6 @@
 #pragma once
 #include "sn_device.h"
 
-// EXPERIMENT (r03, measured and NOT adopted; profiles/r03_l3_mfma_ab.txt): colour layer 3 of the split-precision kernel as 64 x
-// v_mfma_f32_4x4x1_16b_f32 instead of 192 v_fmac (sn_main_field_h).  1428 -> 1236 VALU per wave-step, bit-identical with 2 accumulator
-// chains -- and 6 % SLOWER (2.83 -> 2.99-3.08 ms; 4 chains spill: 3.29 ms): the fp32-input MFMA holds the vector port like the 32x32x2
-// form does (r02), and every one of them waits for a v_max (its ReLU'd operand) and for its predecessor's accumulator.
-#ifndef SN_L3_MFMA
-#define SN_L3_MFMA 0
-#endif
 // LDS weight image of the main field, float offsets.  Built on the host by sn_api.hip
 // (build_main_image) -- keep the two in sync.
 struct SnMainImg {
@@ -39,10 +32,10 @@ struct SnMainImg {
     static constexpr int B2 = 10304;    // [1][2][16]
     static constexpr int BC1 = 10336;   // [2][2][16]
     static constexpr int BC2 = 10400;   // [2][2][16]
-    static constexpr int W3 = 10464;    // [n][h=2][32], n = 3 channels (SN_L3_MFMA: + a row of zeros, which the A operand of its 4x4x1 MFMAs reads as row lane & 3)
-    static constexpr int W3_ROWS = SN_L3_MFMA ? 4 : 3;
+    static constexpr int W3 = 10464;    // [n][h=2][32], n = 3 channels
+    static constexpr int W3_ROWS = 3;
     static constexpr int B3 = W3 + W3_ROWS * 64;  // [4]: the 3 biases; [3] = 1 / (output scale of layer 2) of the split-precision image (h0 = row 0 * that)
-    static constexpr int TOTAL = B3 + 4;  // 10 660 floats = 42 640 bytes (10 724 / 42 896 with SN_L3_MFMA); a multiple of 4
+    static constexpr int TOTAL = B3 + 4;  // 10 660 floats = 42 640 bytes; a multiple of 4
 };
 
 // acc[rt] (tile 0) / acc[rt] (tile 1) <- bias + W . op     (exact fp32 MFMA)
@@ -271,9 +264,6 @@ struct SnOpH {  // one B operand (8 k-slots of one 32-sample tile), hi and lo pa
 #ifndef SN_MFMA_PRIO
 #define SN_MFMA_PRIO 1
 #endif
-#ifndef SN_L3_CHAINS
-#define SN_L3_CHAINS 2
-#endif
 #ifndef SN_MFMA_H  // (tools/probes/mlp_probe.hip overrides it to time the VALU part of the MLP alone)
 #define SN_MFMA_H(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, ACC, 0, 0, 0)
 #endif
@@ -429,50 +419,6 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
     }
     // ---- colour layer 2 (two 32-row passes: halves the live accumulators, same MFMAs) + colour layer 3 ----
     const int h = lane >> 5;
-#if SN_L3_MFMA
-    // Colour layer 3 (64 -> 3) on the matrix cores as 64 x v_mfma_f32_4x4x1_16b_f32 (r03): fp32 operands (no hi / lo split), 16 blocks of
-    // 4 lanes, D[i][j] += A[i] B[j] with A from lane 4 b + i, B from lane 4 b + j, D[i][j] in register i of lane 4 b + j.  Register j of a
-    // layer-2 accumulator tile already holds "hidden unit rho(j) + 4 h (+ 32 rt) of the lane's own sample": B = relu of it, A = the
-    // layer-3 weight of THAT unit for channel (lane & 3) -- the four lanes of a block share h -- read from the image's W3 rows [n][h]
-    // (row n = 3 is zeros), and register n of the 4-register accumulator is channel n of the lane's sample, summed over the lane half's
-    // 32 units in the order the VALU form used (each step a fused multiply-add: the results are bit-identical to it).  192 v_fmac leave the
-    // vector port; tools/probes/mfma4x4_probe.hip (K1-shaped mix of INDEPENDENT instructions, 3 waves per SIMD) promised 5.39 -> 4.94 ms --
-    // the real kernel is slower (see SN_L3_MFMA above).
-    // SN_L3_CHAINS independent accumulators per tile: a 4x4x1 MFMA that reads the previous one's result waits for it
-    constexpr int NCH = SN_L3_CHAINS;
-    f32x4 q0[NCH], q1[NCH];
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) q0[k] = q1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4* w3 = (const f32x4*)(tail + SnMainImgH::W3 + ((lane & 3) * 2 + h) * 32);
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        f32x16 c0[1], c1[1];
-        sn_mlp_layer_h<1, 4>(ldsb + SnMainImgH::WC2 + rt * 8192, tail + SnMainImgH::BC2 + rt * 32, op0, op1, c0, c1, lane);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const f32x4 wv = w3[rt * 4 + r4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                q0[e % NCH] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], sn_relu(c0[0][4 * r4 + e]), q0[e % NCH], 0, 0, 0);
-                q1[e % NCH] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], sn_relu(c1[0][4 * r4 + e]), q1[e % NCH], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    float p0[3], p1[3];
-#pragma unroll
-    for (int n = 0; n < 3; ++n) {
-        float a = q0[0][n], b = q1[0][n];
-#pragma unroll
-        for (int k = 1; k < NCH; ++k) {
-            a += q0[k][n];
-            b += q1[k][n];
-        }
-        p0[n] = a;
-        p1[n] = b;
-    }
-#else
     // plain fp32 FMAs (NOT v_pk_fma_f32: packed fp32 ops are mutually exclusive with the matrix pipe on gfx950 and would stall
     // behind the other waves' MFMAs -- tools/probes/overlap2_probe.hip); two accumulators per channel and tile for issue distance
     float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
@@ -502,7 +448,6 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-#endif
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
         float a = p0[n], b = p1[n];
@@ -699,32 +644,6 @@ SN_DEV void sn_main_field_f16(const char* __restrict__ ldsb, float* feat, const 
         }
     }
     const float inv_s5 = *(const float*)(ldsb + SnMainImgF16::TAILF);
-#ifdef SN_F16_L3_VALU  // debugging aid: colour layer 3 from the same fp16 activations on the vector ALU (fp32 weights of the image's tail)
-    {
-        const int hh = lane >> 5;
-        float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const _Float16 x0 = __builtin_bit_cast(f16x8, q0[s].v)[e], x1 = __builtin_bit_cast(f16x8, q1[s].v)[e];
-#pragma unroll
-                for (int n = 0; n < 3; ++n) {
-                    const float w = tail[SnMainImgH::W3 + (n * 2 + hh) * 32 + (s / 2) * 16 + 8 * (s % 2) + e];
-                    p0[n] = fmaf(w, (float)x0, p0[n]);
-                    p1[n] = fmaf(w, (float)x1, p1[n]);
-                }
-            }
-#pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            float a = p0[n], b = p1[n];
-            sn_swap_halves(a, b);
-            const float x = sn_round_f16(a + b + tail[SnMainImgH::B3 + n]);
-            rgb[n] = __builtin_amdgcn_rcpf(1.0f + sn_exp<true>(-x));
-        }
-        return;
-    }
-#endif
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
         float a = r0[n], b = r1[n];
@@ -743,9 +662,6 @@ SN_DEV void sn_main_field_f16(const char* __restrict__ ldsb, float* feat, const 
 #endif
 #ifndef SN_HASH_GROUP
 #define SN_HASH_GROUP 4
-#endif
-#ifndef SN_MAIN_NCACHE
-#define SN_MAIN_NCACHE 0   // (measured r04, tools/ab_libs.sh: see DESIGN.md K1 "r04")
 #endif
 #ifndef SN_MAIN_WAVES_PER_SIMD
 #define SN_MAIN_WAVES_PER_SIMD 3
@@ -924,10 +840,7 @@ SN_DEV void sn_main_epilogue(const SnMainParams& p, SnComposite& comp, float r, 
     }
 }
 
-// ABLATE (profiling only, images are WRONG when non-zero; selected by the SN_ABLATE environment variable): 2 = hash phase
-// only (no MLP: density / colour faked from the features), 3 = VALU only (no table gathers either).  Measured r01:
-// full 7.7 ms, hash-only 2.8-3.0 ms (= the L1 tag-lookup floor), VALU-only 1.4 ms; the 204.8 M fp32 MFMAs alone are 5.6 ms.
-template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int PREC /*0 fp32 MFMA, 1 fp16 hi+lo split MFMA*/, int ABLATE = 0,
+template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int PREC /*0 fp32 MFMA, 1 fp16 hi+lo split MFMA, 2 single fp16 (opt-in)*/,
           int GRID = 0 /*0 nerfstudio torch-path hash grid, 1 tiny-cuda-nn grid semantics*/,
           int ND = -1 /*GRID 1: number of leading dense levels, fixed at compile time (-1: run-time decision per level)*/,
           bool DUMP = false /*test instrumentation: record what every sample fetches (SnMainParams::dump_*)*/,
@@ -1015,10 +928,6 @@ void sn_render_main_kernel(SnMainParams p) {
     };
     float t0 = bin(i_lo);
     float r = 0.f, g = 0.f, b = 0.f;
-    // experiment knob (r04): the coarsest SN_MAIN_NCACHE levels keep their four fetches across the steps of the march (SnBcCache, as K2 does)
-    SnBcCache bc_cache[SN_MAIN_NCACHE > 0 ? SN_MAIN_NCACHE : 1];
-#pragma unroll
-    for (int c = 0; c < (SN_MAIN_NCACHE > 0 ? SN_MAIN_NCACHE : 1); ++c) bc_cache[c].reset();
 #pragma unroll 1
     for (int i = i_lo; i < i_hi; ++i) {
         // The LDS weight reads are loop-invariant; LICM would hoist them all (368 VGPRs) and spill.  A compiler-only
@@ -1028,30 +937,9 @@ void sn_render_main_kernel(SnMainParams p) {
         float q[3];
         const bool sel = ALT ? sn_sample_q(o, d, t0, t1, q, pm) : sn_sample_q_fast(o, d, t0, t1, q);  // (ALT: the strict form, see sn_sample_q_fast)
         float feat[32];
-        if (ABLATE & 4) {  // no hash phase at all: the MLP phase alone
-#pragma unroll
-            for (int k = 0; k < 32; ++k) feat[k] = q[k % 3] + 0.01f * (float)k;
-        } else if (ABLATE & 1) {
-#pragma unroll
-            for (int l = 0; l < 16; ++l) {
-                SnHashLevel hl;
-                sn_hash_corners(q, p.scal[l], (1u << p.log2_t) - 1u, hl);
-                f32x2 v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    v[k].x = __uint_as_float((hl.boff[k] & 0x7fffffu) | 0x3f800000u) - 1.5f;
-                    v[k].y = -v[k].x;
-                }
-                f32x2 e = sn_hash_blend(v, hl.off);
-                feat[2 * l] = e.x;
-                feat[2 * l + 1] = e.y;
-            }
-        } else {
+        {
             // plain table: the x-paired layout (sn_device.h) measured no gain here (r01: 4.11 vs 4.18 ms) -- splitting a level
             // into per-t tables loses the x-locality of the plain layout (16 consecutive x share a 128-B line)
-#if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 3  // experiment: the hash phase (gather issue) at raised priority
-            __builtin_amdgcn_s_setprio(1);
-#endif
             uint32_t* rec = nullptr;
             if (DUMP && valid) {
                 const size_t smp = (size_t)ray * (size_t)S + (size_t)i;
@@ -1074,36 +962,17 @@ void sn_render_main_kernel(SnMainParams p) {
                 sn_hash_encode<16, SHAPE::HASH_GROUP, AR, ND, DUMP, NBC, 0, true>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
             } else if (SN_MAIN_PAIRS && MODE == 1 && ND > 0 && ND < 16) {
                 // de-hashed levels [0, ND), then the hashed levels [ND, 16) from the x-paired tables
-                sn_hash_encode<(ND > 0 ? ND : 1), SHAPE::HASH_GROUP, AR, ND, DUMP, NBC, (NBC >= SN_MAIN_NCACHE && !DUMP ? SN_MAIN_NCACHE : 0)>(
-                    rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale, bc_cache);
+                sn_hash_encode<(ND > 0 ? ND : 1), SHAPE::HASH_GROUP, AR, ND, DUMP, NBC>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
                 __builtin_amdgcn_sched_barrier(0);
                 sn_hash_encode_pairs<16, SHAPE::HASH_GROUP, true, (ND > 0 && ND < 16 ? ND : 0), GRID == 1, DUMP>(sn_table_rsrc(p.pairs, p.pairs_bytes), p.pinfo,
                                                                                                            p.scal, p.log2_t, q, feat, rec);
             } else {
-                sn_hash_encode<16, SHAPE::HASH_GROUP, AR, ND, DUMP, NBC, (NBC >= SN_MAIN_NCACHE && !DUMP ? SN_MAIN_NCACHE : 0)>(rsrc, p.scal, p.log2_t, q, feat, &p.grid,
-                                                                                                                    &p.dense, rec, p.feat_scale, bc_cache);
+                sn_hash_encode<16, SHAPE::HASH_GROUP, AR, ND, DUMP, NBC>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
             }
-#if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 3
-            __builtin_amdgcn_s_setprio(0);
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
-#if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 2  // experiment: the whole MLP phase at raised priority
-        __builtin_amdgcn_s_setprio(1);
-#endif
         float h0, rgb[3];
-        if (ABLATE & 2) {
-            float a = 0.f, bsum = 0.f;
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                a += feat[k];
-                bsum = fmaf(feat[k], (float)(k & 3), bsum);
-            }
-            h0 = a * 0.1f + d[0];
-            rgb[0] = 0.5f + 0.1f * a;
-            rgb[1] = 0.5f + 0.1f * bsum;
-            rgb[2] = 0.5f - 0.1f * a;
-        } else if (PREC == 0) {
+        if (PREC == 0) {
             sn_main_field_f32(lds, feat, sh, lane, h0, rgb);
         } else if (PREC == 2) {
             sn_main_field_f16((const char*)lds, feat, shf, lane, h0, rgb);
@@ -1111,9 +980,6 @@ void sn_render_main_kernel(SnMainParams p) {
             sn_main_field_h((const char*)lds, feat, shh, lane, h0, rgb);
         }
         __builtin_amdgcn_sched_barrier(0);
-#if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 2
-        __builtin_amdgcn_s_setprio(0);
-#endif
         float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
         // A NaN position (e.g. the 1e10 sentinel of a ray that misses render_aabb overflows to inf/inf) is NaN all the
         // way through the reference's field; v_max-based ReLU would launder it, so restore it here -- by arithmetic, not selects
@@ -1134,7 +1000,7 @@ void sn_render_main_kernel(SnMainParams p) {
         // sum w)).  Outputs are bit-identical (tests/test_gpu_early_term.py); the synthetic benchmark scene never saturates (its
         // densities are O(1): max cumsum(tau) < 88), so the check costs it one v_cmp and one branch per step.  Segment jobs store every
         // sample and the DUMP instantiations record every fetch: not for them.
-        if (!DUMP && ABLATE == 0 && p.early_term && !seg_out && i < i_hi - 2 && __all(comp.last_trans == 0.0f)) {
+        if (!DUMP && p.early_term && !seg_out && i < i_hi - 2 && __all(comp.last_trans == 0.0f)) {
             if (p.march_stats && lane == 0) atomicAdd(&p.march_stats[0], (unsigned long long)(i_hi - 2 - i));  // (here, not behind the loop: no state carried)
             i = i_hi - 2;
             t0 = bin(i_hi - 1);
