@@ -732,7 +732,7 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import kernel_counts
 
-                cnt = kernel_counts.loop_counts("sn_render_main_kernelILi0ELi%dELi0ELi0ELi11E" % (0 if args.precision == "fp32" else 1))
+                cnt = kernel_counts.loop_counts("sn_render_main_kernelILi0ELi%dELi0ELi11E" % (0 if args.precision == "fp32" else 1))
             except Exception as e:  # noqa: BLE001  (no llvm-objdump: the roofs are then unavailable, the throughput line is not)
                 cnt = {"error": repr(e)}
             clock = sustained_clock_ghz()
@@ -806,7 +806,7 @@ def main():
                 import kernel_counts
 
                 k2 = kernel_counts.mfma_loops("sn_proposal_kernelILi0ELi5ELi4E")
-                k1 = kernel_counts.loop_counts("sn_render_main_kernelILi1ELi%dELi0ELi0ELi11E" % (0 if args.precision == "fp32" else 1))
+                k1 = kernel_counts.loop_counts("sn_render_main_kernelILi1ELi%dELi0ELi11E" % (0 if args.precision == "fp32" else 1))
                 steps_k2 = list(cfg.num_proposal_samples_per_ray[:cfg.num_proposal_iterations])
                 if len(k2) != len(steps_k2):
                     raise RuntimeError("expected one marching loop per proposal net, found %d" % len(k2))

@@ -31,17 +31,20 @@
  *     process wait for the previous one on its device.  Off by default.
  *   - sn_last_error returns a per-thread copy of the text: valid until the calling thread's next
  *     sn_last_error call.
- *   - other environment switches, all off / at their defaults in normal use and none of them changes what a render means:
- *     SN_DENSE_LEVELS=n / SN_DENSE_CAP_MB=m (read by sn_finalize_weights: how many leading levels get de-hashed copies; 0 = none),
- *     SN_PROP_CACHE_OFF=1 (the proposal kernel re-fetches its cached level coefficients on every step; bit-identical results,
- *     tests/test_gpu_render.py), SN_PDF_IEEE=1 (its resampler divides with plain IEEE divisions instead of the reciprocal + exact
- *     residual form; bit-identical results, same test file), SN_PDF_FAST=1 (reciprocal instead of IEEE divisions in the fused resampler: A/B knob, changes low bits),
- *     SN_HASH_PLAIN=1 (sn_hash_encode ignores the copies), SN_ABLATE=k (profiling only: WRONG images),
- *     SN_EARLY_TERM=0 (r04: every sample of every ray is evaluated; by default a wave whose 64 rays all have an exactly-zero transmittance
- *     skips the samples that can no longer change any output -- bit-identical results, tests/test_gpu_early_term.py),
- *     SN_K1_WIDE=1 (r04: the main kernel as 8-wave workgroups at four waves per SIMD for large frames; bit-identical, measured slower),
- *     SN_HALF_GRID=0 (r04, read by sn_finalize_weights: SnFieldDesc.half_grid is ignored -- a precision-2 render then rounds the rows of
- *     the uploaded table on the fly; bit-identical to the fp16 storage, tests/test_gpu_fp16_mode.py).
+ *   - SIX environment switches, all off / at their defaults in normal use; none of them changes what a render means -- each turns an
+ *     optimisation off so that a test can show it bit-identical to its plain form (read at sn_create / sn_finalize_weights and by
+ *     sn_debug_reload_env, never by a render call):
+ *       SN_EARLY_TERM=0       every sample of every ray is evaluated (default: a wave whose 64 rays all have an exactly-zero
+ *                             transmittance skips the samples that can no longer change any output; tests/test_gpu_early_term.py)
+ *       SN_TAIL_SPLIT=0       the last, partly filled round of the main kernel's workgroups marches whole rays (default: cut into
+ *                             segment jobs + an ordered combine; tests/test_gpu_render.py)
+ *       SN_PROP_CACHE_OFF=1   the proposal kernel re-fetches its cached level coefficients on every step (tests/test_gpu_render.py)
+ *       SN_PDF_IEEE=1         its resampler divides with plain IEEE divisions instead of the reciprocal + exact-residual form (same file)
+ *       SN_HALF_GRID=0        SnFieldDesc.half_grid is ignored: a precision-2 render rounds the rows of the uploaded table on the fly
+ *                             (read by sn_finalize_weights; tests/test_gpu_fp16_mode.py)
+ *       SN_RENDER_CHAIN=1     (above) renders of the process serialised on the device
+ *     The measured-and-rejected variants of earlier rounds (4 waves per SIMD, colour layer 3 on the matrix cores, phase ablations,
+ *     reciprocal CDF divisions, XCD tile orders ...) live in tools/patches/, each with the profile that rejected it -- not in the library.
  *   - architecture limits (sn_create returns SN_ERR_INVALID otherwise -- the kernels are written
  *     for nerfacto's shapes): main field 16 levels x 2 features, hidden 64, out 16, 2 layers,
  *     log2_hashmap_size in [4, 21]; colour head 15 geo features + SH degree 4 (+ <= 256
@@ -106,12 +109,13 @@ typedef struct SnFieldDesc {
     /* Memory budget of the DERIVED gather buffers sn_finalize_weights builds beside the uploaded tables (appended in r04; zero = the
      * library defaults, so a zero-initialised descriptor behaves as before).  A viewer holding several models bounds them here instead of
      * through the environment:
-     *   dense_levels        how many leading levels of the main grid get a de-hashed copy: 0 = default (11, 1.26 GB for nerfacto's
-     *                       grid), -1 = none (the kernels then read the uploaded table: ~14 % slower, no extra memory), 1..12 = that many;
+     *   dense_levels        how many leading levels of the main grid get a de-hashed copy: 0 = default (11: 1.26 GB for nerfacto's grid),
+     *                       -1 = none (the kernels then read the uploaded table: ~14 % slower, no extra memory); any other count -- and
+     *                       whatever the per-level cap leaves of it -- is rounded DOWN to a count the main kernel is instantiated for:
+     *                       11, 9 (the coefficient-form levels alone: 0.51 GB, ~2 % slower than 11) or none;
      *   dense_copy_cap_mb   per-level size cap of those copies in MB, measured on the plain-row form (R^3 x 8 bytes; the coefficient form of
      *                       the first nine levels takes 4x that): 0 = default (600); the first level above the cap ends the run of copies.
-     * The proposal nets' copies (90 + 81 MB) follow dense_levels with their own 100 MB cap.  SN_DENSE_LEVELS / SN_DENSE_CAP_MB in the
-     * environment still override both (diagnostics).  sn_debug_layout reports what a handle actually holds. */
+     * The proposal nets' copies (90 + 81 MB) follow dense_levels with their own 100 MB cap.  sn_debug_layout reports what a handle holds. */
     int32_t dense_levels;
     int32_t dense_copy_cap_mb;
     /*   half_grid           1 = also keep the main grid in fp16 STORAGE for SnRenderOpts.precision = 2 (tiny-cuda-nn grids only, ignored
@@ -344,8 +348,7 @@ typedef struct SnDebugLayout {
 int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out);
 /* what: 0 = the buffer of de-hashed copies, 1 = the x-paired tables (proposal nets).  dst: device pointer, bytes must match. */
 int sn_debug_read(SnHandle h, int32_t which, int32_t what, void* dst, size_t bytes, SnStream stream);
-/* The diagnostic switches of the environment (SN_RENDER_CHAIN, SN_PROP_CACHE_OFF, SN_PDF_IEEE, SN_PDF_FAST, SN_ABLATE,
- * SN_HASH_PLAIN) are read by sn_create and sn_finalize_weights, never by a render call; a test that flips one between two renders
+/* The switches of the environment ("Conventions") are read by sn_create and sn_finalize_weights, never by a render call; a test that flips one between two renders
  * of the same handle calls this to have it re-read. */
 int sn_debug_reload_env(SnHandle h);
 

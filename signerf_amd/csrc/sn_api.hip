@@ -38,11 +38,6 @@ struct DevBuf {
 
 }  // namespace
 
-// K1's launch shape for large frames (sn_main.h SnK1Shape): 1 = 8-wave workgroups at four waves per SIMD; SN_K1_WIDE=0/1 in the
-// environment overrides it per handle (A/B in one library)
-#ifndef SN_K1_WIDE_DEFAULT
-#define SN_K1_WIDE_DEFAULT 0
-#endif
 struct SnContext {
     SnFieldDesc desc;
     int device = 0;
@@ -94,7 +89,7 @@ struct SnContext {
     // diagnostic / test switches of the environment, read when the handle is created, when its weights are finalized and by
     // sn_debug_reload_env -- not by every render call (getenv on the render path of several threads)
     struct Switches {
-        std::atomic<int> render_chain{0}, prop_cache_off{0}, pdf_ieee{0}, pdf_fast{0}, ablate{0}, hash_plain{0}, tail_split_off{0}, k1_wide{SN_K1_WIDE_DEFAULT}, early_term{1};
+        std::atomic<int> render_chain{0}, prop_cache_off{0}, pdf_ieee{0},  tail_split_off{0}, early_term{1};
     } sw;
 };
 
@@ -130,9 +125,6 @@ void load_switches(SnHandle h) {
     h->sw.render_chain = env_int("SN_RENDER_CHAIN") != 0;
     h->sw.prop_cache_off = env_int("SN_PROP_CACHE_OFF") != 0;  // test switch, see SnPropParams::cache_off
     h->sw.pdf_ieee = env_int("SN_PDF_IEEE") != 0;              // test switch, see SnPropParams::pdf_ieee
-    h->sw.pdf_fast = env_int("SN_PDF_FAST") != 0;              // A/B knob (sn_pdf_lane): reciprocal multiplications instead of IEEE divisions
-    h->sw.ablate = env_int("SN_ABLATE");                       // profiling only: non-zero gives WRONG images (see sn_main.h)
-    h->sw.hash_plain = env_int("SN_HASH_PLAIN") != 0;          // stage kernel: plain table instead of the x-paired one
     {
         const char* e = getenv("SN_TAIL_SPLIT");                  // test / A-B switch: SN_TAIL_SPLIT=0 renders the last round of workgroups whole
         h->sw.tail_split_off = e && atoi(e) == 0;
@@ -140,10 +132,6 @@ void load_switches(SnHandle h) {
     {
         const char* e = getenv("SN_EARLY_TERM");   // 0: every sample of every ray is evaluated (bit-identical outputs; A/B and test switch)
         h->sw.early_term = e ? (atoi(e) != 0) : 1;
-    }
-    {
-        const char* e = getenv("SN_K1_WIDE");
-        h->sw.k1_wide = e ? (atoi(e) != 0) : SN_K1_WIDE_DEFAULT;
     }
 }
 
@@ -260,12 +248,26 @@ SnGridLevels grid_levels(const SnHashMlpDesc& d) {
 // the main grid (T = 2^19, one pass of 48-64 samples per ray) still gains from level 10 (R = 408, 543 MB; same-box 3.85 / 3.55 /
 // 3.33 / 3.30 / 3.26 ms for 0 / 8 / 9 / 10 / 11 copied levels), the proposal nets (352 samples per ray over the coarse levels)
 // lose with the 137 MB copy of the second net's finest level (frame 18.8 vs 17.5 ms) -- hence the two caps.
+// how many of the `want` leading levels fit the per-level cap (the first level above it ends the run; build_dense_copies applies the same rule)
+int dense_levels_under_cap(const SnHashMlpDesc& d, int want, uint64_t cap_mb) {
+    int nd = 0;
+    for (int l = 0; l < want && l < d.num_levels && l < 12; ++l) {
+        const uint64_t r = d.grid_mode == 0 ? (uint64_t)d.scalings[l] + 2 : (uint64_t)floorf(d.scalings[l] + 0.5f) + 2;
+        if (r > 700 || r * r * r * 8 > cap_mb * 1000 * 1000) break;
+        ++nd;
+    }
+    return nd;
+}
+
 int build_dense_copies(SnHandle h, const SnHashMlpDesc& d, const DevBuf& table, int want, uint64_t cap_mb, DevBuf& buf, SnDenseCopy& info,
                        SnGridLevels& res, int& nd_out, hipStream_t st, int bc_levels, float scale = 1.0f) {
     nd_out = 0;
     memset(&info, 0, sizeof(info));
     memset(&res, 0, sizeof(res));
-    if (want <= 0 || !table.ptr) return SN_OK;
+    if (want <= 0 || !table.ptr) {
+        buf.release();
+        return SN_OK;
+    }
     const SnGridLevels tcnn_dense = grid_levels(d);  // tiny-cuda-nn: resolution of the levels it indexes densely (all 0 for torch grids)
     uint64_t bytes = 0;
     uint32_t R[12];
@@ -1249,16 +1251,17 @@ int sn_finalize_weights(SnHandle h, SnStream stream) {
         }
         SN_HIP(h, hipMemcpyAsync(h->wpack_prop[i].ptr, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, st));
     }
-    // torch grids: de-hashed copies of the coarse levels (SN_DENSE_LEVELS caps the count; 0 = off)
+    // de-hashed copies of the coarse levels
     {
-        // the budget comes from the descriptor (SnFieldDesc.dense_levels / dense_copy_cap_mb: 0 = default, -1 = no copies); the
-        // environment still overrides it (diagnostics, tools/dense_sweep.py)
-        const char* e = getenv("SN_DENSE_LEVELS");
-        const int asked = e ? atoi(e) : (d.dense_levels == 0 ? SN_DENSE_LEVELS_DEFAULT : std::max(0, d.dense_levels));
+        // the budget comes from the descriptor (SnFieldDesc.dense_levels / dense_copy_cap_mb: 0 = default, -1 = no copies).  The main kernel
+        // is instantiated for SN_DENSE_LEVELS_DEFAULT (11) and SN_BC_MAIN (9: the coefficient-form levels alone, 0.51 GB) copied levels:
+        // what the budget and the per-level cap allow is rounded DOWN to one of those counts (or to none)
+        const int asked = d.dense_levels == 0 ? SN_DENSE_LEVELS_DEFAULT : std::max(0, d.dense_levels);
         const int want = std::max(0, std::min(asked, 12));
-        const char* cap_env = getenv("SN_DENSE_CAP_MB");  // per-level size cap of the main grid's copies
-        const uint64_t cap_main = cap_env ? (uint64_t)std::max(1, atoi(cap_env)) : (d.dense_copy_cap_mb > 0 ? (uint64_t)d.dense_copy_cap_mb : 600);
-        if (int rc = build_dense_copies(h, d.main_field, h->table_main, want, cap_main, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st,
+        const uint64_t cap_main = d.dense_copy_cap_mb > 0 ? (uint64_t)d.dense_copy_cap_mb : 600;
+        int want_main = dense_levels_under_cap(d.main_field, want, cap_main);
+        want_main = want_main >= SN_DENSE_LEVELS_DEFAULT ? SN_DENSE_LEVELS_DEFAULT : (want_main >= SN_BC_MAIN ? SN_BC_MAIN : 0);
+        if (int rc = build_dense_copies(h, d.main_field, h->table_main, want_main, cap_main, h->dense_main, h->dense_info, h->dense_res, h->nd_torch, st,
                                         SN_BC_MAIN, h->feat_scale_main))
             return rc;
         for (int i = 0; i < d.num_proposals; ++i)
@@ -1450,8 +1453,8 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     const bool alt = needs_generic_kernels(h, opts);
     if (dump && alt) return fail(h, SN_ERR_INVALID, "sn_render_rays_debug: the dump exists for the default sampler and scene contraction only");
     if (alt) {
-        if (d.proposals[0].grid_mode == 1) hipLaunchKernelGGL((sn_proposal_kernel<1, -1, -1, false, false, true>), pgrid, pblock, 0, st, pp);
-        else hipLaunchKernelGGL((sn_proposal_kernel<0, -1, -1, false, false, true>), pgrid, pblock, 0, st, pp);
+        if (d.proposals[0].grid_mode == 1) hipLaunchKernelGGL((sn_proposal_kernel<1, -1, -1, false, true>), pgrid, pblock, 0, st, pp);
+        else hipLaunchKernelGGL((sn_proposal_kernel<0, -1, -1, false, true>), pgrid, pblock, 0, st, pp);
     } else
     if (dump) {
         // the instrumented instantiation exists for the production variant of nerfacto's proposal nets only
@@ -1478,8 +1481,7 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     } else if (nprop == 2 && h->nd_prop[0] == 5 && h->nd_prop[1] == 4) {
         // nerfacto's nets (max_res 128 / 256): every level but the finest of the second net has a de-hashed copy
         for (int i = 0; i < nprop; ++i) pp.grid[i] = h->dense_res_prop[i];
-        if (h->sw.pdf_fast.load(std::memory_order_relaxed)) hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4, false, true>), pgrid, pblock, 0, st, pp);
-        else hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4>), pgrid, pblock, 0, st, pp);
+        hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4>), pgrid, pblock, 0, st, pp);
     } else {
         hipLaunchKernelGGL((sn_proposal_kernel<0, -1, -1>), pgrid, pblock, 0, st, pp);
     }
@@ -1580,16 +1582,12 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
         p.grid = h->dense_res;
         p.dense = h->dense_info;
     }
-    int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
-    p.wg_tx = 2;
-    p.wg_ty = 2;
-    p.sh_lds_off = 0;
+    const int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
     // weight image + (uniform sampler) the frame's S + 1 euclidean bins
     const size_t etab_bytes = nprop == 0 ? ((size_t)opts->num_nerf_samples + 1 + 3) / 4 * 16 : 0;
-    size_t lds_bytes = (half1 ? (size_t)SnMainImgF16::TOTAL_BYTES : (size_t)SnMainImg::TOTAL * 4) + etab_bytes;
+    const size_t lds_bytes = (half1 ? (size_t)SnMainImgF16::TOTAL_BYTES : (size_t)SnMainImg::TOTAL * 4) + etab_bytes;
     // split-depth tail (plan_tail): the workgroups of the last, partly filled round become n_seg segment jobs each
-    const int ablate = h->sw.ablate.load(std::memory_order_relaxed);
-    const bool tail_split = !dump && !half1 && ablate == 0 && !h->sw.tail_split_off.load(std::memory_order_relaxed) && wp.n_seg > 1;
+    const bool tail_split = !dump && !half1 && !h->sw.tail_split_off.load(std::memory_order_relaxed) && wp.n_seg > 1;
     p.seg_first_block = gbx * gby;
     p.n_seg = 1;
     p.seg_len = opts->num_nerf_samples;
@@ -1601,44 +1599,15 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
         p.seg_len = wp.seg_len;
         p.seg_scratch = (f32x4*)(ws + wp.off_seg);
     }
-    dim3 grid((unsigned)(gbx * gby - n_tail + ((n_tail + 7) / 8 * 8) * p.n_seg)), block(256);  // (segment jobs: the tail padded to whole XCD rows)
-    // The wide shape (SnK1Shape::W4: 8-wave workgroups of 4x2 tiles, four waves per SIMD, the waves' direction operands in LDS) for the
-    // production split-precision kernel on frames that fill the chip at least twice over; small frames and frames whose tail is split
-    // keep the 4-wave shape.  Instantiated for the default copy count only.
-    const bool wide = split && !half1 && !dump && !alt && ablate == 0 && !tail_split && use_copies && h->nd_torch == 11 &&
-                      h->sw.k1_wide.load(std::memory_order_relaxed) != 0 && g.tiles_x * g.tiles_y >= 2 * 16 * h->n_cus;
-    if (wide) {
-        p.wg_tx = 4;
-        gbx = (g.tiles_x + 3) / 4;
-        p.seg_first_block = gbx * gby;
-        p.sh_lds_off = (int)lds_bytes;
-        lds_bytes += 8 * SnShLds::BYTES_PER_WAVE;
-        grid = dim3((unsigned)(gbx * gby));
-        block = dim3(512);
-    }
-#define SN_LAUNCH_MAIN_WIDE(MODE, GRID)                                                                                        \
-    {                                                                                                                          \
-        static std::once_flag once;                                                                                            \
-        std::call_once(once, [&] {                                                                                             \
-            (void)hipFuncSetAttribute((const void*)sn_render_main_kernel<MODE, 1, 0, GRID, 11, false, false, true>,                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                       \
-        });                                                                                                                    \
-        hipLaunchKernelGGL((sn_render_main_kernel<MODE, 1, 0, GRID, 11, false, false, true>), grid, block, lds_bytes, st, p); \
-    }
-#define SN_LAUNCH_MAIN(MODE, PREC, ABL, GRID, ND) \
-    hipLaunchKernelGGL((sn_render_main_kernel<MODE, PREC, ABL, GRID, ND>), grid, block, lds_bytes, st, p)
+    const dim3 grid((unsigned)(gbx * gby - n_tail + ((n_tail + 7) / 8 * 8) * p.n_seg)), block(256);  // (segment jobs: the tail padded to whole XCD rows)
+#define SN_LAUNCH_MAIN(MODE, PREC, GRID, ND) \
+    hipLaunchKernelGGL((sn_render_main_kernel<MODE, PREC, GRID, ND>), grid, block, lds_bytes, st, p)
     const int nd_launch = use_copies ? h->nd_torch : -1;
 #define SN_LAUNCH_MAIN_ND(MODE, PREC, GRID)                          \
-    switch (nd_launch) {                                             \
-        case 5: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 5); break;       \
-        case 6: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 6); break;       \
-        case 7: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 7); break;       \
-        case 8: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 8); break;       \
-        case 9: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 9); break;       \
-        case 10: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 10); break;     \
-        case 11: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 11); break;     \
-        case 12: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, 12); break;     \
-        default: SN_LAUNCH_MAIN(MODE, PREC, 0, GRID, -1); break;     \
+    switch (nd_launch) { /* the copy counts sn_finalize_weights can leave a handle with */ \
+        case SN_BC_MAIN: SN_LAUNCH_MAIN(MODE, PREC, GRID, SN_BC_MAIN); break;       \
+        case SN_DENSE_LEVELS_DEFAULT: SN_LAUNCH_MAIN(MODE, PREC, GRID, SN_DENSE_LEVELS_DEFAULT); break;     \
+        default: SN_LAUNCH_MAIN(MODE, PREC, GRID, -1); break;     \
     }
 #define SN_LAUNCH_MAIN_TORCH(MODE, PREC) SN_LAUNCH_MAIN_ND(MODE, PREC, 0)
 #define SN_LAUNCH_MAIN_TCNN(MODE, PREC) SN_LAUNCH_MAIN_ND(MODE, PREC, 1)
@@ -1650,9 +1619,9 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
         const bool hgrid = nd_launch == 11 && h->hquads_main.ptr && h->hrows_main.ptr;
         if (!hgrid) p.grid = grid_levels(d.main_field);
         if (nprop > 0) {
-            if (hgrid) SN_LAUNCH_MAIN(1, 2, 0, 1, 11); else SN_LAUNCH_MAIN(1, 2, 0, 1, -1);
+            if (hgrid) SN_LAUNCH_MAIN(1, 2, 1, 11); else SN_LAUNCH_MAIN(1, 2, 1, -1);
         } else {
-            if (hgrid) SN_LAUNCH_MAIN(0, 2, 0, 1, 11); else SN_LAUNCH_MAIN(0, 2, 0, 1, -1);
+            if (hgrid) SN_LAUNCH_MAIN(0, 2, 1, 11); else SN_LAUNCH_MAIN(0, 2, 1, -1);
         }
     } else
     if (dump) {
@@ -1663,14 +1632,14 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
         p.dump_q = dump->main_q;
         p.dump_median = dump->median_index;
         if (nprop > 0) {
-            if (split) hipLaunchKernelGGL((sn_render_main_kernel<1, 1, 0, 0, 11, true>), grid, block, lds_bytes, st, p);
-            else hipLaunchKernelGGL((sn_render_main_kernel<1, 0, 0, 0, 11, true>), grid, block, lds_bytes, st, p);
+            if (split) hipLaunchKernelGGL((sn_render_main_kernel<1, 1, 0, 11, true>), grid, block, lds_bytes, st, p);
+            else hipLaunchKernelGGL((sn_render_main_kernel<1, 0, 0, 11, true>), grid, block, lds_bytes, st, p);
         } else {
-            if (split) hipLaunchKernelGGL((sn_render_main_kernel<0, 1, 0, 0, 11, true>), grid, block, lds_bytes, st, p);
-            else hipLaunchKernelGGL((sn_render_main_kernel<0, 0, 0, 0, 11, true>), grid, block, lds_bytes, st, p);
+            if (split) hipLaunchKernelGGL((sn_render_main_kernel<0, 1, 0, 11, true>), grid, block, lds_bytes, st, p);
+            else hipLaunchKernelGGL((sn_render_main_kernel<0, 0, 0, 11, true>), grid, block, lds_bytes, st, p);
         }
     } else if (alt) {
-#define SN_LAUNCH_MAIN_ALT(MODE, PREC, GRID) hipLaunchKernelGGL((sn_render_main_kernel<MODE, PREC, 0, GRID, -1, false, true>), grid, block, lds_bytes, st, p)
+#define SN_LAUNCH_MAIN_ALT(MODE, PREC, GRID) hipLaunchKernelGGL((sn_render_main_kernel<MODE, PREC, GRID, -1, false, true>), grid, block, lds_bytes, st, p)
         if (nprop > 0) {
             if (split) { if (tcnn) SN_LAUNCH_MAIN_ALT(1, 1, 1); else SN_LAUNCH_MAIN_ALT(1, 1, 0); }
             else { if (tcnn) SN_LAUNCH_MAIN_ALT(1, 0, 1); else SN_LAUNCH_MAIN_ALT(1, 0, 0); }
@@ -1679,23 +1648,14 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
             else { if (tcnn) SN_LAUNCH_MAIN_ALT(0, 0, 1); else SN_LAUNCH_MAIN_ALT(0, 0, 0); }
         }
 #undef SN_LAUNCH_MAIN_ALT
-    } else if (wide) {
-        if (nprop > 0) { if (tcnn) SN_LAUNCH_MAIN_WIDE(1, 1) else SN_LAUNCH_MAIN_WIDE(1, 0) }
-        else { if (tcnn) SN_LAUNCH_MAIN_WIDE(0, 1) else SN_LAUNCH_MAIN_WIDE(0, 0) }
     } else
-    if (ablate == 12 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 1, 2, 0, 11);        // fp16x2 kernel: hash phase (11 de-hashed levels) only
-    else if (ablate == 14 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 1, 4, 0, -1);   // fp16x2 kernel: MLP phase only
-    else if (ablate == 13 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 1, 3, 0, -1);   // fp16x2 kernel: hash VALU only (no gathers, no MLP)
-    else if (ablate == 2 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 0, 2, 0, -1);
-    else if (ablate == 3 && nprop == 0 && !tcnn) SN_LAUNCH_MAIN(0, 0, 3, 0, -1);
-    else if (nprop > 0) {
+    if (nprop > 0) {
         if (split) { if (tcnn) { SN_LAUNCH_MAIN_TCNN(1, 1) } else { SN_LAUNCH_MAIN_TORCH(1, 1) } }
         else { if (tcnn) { SN_LAUNCH_MAIN_TCNN(1, 0) } else { SN_LAUNCH_MAIN_TORCH(1, 0) } }
     } else {
         if (split) { if (tcnn) { SN_LAUNCH_MAIN_TCNN(0, 1) } else { SN_LAUNCH_MAIN_TORCH(0, 1) } }
         else { if (tcnn) { SN_LAUNCH_MAIN_TCNN(0, 0) } else { SN_LAUNCH_MAIN_TORCH(0, 0) } }
     }
-#undef SN_LAUNCH_MAIN_WIDE
 #undef SN_LAUNCH_MAIN_TCNN
 #undef SN_LAUNCH_MAIN_TORCH
 #undef SN_LAUNCH_MAIN_ND
@@ -1918,9 +1878,8 @@ int sn_hash_encode(SnHandle h, int32_t which, const float* q, int64_t n, float* 
     p.log2_t = d.log2_hashmap_size;
     p.features = features;
     p.indices = indices;
-    // Proposal nets: when the weights are finalized the features come from the x-paired tables (the production layout of K2);
-    // SN_HASH_PLAIN=1 forces the plain table so that tests can check the two layouts against each other.
-    const bool use_pairs = which >= 0 && h->finalized && !h->sw.hash_plain.load(std::memory_order_relaxed) && d.grid_mode == 0;
+    // Proposal nets: when the weights are finalized the features come from the x-paired tables (the production layout of K2)
+    const bool use_pairs = which >= 0 && h->finalized && d.grid_mode == 0;
     p.grid_mode = d.grid_mode;
     p.grid = grid_levels(d);
     p.pairs = use_pairs ? (const float*)h->pairs_prop[which].ptr : nullptr;

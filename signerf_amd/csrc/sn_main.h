@@ -21,13 +21,6 @@
 #pragma once
 #include "sn_device.h"
 
-// EXPERIMENT (r03, measured and NOT adopted; profiles/r03_l3_mfma_ab.txt): colour layer 3 of the split-precision kernel as 64 x
-// v_mfma_f32_4x4x1_16b_f32 instead of 192 v_fmac (sn_main_field_h).  1428 -> 1236 VALU per wave-step, bit-identical with 2 accumulator
-// chains -- and 6 % SLOWER (2.83 -> 2.99-3.08 ms; 4 chains spill: 3.29 ms): the fp32-input MFMA holds the vector port like the 32x32x2
-// form does (r02), and every one of them waits for a v_max (its ReLU'd operand) and for its predecessor's accumulator.
-#ifndef SN_L3_MFMA
-#define SN_L3_MFMA 0
-#endif
 // LDS weight image of the main field, float offsets.  Built on the host by sn_api.hip
 // (build_main_image) -- keep the two in sync.
 struct SnMainImg {
@@ -39,10 +32,10 @@ struct SnMainImg {
     static constexpr int B2 = 10304;    // [1][2][16]
     static constexpr int BC1 = 10336;   // [2][2][16]
     static constexpr int BC2 = 10400;   // [2][2][16]
-    static constexpr int W3 = 10464;    // [n][h=2][32], n = 3 channels (SN_L3_MFMA: + a row of zeros, which the A operand of its 4x4x1 MFMAs reads as row lane & 3)
-    static constexpr int W3_ROWS = SN_L3_MFMA ? 4 : 3;
+    static constexpr int W3 = 10464;    // [n][h=2][32], n = 3 channels
+    static constexpr int W3_ROWS = 3;
     static constexpr int B3 = W3 + W3_ROWS * 64;  // [4]: the 3 biases; [3] = 1 / (output scale of layer 2) of the split-precision image (h0 = row 0 * that)
-    static constexpr int TOTAL = B3 + 4;  // 10 660 floats = 42 640 bytes (10 724 / 42 896 with SN_L3_MFMA); a multiple of 4
+    static constexpr int TOTAL = B3 + 4;  // 10 660 floats = 42 640 bytes; a multiple of 4
 };
 
 // acc[rt] (tile 0) / acc[rt] (tile 1) <- bias + W . op     (exact fp32 MFMA)
@@ -271,9 +264,6 @@ struct SnOpH {  // one B operand (8 k-slots of one 32-sample tile), hi and lo pa
 #ifndef SN_MFMA_PRIO
 #define SN_MFMA_PRIO 1
 #endif
-#ifndef SN_L3_CHAINS
-#define SN_L3_CHAINS 2
-#endif
 #ifndef SN_MFMA_H  // (tools/probes/mlp_probe.hip overrides it to time the VALU part of the MLP alone)
 #define SN_MFMA_H(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, ACC, 0, 0, 0)
 #endif
@@ -429,50 +419,6 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
     }
     // ---- colour layer 2 (two 32-row passes: halves the live accumulators, same MFMAs) + colour layer 3 ----
     const int h = lane >> 5;
-#if SN_L3_MFMA
-    // Colour layer 3 (64 -> 3) on the matrix cores as 64 x v_mfma_f32_4x4x1_16b_f32 (r03): fp32 operands (no hi / lo split), 16 blocks of
-    // 4 lanes, D[i][j] += A[i] B[j] with A from lane 4 b + i, B from lane 4 b + j, D[i][j] in register i of lane 4 b + j.  Register j of a
-    // layer-2 accumulator tile already holds "hidden unit rho(j) + 4 h (+ 32 rt) of the lane's own sample": B = relu of it, A = the
-    // layer-3 weight of THAT unit for channel (lane & 3) -- the four lanes of a block share h -- read from the image's W3 rows [n][h]
-    // (row n = 3 is zeros), and register n of the 4-register accumulator is channel n of the lane's sample, summed over the lane half's
-    // 32 units in the order the VALU form used (each step a fused multiply-add: the results are bit-identical to it).  192 v_fmac leave the
-    // vector port; tools/probes/mfma4x4_probe.hip (K1-shaped mix of INDEPENDENT instructions, 3 waves per SIMD) promised 5.39 -> 4.94 ms --
-    // the real kernel is slower (see SN_L3_MFMA above).
-    // SN_L3_CHAINS independent accumulators per tile: a 4x4x1 MFMA that reads the previous one's result waits for it
-    constexpr int NCH = SN_L3_CHAINS;
-    f32x4 q0[NCH], q1[NCH];
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) q0[k] = q1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4* w3 = (const f32x4*)(tail + SnMainImgH::W3 + ((lane & 3) * 2 + h) * 32);
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        f32x16 c0[1], c1[1];
-        sn_mlp_layer_h<1, 4>(ldsb + SnMainImgH::WC2 + rt * 8192, tail + SnMainImgH::BC2 + rt * 32, op0, op1, c0, c1, lane);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const f32x4 wv = w3[rt * 4 + r4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                q0[e % NCH] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], sn_relu(c0[0][4 * r4 + e]), q0[e % NCH], 0, 0, 0);
-                q1[e % NCH] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], sn_relu(c1[0][4 * r4 + e]), q1[e % NCH], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    float p0[3], p1[3];
-#pragma unroll
-    for (int n = 0; n < 3; ++n) {
-        float a = q0[0][n], b = q1[0][n];
-#pragma unroll
-        for (int k = 1; k < NCH; ++k) {
-            a += q0[k][n];
-            b += q1[k][n];
-        }
-        p0[n] = a;
-        p1[n] = b;
-    }
-#else
     // plain fp32 FMAs (NOT v_pk_fma_f32: packed fp32 ops are mutually exclusive with the matrix pipe on gfx950 and would stall
     // behind the other waves' MFMAs -- tools/probes/overlap2_probe.hip); two accumulators per channel and tile for issue distance
     float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
@@ -502,7 +448,6 @@ SN_DEV void sn_main_field_h(const char* __restrict__ ldsb, float* feat, const Sn
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-#endif
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
         float a = p0[n], b = p1[n];
@@ -699,234 +644,11 @@ SN_DEV void sn_main_field_f16(const char* __restrict__ ldsb, float* feat, const 
         }
     }
     const float inv_s5 = *(const float*)(ldsb + SnMainImgF16::TAILF);
-#ifdef SN_F16_L3_VALU  // debugging aid: colour layer 3 from the same fp16 activations on the vector ALU (fp32 weights of the image's tail)
-    {
-        const int hh = lane >> 5;
-        float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const _Float16 x0 = __builtin_bit_cast(f16x8, q0[s].v)[e], x1 = __builtin_bit_cast(f16x8, q1[s].v)[e];
-#pragma unroll
-                for (int n = 0; n < 3; ++n) {
-                    const float w = tail[SnMainImgH::W3 + (n * 2 + hh) * 32 + (s / 2) * 16 + 8 * (s % 2) + e];
-                    p0[n] = fmaf(w, (float)x0, p0[n]);
-                    p1[n] = fmaf(w, (float)x1, p1[n]);
-                }
-            }
-#pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            float a = p0[n], b = p1[n];
-            sn_swap_halves(a, b);
-            const float x = sn_round_f16(a + b + tail[SnMainImgH::B3 + n]);
-            rgb[n] = __builtin_amdgcn_rcpf(1.0f + sn_exp<true>(-x));
-        }
-        return;
-    }
-#endif
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
         float a = r0[n], b = r1[n];
         sn_swap_halves(a, b);  // lower lanes keep tile 0's row n of their own sample; upper lanes receive tile 1's from their partner
         const float x = sn_round_f16(fmaf(a, inv_s5, tail[SnMainImgH::B3 + n]));
-        rgb[n] = __builtin_amdgcn_rcpf(1.0f + sn_exp<true>(-x));
-    }
-}
-
-// ==========================================================================================
-// Tile-sequential form of the split-precision field (r04, the "4 waves per SIMD" variant: SN_K1_4W).
-// sn_main_field_h carries BOTH 32-sample column tiles of the wave through every layer together: 64 accumulator registers and 64 operand
-// registers are live at the layer boundaries, 161-168 VGPRs with the ray's state, three waves per SIMD.  Here one tile runs through the
-// density MLP, then the other, then the same for the colour MLP: the live set of a tile is 16 (its operands) + 32 (accumulators) + 32
-// (next operands), the other tile waits as 16 / 8 registers, and the per-ray direction operands (16 registers for the whole march)
-// live in LDS (4 KB per wave, written once in the prologue).  Same MFMAs (120 per wave-step), same operand splits, same values --
-// each accumulator sees its products in the order sn_mlp_layer_h issues them, so the outputs are bit-identical -- at twice the LDS
-// weight reads (every tile reads the image: 80 ds_read_b128 per wave-step) and two instead of four independent accumulator chains.
-// ==========================================================================================
-// SN_W4_PIPE: the A operand (weights) of k-step s + 1 is fetched from LDS BEFORE the MFMAs of k-step s are issued (double-buffered:
-// +8 registers per row tile), so that a k-step's three MFMAs per accumulator do not wait for their own ds_reads.  The s_setprio pair
-// around every cluster is a scheduling barrier for hipcc, which otherwise places each k-step's reads directly in front of its MFMAs.
-#ifndef SN_W4_PIPE
-#define SN_W4_PIPE 0
-#endif
-#ifndef SN_W4_C2RT2
-#define SN_W4_C2RT2 0
-#endif
-template <int RT, int KS>
-SN_DEV void sn_mlp_layer_h1(const char* __restrict__ wimg, const float* __restrict__ bimg, const SnOpH* op, f32x16* acc, int lane) {
-    const int h = lane >> 5;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const f32x4* b = (const f32x4*)(bimg + (rt * 2 + h) * 16);
-        f32x4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
-        acc[rt] = f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
-    }
-    u32x4 wh[2][RT], wl[2][RT];
-    auto fetch = [&](int s, int buf) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const char* base = wimg + (((rt * KS + s) * 2) * 64 + lane) * 16;
-            wh[buf][rt] = *(const u32x4*)base;
-            wl[buf][rt] = *(const u32x4*)(base + 1024);
-        }
-    };
-    constexpr bool PIPE = SN_W4_PIPE == 1 || (SN_W4_PIPE == 2 && RT == 1);   // 2: only the single-row-tile layers (8 extra registers)
-    if (PIPE) fetch(0, 0);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int cur = PIPE ? (s & 1) : 0;
-        if (PIPE) {
-            if (s + 1 < KS) fetch(s + 1, cur ^ 1);
-        } else {
-            fetch(s, 0);
-        }
-        f16x8 ah[RT], al[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            ah[rt] = __builtin_bit_cast(f16x8, wh[cur][rt]);
-            al[rt] = __builtin_bit_cast(f16x8, wl[cur][rt]);
-        }
-        const f16x8 bh = __builtin_bit_cast(f16x8, op[s].hi), bl = __builtin_bit_cast(f16x8, op[s].lo);
-#if SN_MFMA_PRIO
-        __builtin_amdgcn_s_setprio(SN_MFMA_PRIO);
-#endif
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) SN_MFMA_H(acc[rt], al[rt], bh);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) SN_MFMA_H(acc[rt], ah[rt], bl);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) SN_MFMA_H(acc[rt], ah[rt], bh);
-#if SN_MFMA_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-    }
-}
-
-// density MLP of one column tile: layer-1 operands (2 k-steps) -> the layer-2 accumulator tile
-SN_DEV void sn_density_tile_h(const char* __restrict__ ldsb, const float* __restrict__ tail, const SnOpH* in, f32x16& g, int lane) {
-    f32x16 a[2];
-    sn_mlp_layer_h1<2, 2>(ldsb + SnMainImgH::W1, tail + SnMainImgH::B1, in, a, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    SnOpH ops[4];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) sn_acc_to_ops<SN_RELU_FOLD != 0>(a[rt], true, ops[2 * rt], ops[2 * rt + 1]);
-    sn_mlp_layer_h1<1, 4>(ldsb + SnMainImgH::W2, tail + SnMainImgH::B2, ops, &g, lane);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// colour MLP of one column tile: its layer-2 rows (k-step 0) and direction operand (k-step 1) -> this lane half's partial sums of layer 3
-SN_DEV void sn_colour_tile_h(const char* __restrict__ ldsb, const float* __restrict__ tail, const SnOpH* in, float p[3], int lane) {
-    const int h = lane >> 5;
-    f32x16 a[2];
-    sn_mlp_layer_h1<2, 2>(ldsb + SnMainImgH::WC1, tail + SnMainImgH::BC1, in, a, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    SnOpH ops[4];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) sn_acc_to_ops<SN_RELU_FOLD != 0>(a[rt], true, ops[2 * rt], ops[2 * rt + 1]);
-    p[0] = p[1] = p[2] = 0.f;
-#if SN_W4_C2RT2   // colour layer 2 as ONE pass over both row tiles: two independent accumulator chains instead of one, 32 accumulator registers
-    f32x16 c2[2];
-    {
-        // (the two row tiles of WC2 are 8192 bytes apart, the layout sn_mlp_layer_h1<2, 4> expects; the bias rows likewise)
-        sn_mlp_layer_h1<2, 4>(ldsb + SnMainImgH::WC2, tail + SnMainImgH::BC2, ops, c2, lane);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#endif
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-#if SN_W4_C2RT2
-        const f32x16 c = c2[rt];
-#else
-        f32x16 c;
-        sn_mlp_layer_h1<1, 4>(ldsb + SnMainImgH::WC2 + rt * 8192, tail + SnMainImgH::BC2 + rt * 32, ops, &c, lane);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        float r[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) r[j] = sn_relu(c[j]);
-#pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            const f32x4* w = (const f32x4*)(tail + SnMainImgH::W3 + (n * 2 + h) * 32);
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const f32x4 wv = w[rt * 4 + r4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) p[n] = fmaf(wv[e], r[4 * r4 + e], p[n]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// LDS home of a wave's direction operands: [tile][hi | lo][lane][4 dwords] = 4 KB
-struct SnShLds {
-    static constexpr int BYTES_PER_WAVE = 4096;
-    SN_DEV static void store(char* base, int lane, const SnShOpsH& sh) {
-        *(u32x4*)(base + (0 * 64 + lane) * 16) = sh.t0.hi;
-        *(u32x4*)(base + (1 * 64 + lane) * 16) = sh.t0.lo;
-        *(u32x4*)(base + (2 * 64 + lane) * 16) = sh.t1.hi;
-        *(u32x4*)(base + (3 * 64 + lane) * 16) = sh.t1.lo;
-    }
-    SN_DEV static SnOpH load(const char* base, int lane, int tile) {
-        SnOpH o;
-        o.hi = *(const u32x4*)(base + ((2 * tile) * 64 + lane) * 16);
-        o.lo = *(const u32x4*)(base + ((2 * tile + 1) * 64 + lane) * 16);
-        return o;
-    }
-};
-
-SN_DEV void sn_main_field_h4(const char* __restrict__ ldsb, const char* __restrict__ shl, float* feat, int lane, float& h0, float rgb[3]) {
-    const bool upper = lane >= 32;
-    const float* tail = (const float*)(ldsb + SnMainImgH::FP32);
-    // layer-1 operands of both tiles (slot (s, h, e) <-> feature 16 s + 8 h + e); tile 1's wait as fp32
-    SnOpH in[2];
-    float w1[2][8];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        float v0[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float a = feat[16 * s + e], b = feat[16 * s + 8 + e];
-            sn_swap_halves(a, b);
-            v0[e] = a;
-            w1[s][e] = b;
-        }
-        in[s].set(v0);
-    }
-    SnOpH cin0[2], cin1[2];
-    float hl, hu;
-    {
-        f32x16 g;
-        sn_density_tile_h(ldsb, tail, in, g, lane);
-        hl = g[0];
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = g[e];
-        cin0[0].set(v);
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) in[s].set(w1[s]);
-    {
-        f32x16 g;
-        sn_density_tile_h(ldsb, tail, in, g, lane);
-        hu = g[8];
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = g[e];
-        cin1[0].set(v);
-    }
-    h0 = (upper ? hu : hl) * tail[SnMainImgH::B3 + 3];
-    float p0[3], p1[3];
-    cin0[1] = SnShLds::load(shl, lane, 0);
-    sn_colour_tile_h(ldsb, tail, cin0, p0, lane);
-    cin1[1] = SnShLds::load(shl, lane, 1);
-    sn_colour_tile_h(ldsb, tail, cin1, p1, lane);
-#pragma unroll
-    for (int n = 0; n < 3; ++n) {
-        float a = p0[n], b = p1[n];
-        sn_swap_halves(a, b);
-        float x = a + b + tail[SnMainImgH::B3 + n];
         rgb[n] = __builtin_amdgcn_rcpf(1.0f + sn_exp<true>(-x));
     }
 }
@@ -940,9 +662,6 @@ SN_DEV void sn_main_field_h4(const char* __restrict__ ldsb, const char* __restri
 #endif
 #ifndef SN_HASH_GROUP
 #define SN_HASH_GROUP 4
-#endif
-#ifndef SN_MAIN_NCACHE
-#define SN_MAIN_NCACHE 0   // (measured r04, tools/ab_libs.sh: see DESIGN.md K1 "r04")
 #endif
 #ifndef SN_MAIN_WAVES_PER_SIMD
 #define SN_MAIN_WAVES_PER_SIMD 3
@@ -975,25 +694,17 @@ SN_DEV void sn_main_field_h4(const char* __restrict__ ldsb, const char* __restri
 #define SN_STRIP_W 8  // r02 same-box A/B over widths 0 / 4 / 8 / 12 / 16: 2.826 / 2.803 / 2.805 / 2.817 / 2.823 ms (camera 0)
 #endif
 
-// Launch shape of a K1 instantiation.  WIDE (r04): the production split-precision kernel (whole-ray workgroups, de-hashed copies) as
-// 8-wave workgroups (4x2 tiles) that share ONE weight image -- 2 workgroups = 16 waves per CU, four per SIMD, <= 128 VGPRs through the
-// tile-sequential MLP (sn_main_field_h4), gathers fenced in groups of 2 levels -- instead of 4-wave workgroups at three per SIMD.
-#ifndef SN_K1_4W_GROUP
-#define SN_K1_4W_GROUP 2
-#endif
-template <int PREC, int ABLATE, int ND, bool DUMP, bool ALT, bool WIDE>
+// Launch shape of a K1 instantiation: 4-wave workgroups of 2x2 tiles, SN_MAIN_WAVES_PER_SIMD of them per CU.
+template <int PREC>
 struct SnK1Shape {
-    static constexpr bool W4 = WIDE && PREC == 1 && ABLATE == 0 && ND > 0 && !DUMP && !ALT;
-    static constexpr int WG_WAVES = W4 ? 8 : 4;
-    static constexpr int TX = W4 ? 4 : 2, TY = 2;             // tiles per workgroup
+    static constexpr int WG_WAVES = 4;
+    static constexpr int TX = 2, TY = 2;             // tiles per workgroup
     static constexpr int THREADS = WG_WAVES * 64;
-    static constexpr int WAVES_PER_SIMD = W4 ? 4 : SN_MAIN_WAVES_PER_SIMD;
-    static constexpr int HASH_GROUP = W4 ? SN_K1_4W_GROUP : (PREC == 2 ? SN_H16_GROUP : SN_HASH_GROUP);
+    static constexpr int WAVES_PER_SIMD = SN_MAIN_WAVES_PER_SIMD;
+    static constexpr int HASH_GROUP = PREC == 2 ? SN_H16_GROUP : SN_HASH_GROUP;
 };
 
 struct SnMainParams {
-    int wg_tx, wg_ty;         // tiles per workgroup (SnK1Shape::TX / TY of the instantiation that is launched)
-    int sh_lds_off;           // W4: byte offset of the waves' direction operands in LDS (behind the weight image and the bins)
     const float* origins;     // [H*W,3]
     const float* directions;  // [H*W,3]
     const float* nears;       // [H*W] or null
@@ -1058,7 +769,7 @@ SN_DEV int sn_xcd_remap(int b, int n) {
 // workgroups wide, each walked row by row, so that the ~96 workgroups an XCD runs at a time cover a squarer patch of the image (more
 // voxels shared in its L2) than two full-width rows
 SN_DEV void sn_main_wg_coords(const SnMainParams& p, int logical_block, int& bx, int& by) {
-    const int gbx = (p.tiles_x + p.wg_tx - 1) / p.wg_tx, gby = (p.tiles_y + p.wg_ty - 1) / p.wg_ty;
+    const int gbx = (p.tiles_x + 1) / 2, gby = (p.tiles_y + 1) / 2;
     const int blk = sn_xcd_remap(logical_block, gbx * gby);
     if (SN_STRIP_W > 0) {
         const int full = (gbx / SN_STRIP_W) * SN_STRIP_W * gby;  // workgroups inside complete strips
@@ -1129,18 +840,14 @@ SN_DEV void sn_main_epilogue(const SnMainParams& p, SnComposite& comp, float r, 
     }
 }
 
-// ABLATE (profiling only, images are WRONG when non-zero; selected by the SN_ABLATE environment variable): 2 = hash phase
-// only (no MLP: density / colour faked from the features), 3 = VALU only (no table gathers either).  Measured r01:
-// full 7.7 ms, hash-only 2.8-3.0 ms (= the L1 tag-lookup floor), VALU-only 1.4 ms; the 204.8 M fp32 MFMAs alone are 5.6 ms.
-template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int PREC /*0 fp32 MFMA, 1 fp16 hi+lo split MFMA*/, int ABLATE = 0,
+template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int PREC /*0 fp32 MFMA, 1 fp16 hi+lo split MFMA, 2 single fp16 (opt-in)*/,
           int GRID = 0 /*0 nerfstudio torch-path hash grid, 1 tiny-cuda-nn grid semantics*/,
           int ND = -1 /*GRID 1: number of leading dense levels, fixed at compile time (-1: run-time decision per level)*/,
           bool DUMP = false /*test instrumentation: record what every sample fetches (SnMainParams::dump_*)*/,
-          bool ALT = false /*the non-default sampler / position map: SnMainParams::spacing_uniform and pm are honoured*/,
-          bool WIDE = false /*8-wave workgroups at four waves per SIMD (SnK1Shape)*/>
-__global__ __launch_bounds__((SnK1Shape<PREC, ABLATE, ND, DUMP, ALT, WIDE>::THREADS), (SnK1Shape<PREC, ABLATE, ND, DUMP, ALT, WIDE>::WAVES_PER_SIMD))
+          bool ALT = false /*the non-default sampler / position map: SnMainParams::spacing_uniform and pm are honoured*/>
+__global__ __launch_bounds__((SnK1Shape<PREC>::THREADS), (SnK1Shape<PREC>::WAVES_PER_SIMD))
 void sn_render_main_kernel(SnMainParams p) {
-    using SHAPE = SnK1Shape<PREC, ABLATE, ND, DUMP, ALT, WIDE>;
+    using SHAPE = SnK1Shape<PREC>;
     constexpr int NT = SHAPE::THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -1204,14 +911,8 @@ void sn_render_main_kernel(SnMainParams p) {
     SnShOps sh;
     SnShOpsH shh;
     SnShOpsF shf;
-    char* shl = nullptr;  // W4: this wave's direction operands live in LDS, not in 16 registers
     if (PREC == 2) shf.build(d, p.sh_remap);
-    else if (SHAPE::W4) {
-        shl = (char*)lds + p.sh_lds_off + wave * SnShLds::BYTES_PER_WAVE;
-        SnShOpsH tmp;
-        tmp.build(d, p.sh_remap);
-        SnShLds::store(shl, lane, tmp);
-    } else if (PREC == 0) sh.build(d, p.sh_remap);
+    else if (PREC == 0) sh.build(d, p.sh_remap);
     else shh.build(d, p.sh_remap);
 
     const __amdgpu_buffer_rsrc_t rsrc = sn_table_rsrc(p.table, (16u << p.log2_t) * 8u);
@@ -1227,10 +928,6 @@ void sn_render_main_kernel(SnMainParams p) {
     };
     float t0 = bin(i_lo);
     float r = 0.f, g = 0.f, b = 0.f;
-    // experiment knob (r04): the coarsest SN_MAIN_NCACHE levels keep their four fetches across the steps of the march (SnBcCache, as K2 does)
-    SnBcCache bc_cache[SN_MAIN_NCACHE > 0 ? SN_MAIN_NCACHE : 1];
-#pragma unroll
-    for (int c = 0; c < (SN_MAIN_NCACHE > 0 ? SN_MAIN_NCACHE : 1); ++c) bc_cache[c].reset();
 #pragma unroll 1
     for (int i = i_lo; i < i_hi; ++i) {
         // The LDS weight reads are loop-invariant; LICM would hoist them all (368 VGPRs) and spill.  A compiler-only
@@ -1240,30 +937,9 @@ void sn_render_main_kernel(SnMainParams p) {
         float q[3];
         const bool sel = ALT ? sn_sample_q(o, d, t0, t1, q, pm) : sn_sample_q_fast(o, d, t0, t1, q);  // (ALT: the strict form, see sn_sample_q_fast)
         float feat[32];
-        if (ABLATE & 4) {  // no hash phase at all: the MLP phase alone
-#pragma unroll
-            for (int k = 0; k < 32; ++k) feat[k] = q[k % 3] + 0.01f * (float)k;
-        } else if (ABLATE & 1) {
-#pragma unroll
-            for (int l = 0; l < 16; ++l) {
-                SnHashLevel hl;
-                sn_hash_corners(q, p.scal[l], (1u << p.log2_t) - 1u, hl);
-                f32x2 v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    v[k].x = __uint_as_float((hl.boff[k] & 0x7fffffu) | 0x3f800000u) - 1.5f;
-                    v[k].y = -v[k].x;
-                }
-                f32x2 e = sn_hash_blend(v, hl.off);
-                feat[2 * l] = e.x;
-                feat[2 * l + 1] = e.y;
-            }
-        } else {
+        {
             // plain table: the x-paired layout (sn_device.h) measured no gain here (r01: 4.11 vs 4.18 ms) -- splitting a level
             // into per-t tables loses the x-locality of the plain layout (16 consecutive x share a 128-B line)
-#if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 3  // experiment: the hash phase (gather issue) at raised priority
-            __builtin_amdgcn_s_setprio(1);
-#endif
             uint32_t* rec = nullptr;
             if (DUMP && valid) {
                 const size_t smp = (size_t)ray * (size_t)S + (size_t)i;
@@ -1286,48 +962,24 @@ void sn_render_main_kernel(SnMainParams p) {
                 sn_hash_encode<16, SHAPE::HASH_GROUP, AR, ND, DUMP, NBC, 0, true>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
             } else if (SN_MAIN_PAIRS && MODE == 1 && ND > 0 && ND < 16) {
                 // de-hashed levels [0, ND), then the hashed levels [ND, 16) from the x-paired tables
-                sn_hash_encode<(ND > 0 ? ND : 1), SHAPE::HASH_GROUP, AR, ND, DUMP, NBC, (NBC >= SN_MAIN_NCACHE && !DUMP ? SN_MAIN_NCACHE : 0)>(
-                    rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale, bc_cache);
+                sn_hash_encode<(ND > 0 ? ND : 1), SHAPE::HASH_GROUP, AR, ND, DUMP, NBC>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
                 __builtin_amdgcn_sched_barrier(0);
                 sn_hash_encode_pairs<16, SHAPE::HASH_GROUP, true, (ND > 0 && ND < 16 ? ND : 0), GRID == 1, DUMP>(sn_table_rsrc(p.pairs, p.pairs_bytes), p.pinfo,
                                                                                                            p.scal, p.log2_t, q, feat, rec);
             } else {
-                sn_hash_encode<16, SHAPE::HASH_GROUP, AR, ND, DUMP, NBC, (NBC >= SN_MAIN_NCACHE && !DUMP ? SN_MAIN_NCACHE : 0)>(rsrc, p.scal, p.log2_t, q, feat, &p.grid,
-                                                                                                                    &p.dense, rec, p.feat_scale, bc_cache);
+                sn_hash_encode<16, SHAPE::HASH_GROUP, AR, ND, DUMP, NBC>(rsrc, p.scal, p.log2_t, q, feat, &p.grid, &p.dense, rec, p.feat_scale);
             }
-#if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 3
-            __builtin_amdgcn_s_setprio(0);
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
-#if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 2  // experiment: the whole MLP phase at raised priority
-        __builtin_amdgcn_s_setprio(1);
-#endif
         float h0, rgb[3];
-        if (ABLATE & 2) {
-            float a = 0.f, bsum = 0.f;
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                a += feat[k];
-                bsum = fmaf(feat[k], (float)(k & 3), bsum);
-            }
-            h0 = a * 0.1f + d[0];
-            rgb[0] = 0.5f + 0.1f * a;
-            rgb[1] = 0.5f + 0.1f * bsum;
-            rgb[2] = 0.5f - 0.1f * a;
-        } else if (PREC == 0) {
+        if (PREC == 0) {
             sn_main_field_f32(lds, feat, sh, lane, h0, rgb);
         } else if (PREC == 2) {
             sn_main_field_f16((const char*)lds, feat, shf, lane, h0, rgb);
-        } else if (SHAPE::W4) {
-            sn_main_field_h4((const char*)lds, shl, feat, lane, h0, rgb);
         } else {
             sn_main_field_h((const char*)lds, feat, shh, lane, h0, rgb);
         }
         __builtin_amdgcn_sched_barrier(0);
-#if defined(SN_PRIO_PHASE) && SN_PRIO_PHASE == 2
-        __builtin_amdgcn_s_setprio(0);
-#endif
         float density = p.avg_density * sn_exp<true>(h0) * (sel ? 1.0f : 0.0f);
         // A NaN position (e.g. the 1e10 sentinel of a ray that misses render_aabb overflows to inf/inf) is NaN all the
         // way through the reference's field; v_max-based ReLU would launder it, so restore it here -- by arithmetic, not selects
@@ -1348,7 +1000,7 @@ void sn_render_main_kernel(SnMainParams p) {
         // sum w)).  Outputs are bit-identical (tests/test_gpu_early_term.py); the synthetic benchmark scene never saturates (its
         // densities are O(1): max cumsum(tau) < 88), so the check costs it one v_cmp and one branch per step.  Segment jobs store every
         // sample and the DUMP instantiations record every fetch: not for them.
-        if (!DUMP && ABLATE == 0 && p.early_term && !seg_out && i < i_hi - 2 && __all(comp.last_trans == 0.0f)) {
+        if (!DUMP && p.early_term && !seg_out && i < i_hi - 2 && __all(comp.last_trans == 0.0f)) {
             if (p.march_stats && lane == 0) atomicAdd(&p.march_stats[0], (unsigned long long)(i_hi - 2 - i));  // (here, not behind the loop: no state carried)
             i = i_hi - 2;
             t0 = bin(i_hi - 1);

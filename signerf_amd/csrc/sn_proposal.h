@@ -50,9 +50,6 @@
 // sum_r W1[r] b0[r] / 2 + b1
 #define SN_PROP_LIN 1236
 #define SN_PROP_PACK_FLOATS 1252
-#ifndef SN_PROP_MFMA
-#define SN_PROP_MFMA 1
-#endif
 
 struct SnScal5 {
     float v[5];
@@ -98,9 +95,6 @@ SN_DEV float sn_prop_mlp_mfma(const float* __restrict__ w, const float* feat, in
     const f16x8 b1h = __builtin_bit_cast(f16x8, xh), b1l = __builtin_bit_cast(f16x8, xl);
     const f16x8 b2h = __builtin_bit_cast(f16x8, yh), b2l = __builtin_bit_cast(f16x8, yl);
     f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#if defined(SN_PROP_PRIO) && SN_PROP_PRIO  // experiment (tools/ab_lib.sh): priority around the layer's six MFMAs
-    __builtin_amdgcn_s_setprio(SN_PROP_PRIO);
-#endif
     // small terms first
     SN_MFMA_H(c, a1l, b1h);
     SN_MFMA_H(c, a2l, b2h);
@@ -108,9 +102,6 @@ SN_DEV float sn_prop_mlp_mfma(const float* __restrict__ w, const float* feat, in
     SN_MFMA_H(c, a2h, b2l);
     SN_MFMA_H(c, a1h, b1h);
     SN_MFMA_H(c, a2h, b2h);
-#if defined(SN_PROP_PRIO) && SN_PROP_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     // layer 2: accumulator register r holds hidden unit (r & 3) + 8 ((r & 7) >> 2) + 4 h of ray j (r < 8) / ray j + 32 (r >= 8).
     // w relu(x) = (w x + w |x|) / 2: the |x| half is ONE fma per unit (the absolute value is a source modifier) instead of a max and an
     // fma; the linear half, sum_r w_r x_r, is a linear function of the ray's 10 features and is evaluated as such by the ray's own lane
@@ -134,8 +125,8 @@ SN_DEV float sn_prop_mlp_mfma(const float* __restrict__ w, const float* feat, in
 }
 
 // pre-activation density of one proposal net at normalised position q.
-// The MLP (10 -> 16 -> 1) runs on the matrix cores in split precision (sn_prop_mlp_mfma above; SN_PROP_MFMA=0 keeps the VALU form:
-// weights broadcast from LDS, two hidden units per v_pk_fma_f32).  History (r01): an exact-fp32 version (v_mfma_f32_32x32x2_f32,
+// The MLP (10 -> 16 -> 1) runs on the matrix cores in split precision (sn_prop_mlp_mfma above).  History (r01; the VALU form -- weights
+// broadcast from LDS, two hidden units per v_pk_fma_f32 -- left the product in r05, tools/patches/): an exact-fp32 version (v_mfma_f32_32x32x2_f32,
 // 11 MFMAs x 64 cycles) was 9 % SLOWER than the VALU form -- the f32-input MFMA runs at the vector rate and does not overlap with VALU
 // work at all (re-measured r02, tools/probes/overlap2_probe.hip), so its cycles simply replace VALU cycles; the fp16 hi+lo form needs
 // 6 MFMAs x 32 cycles for the whole layer (K = 16 in one k-step), which plain VALU instructions do overlap with, and measured 4 %
@@ -177,36 +168,7 @@ SN_DEV float sn_prop_h0(__amdgpu_buffer_rsrc_t prsrc, const SnPairInfo& pi, cons
     } else {
         sn_hash_encode_pairs<5, 0, true, 0, false, DUMP>(prsrc, pi, scal.v, log2_t, q, feat, rec);
     }
-#if SN_PROP_MFMA
     float out = sn_prop_mlp_mfma(w, feat, (int)(threadIdx.x & 63));
-#else
-    // hidden units in pairs: one v_pk_fma_f32 per (pair, k); every unit still sums bias, k = 0..9 in order with fused multiply-adds
-    const f32x2* w2 = (const f32x2*)w;
-    f32x2 a[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = w2[SN_PROP_B0 / 2 + j];
-#pragma unroll
-    for (int k = 0; k < 10; ++k) {
-        // gfx950 hazard found on hardware (r01, tools/concurrency_probe.py, tools/stage_concurrency_probe.py): feat[k] is one half of
-        // a register pair written by the blend's packed ops (v_pk_fma_f32); the packed FMAs below read it with an op_sel
-        // broadcast.  hipcc (ROCm 7.2) lets the two sit back to back, and when MFMA-heavy waves of ANOTHER kernel share the SIMD
-        // (two renders on two hardware queues) the consumer sees the pair's previous contents in lanes 48-63 (the last 16-lane
-        // pass) -- a few 8x8 tiles per frame.  The same family as the v_permlane32_swap hazard (sn_swap_halves).  A copy through a
-        // plain v_mov_b32 behind one wait state removes it (0 differences in the probes; ~100 000 per run without).
-        float fs;
-        asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(fs) : "v"(feat[k]));
-        const f32x2 fk = {fs, fs};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = __builtin_elementwise_fma(w2[(SN_PROP_W0 + k * 16) / 2 + j], fk, a[j]);
-    }
-    f32x2 o2 = {w[SN_PROP_B1], 0.0f};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const f32x2 r = {sn_relu(a[j].x), sn_relu(a[j].y)};
-        o2 = __builtin_elementwise_fma(w2[SN_PROP_W1 / 2 + j], r, o2);
-    }
-    float out = o2.x + o2.y;
-#endif
     // the reference's field is NaN all the way for a NaN position (and a v_max-based ReLU would launder it anyway): restored by arithmetic
     // (+-0 or NaN), not by a select -- sn_sample_q_fast explains why
     return out + nanq;
@@ -228,10 +190,6 @@ struct SnPdfNorm {
     }
 };
 
-// FAST (experiment, SN_PDF_FAST=1; NOT the default): the two divisions -- weight / sum and the inverse-CDF interpolation ratio -- as a
-// multiplication by a reciprocal, each within 1-2 ulp of the true quotient.  Measured r02 on the 1080p nerfacto frame: 16.37 vs 16.50 ms
-// (-0.8 %); not worth giving up the literal arithmetic of the CDF search, so the fused kernel keeps the IEEE divisions like the stage
-// entry point sn_pdf_sample does.
 // RECIP (the fused kernel, r02): the per-weight division num / denom has a loop-invariant denominator, so the IEEE quotient is formed
 // from its correctly rounded reciprocal y = RN(1 / denom) (one IEEE division per ray) as  q0 = RN(num y);  e = num - q0 denom (exact,
 // one fma);  q = RN(q0 + e y).  Markstein's theorem gives q == RN(num / denom) when q0 is a FAITHFUL rounding of the quotient and the
@@ -241,7 +199,7 @@ struct SnPdfNorm {
 // 80 M + 400 M pairs), and tests/test_gpu_render.py::test_resampler_reciprocal_division_is_bit_identical compares whole renders with
 // SN_PDF_IEEE=1 (the plain divisions).  A denominator with an all-ones significand (1 in 8 M), or one outside [2^-60, 2^60] (residual
 // underflow; never the case: 1e-5 <= denom <= ~260), sends the whole wave down the plain IEEE path.  3 instead of ~10 VALU per weight.
-template <bool FAST = false, bool RECIP = false, typename SB, typename EMIT>
+template <bool RECIP = false, typename SB, typename EMIT>
 SN_DEV void sn_pdf_lane(const float* __restrict__ w, int wstride, int N, int M, const float* u, float pad, const SnPdfNorm& nm, SB sb,
                         EMIT emit, bool force_ieee = false) {
     int j = 0;
@@ -252,9 +210,9 @@ SN_DEV void sn_pdf_lane(const float* __restrict__ w, int wstride, int N, int M, 
     bool recip = false;
     {
 #pragma clang fp contract(off)
-        if (FAST || RECIP) inv_denom = 1.0f / nm.denom;
+        if (RECIP) inv_denom = 1.0f / nm.denom;
     }
-    if (RECIP && !FAST) {
+    if (RECIP) {
         const uint32_t bits = __float_as_uint(nm.denom);
         const bool unsafe = (bits & 0x7fffffu) == 0x7fffffu || !(nm.denom >= 0x1p-60f && nm.denom <= 0x1p60f);
         recip = !force_ieee && !__any(unsafe);  // wave-uniform
@@ -265,9 +223,7 @@ SN_DEV void sn_pdf_lane(const float* __restrict__ w, int wstride, int N, int M, 
 #pragma clang fp contract(off)
             const float num = (w[(int64_t)i * wstride] + pad) + nm.padding;
             float pdf;
-            if (FAST) {
-                pdf = num * inv_denom;
-            } else if (RECIP && recip) {
+            if (RECIP && recip) {
                 const float q0 = num * inv_denom;
                 pdf = __builtin_fmaf(__builtin_fmaf(-q0, nm.denom, num), inv_denom, q0);
             } else {
@@ -281,7 +237,7 @@ SN_DEV void sn_pdf_lane(const float* __restrict__ w, int wstride, int N, int M, 
                 float t, v;
                 {
 #pragma clang fp contract(off)
-                    t = FAST ? (uj - c_prev) * __builtin_amdgcn_rcpf(c_next - c_prev) : (uj - c_prev) / (c_next - c_prev);
+                    t = (uj - c_prev) / (c_next - c_prev);
                     if (t != t) t = 0.0f;
                     t = fminf(fmaxf(t, 0.0f), 1.0f);
                     v = b_prev + t * (b_next - b_prev);
@@ -447,7 +403,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
 }
 
 // GRID 1: ND0 / ND1 = leading dense levels of the two nets (-1: run-time decision per level)
-template <int GRID, int ND0 = -1, int ND1 = -1, bool DUMP = false, bool FASTPDF = false, bool ALT = false>
+template <int GRID, int ND0 = -1, int ND1 = -1, bool DUMP = false, bool ALT = false>
 __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_proposal_kernel(SnPropParams p) {
     __shared__ __attribute__((aligned(16))) SnPropLds L;
     const int su = ALT ? p.spacing_uniform : 0;
@@ -481,20 +437,8 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
     float* __restrict__ B1 = sc + SN_PROP_SCRATCH_B1;
     const int tw = 1 << p.tile_w_log2;
 
-#ifndef SN_PROP_XCD
-#define SN_PROP_XCD 0   // experiment (r04, tools/ab_k2.sh): XCD-banded tile order, see below
-#endif
-    // Default: wave w of the grid walks tiles w, w + n_waves, ...  SN_PROP_XCD: the dispatcher places block b on XCD b % 8 -- every XCD gets a
-    // contiguous band of tiles and its waves walk the band together, so that the tiles in flight on one XCD are neighbours and share its L2 (the
-    // main kernel's sn_xcd_remap, for persistent waves).  A bijection of [0, n_tiles) whenever the grid is a multiple of 8 blocks.
-    int t_first = wave_global, t_stride = n_waves, t_base = 0, t_len = n_tiles;
-    if (SN_PROP_XCD && ((int)gridDim.x & 7) == 0) {
-        const int xcd = (int)blockIdx.x & 7, qn = n_tiles >> 3, rn = n_tiles & 7;
-        t_first = ((int)blockIdx.x >> 3) * SN_PROP_WAVES + wave;
-        t_stride = ((int)gridDim.x >> 3) * SN_PROP_WAVES;
-        t_base = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
-        t_len = qn + (xcd < rn ? 1 : 0);
-    }
+    // wave w of the grid walks tiles w, w + n_waves, ...  (an XCD-banded tile order measured nil, r04: tools/patches/)
+    const int t_first = wave_global, t_stride = n_waves, t_base = 0, t_len = n_tiles;
 #pragma unroll 1
     for (int t_it = t_first; t_it < t_len; t_it += t_stride) {
         const int tile = t_base + t_it;
@@ -528,20 +472,20 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
             if (DUMP && dump_ray >= 0 && p.dump_pdf[k]) p.dump_pdf[k][(size_t)dump_ray * (size_t)(m + 1) + (size_t)j] = idx;
         };
         if (p.n_levels == 1) {
-            sn_pdf_lane<FASTPDF, true>(W, 64, n0, p.n_final, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; }, [&](int j, float v, int idx) {
+            sn_pdf_lane<true>(W, 64, n0, p.n_final, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; }, [&](int j, float v, int idx) {
                 eb_tile[(int64_t)j * 64] = sn_euclid(v, s_near, s_far, su);
                 dump_idx(0, p.n_final, j, idx);
             }, p.pdf_ieee != 0);
         } else {
             const int n1 = p.n_samples[1];
-            sn_pdf_lane<FASTPDF, true>(W, 64, n0, n1, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; }, [&](int j, float v, int idx) {
+            sn_pdf_lane<true>(W, 64, n0, n1, L.u[0], p.hist_pad, nm, [&](int i) { return L.sb0[i]; }, [&](int j, float v, int idx) {
                 B0[(int64_t)j * 64] = v;
                 dump_idx(0, n1, j, idx);
             }, p.pdf_ieee != 0);
             sn_prop_level<1, GRID, ND1, DUMP, ALT>(p, L.wpack[1], [&](int i) { return B0[(int64_t)i * 64]; }, W, n1, o, d, s_near, s_far, sum_wp, med, dump_ray);
             if (valid && p.prop_depth[1]) p.prop_depth[1][pix] = med;
             nm.set(sum_wp, n1);
-            sn_pdf_lane<FASTPDF, true>(W, 64, n1, p.n_final, L.u[1], p.hist_pad, nm, [&](int i) { return B0[(int64_t)i * 64]; }, [&](int j, float v, int idx) {
+            sn_pdf_lane<true>(W, 64, n1, p.n_final, L.u[1], p.hist_pad, nm, [&](int i) { return B0[(int64_t)i * 64]; }, [&](int j, float v, int idx) {
                 eb_tile[(int64_t)j * 64] = sn_euclid(v, s_near, s_far, su);
                 dump_idx(1, p.n_final, j, idx);
             }, p.pdf_ieee != 0);

@@ -135,7 +135,7 @@ def test_static_instruction_counts_of_the_fused_kernels(built_lib):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import kernel_counts
 
-    k1 = kernel_counts.loop_counts("sn_render_main_kernelILi0ELi1ELi0ELi0ELi11E")       # (a prefix: trailing defaulted arguments are matched)
+    k1 = kernel_counts.loop_counts("sn_render_main_kernelILi0ELi1ELi0ELi11E")       # (a prefix: trailing defaulted arguments are matched)
     assert k1["mfma"] == 120 and k1["gather"] == 84 and k1["packed_f32"] == 0 and 1300 < k1["valu"] < 1500
     k2 = kernel_counts.mfma_loops("sn_proposal_kernelILi0ELi5ELi4E")
     assert [c["mfma"] for c in k2] == [6, 6] and all(c["gather"] == 20 and 220 < c["valu"] < 340 for c in k2)

@@ -406,10 +406,10 @@ def test_viewer_crop_box_bounds_the_rays(gpu):
 
 def test_dehashed_and_plain_reads_agree(gpu, monkeypatch):
     """K1 reads 11 of 16 levels from de-hashed copies (9 of them in bilinear-coefficient form: A + ox B + oy (C + ox D) per z slice).
-    With SN_DENSE_LEVELS=0 every level comes from the uploaded table through the lerp-form blend: the two renders must agree to
-    rounding (the coefficient form differs from the lerp form by a few ulp of the table magnitude per level)."""
+    With `dense_levels = -1` (SnFieldDesc) every level comes from the uploaded table through the lerp-form blend: the two renders must agree
+    to rounding (the coefficient form differs from the lerp form by a few ulp of the table magnitude per level)."""
     cfg = scene.benchmark_config(32)
-    monkeypatch.setenv("SN_DENSE_LEVELS", "0")
+    cfg.dense_levels = -1
     plain, _ = make_model(cfg, gpu)
     H = W = 64
     cams = Cameras(scene.benchmark_cameras(8)[:, :3], 64.0, 64.0, W / 2, H / 2, W, H).to(gpu)
@@ -417,7 +417,7 @@ def test_dehashed_and_plain_reads_agree(gpu, monkeypatch):
     base = [{k: plain.get_outputs_for_camera_ray_bundle(b)[k].clone() for k in ("rgb", "depth", "accumulation")} for b in bundles]
     from signerf_amd import ops
     assert ops.debug_layout(plain, -1)["n_dense"] == 0
-    monkeypatch.delenv("SN_DENSE_LEVELS")
+    cfg = scene.benchmark_config(32)
     dense, _ = make_model(cfg, gpu)
     for b, ref in zip(bundles, base):
         out = dense.get_outputs_for_camera_ray_bundle(b)
@@ -436,7 +436,9 @@ def test_copy_budget_through_the_descriptor(gpu):
     cams = Cameras(scene.benchmark_cameras(8)[:, :3], 64.0, 64.0, W / 2, H / 2, W, H).to(gpu)
     b = cams[1].generate_rays(0)
     held, ref = {}, None
-    for levels, cap, want in ((0, 0, 11), (-1, 0, 0), (6, 0, 6), (0, 100, 9)):   # (0, 100): level 9 (R = 296: 207 MB at 8 B per grid point) exceeds the cap
+    # the main kernel is instantiated for 11 and 9 copied levels: any other count is rounded down to one of them (or to none).
+    # (0, 100): level 9 (R = 296: 207 MB at 8 B per grid point) exceeds the cap
+    for levels, cap, want in ((0, 0, 11), (-1, 0, 0), (6, 0, 0), (9, 0, 9), (10, 0, 9), (12, 0, 11), (0, 100, 9)):
         cfg = scene.benchmark_config(32)
         cfg.dense_levels, cfg.dense_copy_cap_mb = levels, cap
         model, _ = make_model(cfg, gpu)
@@ -450,7 +452,8 @@ def test_copy_budget_through_the_descriptor(gpu):
             ref = {k: out[k].clone() for k in ("rgb", "accumulation")}
         else:
             assert rmse(out["rgb"], ref["rgb"]) <= 2e-6 and rmse(out["accumulation"], ref["accumulation"]) <= 2e-6
-    assert held[(-1, 0)] < 70e6 < held[(6, 0)] < held[(0, 100)] < held[(0, 0)] and 1.2e9 < held[(0, 0)] < 1.5e9, held
+    assert held[(-1, 0)] == held[(6, 0)] < 70e6 < held[(9, 0)] == held[(10, 0)] == held[(0, 100)] < held[(0, 0)] == held[(12, 0)], held
+    assert 0.5e9 < held[(9, 0)] < 0.65e9 and 1.2e9 < held[(0, 0)] < 1.5e9, held
 
 
 def test_proposal_coefficient_cache_is_bit_identical(gpu, monkeypatch):

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Value per byte of the de-hashed copies of the main grid: K1 time over the 8 reference-sheet cameras and the
-HBM footprint of the copies for 0 / 8 / 9 / 10 / 11 copied levels, interleaved in one process.
+"""Value per byte of the de-hashed copies of the main grid: K1 time over the 8 reference-sheet cameras (800x800x64) and the device
+memory a handle holds for each copy count a descriptor can select -- `SnFieldDesc.dense_levels` = -1 (no copies), 9 (the
+coefficient-form levels alone) and 0 (the default: 11 levels) -- one model per setting, settings interleaved.  The line a viewer
+holding several models needs (VERDICT r04 "weak 8"): what the default costs, and what the cheaper points of the curve give up.
 
     python tools/dense_sweep.py [--reps 3] [--frames 6]
 """
@@ -22,22 +24,23 @@ def main():
     ap.add_argument("--frames", type=int, default=6)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
-    cfg = scene.benchmark_config(64)
-    model = cfg.setup()
-    model.load_state_dict(scene.synthetic_state_dict(cfg), strict=False)
-    model = model.to(dev).eval()
+    sd = scene.synthetic_state_dict(scene.benchmark_config(64))
+    models, held = {}, {}
+    for lv in (-1, 9, 0):
+        cfg = scene.benchmark_config(64)
+        cfg.dense_levels = lv
+        m = cfg.setup()
+        m.load_state_dict(sd, strict=False)
+        models[lv] = m.to(dev).eval()
     W = H = 800
     cams = Cameras(scene.benchmark_cameras(8)[:, :3], 800.0, 800.0, 400.0, 400.0, W, H).to(dev)
     bundles = [cams[i].generate_rays(0) for i in range(8)]
-    configs = [(lv, 1) for lv in (0, 8, 9, 10, 11)]   # (orientation sets, the second column of r02's sweep, were removed afterwards)
-    times = {c: [[] for _ in range(8)] for c in configs}
-    bytes_ = {}
+    times = {lv: [[] for _ in range(8)] for lv in models}
     for rep in range(a.reps):
-        for lv, st in configs:
-            os.environ["SN_DENSE_LEVELS"] = str(lv)
-            model.mark_weights_dirty()
-            model.get_outputs_for_camera_ray_bundle(bundles[0])  # re-finalize + warm
-            bytes_[(lv, st)] = ops.debug_layout(model, -1)["dense_bytes"]
+        for lv, model in models.items():
+            model.get_outputs_for_camera_ray_bundle(bundles[0])
+            lay = ops.debug_layout(model, -1)
+            held[lv] = (lay["n_dense"], lay["dense_bytes"], lay["handle_bytes"])
             for cam in range(8):
                 model.get_outputs_for_camera_ray_bundle(bundles[cam])
                 ev = []
@@ -48,14 +51,14 @@ def main():
                     e1.record()
                     ev.append((e0, e1))
                 torch.cuda.synchronize()
-                times[(lv, st)][cam] += [x.elapsed_time(y) for x, y in ev]
-    best = min(statistics.mean(statistics.median(t) for t in times[c]) for c in configs)
-    print("levels sets  copies[MB]   mean-of-8-cameras[ms]  vs best   camera 0 [ms]  slowest camera [ms]   per camera")
-    for c in configs:
-        per_cam = [statistics.median(t) for t in times[c]]
+                times[lv][cam] += [x.elapsed_time(y) for x, y in ev]
+    best = min(statistics.mean(statistics.median(t) for t in times[lv]) for lv in models)
+    print("dense_levels  copied  copies[MB]  handle[MB]   mean-of-8-cameras[ms]  vs best   camera 0 [ms]   per camera")
+    for lv in models:
+        per_cam = [statistics.median(t) for t in times[lv]]
         m = statistics.mean(per_cam)
-        print(f"{c[0]:6d} {c[1]:4d}  {bytes_[c] / 1e6:10.1f}   {m:21.3f}  {100 * (m / best - 1):+6.1f}%   {per_cam[0]:13.3f}  {max(per_cam):19.3f}   "
-              + " ".join(f"{x:.2f}" for x in per_cam))
+        nd, cb, hb = held[lv]
+        print(f"{lv:12d}  {nd:6d}  {cb / 1e6:10.1f}  {hb / 1e6:10.1f}   {m:21.3f}  {100 * (m / best - 1):+6.1f}%   {per_cam[0]:13.3f}   " + " ".join(f"{x:.2f}" for x in per_cam))
 
 
 if __name__ == "__main__":

@@ -178,5 +178,5 @@ def loop_counts(kernel_substr: str, lib: str = LIB) -> dict:
 
 
 if __name__ == "__main__":
-    pat = sys.argv[1] if len(sys.argv) > 1 else "sn_render_main_kernelILi0ELi1ELi0ELi0ELi11ELb0E"
+    pat = sys.argv[1] if len(sys.argv) > 1 else "sn_render_main_kernelILi0ELi1ELi0ELi11ELb0E"
     print(loop_counts(pat))

@@ -11,7 +11,7 @@ cd "$ROOT"
 timeout 600 python bench.py > "$OUT/bench_sheet64.json" 2> "$OUT/bench_sheet64.err"
 timeout 600 python bench.py --workload nerfacto1080 --steps 60 --warmup 5 --no-others --no-traffic > "$OUT/bench_nerfacto1080.json" 2> "$OUT/bench_nerfacto1080.err"
 timeout 300 python tools/kernel_counts.py > "$OUT/kernel_counts.txt" 2>&1
-timeout 300 python tools/kernel_counts.py sn_render_main_kernelILi1ELi1ELi0ELi0ELi11E >> "$OUT/kernel_counts.txt" 2>&1
+timeout 300 python tools/kernel_counts.py sn_render_main_kernelILi1ELi1ELi0ELi11E >> "$OUT/kernel_counts.txt" 2>&1
 timeout 300 python -c "import sys; sys.path.insert(0, 'tools'); import kernel_counts as k; print('K2 marching loops (net 0, net 1):', [{x: c.get(x, 0) for x in ('valu', 'mfma', 'gather', 'packed_f32')} for c in k.mfma_loops('sn_proposal_kernelILi0ELi5ELi4E')])" >> "$OUT/kernel_counts.txt" 2>&1
 timeout 600 python bench.py --scaling strong --steps 40 --no-cpu-baseline --no-others --no-traffic > "$OUT/bench_strong_n1.json" 2> "$OUT/bench_strong_n1.err"
 timeout 300 python tools/normals_bench.py > "$OUT/normals_bench.txt" 2>&1
