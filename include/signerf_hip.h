@@ -162,7 +162,9 @@ typedef struct SnRenderOpts {
      * (SN_EARLY_TERM) SKIPPED in [0] the main kernel, [1] proposal level 0, [2] proposal level 1.  A full march is tiles x samples of
      * the level wave-steps (tiles = ceil(W / 8) x ceil(H / 8); H < 8: ceil(W / 64) x H).  One atomic where a wave stops, nothing on
      * the path of a wave that does not.  Diagnostics: bench.py's `trained` leg and tests/test_gpu_trained.py report the skipped
-     * fraction with it. */
+     * fraction with it.  A render with march_stats set runs the COUNTING instantiations of the kernels (the production kernels hold no
+     * atomic: one in their exit branch cost the schedule of the whole hash phase, r05) -- same outputs bit for bit, a few per cent slower,
+     * and only for the default variant (torch grid, 11 + 5 + 4 de-hashed levels, precision 1, default sampler); SN_ERR_INVALID otherwise. */
     uint64_t* march_stats;
 } SnRenderOpts;
 

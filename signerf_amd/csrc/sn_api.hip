@@ -1452,6 +1452,8 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     // instantiations -- the run-time-generic ones: uploaded tables, no de-hashed copies -- so the production kernels' code does not change
     const bool alt = needs_generic_kernels(h, opts);
     if (dump && alt) return fail(h, SN_ERR_INVALID, "sn_render_rays_debug: the dump exists for the default sampler and scene contraction only");
+    if (pp.march_stats && (dump || alt || d.proposals[0].grid_mode != 0 || !(nprop == 2 && h->nd_prop[0] == 5 && h->nd_prop[1] == 4)))
+        return fail(h, SN_ERR_INVALID, "SnRenderOpts.march_stats: the counting instantiation of the proposal kernel exists for the default variant only (torch grid, 2 nets, 5 + 4 de-hashed levels, default sampler)");
     if (alt) {
         if (d.proposals[0].grid_mode == 1) hipLaunchKernelGGL((sn_proposal_kernel<1, -1, -1, false, true>), pgrid, pblock, 0, st, pp);
         else hipLaunchKernelGGL((sn_proposal_kernel<0, -1, -1, false, true>), pgrid, pblock, 0, st, pp);
@@ -1481,7 +1483,8 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     } else if (nprop == 2 && h->nd_prop[0] == 5 && h->nd_prop[1] == 4) {
         // nerfacto's nets (max_res 128 / 256): every level but the finest of the second net has a de-hashed copy
         for (int i = 0; i < nprop; ++i) pp.grid[i] = h->dense_res_prop[i];
-        hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4>), pgrid, pblock, 0, st, pp);
+        if (pp.march_stats) hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4, false, false, true>), pgrid, pblock, 0, st, pp);   // (the counting instantiation)
+        else hipLaunchKernelGGL((sn_proposal_kernel<0, 5, 4>), pgrid, pblock, 0, st, pp);
     } else {
         hipLaunchKernelGGL((sn_proposal_kernel<0, -1, -1>), pgrid, pblock, 0, st, pp);
     }
@@ -1611,6 +1614,8 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
     }
 #define SN_LAUNCH_MAIN_TORCH(MODE, PREC) SN_LAUNCH_MAIN_ND(MODE, PREC, 0)
 #define SN_LAUNCH_MAIN_TCNN(MODE, PREC) SN_LAUNCH_MAIN_ND(MODE, PREC, 1)
+    if (p.march_stats && (half1 || dump || alt))
+        return fail(h, SN_ERR_INVALID, "SnRenderOpts.march_stats: no counting instantiation for this variant (single fp16 / instrumented / generic sampler)");
     if (half1) {
         // single-fp16 mode: the tiny-cuda-nn grid's kernels, with the de-hashed copies when the handle has the default 11 of them
         if (dump || alt) return fail(h, SN_ERR_INVALID, "precision 2 (single fp16) has no instrumented / generic-sampler instantiation");
@@ -1648,6 +1653,13 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
             else { if (tcnn) SN_LAUNCH_MAIN_ALT(0, 0, 1); else SN_LAUNCH_MAIN_ALT(0, 0, 0); }
         }
 #undef SN_LAUNCH_MAIN_ALT
+    } else
+    if (p.march_stats) {
+        // the counting instantiations (diagnostics): the production variant of nerfacto's torch grid, split precision, both samplers
+        if (!(split && !tcnn && nd_launch == SN_DENSE_LEVELS_DEFAULT))
+            return fail(h, SN_ERR_INVALID, "SnRenderOpts.march_stats: the counting instantiation of the main kernel exists for the default variant only (torch grid, 11 de-hashed levels, precision 1)");
+        if (nprop > 0) hipLaunchKernelGGL((sn_render_main_kernel<1, 1, 0, SN_DENSE_LEVELS_DEFAULT, false, false, true>), grid, block, lds_bytes, st, p);
+        else hipLaunchKernelGGL((sn_render_main_kernel<0, 1, 0, SN_DENSE_LEVELS_DEFAULT, false, false, true>), grid, block, lds_bytes, st, p);
     } else
     if (nprop > 0) {
         if (split) { if (tcnn) { SN_LAUNCH_MAIN_TCNN(1, 1) } else { SN_LAUNCH_MAIN_TORCH(1, 1) } }

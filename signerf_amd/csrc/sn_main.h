@@ -744,7 +744,7 @@ struct SnMainParams {
     int seg_first_block, n_seg, seg_len;
     f32x4* seg_scratch;
     int early_term;   // exact early termination of saturated waves (below); 0 = off (SN_EARLY_TERM=0: the A/B and bit-identity switch)
-    unsigned long long* march_stats;  // SnRenderOpts.march_stats ([0]: wave-steps this kernel's early termination skipped) or null
+    unsigned long long* march_stats;  // SnRenderOpts.march_stats ([0]: wave-steps this kernel's early termination skipped) or null; STATS instantiations only
     int bg_mode;      // RGBRenderer background: 0 = the ray's last sample, 1 = the constant colour bg
     float bg[3];
     int spacing_uniform;  // SnRenderOpts.spacing_mode: the initial sampler's s(x) is the identity (sn_spacing)
@@ -844,7 +844,10 @@ template <int MODE /*0 uniform-in-s bins, 1 explicit bins*/, int PREC /*0 fp32 M
           int GRID = 0 /*0 nerfstudio torch-path hash grid, 1 tiny-cuda-nn grid semantics*/,
           int ND = -1 /*GRID 1: number of leading dense levels, fixed at compile time (-1: run-time decision per level)*/,
           bool DUMP = false /*test instrumentation: record what every sample fetches (SnMainParams::dump_*)*/,
-          bool ALT = false /*the non-default sampler / position map: SnMainParams::spacing_uniform and pm are honoured*/>
+          bool ALT = false /*the non-default sampler / position map: SnMainParams::spacing_uniform and pm are honoured*/,
+          bool STATS = false /*diagnostics: count the wave-steps the early termination skips (SnMainParams::march_stats).  Its own instantiation: an
+                               atomic in the exit branch of the PRODUCTION kernel changed hipcc's schedule of the whole hash phase -- 4 instead of 16
+                               gathers in flight, +10 % per launch (r05, found by a same-box A/B against the r04 library) */>
 __global__ __launch_bounds__((SnK1Shape<PREC>::THREADS), (SnK1Shape<PREC>::WAVES_PER_SIMD))
 void sn_render_main_kernel(SnMainParams p) {
     using SHAPE = SnK1Shape<PREC>;
@@ -1001,7 +1004,7 @@ void sn_render_main_kernel(SnMainParams p) {
         // densities are O(1): max cumsum(tau) < 88), so the check costs it one v_cmp and one branch per step.  Segment jobs store every
         // sample and the DUMP instantiations record every fetch: not for them.
         if (!DUMP && p.early_term && !seg_out && i < i_hi - 2 && __all(comp.last_trans == 0.0f)) {
-            if (p.march_stats && lane == 0) atomicAdd(&p.march_stats[0], (unsigned long long)(i_hi - 2 - i));  // (here, not behind the loop: no state carried)
+            if (STATS && p.march_stats && lane == 0) atomicAdd(&p.march_stats[0], (unsigned long long)(i_hi - 2 - i));
             i = i_hi - 2;
             t0 = bin(i_hi - 1);
         }

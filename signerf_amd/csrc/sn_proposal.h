@@ -292,7 +292,7 @@ struct SnPropParams {
     float near_plane, far_plane, avg_density, hist_pad;
     int pdf_ieee;   // test switch (SN_PDF_IEEE=1): the resampler divides with the plain IEEE sequence instead of sn_pdf_lane's RECIP form
     int early_term; // exact early termination of saturated waves (sn_prop_level); 0 = off (SN_EARLY_TERM=0)
-    unsigned long long* march_stats;  // SnRenderOpts.march_stats ([1 + LV]: wave-steps the early termination of level LV skipped) or null
+    unsigned long long* march_stats;  // SnRenderOpts.march_stats ([1 + LV]: wave-steps the early termination of level LV skipped) or null; STATS instantiation only
     int cache_off;  // test switch: the coefficient cache re-fetches on every step (tests/test_gpu_render.py compares the two bit for bit)
     int spacing_uniform;  // SnRenderOpts.spacing_mode (sn_spacing)
     SnPosMap pm;          // SnFieldDesc.disable_scene_contraction (sn_sample_q_fast)
@@ -318,7 +318,7 @@ struct SnPropLds {
 // One proposal level for this lane's ray: density net LV at the N samples whose spacing bins are sb(0..N); writes the
 // weights to w[i * 64] and returns sum(w + pad) (fp64) and the level's median depth.
 // eb_shared: LV 0 only -- the level's euclidean bins from LDS (frames without per-ray nears / fars), else null
-template <int LV, int GRID, int ND, bool DUMP, bool ALT, typename SB>
+template <int LV, int GRID, int ND, bool DUMP, bool ALT, bool STATS, typename SB>
 SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* __restrict__ w, int N, const float o[3], const float d[3], float s_near,
                           float s_far, double& sum_wp, float& median_out, int64_t dump_ray = -1, const float* eb_shared = nullptr) {
     const int su = ALT ? p.spacing_uniform : 0;
@@ -384,7 +384,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
         // every ray of the wave, so every later weight is exactly +0 -- written as such, and added to the padded sum one by one as the
         // full march does (fp64 additions of the same constant, the same roundings); cumsum(w) and the median count stay what they are.
         if (!DUMP && p.early_term && __all(trans == 0.0f)) {
-            if (p.march_stats && (threadIdx.x & 63) == 0) atomicAdd(&p.march_stats[1 + LV], (unsigned long long)(N - 1 - i));
+            if (STATS && p.march_stats && (threadIdx.x & 63) == 0) atomicAdd(&p.march_stats[1 + LV], (unsigned long long)(N - 1 - i));
             for (int k = i + 1; k < N; ++k) {
 #pragma clang fp contract(off)
                 swp += (double)(0.0f + p.hist_pad);
@@ -403,7 +403,7 @@ SN_DEV void sn_prop_level(const SnPropParams& p, const float* wp, SB sb, float* 
 }
 
 // GRID 1: ND0 / ND1 = leading dense levels of the two nets (-1: run-time decision per level)
-template <int GRID, int ND0 = -1, int ND1 = -1, bool DUMP = false, bool ALT = false>
+template <int GRID, int ND0 = -1, int ND1 = -1, bool DUMP = false, bool ALT = false, bool STATS = false /*diagnostics instantiation, see sn_main.h*/>
 __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_proposal_kernel(SnPropParams p) {
     __shared__ __attribute__((aligned(16))) SnPropLds L;
     const int su = ALT ? p.spacing_uniform : 0;
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
         double sum_wp;
         float med;
         const int64_t dump_ray = DUMP && valid ? pix : -1;
-        sn_prop_level<0, GRID, ND0, DUMP, ALT>(p, L.wpack[0], [&](int i) { return L.sb0[i]; }, W, n0, o, d, s_near, s_far, sum_wp, med, dump_ray,
+        sn_prop_level<0, GRID, ND0, DUMP, ALT, STATS>(p, L.wpack[0], [&](int i) { return L.sb0[i]; }, W, n0, o, d, s_near, s_far, sum_wp, med, dump_ray,
                                           shared_bins ? L.eb0 : nullptr);
         if (valid && p.prop_depth[0]) p.prop_depth[0][pix] = med;
         SnPdfNorm nm;
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(64 * SN_PROP_WAVES, SN_PROP_WG_PER_CU) void sn_prop
                 B0[(int64_t)j * 64] = v;
                 dump_idx(0, n1, j, idx);
             }, p.pdf_ieee != 0);
-            sn_prop_level<1, GRID, ND1, DUMP, ALT>(p, L.wpack[1], [&](int i) { return B0[(int64_t)i * 64]; }, W, n1, o, d, s_near, s_far, sum_wp, med, dump_ray);
+            sn_prop_level<1, GRID, ND1, DUMP, ALT, STATS>(p, L.wpack[1], [&](int i) { return B0[(int64_t)i * 64]; }, W, n1, o, d, s_near, s_far, sum_wp, med, dump_ray);
             if (valid && p.prop_depth[1]) p.prop_depth[1][pix] = med;
             nm.set(sum_wp, n1);
             sn_pdf_lane<true>(W, 64, n1, p.n_final, L.u[1], p.hist_pad, nm, [&](int i) { return B0[(int64_t)i * 64]; }, [&](int j, float v, int idx) {

@@ -137,6 +137,12 @@ def test_static_instruction_counts_of_the_fused_kernels(built_lib):
 
     k1 = kernel_counts.loop_counts("sn_render_main_kernelILi0ELi1ELi0ELi11E")       # (a prefix: trailing defaulted arguments are matched)
     assert k1["mfma"] == 120 and k1["gather"] == 84 and k1["packed_f32"] == 0 and 1300 < k1["valu"] < 1500
+    # the hash phase keeps its gathers in flight in groups of 4 levels (SN_HASH_GROUP).  Same instruction COUNTS do not guarantee it: r05's
+    # first march_stats (one atomicAdd in the exit branch of this loop) left every count above unchanged and cost 10 % per launch, because
+    # hipcc then waited for each level's 4 loads before issuing the next (vmcnt never above 4).  Static guard for that class of regression:
+    assert k1["vmcnt_max"] >= 16 and k1["vmcnt_mean"] >= 6.0, (k1["vmcnt_max"], k1["vmcnt_mean"])
+    k1b = kernel_counts.loop_counts("sn_render_main_kernelILi1ELi1ELi0ELi11E")      # behind the proposal sampler (bins mode, x-paired hashed levels)
+    assert k1b["mfma"] == 120 and k1b["gather"] == 64 and k1b["vmcnt_max"] >= 12, k1b
     k2 = kernel_counts.mfma_loops("sn_proposal_kernelILi0ELi5ELi4E")
     assert [c["mfma"] for c in k2] == [6, 6] and all(c["gather"] == 20 and 220 < c["valu"] < 340 for c in k2)
     assert all(c.get("packed_f32", 0) == 0 for c in k2)   # r03 re-measured a packed blend in K2: slower (profiles/r03_pk_blend_ab.txt)

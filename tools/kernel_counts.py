@@ -164,16 +164,25 @@ def loop_counts(kernel_substr: str, lib: str = LIB) -> dict:
     else:
         best = max(spans, key=lambda sp: sp[1] - sp[0])
     out = {"kernel": names[0], "loop_bytes": best[1] - best[0]}
+    vmcnt = []
     for addr, op, ln in insts:
         if best[0] <= addr <= best[1]:
             c = classify(op)
             out[c] = out.get(c, 0) + 1
+            m = re.search(r"vmcnt\((\d+)\)", ln) if op == "s_waitcnt" else None
+            if m:
+                vmcnt.append(int(m.group(1)))
             if op.startswith("v_pk_") and op.endswith("_f32"):
                 out["packed_f32"] = out.get("packed_f32", 0) + 1
             if op.startswith(("buffer_load_dwordx2", "buffer_load_dwordx4")):  # the hash-grid gathers (spill reloads are scratch_load)
                 out["gather"] = out.get("gather", 0) + 1
     for k in ("valu", "mfma", "vmem_load", "lds", "packed_f32", "gather"):
         out.setdefault(k, 0)
+    # how deep the loop lets its vector loads run ahead: the largest N of an `s_waitcnt vmcnt(N)` = loads still in flight when the first
+    # result is consumed, and the mean over all such waits.  r05: one global atomic in a rarely taken branch of K1's loop made hipcc
+    # schedule the hash phase load -> wait -> blend level by level (max 4 instead of 20 in flight): identical instruction counts, +10 % time
+    out["vmcnt_max"] = max(vmcnt) if vmcnt else 0
+    out["vmcnt_mean"] = sum(vmcnt) / len(vmcnt) if vmcnt else 0.0
     return out
 
 
