@@ -68,7 +68,7 @@ def _check(name, out, ref, max_tie_rate=2e-3):
     print(f"{name}: rgb rmse {e_rgb:.2e}, accumulation rmse {e_acc:.2e}; oracle accumulation mean {float(acc.mean()):.3f}, "
           f"> 0.99: {float((acc > 0.99).float().mean()):.3f}, < 0.01: {float((acc < 0.01).float().mean()):.3f}; rgb std {float(ref['rgb'].std()):.3f}")
     assert e_rgb <= RMSE_TOL and e_acc <= RMSE_TOL
-    assert float(ref["rgb"].std()) > 0.05
+    assert float(ref["rgb"].std()) > 0.05, "the crop is nearly flat: pick one that holds a silhouette"
     report = {"rgb_rmse": e_rgb, "acc_rmse": e_acc}
     for k in ("depth", "expected_depth") + tuple(x for x in ("prop_depth_0", "prop_depth_1") if x in ref):
         g, w = out[k].double().cpu().reshape(-1), ref[k].double().reshape(-1)
@@ -135,7 +135,7 @@ def _crop(cam_full, y0, x0, h, w):
     return cam_full.generate_rays(camera_indices=0)._map(lambda t: t[y0:y0 + h, x0:x0 + w].contiguous())
 
 
-@pytest.mark.parametrize("cam,y0,x0", [(0, 420, 330), (3, 300, 560)])   # sphere silhouettes against ground and sky / the horizon band
+@pytest.mark.parametrize("cam,y0,x0", [(0, 312, 408), (3, 384, 576)])   # crops that hold sphere, ground AND sky (picked on the analytic picture)
 def test_trained_config2_full_size_crop(trained_main_only, gpu, cam, y0, x0):
     cfg, sd, model = trained_main_only
     cams = Cameras(scene.benchmark_cameras(8)[:, :3], 800.0, 800.0, 400.0, 400.0, 800, 800).to(gpu)
@@ -143,11 +143,15 @@ def test_trained_config2_full_size_crop(trained_main_only, gpu, cam, y0, x0):
     _check(f"trained, 48x48 crop of camera {cam}'s 800x800x64 frame", out, ref)
 
 
-@pytest.mark.parametrize("cam,y0,x0", [(0, 560, 820), (5, 420, 1000)])
+@pytest.mark.parametrize("cam,y0,x0", [(0, 504, 1128), (5, 552, 1008)])
 def test_trained_config4_full_size_crop_with_indices(trained, gpu, cam, y0, x0):
-    """48x48 crops of the 1920x1080 nerfacto frame of the trained scene: the render gates, and -- through the instrumented kernels
-    (sn_render_rays_debug) -- the searchsorted indices of both resampling steps and the median index against the oracle's, the
-    +-1 rate REPORTED (weights are near one-hot here: the CDF has long flat runs and one steep step)."""
+    """48x48 crops (sphere + ground + sky) of the 1920x1080 nerfacto frame of the trained scene: the render gates, and -- through the
+    instrumented kernels (sn_render_rays_debug) -- the searchsorted indices of both resampling steps and the median index against the
+    oracle's.  The +-1 RATE is reported, not gated at the random scenes' 1e-5: behind a trained surface the field changes by e^22 over 0.01
+    units, so the proposal weights -- and with them every CDF knot behind the peak -- move by 1e-4 .. 1e-3 when a position moves by one
+    ulp, and the ORACLE ITSELF flips 1e-4 / 5e-2 of its step-0 / step-1 indices when its ray origins are shifted by one ulp (measured
+    here, as the yardstick).  What is gated is what the indices are for: the final sample positions (continuous in the CDF: a u next to a
+    knot interpolates to the same place from either side), max |delta| = 1, the median index."""
     cfg, sd, model, _ = trained
     W, H = 1920, 1080
     cams = Cameras(scene.benchmark_cameras(8)[:, :3], 1.2 * H, 1.2 * H, W / 2, H / 2, W, H).to(gpu)
@@ -155,17 +159,24 @@ def test_trained_config4_full_size_crop_with_indices(trained, gpu, cam, y0, x0):
     out, ref = _pair(cfg, model, sd, bundle)
     name = f"trained, 48x48 crop of camera {cam}'s 1920x1080 frame"
     _check(name, out, ref)
-    dbg_out, dump = ops.render_rays_debug(model, bundle, want=("median_index", "pdf_index"))
+    dbg_out, dump = ops.render_rays_debug(model, bundle, want=("median_index", "pdf_index", "main_q"))
     for k in ("rgb", "depth", "accumulation"):
         assert torch.equal(dbg_out[k], out[k]), k
+    o_cpu, d_cpu = bundle.origins.cpu().reshape(-1, 3), bundle.directions.cpu().reshape(-1, 3)
     with torch.no_grad():
-        dref = onf.get_outputs(sd, oracle_config(cfg), bundle.origins.cpu().reshape(-1, 3), bundle.directions.cpu().reshape(-1, 3), return_debug=True)["_debug"]
+        dref = onf.get_outputs(sd, oracle_config(cfg), o_cpu, d_cpu, return_debug=True)["_debug"]
+        dulp = onf.get_outputs(sd, oracle_config(cfg), torch.nextafter(o_cpu, o_cpu + 1.0), d_cpu, return_debug=True)["_debug"]   # the yardstick
     for k in (0, 1):
         got, want = dump[f"pdf_index_{k}"].cpu().to(torch.int64), dref[f"pdf_inds_{k + 1}"]
         diff = got != want
+        own = float((dulp[f"pdf_inds_{k + 1}"] != want).float().mean())
         print(f"{name}: searchsorted indices, step {k}: {int(diff.sum())} / {got.numel()} differ ({int(diff.sum()) / got.numel():.2e}), "
-              f"max |delta| {int((got - want).abs().max())}")
-        assert int((got - want).abs().max()) <= 1 and int(diff.sum()) / got.numel() <= 2e-2
+              f"max |delta| {int((got - want).abs().max())}; the oracle against itself with origins + 1 ulp: {own:.2e}")
+        assert int((got - want).abs().max()) <= 1 and int(diff.sum()) / got.numel() <= max(2e-3, 20.0 * own)
+    q_err = float((dump["main_q"].cpu().view(-1, 3) - dref["q"].reshape(-1, 3)).abs().max())
+    q_own = float((dulp["q"] - dref["q"]).abs().max())
+    print(f"{name}: final sample positions (normalised, [0, 1)): max |q - q_oracle| {q_err:.2e}; the oracle against itself with origins + 1 ulp: {q_own:.2e}")
+    assert q_err <= max(2e-5, 10.0 * q_own)
     med = dump["median_index"].cpu().to(torch.int64)
     n_med = int((med != dref["median_index"].view(-1)).sum())
     print(f"{name}: median-index mismatches {n_med} / {med.numel()}")
