@@ -144,6 +144,7 @@ def radial_and_tangential_undistort(coords: Tensor, distortion_params: Tensor, e
 
 
 CAMERA_PERSPECTIVE, CAMERA_FISHEYE, CAMERA_EQUIRECTANGULAR = 1, 2, 3  # nerfstudio CameraType values
+NORMALIZE_EPS = float(np.finfo(float).eps * 4.0)  # nerfstudio.cameras.camera_utils._EPS
 
 
 def generate_rays(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, height: int, width: int,
@@ -200,8 +201,10 @@ def generate_rays(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, heigh
         raise ValueError(f"camera_type {camera_type} is not restated")
     rotation = c2w[:3, :3]
     dirs = torch.sum(dirs[..., None, :] * rotation, dim=-1)  # d_world = R . d_cam
+    # camera_utils.normalize_with_norm: the norm is floored at the module's _EPS = np.finfo(float).eps * 4.0 [NS-RECALL, M-H] (r01-r04 restated it
+    # as 1e-20).  Matters only for |d| < 8.9e-16 (a degenerate camera matrix): the fixture holds such a camera
     norm = torch.maximum(
-        torch.linalg.vector_norm(dirs, dim=-1, keepdim=True), torch.tensor([1e-20], dtype=torch.float32)
+        torch.linalg.vector_norm(dirs, dim=-1, keepdim=True), torch.tensor([NORMALIZE_EPS], dtype=torch.float32)
     )
     dirs = dirs / norm
     origins = c2w[:3, 3].expand(*shape, 3).contiguous()

@@ -82,7 +82,9 @@ SN_DEV void sn_cam_dir(const float* c2w, float u, float v, float out[3], float& 
 #pragma unroll
     for (int i = 0; i < 3; ++i) w[i] = (a * c2w[i * 4 + 0] + b * c2w[i * 4 + 1]) + c * c2w[i * 4 + 2];
     float n = sqrtf((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]);
-    n = fmaxf(n, 1e-20f);
+    // nerfstudio's camera_utils.normalize_with_norm floors the norm at its module constant _EPS = np.finfo(float).eps * 4 (8.88e-16 [NS-RECALL, M-H];
+    // r01-r04 used 1e-20): it only matters for a direction shorter than that -- a degenerate camera matrix -- and the fixture decides it by data
+    n = fmaxf(n, 8.8817841970012523e-16f);
 #pragma unroll
     for (int i = 0; i < 3; ++i) out[i] = w[i] / n;
     norm = n;

@@ -289,7 +289,9 @@ class HashMLPDensityField(_HipField):
     def __init__(self, hidden_dim=16, log2_hashmap_size=17, num_levels=5, max_res=128, base_res=16, features_per_level=2,
                  use_linear=False, implementation="torch", **_):
         super().__init__()
-        assert not use_linear, "use_linear proposal nets are not supported"
+        if use_linear:
+            raise NotImplementedError("use_linear proposal nets (a Linear layer instead of the hash grid + MLP) are not supported: nerfacto's and "
+                                      "SIGNeRF's proposal_net_args_list set use_linear=False")
         self.mlp_base = MLPWithHashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level, 2, hidden_dim, 1,
                                             implementation=implementation)
 
@@ -466,9 +468,14 @@ class NerfactoModel(nn.Module):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         self._weights_dirty = True
         # strict=False is how the reference loads (signerf_pipeline.py:131): a FIELD parameter that is not in the checkpoint keeps its random
-        # initialisation without a word from torch, and the render is noise.  The keys the reference strips on purpose (the appearance table,
-        # the camera optimiser; the proposal nets only before retraining, :126-129) are not field weights of the render and are not reported.
-        lost = [k for k in out.missing_keys if k.startswith(("field.mlp_base.", "field.mlp_head.", "proposal_networks."))]
+        # initialisation without a word from torch, and the render is noise.  The keys the reference strips on purpose are not reported: the
+        # appearance table, the camera optimiser -- and the proposal nets when ALL of them are gone, which is SIGNeRFPipeline's default load
+        # (load_model_with_proposal_weights=False deletes every `proposal*` key, :126-129; ADVICE r04: that normal flow must not warn).  A
+        # checkpoint that holds SOME proposal keys and misses others is reported like a missing field parameter.
+        prop_keys = [k for k in self.state_dict() if k.startswith("proposal_networks.")]
+        prop_missing = [k for k in out.missing_keys if k.startswith("proposal_networks.")]
+        stripped = len(prop_missing) == len(prop_keys)
+        lost = [k for k in out.missing_keys if k.startswith(("field.mlp_base.", "field.mlp_head.")) or (not stripped and k.startswith("proposal_networks."))]
         if lost:
             mods = sorted({".".join(k.split(".")[:3 if k.startswith("proposal") else 2]) for k in lost})
             warnings.warn(f"load_state_dict: {len(lost)} render parameters are not in the state dict and keep their random initialisation "

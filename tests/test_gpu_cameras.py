@@ -183,3 +183,20 @@ def test_render_through_an_adopted_foreign_camera(gpu):
     ref = onf.get_outputs_for_camera_ray_bundle(sd, oracle_config(cfg), ref_b["origins"], ref_b["directions"],
                                                 nears=tmin.reshape(H, W, 1), fars=tmax.reshape(H, W, 1))
     assert rmse(out["rgb"], ref["rgb"]) <= 1e-3 and rmse(out["depth"], ref["depth"]) <= 1e-3   # north_star's gate
+
+
+def test_degenerate_camera_matrix_takes_nerfstudios_normalisation_floor(gpu):
+    """nerfstudio's normalize_with_norm floors the norm at camera_utils._EPS = 4 eps(float64) = 8.88e-16 (r05; r01-r04 restated 1e-20 on both
+    sides): a rotation scaled by 1e-16 makes every direction shorter than the floor, so the bundle holds d / _EPS (length ~0.1), not unit
+    vectors, and `directions_norm` is the floor itself.  HIP against the oracle; tools/make_nerfstudio_fixture.py puts the same camera
+    into the fixture, which decides the constant by data."""
+    H, W = 24, 40
+    c2w = scene.benchmark_cameras(8)[1, :3].clone()
+    c2w[:3, :3] *= 1e-16
+    fx, fy, cx, cy = 0.9 * W, 0.95 * W, W / 2 + 0.25, H / 2 - 0.5
+    b = Cameras(c2w[None], fx, fy, cx, cy, W, H).to(gpu)[0].generate_rays(camera_indices=0)
+    ref = onf.generate_rays(c2w, fx, fy, cx, cy, H, W)
+    assert float((b.directions.cpu() - ref["directions"]).abs().max()) <= 2e-7 * float(ref["directions"].abs().max())
+    assert torch.equal(b.metadata["directions_norm"].cpu(), ref["directions_norm"])
+    assert abs(float(ref["directions_norm"].max()) - onf.NORMALIZE_EPS) < 1e-22
+    assert 0.05 < float(ref["directions"].norm(dim=-1).mean()) < 0.5

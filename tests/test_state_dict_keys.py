@@ -47,10 +47,23 @@ def test_sequential_spelling_of_the_hash_mlp_keys_is_accepted():
 
 
 def test_missing_render_parameters_are_reported():
+    import warnings
+
     cfg, model, sd = _model_and_sd()
-    partial = {k: v for k, v in sd.items() if not k.startswith("proposal") and "mlp_head.layers.2" not in k}   # :126-129 strips `proposal*`
-    with pytest.warns(RuntimeWarning, match=r"render parameters are not in the state dict.*field\.mlp_head.*proposal_networks\.0\.mlp_base"):
-        res = model.load_state_dict(partial, strict=False)
+    # the reference's DEFAULT load (signerf_pipeline.py:126-129, load_model_with_proposal_weights=False) strips every `proposal*` key: that
+    # normal flow must not warn (under -W error it turned the reference's own flow into a failure)
+    stripped = {k: v for k, v in sd.items() if not k.startswith("proposal")}
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        res = model.load_state_dict(stripped, strict=False)
     assert any(k.startswith("proposal_networks.1") for k in res.missing_keys)
+    # a FIELD parameter that is missing is reported ...
+    partial = {k: v for k, v in stripped.items() if "mlp_head.layers.2" not in k}
+    with pytest.warns(RuntimeWarning, match=r"render parameters are not in the state dict.*field\.mlp_head"):
+        model.load_state_dict(partial, strict=False)
+    # ... and so is a checkpoint that holds SOME proposal keys and misses others
+    holey = {k: v for k, v in sd.items() if not k.startswith("proposal_networks.0.mlp_base.mlp")}
+    with pytest.warns(RuntimeWarning, match=r"render parameters are not in the state dict.*proposal_networks\.0\.mlp_base"):
+        model.load_state_dict(holey, strict=False)
     with pytest.raises(RuntimeError):     # strict=True stays torch's error
         model.load_state_dict(partial, strict=True)

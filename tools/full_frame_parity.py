@@ -4,6 +4,9 @@ tests/test_gpu_render.py::test_full_size_properties_*): every pixel of
 
     sheet64       BASELINE configs[1]: 800 x 800 rays x 64 samples, hash grid L=16 T=2^19, camera 0 of the sheet   (~2.5 min of oracle)
     nerfacto1080  BASELINE configs[3]: 1920 x 1080, proposal nets 256 + 96 samples + 48 main samples               (~15 min of oracle)
+    trained800    r05: the TRAINED scene (tools/make_trained_scene.py) through nerfacto's sampler, 800 x 800, 256 + 96 + 48 samples
+    trained64     r05: the trained main field behind BASELINE configs[1]'s sampler, 800 x 800 x 64
+                  (--crop N: only the centred N x N region of the frame, rendered as its own bundle by both sides)
 
 rendered once by the HIP path (through the C ABI, like everything else) and once by oracle/nerfacto.py in the reference's own chunks of
 32 768 rays (signerf_config.py:32; expected_depth is clipped per chunk, A17) on the host cores the box grants.  Reported per output:
@@ -56,15 +59,31 @@ def compare(name, got, ref, depth_like):
     return row
 
 
-def run(workload, dev, camera=0):
-    if workload == "sheet64":
+def run(workload, dev, camera=0, crop=0):
+    if workload in ("sheet64", "trained64"):
         cfg, W, H, focal = scene.benchmark_config(64), 800, 800, 800.0
+    elif workload == "trained800":
+        cfg, W, H, focal = scene.proposal_config(), 800, 800, 800.0
     else:
         cfg, W, H = scene.proposal_config(), 1920, 1080
         focal = 1.2 * H
-    model, sd = make_model(cfg, dev)
+    if workload.startswith("trained"):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import make_trained_scene as mts
+
+        sd, _ = mts.trained_state_dict(scene.proposal_config(), device="cuda")
+        model = cfg.setup()
+        model.load_state_dict({k: v for k, v in sd.items() if cfg.num_proposal_iterations > 0 or not k.startswith("proposal_networks.")}, strict=False)
+        model.field.embedding_appearance.embedding.weight.data.copy_(sd["field.embedding_appearance.embedding.weight"])
+        model = model.to(dev).eval()
+    else:
+        model, sd = make_model(cfg, dev)
     cam = Cameras(scene.benchmark_cameras(8)[:, :3], focal, focal, W / 2, H / 2, W, H).to(dev)[camera]
     b = cam.generate_rays(camera_indices=0, aabb_box=model.render_aabb)
+    if crop:
+        y0, x0 = (H - crop) // 2, (W - crop) // 2
+        b = b._map(lambda t: t[y0:y0 + crop, x0:x0 + crop].contiguous())
+        W = H = crop
     out = model.get_outputs_for_camera_ray_bundle(b)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -80,7 +99,8 @@ def run(workload, dev, camera=0):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default=None, choices=["sheet64", "nerfacto1080"])
+    ap.add_argument("--only", default=None, choices=["sheet64", "nerfacto1080", "trained800", "trained64"])
+    ap.add_argument("--crop", type=int, default=0, help="compare the centred N x N region only (rendered as its own bundle by both sides)")
     ap.add_argument("--cameras", default="0", help="comma-separated cameras of the 8-camera reference sheet (BASELINE configs[2]: the eight circle_poses views)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "full_frame_parity.txt"))
     a = ap.parse_args()
@@ -89,7 +109,7 @@ def main():
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
         for w, c in [(w, int(c)) for w in ([a.only] if a.only else ["sheet64", "nerfacto1080"]) for c in a.cameras.split(",")]:
-            r = run(w, dev, c)
+            r = run(w, dev, c, a.crop)
             f.write(json.dumps(r) + "\n")
             f.flush()
             print(f"== {w}, camera {c}: {r['frame'][0]} x {r['frame'][1]}, oracle {r['oracle_seconds']:.0f} s on {r['oracle_threads']} threads "

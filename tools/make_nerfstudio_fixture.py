@@ -15,7 +15,19 @@ the build container and never on the GPU box).  It pins what i
                                                ones, plus cv2.dilate of seeded masks with them (datasetgenerator.py:776-777): pins
                                                oracle/signerf_utils.py::ellipse_element / dilate, which the GPU mask step is tested against
 
-    python tools/make_nerfstudio_fixture.py [--tcnn]
+THE FIVE-MINUTE RECIPE (any machine with network access; CPU is enough for everything but --tcnn):
+
+    python3.10 -m venv /tmp/ns && . /tmp/ns/bin/activate
+    pip install "torch==2.1.2" "nerfstudio==1.0.2" "opencv-python>=4.5,<5"        # (+ tinycudann built for the local GPU, only for --tcnn)
+    python tools/make_nerfstudio_fixture.py --all --self-check
+    git add tests/golden/nerfstudio_nerfacto_torch.npz tests/golden/opencv_morphology.npz   # (+ nerfstudio_nerfacto_tcnn.npz)
+
+--all = the torch-fallback fixture + the OpenCV fixture + (when CUDA and tinycudann import) the tiny-cuda-nn fixture; --self-check then runs
+tests/test_oracle_vs_nerfstudio_fixture.py on the spot and prints which of the oracle's unpinned statements the data confirmed or refuted.
+Expected sizes: nerfstudio_nerfacto_torch.npz ~1.3 MB (the 0.9 MB of small-config parameters + 3 renders of 40 x 32 + 11 ray bundles of
+56 x 40), opencv_morphology.npz ~25 KB, nerfstudio_nerfacto_tcnn.npz ~1 MB.  Runtime: under a minute on a laptop CPU.
+
+    python tools/make_nerfstudio_fixture.py [--tcnn]     (the torch-fallback fixture [+ tiny-cuda-nn])
     python tools/make_nerfstudio_fixture.py --cv2        (only the OpenCV fixture; nerfstudio is not imported)
 
 tests/test_oracle_vs_nerfstudio_fixture.py picks the files up when they exist (and is skipped when they do not).  The parameters are
@@ -87,6 +99,16 @@ def _dataset_camera_rays(c2w, W, H):
             fx[tag + ".directions"] = b.directions.detach().cpu().numpy()
             fx[tag + ".pixel_area"] = b.pixel_area.detach().cpu().numpy()
             fx[tag + ".directions_norm"] = b.metadata["directions_norm"].detach().cpu().numpy()
+    # a DEGENERATE camera matrix (rotation x 1e-16): every direction is shorter than normalize_with_norm's floor, so the bundle shows which
+    # floor nerfstudio applies (the oracle restates _EPS = 4 eps(float64) = 8.88e-16; a 1e-20 floor would return unit vectors)
+    tiny = c2w.clone()
+    tiny[:3, :3] = tiny[:3, :3] * 1e-16
+    cams = Cameras(camera_to_worlds=tiny[None, :3, :4], fx=0.9 * W, fy=0.95 * W, cx=W / 2 + 0.25, cy=H / 2 - 0.5, width=W, height=H,
+                   camera_type=CameraType.PERSPECTIVE)
+    b = cams.generate_rays(camera_indices=0, keep_shape=True)
+    fx["rays.tiny_rotation.c2w"] = tiny[:3, :4].numpy()
+    fx["rays.tiny_rotation.directions"] = b.directions.detach().cpu().numpy()
+    fx["rays.tiny_rotation.directions_norm"] = b.metadata["directions_norm"].detach().cpu().numpy()
     fx["rays.intrinsics"] = np.array([0.9 * W, 0.95 * W, W / 2 + 0.25, H / 2 - 0.5, W, H], dtype=np.float64)
     fx["rays.c2w"] = c2w[:3, :4].numpy()
     for name, lens in DATASET_LENSES.items():
@@ -131,10 +153,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tcnn", action="store_true", help="also emit the tiny-cuda-nn fixture (needs CUDA + tinycudann)")
     ap.add_argument("--cv2", action="store_true", help="emit ONLY the OpenCV morphology fixture (needs opencv-python, not nerfstudio)")
+    ap.add_argument("--all", action="store_true", help="torch-fallback + OpenCV fixtures, and the tiny-cuda-nn one when CUDA + tinycudann are there")
+    ap.add_argument("--self-check", action="store_true", help="afterwards run tests/test_oracle_vs_nerfstudio_fixture.py on the files just written")
     args = ap.parse_args()
-    if args.cv2:
+    if args.cv2 and not args.all:
         emit_cv2_fixture(os.path.join(ROOT, "tests", "golden"))
+        if args.self_check:
+            self_check()
         return
+    if args.all:
+        try:
+            emit_cv2_fixture(os.path.join(ROOT, "tests", "golden"))
+        except ImportError as e:
+            print(f"OpenCV fixture SKIPPED ({e}): pip install opencv-python")
+        try:
+            import tinycudann  # noqa: F401
+
+            args.tcnn = torch.cuda.is_available()
+        except Exception as e:  # noqa: BLE001
+            print(f"tiny-cuda-nn fixture SKIPPED ({type(e).__name__}: {e})")
     from nerfstudio.data.scene_box import SceneBox
 
     from helpers import small_config
@@ -178,6 +215,24 @@ def main():
             fx["cam1." + k] = v
         np.savez_compressed(os.path.join(out_dir, "nerfstudio_nerfacto_tcnn.npz"), **fx)
         print("wrote nerfstudio_nerfacto_tcnn.npz with state keys:", [k for k in fx if k.startswith("state.")])
+    for name in ("nerfstudio_nerfacto_torch.npz", "opencv_morphology.npz", "nerfstudio_nerfacto_tcnn.npz"):
+        path = os.path.join(out_dir, name)
+        print(f"  {name}: {os.path.getsize(path) / 1e6:.2f} MB" if os.path.exists(path) else f"  {name}: not written")
+    if args.self_check:
+        self_check()
+
+
+def self_check():
+    """Runs the consumer tests on the fixtures just written: a failure here IS the finding (the oracle restates nerfstudio from memory)."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_oracle_vs_nerfstudio_fixture.py"), "-v", "-rs", "--no-header"]
+    print("self-check:", " ".join(cmd), flush=True)
+    rc = subprocess.call(cmd, cwd=ROOT)
+    print("self-check:", "every pinned statement of oracle/ agrees with the real libraries" if rc == 0 else
+          "MISMATCH -- the failing assertion names the convention oracle/nerfacto.py (or tcnn_layout.py / signerf_utils.py) restated wrongly; "
+          "fix the oracle, re-run the GPU suite (the HIP kernels follow the oracle), then commit the fixture")
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -25,7 +25,20 @@ from signerf_amd import Cameras, SceneBox, scene  # noqa: E402
 from test_gpu_random_parity import _look_at, _random_c2w  # noqa: E402
 
 
-def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False, lenses=False, fp16=False):
+_TRAINED = {}
+
+
+def trained_sd():
+    """The fitted scene of tools/make_trained_scene.py (r05; fitted once per process, cached on disk)."""
+    if "sd" not in _TRAINED:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import make_trained_scene as mts
+
+        _TRAINED["sd"], _ = mts.trained_state_dict(scene.proposal_config())
+    return _TRAINED["sd"]
+
+
+def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False, lenses=False, fp16=False, trained=False):
     g = torch.Generator().manual_seed(910000 + seed)
 
     def ri(lo, hi):
@@ -38,7 +51,8 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
     S = [1, 2, 3, 5, 8, 13, 24, 33, 48, 64][ri(0, 9)]
     props = tuple([2, 3, 9, 17, 32, 48, 64, 96, 128][ri(0, 8)] for _ in range(iters))
     sampler = "uniform" if ri(0, 3) == 0 else "piecewise"
-    no_contract = ri(0, 3) == 0
+    no_contract = ri(0, 3) == 0 and not trained   # (the trained scene was fitted through the contraction)
+    full_tables = full_tables or trained
     background = ["last_sample", "last_sample", "white", "black", "random"][ri(0, 4)]
     far = [1000.0, 1000.0, ru(2.0, 60.0), ru(3.0, 8.0)][ri(0, 3)] if sampler == "piecewise" else ru(3.0, 9.0)
     precision = "fp32" if ri(0, 2) == 0 else "fp16x2"
@@ -68,7 +82,10 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
         model = model.to(gpu).eval()
         sd = oracle_params_from_tcnn(ck, cfg)
     else:
-        sd = scene.synthetic_state_dict(cfg, seed=seed, density_bias=ru(0.0, 6.0))
+        # trained: surfaces, empty space, near one-hot proposal weights (cameras land anywhere: inside a sphere, under the ground, outside the sky shell)
+        sd = trained_sd() if trained else scene.synthetic_state_dict(cfg, seed=seed, density_bias=ru(0.0, 6.0))
+        if trained:
+            sd = {k: v for k, v in sd.items() if iters > 0 or not k.startswith("proposal_networks.")}
         model = cfg.setup(scene_box=sbox)
         model.load_state_dict(sd, strict=False)
         model.field.embedding_appearance.embedding.weight.data.copy_(sd["field.embedding_appearance.embedding.weight"])
@@ -216,11 +233,12 @@ def main():
     ap.add_argument("--lenses", action="store_true", help="random OPENCV distortion parameters and PERSPECTIVE / FISHEYE / EQUIRECTANGULAR cameras; the bundle is checked too")
     ap.add_argument("--fp16", action="store_true", help="the opt-in single-fp16 mode on tiny-cuda-nn checkpoints against the oracle's emulation of its roundings")
     ap.add_argument("--normals", action="store_true", help="uniform-sampler scenarios only, with the normals kernel's two outputs checked as well")
+    ap.add_argument("--trained", action="store_true", help="r05: the TRAINED scene (tools/make_trained_scene.py, full table sizes) instead of random weights")
     ap.add_argument("--inspect", type=int, nargs="*", default=[], help="print the worst pixels of these seeds instead of running the sweep")
     a = ap.parse_args()
     gpu = torch.device("cuda", 0)
     for seed in a.inspect:
-        tag, msgs, problems = scenario(seed, gpu, inspect=("expected_depth", "depth", "rgb") + (("normals", "pred_normals") if a.normals else ()), normals=a.normals, full_tables=a.full_tables, tcnn=a.tcnn, lenses=a.lenses, fp16=a.fp16)
+        tag, msgs, problems = scenario(seed, gpu, inspect=("expected_depth", "depth", "rgb") + (("normals", "pred_normals") if a.normals else ()), normals=a.normals, full_tables=a.full_tables, tcnn=a.tcnn, lenses=a.lenses, fp16=a.fp16, trained=a.trained)
         print(tag, "|", "; ".join(problems), "|", ", ".join(msgs))
     if a.inspect:
         return
@@ -228,7 +246,7 @@ def main():
     bad = 0
     for seed in range(a.first, a.first + a.n):
         try:
-            tag, msgs, problems = scenario(seed, gpu, normals=a.normals, full_tables=a.full_tables, tcnn=a.tcnn, lenses=a.lenses, fp16=a.fp16)
+            tag, msgs, problems = scenario(seed, gpu, normals=a.normals, full_tables=a.full_tables, tcnn=a.tcnn, lenses=a.lenses, fp16=a.fp16, trained=a.trained)
         except Exception as e:  # noqa: BLE001
             tag, msgs, problems = f"seed {seed}", [], [f"EXCEPTION {type(e).__name__}: {str(e)[:300]}"]
         if problems:
