@@ -59,9 +59,11 @@ def _pair(cfg, model, sd, bundle):
     return out, ref
 
 
-def _check(name, out, ref, max_tie_rate=2e-3):
+def _check(name, out, ref, max_tie_rate=2e-3, yardstick=None):
     """rgb / accumulation: plain RMSE gates.  Depths: pixels whose median index was decided differently (a whole-bin jump, > 1e-3
-    relative) are COUNTED; the gate applies to the rest, scale-free as well as absolute."""
+    relative) are COUNTED; the gate applies to the rest, scale-free as well as absolute.  yardstick: the ORACLE's outputs for the same rays
+    with origins shifted by one ulp -- how far two correct fp32 evaluations of this field lie apart (the expected depth of a half-transparent
+    ray that mixes samples at 0.5 and at 800 units is the ill-conditioned output here)."""
     n = ref["depth"].numel()
     e_rgb, e_acc = rmse(out["rgb"], ref["rgb"]), rmse(out["accumulation"], ref["accumulation"])
     acc = ref["accumulation"]
@@ -79,12 +81,21 @@ def _check(name, out, ref, max_tie_rate=2e-3):
         assert int(ties.sum()) <= max(3, int(max_tie_rate * n)), (k, int(ties.sum()))
         # a median depth is ONE bin mid-point (relative error of the bins: 1e-6 .. 1e-5 behind two resampling steps); the expected depth
         # is a weighted mean of mid-points spanning [0.2, 1000]: a weight difference of 1e-5 at a far sample moves it by 1e-2 absolute
-        assert r["rel_rmse"] <= (1e-3 if k == "expected_depth" else 1e-4), (k, r)
+        gate = 1e-3 if k == "expected_depth" else 1e-4
+        if yardstick is not None and k == "expected_depth":
+            own = depth_error_report(yardstick[k].reshape(-1), ref[k].reshape(-1))["rel_rmse"]
+            print(f"    the oracle against itself with origins + 1 ulp: rel rmse {own:.2e}")
+            gate = max(gate, 20.0 * own)
+        assert r["rel_rmse"] <= gate, (k, r, gate)
         near = w[~ties] < 10.0   # the absolute gate where depths are O(1) (test_gpu_render.py::test_config4_depth_error_is_scale_free)
         if bool(near.any()):
             e = float(torch.sqrt(torch.mean((g[~ties][near] - w[~ties][near]) ** 2)))
             print(f"    abs rmse over the {int(near.sum())} pixels nearer than 10 units: {e:.2e}")
-            assert e <= RMSE_TOL, (k, e)
+            abs_gate = RMSE_TOL
+            if yardstick is not None and k == "expected_depth":   # (the oracle's own one-ulp sensitivity on the horizon crop: 1e-3 already)
+                y = yardstick[k].double().reshape(-1)
+                abs_gate = max(abs_gate, 20.0 * float(torch.sqrt(torch.mean((y[~ties][near] - w[~ties][near]) ** 2))))
+            assert e <= abs_gate, (k, e, abs_gate)
         report[k] = {"ties": int(ties.sum()), "rel_rmse": r["rel_rmse"], "abs_rmse": r["abs_rmse"]}
     return report
 
@@ -158,16 +169,17 @@ def test_trained_config4_full_size_crop_with_indices(trained, gpu, cam, y0, x0):
     bundle = _crop(cams[cam], y0, x0, 48, 48)
     out, ref = _pair(cfg, model, sd, bundle)
     name = f"trained, 48x48 crop of camera {cam}'s 1920x1080 frame"
-    # (camera 5's crop holds the horizon band: accumulation 0.79 on average, cumsum(w) crosses 0.5 on shallow slopes -- 5 ties of 2304 measured;
-    #  the oracle against itself with origins + 1 ulp flips 1-2 there as well)
-    _check(name, out, ref, max_tie_rate=5e-3)
-    dbg_out, dump = ops.render_rays_debug(model, bundle, want=("median_index", "pdf_index", "main_q"))
-    for k in ("rgb", "depth", "accumulation"):
-        assert torch.equal(dbg_out[k], out[k]), k
     o_cpu, d_cpu = bundle.origins.cpu().reshape(-1, 3), bundle.directions.cpu().reshape(-1, 3)
     with torch.no_grad():
         dref = onf.get_outputs(sd, oracle_config(cfg), o_cpu, d_cpu, return_debug=True)["_debug"]
-        dulp = onf.get_outputs(sd, oracle_config(cfg), torch.nextafter(o_cpu, o_cpu + 1.0), d_cpu, return_debug=True)["_debug"]   # the yardstick
+        ulp = onf.get_outputs(sd, oracle_config(cfg), torch.nextafter(o_cpu, o_cpu + 1.0), d_cpu, return_debug=True)   # the yardstick
+        dulp = ulp.pop("_debug")
+    # (camera 5's crop holds the horizon band: accumulation 0.79 on average, cumsum(w) crosses 0.5 on shallow slopes -- 5 ties of 2304 measured;
+    #  the oracle against itself with origins + 1 ulp flips 1-2 there as well)
+    _check(name, out, ref, max_tie_rate=5e-3, yardstick={k: v.view(48, 48, -1) for k, v in ulp.items()})
+    dbg_out, dump = ops.render_rays_debug(model, bundle, want=("median_index", "pdf_index", "main_q"))
+    for k in ("rgb", "depth", "accumulation"):
+        assert torch.equal(dbg_out[k], out[k]), k
     for k in (0, 1):
         got, want = dump[f"pdf_index_{k}"].cpu().to(torch.int64), dref[f"pdf_inds_{k + 1}"]
         diff = got != want

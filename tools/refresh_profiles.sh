@@ -36,6 +36,16 @@ for m in shared two-models vs-uniform; do
 done
 echo "== determinism_probe" >> "$OUT/probes.txt"
 timeout 300 python tools/determinism_probe.py 2>&1 | tail -3 >> "$OUT/probes.txt"
+# r05: the trained scene (fitted once, cached in /tmp for the legs below), the T = 2^21 PMC passes, the copy-budget curve, the early-termination A/B
+timeout 600 python tools/trained_bench.py > "$OUT/trained_bench.json" 2> "$OUT/trained_bench.err"
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_trained" -- python "$ROOT/tools/trained_bench.py" --rounds 2 --frames 4 > "$OUT/prof_trained.log" 2>&1)
+python tools/rocprof_summary.py "$OUT/prof_trained" > "$OUT/kernel_stats_trained.txt" 2>&1
+BENCH_ARGS="--log2-hashmap-size 21" bash tools/pmc_passes.sh "$OUT/pmc_t21" > "$OUT/pmc_t21.log" 2>&1
+python tools/pmc_summary.py "$OUT/pmc_t21" "sn_render_main_kernel<0, 1" > "$OUT/pmc_t21_summary.txt" 2>&1
+timeout 300 python tools/dense_sweep.py > "$OUT/dense_curve.txt" 2>&1
+timeout 300 python tools/early_term_ab.py > "$OUT/early_term_ab.txt" 2>&1
+timeout 900 python tools/full_frame_parity.py --only trained800 --crop 400 --out "$OUT/trained_parity_400.jsonl" > "$OUT/trained_parity_400.txt" 2>&1
+timeout 900 python tools/soak_random_parity.py --trained --n 120 > "$OUT/soak_trained.txt" 2>&1
 # drop the bulky raw traces, keep the stats
 find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
 ls "$OUT"
