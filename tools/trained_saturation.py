@@ -53,6 +53,46 @@ def analyse(sd, cfg, W, H, focal, crop, name):
           f"{float((t.max(-1).values - t.min(-1).values).mean()):.1f} samples; median per-ray index {float(first.median()):.0f} of {S}")
 
 
+def analyse_k2(sd, W, H, focal, crop, name):
+    """The same question for the two proposal levels of K2 (it stops a level once the transmittance IN FRONT of a sample is 0 for every ray
+    of the wave): the oracle's proposal chain, level by level."""
+    cfg = scene.proposal_config()
+    ocfg = oracle_config(cfg)
+    rays = onf.generate_rays(scene.benchmark_cameras(8)[0][:3], focal, focal, W / 2, H / 2, H, W)
+    y0, x0 = (H - crop) // 2 // 8 * 8, (W - crop) // 2 // 8 * 8
+    o = rays["origins"][y0:y0 + crop, x0:x0 + crop].reshape(-1, 3)
+    d = rays["directions"][y0:y0 + crop, x0:x0 + crop].reshape(-1, 3)
+    firsts = [[], []]
+    with torch.no_grad():
+        for i in range(0, o.shape[0], 4096):
+            oo, dd = o[i:i + 4096], d[i:i + 4096]
+            R = oo.shape[0]
+            nears, fars = onf.collider_near_far(R, ocfg)
+            weights, sb = None, None
+            for lv in range(2):
+                n = ocfg.num_proposal_samples_per_ray[lv]
+                if lv == 0:
+                    sb, eb = onf.initial_sampler(nears, fars, n)
+                    sb = sb.expand(R, -1)
+                else:
+                    sb, _, _ = onf.pdf_sample(sb, weights[..., 0], n, ocfg.histogram_padding)
+                    eb = onf.spacing_to_euclidean(sb, nears, fars)
+                st, en = eb[:, :-1, None], eb[:, 1:, None]
+                dens, _, _, _ = onf.density_field(sd, f"proposal_networks.{lv}.mlp_base", ocfg.proposals[lv], onf.sample_positions(oo, dd, st, en), ocfg.average_init_density)
+                weights = onf.get_weights(en - st, dens)
+                tau = torch.cumsum(((en - st) * dens)[..., 0], -1)
+                z = torch.cat([torch.ones(R, 1), torch.exp(-tau[:, :-1])], 1) < 2.0 ** -126
+                firsts[lv].append(torch.where(z.any(-1), z.float().argmax(-1), torch.full((R,), n)))
+    print(f"{name} (centred {crop}x{crop} crop of camera 0)")
+    for lv in range(2):
+        n = ocfg.num_proposal_samples_per_ray[lv]
+        f = torch.cat(firsts[lv]).view(crop, crop).float()
+        tiles = lambda x, th, tw: x.view(crop // th, th, crop // tw, tw).permute(0, 2, 1, 3).reshape(crop // th, crop // tw, -1)  # noqa: E731
+        ex = lambda x: torch.clamp(x + 1, max=n)   # noqa: E731
+        print(f"   K2 level {lv} ({n} samples): steps executed / full march: per ray {float(ex(f).mean() / n):.3f} | per half wave 8x4 {float(ex(tiles(f, 4, 8).max(-1).values).mean() / n):.3f} | "
+              f"per wave 8x8 (built) {float(ex(tiles(f, 8, 8).max(-1).values).mean() / n):.3f}; tiles that never terminate: {float((tiles(f, 8, 8).max(-1).values >= n).float().mean()):.1%}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--crop", type=int, default=256)
@@ -61,6 +101,8 @@ def main():
     print("scene:", meta)
     analyse(sd, scene.proposal_config(), 1920, 1080, 1.2 * 1080, a.crop, "1920x1080, 256 + 96 + 48 samples")
     analyse(sd, scene.benchmark_config(64), 800, 800, 800.0, a.crop, "800x800, 64 uniform samples")
+    analyse_k2(sd, 1920, 1080, 1.2 * 1080, a.crop, "1920x1080, proposal levels")
+    analyse_k2(sd, 800, 800, 800.0, a.crop, "800x800, proposal levels")
 
 
 if __name__ == "__main__":
