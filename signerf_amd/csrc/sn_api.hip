@@ -715,7 +715,7 @@ TileGeom tile_geometry(int height, int width) {
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WorkspacePlan {
-    size_t off_exp_raw, off_minmax, off_ebins, off_prop_scratch, off_seg, total;
+    size_t off_exp_raw, off_minmax, off_ebins, off_prop_scratch, off_prop_counter, off_seg, total;
     int prop_blocks;
     int n_chunks;
     int seg_first_block, n_seg, seg_len;  // split-depth tail of the main kernel (n_seg <= 1: none)
@@ -775,6 +775,7 @@ WorkspacePlan plan_workspace(int height, int width, const SnRenderOpts& o, int n
     off += align256((size_t)w.n_chunks * 8);
     w.off_ebins = off;
     w.off_prop_scratch = off;
+    w.off_prop_counter = off;
     w.prop_blocks = 0;
     if (o.num_proposal_iterations > 0) {
         off += align256((size_t)g.tiles_x * g.tiles_y * 64 * (o.num_nerf_samples + 1) * 4);
@@ -783,6 +784,8 @@ WorkspacePlan plan_workspace(int height, int width, const SnRenderOpts& o, int n
         w.prop_blocks = std::min((ntiles + SN_PROP_WAVES - 1) / SN_PROP_WAVES, 256 * SN_PROP_WG_PER_CU);
         w.off_prop_scratch = off;
         off += align256((size_t)w.prop_blocks * SN_PROP_WAVES * SN_PROP_SCRATCH_FLOATS * 4);
+        w.off_prop_counter = off;   // the proposal kernel's tile queue (one uint32, zeroed per launch)
+        off += 256;
     }
     {
         const int gbx = (g.tiles_x + 1) / 2, gby = (g.tiles_y + 1) / 2;
@@ -1413,6 +1416,15 @@ static int launch_proposals(SnHandle h, const float* origins, const float* direc
     for (int i = 0; i < SN_MAX_PROPOSALS; ++i) pp.pdf_u[i] = opts->pdf_u[i];
     pp.ebins_out = d_ebins;
     pp.scratch = (float*)(ws + wp.off_prop_scratch);
+    {
+        // the tile queue of the persistent waves (sn_proposal.h): only when some wave gets more than one tile
+        const int n_waves = wp.prop_blocks * SN_PROP_WAVES, n_tiles = g.tiles_x * g.tiles_y;
+        pp.tile_counter = nullptr;
+        if (n_tiles > n_waves) {
+            pp.tile_counter = (unsigned int*)(ws + wp.off_prop_counter);
+            SN_HIP(h, hipMemsetD32Async((hipDeviceptr_t)pp.tile_counter, n_waves, 1, st));
+        }
+    }
     pp.cache_off = h->sw.prop_cache_off.load(std::memory_order_relaxed);
     pp.early_term = h->sw.early_term.load(std::memory_order_relaxed);
     pp.march_stats = (unsigned long long*)opts->march_stats;
