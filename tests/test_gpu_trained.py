@@ -245,3 +245,24 @@ def test_trained_normals_uniform_sampler(trained_main_only, gpu):
     assert e_pred <= RMSE_TOL and e_rest <= RMSE_TOL and float(d.median()) <= 3e-4
     assert int(ties.sum()) <= max(3, d.numel() // 20)
     assert float(ref["normals"].std()) > 0.05 and rmse(out["rgb"], ref["rgb"]) <= RMSE_TOL
+
+
+def test_trained_full_frame_is_deterministic_under_the_tile_queue(trained, gpu):
+    """K2's persistent waves take their tiles from a queue (r05): which wave renders which tile differs from run to run, and on the trained
+    scene tiles cost very different amounts (early termination), so the order really varies.  Every output belongs to a tile: five renders of
+    the 1920x1080 frame must be bit-identical, and a crop rendered as its own bundle (another tile set, below the queue's threshold: static
+    stride) must equal the frame's pixels."""
+    cfg, sd, model, _ = trained
+    W, H = 1920, 1080
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 1.2 * H, 1.2 * H, W / 2, H / 2, W, H).to(gpu)
+    b = cams[2].generate_rays(camera_indices=0)
+    keys = ("rgb", "depth", "accumulation", "prop_depth_0", "prop_depth_1")
+    first = {k: v.clone() for k, v in model.get_outputs_for_camera_ray_bundle(b).items() if k in keys}
+    for _ in range(4):
+        again = model.get_outputs_for_camera_ray_bundle(b)
+        for k in keys:
+            assert torch.equal(first[k].nan_to_num(-7.0), again[k].nan_to_num(-7.0)), k
+    y0, x0 = 480, 880
+    crop = model.get_outputs_for_camera_ray_bundle(b._map(lambda t: t[y0:y0 + 64, x0:x0 + 64].contiguous()))
+    for k in keys:
+        assert torch.equal(crop[k].nan_to_num(-7.0), first[k][y0:y0 + 64, x0:x0 + 64].nan_to_num(-7.0)), k
