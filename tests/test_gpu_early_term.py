@@ -93,3 +93,27 @@ def test_early_termination_pays_on_an_opaque_scene(gpu, monkeypatch):
     assert res["opaque, uniform sampler"][1] < 0.8 * res["opaque, uniform sampler"][0]
     assert res["opaque, proposal sampler"][1] < 0.9 * res["opaque, proposal sampler"][0]
     assert res["benchmark medium"][1] < 1.03 * res["benchmark medium"][0]
+
+
+@pytest.mark.parametrize("colour_bias", [-12.0, -25.0, 6.0])
+def test_early_termination_with_near_black_and_near_white_colours(gpu, monkeypatch, colour_bias):
+    """Scenes whose colours are ~1e-5 / ~1e-11 (sigmoid of a strongly negative last-layer bias: a black object) or ~1: the colour sums are
+    the smallest / largest accumulators a ray holds.  The termination (T == 0 for the whole wave) must be bit-identical to the full march in all
+    of them, dense and opaque media, with and without a render box.  (r05 built and measured an EARLIER exact exit that hangs on exactly these
+    accumulators -- T 2^26 below every fp32 sum of the ray -- and rejected it on speed: tools/patches/r05_k1_earlier_exact_exit.patch; this test
+    is what showed it bit-identical.)"""
+    cfg = small_config(num_proposal_iterations=2, num_proposal_samples_per_ray=(64, 32), num_nerf_samples_per_ray=32)
+    for density_bias in (9.0, 14.0):
+        model, sd = make_model(cfg, gpu, density_bias=density_bias)
+        sd["field.mlp_head.layers.2.bias"] = sd["field.mlp_head.layers.2.bias"] + colour_bias
+        model.load_state_dict(sd, strict=False)
+        model = model.to(gpu).eval()
+        H, W = 80, 96
+        cams = Cameras(scene.benchmark_cameras(8)[:, :3], 1.1 * H, 1.1 * H, W / 2, H / 2, W, H).to(gpu)
+        for cam, box in ((1, None), (6, SceneBox(aabb=torch.tensor([[-0.3, -0.25, -0.2], [0.25, 0.3, 0.2]])))):
+            model.render_aabb = box
+            a, b = _both(model, cams[cam].generate_rays(0, aabb_box=box), monkeypatch)
+            _same(a, b)
+            if box is None:
+                assert float(a["accumulation"].mean()) > 0.9
+                print(f"colour bias {colour_bias:+.0f}, density bias {density_bias:+.0f}: rgb mean {float(a['rgb'].mean()):.3e}")
