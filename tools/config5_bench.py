@@ -31,6 +31,8 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
 ap.add_argument("--only-nopng", action="store_true", help="only the PNG-writes-off leg (bench.py's `others`)")
 ap.add_argument("--save-workers", type=int, default=None, help="host threads for PNG encoding (default: min(32, cores / 2))")
+ap.add_argument("--trained", action="store_true", help="r05: the TRAINED scene of tools/make_trained_scene.py (fitted here with torch when it is not cached; test "
+                                                     "infrastructure -- the timed path is the HIP library) instead of the random-weight one")
 a = ap.parse_args()
 world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
 dev = torch.device("cuda", local_rank % torch.cuda.device_count())
@@ -40,7 +42,16 @@ if world > 1:
     dist.init_process_group(a.backend, **({"device_id": dev} if a.backend == "nccl" else {}))
 cfg = scene.proposal_config()
 model = cfg.setup()
-model.load_state_dict(scene.synthetic_state_dict(cfg, seed=0, density_bias=5.0), strict=False)
+if a.trained:   # surfaces inside the default +-0.1 box, empty space, a far sky: the exact early termination has work to skip
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import make_trained_scene as mts
+
+    sd, _ = mts.trained_state_dict(cfg, device="cuda")
+    model.load_state_dict(sd, strict=False)
+    model.field.embedding_appearance.embedding.weight.data.copy_(sd["field.embedding_appearance.embedding.weight"])
+else:
+    model.load_state_dict(scene.synthetic_state_dict(cfg, seed=0, density_bias=5.0), strict=False)
 model = model.to(dev).eval()
 ref = scene.benchmark_cameras(8)[:, :3]
 torch.manual_seed(1)
@@ -74,6 +85,7 @@ def run(write_images: bool, tag: str, png_level=None, encoder="native"):
 
 n = 8 + a.views
 out = {"views": n, "size": [S, S], "ranks": world, "backend": (dist.get_backend() if world > 1 else None),
+       "scene": "trained (tools/make_trained_scene.py)" if a.trained else "random weights, density bias +5",
        "workload": "8 reference + %d random_sphere_poses views, 256+96+48 samples, aabb +-0.1, dilation 50x50, downscale 2, identity diffuser" % a.views}
 legs = ((False, "nopng", None, "native"),) if a.only_nopng else ((False, "nopng", None, "native"), (True, "png", None, "native"), (True, "pngl1", 1, "native"),
                                                                   (True, "pngpil", None, "pil"))
