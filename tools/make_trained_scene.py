@@ -210,6 +210,21 @@ def fit(cfg, device: str = "cpu", steps: int = STEPS, points: int = POINTS, seed
     from oracle import nerfacto as onf
 
     dev = torch.device(device)
+    # Run-to-run identical on one machine type: the gather's backward is an index_add (atomics on the GPU: the order of the float adds,
+    # and with it the fitted tables, would change from run to run) and rocBLAS may split a GEMM's k over atomics; deterministic mode
+    # takes the sorted scatter and forbids the atomics.  The gates of tests/test_gpu_trained.py were set on what THIS fit renders.
+    det_was, warn_was = torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled()
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        return _fit(cfg, dev, steps, points, seed, lr, log)
+    finally:
+        torch.use_deterministic_algorithms(det_was, warn_only=warn_was)
+
+
+def _fit(cfg, dev, steps, points, seed, lr, log):
+    from helpers import oracle_config
+    from oracle import nerfacto as onf
+
     ocfg = oracle_config(cfg)
     sd = {k: v.to(dev) for k, v in initial_state_dict(cfg, seed).items()}
     fit_keys = [k for k in sd if k.endswith("hash_table") or ".mlp.layers." in k or k.startswith("field.mlp_head.layers.")]
@@ -321,6 +336,7 @@ def main():
     ap.add_argument("--fingerprint", default=None, help="write the 64x64 oracle-render statistics (JSON) here")
     ap.add_argument("--render-npz", default=None, help="write the 64x64 oracle render + the analytic picture here")
     ap.add_argument("--no-cache", action="store_true")
+    ap.add_argument("--digest", action="store_true", help="print a sha256 over every tensor of the fitted state dict (two runs on one machine type must agree)")
     args = ap.parse_args()
     from helpers import small_config
     from signerf_amd import scene
@@ -330,6 +346,12 @@ def main():
         cfg.predict_normals = False
     sd, meta = trained_state_dict(cfg, args.device, args.steps, args.points, args.seed, cache=not args.no_cache, log=lambda s: print(s, flush=True))
     print(json.dumps(meta))
+    if args.digest:
+        dg = hashlib.sha256()
+        for k in sorted(sd):
+            dg.update(k.encode())
+            dg.update(sd[k].contiguous().numpy().tobytes())
+        print("state dict sha256", dg.hexdigest())
     if args.out:
         torch.save({"state_dict": sd, "meta": meta}, args.out)
     if args.fingerprint or args.render_npz:
