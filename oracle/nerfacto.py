@@ -715,9 +715,12 @@ def get_outputs(params: Dict[str, Tensor], cfg: NerfactoConfig, origins: Tensor,
         starts, ends = ebins[:, :-1, None], ebins[:, 1:, None]
         if is_prop:
             pos = sample_positions(origins, directions, starts, ends)
-            density, _, _, _ = density_field(params, f"proposal_networks.{level}.mlp_base", cfg.proposals[level], pos, cfg.average_init_density,
-                                             scene_aabb(cfg))
+            density, _, pq, _ = density_field(params, f"proposal_networks.{level}.mlp_base", cfg.proposals[level], pos, cfg.average_init_density,
+                                              scene_aabb(cfg))
             weights = get_weights(ends - starts, density)
+            if return_debug:
+                dbg[f"prop_q_{level}"], dbg[f"prop_density_{level}"], dbg[f"prop_weights_{level}"] = pq, density, weights
+                dbg[f"prop_sbins_{level}"], dbg[f"prop_pos_{level}"] = sbins, pos
             d, _ = render_depth_median(weights, starts, ends)
             prop_depths.append(d)
     pos = sample_positions(origins, directions, starts, ends)

@@ -38,6 +38,49 @@ def trained_sd():
     return _TRAINED["sd"]
 
 
+def _diagnose_worst_ray(model, bundle, sd, ocfg, out, ref, n, f, W):
+    """--inspect on a trained scenario with both proposal nets: WHERE along the chain does the ray of the worst rgb pixel leave the
+    oracle?  The instrumented kernels (sn_render_rays_debug) give the positions every stage evaluated and the searchsorted indices; the
+    oracle gives its own, plus its densities and weights per level; the HIP field stages are then evaluated AT THE ORACLE'S positions
+    (ops.field_forward), which separates a field difference from a placement difference."""
+    from signerf_amd import ops
+
+    d = (out["rgb"].cpu() - ref["rgb"]).abs().amax(-1)
+    d = torch.where(torch.isfinite(d), d, torch.zeros_like(d))
+    r = int(d.flatten().argmax())
+    y, x = divmod(r, W)
+    o_, d_ = bundle.origins.cpu().reshape(-1, 3), bundle.directions.cpu().reshape(-1, 3)
+    nn = None if n is None else n.reshape(-1, 1)
+    ff = None if f is None else f.reshape(-1, 1)
+    with torch.no_grad():
+        dbg = onf.get_outputs(sd, ocfg, o_, d_, nn, ff, return_debug=True)["_debug"]
+        dbg1 = onf.get_outputs(sd, ocfg, torch.nextafter(o_, o_ + 1.0), d_, nn, ff, return_debug=True)["_debug"]
+    _, dump = ops.render_rays_debug(model, bundle, want=("main_q", "median_index", "prop_q", "pdf_index"))
+    torch.set_printoptions(precision=8, linewidth=220, sci_mode=False)
+    print(f"-- chain of the worst rgb pixel ({y},{x}) = ray {r}")
+    for k in (0, 1):
+        hq, oq = dump[f"prop_q_{k}"][r].cpu(), dbg[f"prop_q_{k}"][r]
+        print(f"   level {k}: max |q_hip - q_oracle| over its {hq.shape[0]} samples {float((hq - oq).abs().max()):.3e} "
+              f"(the oracle against itself with origins + 1 ulp: {float((dbg1[f'prop_q_{k}'][r] - oq).abs().max()):.3e})")
+        # the HIP density net of this level AT THE ORACLE'S positions of this ray
+        dens = ops.field_forward(model, dbg[f"prop_pos_{k}"][r].reshape(-1, 3).to(model.device), which=k)[0].reshape(-1).cpu()
+        od = dbg[f"prop_density_{k}"][r].reshape(-1)
+        rel = ((dens - od).abs() / od.abs().clamp_min(1e-30))
+        print(f"      density net {k} at the oracle's positions: max relative difference {float(rel.max()):.3e}; oracle densities {od.tolist()}")
+        print(f"      oracle weights {dbg[f'prop_weights_{k}'][r].reshape(-1).tolist()}")
+        gi, wi = dump[f"pdf_index_{k}"][r].cpu().to(torch.int64), dbg[f"pdf_inds_{k + 1}"][r]
+        print(f"      searchsorted indices of resampling step {k}: hip {gi.tolist()}")
+        print(f"      {' ' * 43}oracle {wi.tolist()}")
+        print(f"      {' ' * 29}oracle, origins + 1 ulp {dbg1[f'pdf_inds_{k + 1}'][r].tolist()}")
+    mq, oq = dump["main_q"][r].cpu(), dbg["q"][r]
+    print(f"   main field: max |q_hip - q_oracle| {float((mq - oq).abs().max()):.3e} (oracle vs itself + 1 ulp {float((dbg1['q'][r] - oq).abs().max()):.3e}); "
+          f"median index hip {int(dump['median_index'][r])} oracle {int(dbg['median_index'].view(-1)[r])}")
+    print(f"      oracle main weights {dbg['weights'][r].reshape(-1).tolist()}")
+    print(f"      oracle main densities {dbg['density'][r].reshape(-1).tolist()}")
+    per = (mq - oq).abs().amax(-1)
+    print(f"      per-sample |q_hip - q_oracle| {per.tolist()}")
+
+
 def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False, lenses=False, fp16=False, trained=False):
     g = torch.Generator().manual_seed(910000 + seed)
 
@@ -232,6 +275,8 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
                 print(f"   ({y},{x}) got {got[y, x].tolist()} want {want[y, x].tolist()} near {None if n is None else float(n[y, x])} far "
                       f"{None if f is None else float(f[y, x])} acc {float(ref['accumulation'][y, x]):.6g} depth {float(ref['depth'][y, x]):.6g} "
                       f"expected (hip / ref) {float(out['expected_depth'][y, x]):.8g} / {float(ref['expected_depth'][y, x]):.8g}")
+        if trained and iters == 2 and obb is None and sampler == "piecewise":
+            _diagnose_worst_ray(model, bundle, sd, ocfg, out, ref, n, f, W)
         ed = ref["expected_depth"]
         print("   reference expected_depth: min %.6g max %.6g, finite %d of %d" % (float(ed[torch.isfinite(ed)].min()), float(ed[torch.isfinite(ed)].max()),
                                                                                    int(torch.isfinite(ed).sum()), ed.numel()))
