@@ -38,6 +38,26 @@ def trained_sd():
     return _TRAINED["sd"]
 
 
+def _oracle_ensemble(sd, ocfg, bundle, n, f, ref, seed, draws=8):
+    """The oracle against itself: `draws` renders of the same bundle with every component of the ray origins and directions moved by
+    one ulp up or down at random -> per draw, the number of pixels whose rgb / accumulation moved by more than 1e-2."""
+    g = torch.Generator().manual_seed(77000 + seed)
+    o, d = bundle.origins.cpu(), bundle.directions.cpu()
+    out = []
+    for _ in range(draws):
+        def jiggle(t):
+            up = torch.rand(t.shape, generator=g) < 0.5
+            return torch.where(up, torch.nextafter(t, torch.full_like(t, float("inf"))), torch.nextafter(t, torch.full_like(t, float("-inf"))))
+
+        r1 = onf.get_outputs_for_camera_ray_bundle(sd, ocfg, jiggle(o), jiggle(d), n, f)
+        cnt = {}
+        for k in ("rgb", "accumulation"):
+            px = (r1[k] - ref[k]).abs().amax(-1)
+            cnt[k] = int((torch.where(torch.isfinite(px), px, torch.zeros_like(px)) > 1e-2).sum())
+        out.append(cnt)
+    return out
+
+
 def _diagnose_worst_ray(model, bundle, sd, ocfg, out, ref, n, f, W):
     """--inspect on a trained scenario with both proposal nets: WHERE along the chain does the ray of the worst rgb pixel leave the
     oracle?  The instrumented kernels (sn_render_rays_debug) give the positions every stage evaluated and the searchsorted indices; the
@@ -179,6 +199,7 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
     tag = (f"seed {seed}: {H}x{W}, samples {props}+{S}, far {far:.3g}, {sampler}, box-normalised {no_contract}, {background}, {precision}, "
            f"camera kind {kind}, render box {box is not None}, crop box {obb is not None}")
     problems, msgs = [], []
+    ens = None
     if lenses:   # the bundle itself against the oracle's restatement of nerfstudio's ray generation
         rr = onf.generate_rays(c2w[:3], focal, fy_, cx_, cy_, H, W, distortion_params=lens, camera_type=ctype)
         gd, wd = bundle.directions.cpu(), rr["directions"]
@@ -260,6 +281,24 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
                 problems.append(f"{k}: {int(ties.sum())} pixels of {px.numel()} beyond 1e-3")
             d = (got - want)[ok.all(-1)][~ties].double().flatten()
         err = float(torch.sqrt(torch.mean(d ** 2))) if d.numel() else 0.0
+        if err > 1e-3 and trained and iters > 0 and k in ("rgb", "accumulation"):
+            # r05, seed 236 analysed stage by stage (profiles/r05_soak_trained_outlier_chain.txt): behind TWO resampling steps a trained surface
+            # (density x e^22 over 0.01 units) amplifies a last-bit difference of a level-0 position (6e-8, the same as the oracle against
+            # itself) to 4e-6 at level 1 and to 1.6e-3 at the main field when a coarse level puts a sample ON the flank -- one pixel of
+            # the frame then shows another picture, in either implementation.  Whether a frame holds such pixels is a property of the
+            # oracle: an ENSEMBLE of it against itself (origins and directions moved by +-1 ulp at random) is the yardstick; pixels beyond
+            # 1e-2 are counted against the ensemble's worst member, the rmse is gated on the others.
+            if ens is None:
+                ens = _oracle_ensemble(sd, ocfg, bundle, n, f, ref, seed)
+            px = (got - want).abs().amax(-1)
+            px = torch.where(torch.isfinite(px), px, torch.zeros_like(px))
+            outl = px > 1e-2
+            worst = max(e[k] for e in ens)
+            msgs.append(f"{k}: {int(outl.sum())} pixels beyond 1e-2; the oracle against itself under +-1 ulp of the rays, {len(ens)} draws: {[e[k] for e in ens]}")
+            if int(outl.sum()) <= worst:
+                keep = ok & ~outl[..., None]
+                d = got[keep].double() - want[keep].double()
+                err = float(torch.sqrt(torch.mean(d ** 2))) if d.numel() else 0.0
         msgs.append(f"{k} {err:.1e}")
         if err > 1e-3:
             problems.append(f"{k}: rmse {err:.2e}")
