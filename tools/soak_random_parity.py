@@ -289,7 +289,7 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
             # oracle: an ENSEMBLE of it against itself (origins and directions moved by +-1 ulp at random) is the yardstick; pixels beyond
             # 1e-2 are counted against the ensemble's worst member, the rmse is gated on the others.
             if ens is None:
-                ens = _oracle_ensemble(sd, ocfg, bundle, n, f, ref, seed)
+                ens = _oracle_ensemble(sd, ocfg, bundle, n, f, ref, seed, draws=48 if inspect else 8)
             px = (got - want).abs().amax(-1)
             px = torch.where(torch.isfinite(px), px, torch.zeros_like(px))
             outl = px > 1e-2
