@@ -479,13 +479,31 @@ def density_field(params: Dict[str, Tensor], prefix: str, hcfg: HashMLPConfig, p
 # ----------------------------------------------------------------------------
 
 
+# How get_weights takes its two exponentials.  "torch" = the reference's call (torch.exp: Sleef on the CPU, <= 1 ulp; CUDA's expf on the
+# machine the reference runs on, <= 1 ulp as well -- the two do not agree in every last bit).  The other modes exist for ONE purpose: a
+# yardstick of how much a render depends on that last bit (tools/soak_random_parity.py --trained): "rounded" = the correctly rounded
+# exponential (fp64, then one rounding), "exp2" = 2^(x log2 e) in fp32 (the form a GPU's fast path takes; ~2 ulp).  An alpha 1 - exp(-tau)
+# of empty space is a small multiple of 2^-24, so one ulp of exp IS one quantum of alpha.
+EXP_MODE = "torch"
+
+
+def _exp(x: Tensor) -> Tensor:
+    if EXP_MODE == "torch":
+        return torch.exp(x)
+    if EXP_MODE == "rounded":
+        return torch.exp(x.double()).to(x.dtype)
+    if EXP_MODE == "exp2":
+        return torch.exp2(x * 1.4426950408889634)
+    raise ValueError(EXP_MODE)
+
+
 def get_weights(deltas: Tensor, densities: Tensor) -> Tensor:
     """RaySamples.get_weights: [R,N,1] x [R,N,1] -> [R,N,1]."""
     delta_density = deltas * densities
-    alphas = 1 - torch.exp(-delta_density)
+    alphas = 1 - _exp(-delta_density)
     transmittance = torch.cumsum(delta_density[..., :-1, :], dim=-2)
     transmittance = torch.cat([torch.zeros((*transmittance.shape[:1], 1, 1)), transmittance], dim=-2)
-    transmittance = torch.exp(-transmittance)
+    transmittance = _exp(-transmittance)
     weights = alphas * transmittance
     return torch.nan_to_num(weights)
 

@@ -38,6 +38,18 @@ def trained_sd():
     return _TRAINED["sd"]
 
 
+_SENSITIVE_KEYS = ("rgb", "accumulation", "expected_depth")
+_TOTALS = {"pixels": 0, "scenarios": 0, **{who: {k: 0 for k in _SENSITIVE_KEYS} for who in ("hip", "rounded", "exp2")}}
+
+
+def _outliers(k, got, want, ok):
+    """[H,W] bool: pixels whose value is off by more than 1e-2 (depths: relative to max(|want|, 1)) among the gated elements `ok`."""
+    e = (got - want).abs()
+    if "depth" in k:
+        e = e / want.abs().clamp_min(1.0)
+    return torch.where(ok, e, torch.zeros_like(e)).amax(-1) > 1e-2
+
+
 def _oracle_ensemble(sd, ocfg, bundle, n, f, ref, seed, draws=8):
     """The oracle against itself: `draws` renders of the same bundle with every component of the ray origins and directions moved by
     one ulp up or down at random -> per draw, the number of pixels whose rgb / accumulation moved by more than 1e-2."""
@@ -199,7 +211,21 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
     tag = (f"seed {seed}: {H}x{W}, samples {props}+{S}, far {far:.3g}, {sampler}, box-normalised {no_contract}, {background}, {precision}, "
            f"camera kind {kind}, render box {box is not None}, crop box {obb is not None}")
     problems, msgs = [], []
-    ens = None
+    sensitive = trained and iters > 0
+    if sensitive:   # the yardstick: the oracle against itself with the last bit of its exponentials taken another way
+        _TOTALS["pixels"] += H * W
+        _TOTALS["scenarios"] += 1
+        for mode in ("rounded", "exp2"):
+            onf.EXP_MODE = mode
+            try:
+                r1 = onf.get_outputs_for_camera_ray_bundle(sd, ocfg, bundle.origins.cpu(), bundle.directions.cpu(), n, f)
+            finally:
+                onf.EXP_MODE = "torch"
+            for k in _SENSITIVE_KEYS:
+                okk = torch.isfinite(ref[k]) & torch.isfinite(r1[k])
+                if k == "expected_depth":
+                    okk = okk & (ref["accumulation"] > 1e-3)
+                _TOTALS[mode][k] += int(_outliers(k, r1[k], ref[k], okk).sum())
     if lenses:   # the bundle itself against the oracle's restatement of nerfstudio's ray generation
         rr = onf.generate_rays(c2w[:3], focal, fy_, cx_, cy_, H, W, distortion_params=lens, camera_type=ctype)
         gd, wd = bundle.directions.cpu(), rr["directions"]
@@ -280,25 +306,23 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
             if int(ties.sum()) > max(1, px.numel() // 500):
                 problems.append(f"{k}: {int(ties.sum())} pixels of {px.numel()} beyond 1e-3")
             d = (got - want)[ok.all(-1)][~ties].double().flatten()
-        err = float(torch.sqrt(torch.mean(d ** 2))) if d.numel() else 0.0
-        if err > 1e-3 and trained and iters > 0 and k in ("rgb", "accumulation"):
-            # r05, seed 236 analysed stage by stage (profiles/r05_soak_trained_outlier_chain.txt): behind TWO resampling steps a trained surface
-            # (density x e^22 over 0.01 units) amplifies a last-bit difference of a level-0 position (6e-8, the same as the oracle against
-            # itself) to 4e-6 at level 1 and to 1.6e-3 at the main field when a coarse level puts a sample ON the flank -- one pixel of
-            # the frame then shows another picture, in either implementation.  Whether a frame holds such pixels is a property of the
-            # oracle: an ENSEMBLE of it against itself (origins and directions moved by +-1 ulp at random) is the yardstick; pixels beyond
-            # 1e-2 are counted against the ensemble's worst member, the rmse is gated on the others.
-            if ens is None:
-                ens = _oracle_ensemble(sd, ocfg, bundle, n, f, ref, seed, draws=48 if inspect else 8)
-            px = (got - want).abs().amax(-1)
-            px = torch.where(torch.isfinite(px), px, torch.zeros_like(px))
-            outl = px > 1e-2
-            worst = max(e[k] for e in ens)
-            msgs.append(f"{k}: {int(outl.sum())} pixels beyond 1e-2; the oracle against itself under +-1 ulp of the rays, {len(ens)} draws: {[e[k] for e in ens]}")
-            if int(outl.sum()) <= worst:
+        if sensitive and k in _SENSITIVE_KEYS:
+            # r05 (profiles/r05_soak_trained_outlier_chain.txt: seeds 236 and 597 followed stage by stage).  An alpha 1 - exp(-tau) of empty
+            # space is a small multiple of 2^-24, so the last bit of exp -- where torch's CPU exp, CUDA's expf and the kernels' v_exp_f32 form all
+            # differ on some inputs -- is one QUANTUM of a weight.  In a histogram of few samples that is all padding (sum = N x 0.01) one quantum
+            # moves the next level's samples by 1e-6; a trained surface (density x e^22 over 0.01 units) turns that into per cent of a flank
+            # sample's weight, the next resampling into 1e-5 .. 1e-3 of position, and one pixel of the frame shows another picture; far samples
+            # (t ~ 800) do the same to the expected depth of a nearly empty ray.  Such pixels are counted (<= 1 in 300 per frame, and in total
+            # against the ORACLE ITSELF with another exp: oracle/nerfacto.py EXP_MODE, the totals line of the sweep); the rmse gates the others.
+            outl = _outliers(k, got, want, ok)
+            _TOTALS["hip"][k] += int(outl.sum())
+            if 0 < int(outl.sum()) <= max(1, outl.numel() // 300):
+                msgs.append(f"{k}: {int(outl.sum())} outlier pixel(s) of {outl.numel()} beyond 1e-2 counted")
                 keep = ok & ~outl[..., None]
                 d = got[keep].double() - want[keep].double()
-                err = float(torch.sqrt(torch.mean(d ** 2))) if d.numel() else 0.0
+                if "depth" in k:
+                    d = d / want[keep].double().abs().clamp_min(1.0)
+        err = float(torch.sqrt(torch.mean(d ** 2))) if d.numel() else 0.0
         msgs.append(f"{k} {err:.1e}")
         if err > 1e-3:
             problems.append(f"{k}: rmse {err:.2e}")
@@ -314,6 +338,8 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
                 print(f"   ({y},{x}) got {got[y, x].tolist()} want {want[y, x].tolist()} near {None if n is None else float(n[y, x])} far "
                       f"{None if f is None else float(f[y, x])} acc {float(ref['accumulation'][y, x]):.6g} depth {float(ref['depth'][y, x]):.6g} "
                       f"expected (hip / ref) {float(out['expected_depth'][y, x]):.8g} / {float(ref['expected_depth'][y, x]):.8g}")
+        if sensitive:
+            print("   the oracle against itself under +-1 ulp of the rays, 48 draws, pixels beyond 1e-2:", _oracle_ensemble(sd, ocfg, bundle, n, f, ref, seed, draws=48))
         if trained and iters == 2 and obb is None and sampler == "piecewise":
             _diagnose_worst_ray(model, bundle, sd, ocfg, out, ref, n, f, W)
         ed = ref["expected_depth"]
@@ -352,6 +378,14 @@ def main():
             print("FAIL", tag, "|", "; ".join(problems), "|", ", ".join(msgs), flush=True)
         else:
             print("ok  ", tag, "|", ", ".join(msgs), flush=True)
+    if _TOTALS["scenarios"]:
+        t = _TOTALS
+        print(f"outlier pixels (beyond 1e-2) over the {t['scenarios']} scenarios behind a proposal sampler, {t['pixels']} pixels: "
+              f"HIP vs oracle {t['hip']}; the oracle against itself with a correctly rounded exp {t['rounded']}, with exp2(x log2 e) {t['exp2']}")
+        for k in _SENSITIVE_KEYS:
+            if t["hip"][k] > 3 * max(t["rounded"][k], t["exp2"][k]) + 3:
+                bad += 1
+                print(f"FAIL totals: {k}: {t['hip'][k]} outlier pixels against {max(t['rounded'][k], t['exp2'][k])} of the oracle's own")
     print(f"{a.n} scenarios, {bad} with problems, {time.time() - t0:.0f} s")
 
 
