@@ -707,8 +707,11 @@ def render_depth_expected(weights: Tensor, starts: Tensor, ends: Tensor) -> Tens
 
 
 def get_outputs(params: Dict[str, Tensor], cfg: NerfactoConfig, origins: Tensor, directions: Tensor,
-                nears: Optional[Tensor] = None, fars: Optional[Tensor] = None, return_debug: bool = False):
-    """One chunk of rays [R,3] -> dict of [R,C] outputs (eval mode)."""
+                nears: Optional[Tensor] = None, fars: Optional[Tensor] = None, return_debug: bool = False,
+                weight_nudge: Optional[Dict[int, Tensor]] = None):
+    """One chunk of rays [R,3] -> dict of [R,C] outputs (eval mode).
+    weight_nudge {proposal level: [R,N,1]} is a SENSITIVITY PROBE, not part of the algorithm: added to that level's weights before they
+    are resampled (tools/soak_random_parity.py --inspect asks what one 2^-24 quantum of one proposal weight does to a pixel)."""
     R = origins.shape[0]
     if nears is None or fars is None:
         nears, fars = collider_near_far(R, cfg)
@@ -736,6 +739,8 @@ def get_outputs(params: Dict[str, Tensor], cfg: NerfactoConfig, origins: Tensor,
             density, _, pq, _ = density_field(params, f"proposal_networks.{level}.mlp_base", cfg.proposals[level], pos, cfg.average_init_density,
                                               scene_aabb(cfg))
             weights = get_weights(ends - starts, density)
+            if weight_nudge is not None and level in weight_nudge:
+                weights = weights + weight_nudge[level]
             if return_debug:
                 dbg[f"prop_q_{level}"], dbg[f"prop_density_{level}"], dbg[f"prop_weights_{level}"] = pq, density, weights
                 dbg[f"prop_sbins_{level}"], dbg[f"prop_pos_{level}"] = sbins, pos

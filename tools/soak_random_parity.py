@@ -111,6 +111,26 @@ def _diagnose_worst_ray(model, bundle, sd, ocfg, out, ref, n, f, W):
     print(f"      oracle main densities {dbg['density'][r].reshape(-1).tolist()}")
     per = (mq - oq).abs().amax(-1)
     print(f"      per-sample |q_hip - q_oracle| {per.tolist()}")
+    # What does ONE quantum (2^-24) of ONE proposal weight do to this pixel?  The oracle on this ray alone, a level's weight i nudged up / down.
+    o1, d1 = o_[r:r + 1], d_[r:r + 1]
+    n1 = None if nn is None else nn[r:r + 1]
+    f1 = None if ff is None else ff[r:r + 1]
+    with torch.no_grad():
+        base = onf.get_outputs(sd, ocfg, o1, d1, n1, f1)
+        for k in (0, 1):
+            N = dbg[f"prop_weights_{k}"].shape[1]
+            worst = (0.0, None)
+            for i in range(N):
+                for sgn in (1.0, -1.0):
+                    nudge = torch.zeros(1, N, 1)
+                    nudge[0, i, 0] = sgn * 2.0 ** -24
+                    alt = onf.get_outputs(sd, ocfg, o1, d1, n1, f1, weight_nudge={k: nudge})
+                    e = float((alt["rgb"] - base["rgb"]).abs().max())
+                    if e > worst[0]:
+                        worst = (e, (i, sgn, alt["rgb"][0].tolist(), float(alt["accumulation"][0, 0]), float(alt["depth"][0, 0])))
+            print(f"   one quantum (2^-24) on one weight of level {k}: the largest change of this pixel's oracle rgb over the {2 * N} nudges = {worst[0]:.3e}"
+                  + ("" if worst[1] is None else f" (sample {worst[1][0]}, sign {worst[1][1]:+.0f}: rgb {worst[1][2]}, accumulation {worst[1][3]:.6g}, depth {worst[1][4]:.6g})"))
+    print(f"      for comparison: HIP rgb {out['rgb'].cpu()[y, x].tolist()} oracle rgb {ref['rgb'][y, x].tolist()}")
 
 
 def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False, lenses=False, fp16=False, trained=False):
