@@ -45,7 +45,7 @@ python tools/pmc_summary.py "$OUT/pmc_t21" "sn_render_main_kernel<0, 1" > "$OUT/
 timeout 300 python tools/dense_sweep.py > "$OUT/dense_curve.txt" 2>&1
 timeout 300 python tools/early_term_ab.py > "$OUT/early_term_ab.txt" 2>&1
 timeout 900 python tools/full_frame_parity.py --only trained800 --crop 400 --out "$OUT/trained_parity_400.jsonl" > "$OUT/trained_parity_400.txt" 2>&1
-timeout 900 python tools/soak_random_parity.py --trained --n 120 > "$OUT/soak_trained.txt" 2>&1
+timeout 1500 python tools/soak_random_parity.py --trained --n 600 > "$OUT/soak_trained.txt" 2>&1
 # drop the bulky raw traces, keep the stats
 find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
 ls "$OUT"
