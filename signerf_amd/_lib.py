@@ -68,6 +68,7 @@ class SnRenderOpts(C.Structure):
         ("background_rgb", C.c_float * 3),
         ("spacing_mode", C.c_int32),
         ("march_stats", C.c_void_p),
+        ("reuse_final_bins", C.c_int32),
     ]
 
 

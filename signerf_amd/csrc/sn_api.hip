@@ -1818,9 +1818,13 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
     const TileGeom g = tile_geometry(height, width);
     const int nprop = opts->num_proposal_iterations;
     float* d_ebins = nullptr;
-    if (nprop > 0)
-        if (int rc = launch_proposals(h, origins, directions, nears, fars, height, width, opts, wp, g, ws, nullptr, nullptr, st, &d_ebins))
+    if (nprop > 0) {
+        if (opts->reuse_final_bins) {   // the bins of the preceding sn_render_rays on this workspace (the caller vouches: signerf_hip.h)
+            d_ebins = (float*)(ws + wp.off_ebins);
+        } else if (int rc = launch_proposals(h, origins, directions, nears, fars, height, width, opts, wp, g, ws, nullptr, nullptr, st, &d_ebins)) {
             return rc;
+        }
+    }
     SnNormalsParams p;
     memset(&p, 0, sizeof(p));
     p.origins = origins;

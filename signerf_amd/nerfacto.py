@@ -386,6 +386,7 @@ class NerfactoModel(nn.Module):
         self._handle_device = None
         self._handle_half_grid = False   # whether the handle holds the grid's fp16 storage (SnFieldDesc.half_grid)
         self._weights_dirty = True
+        self._engine_generation = 0      # bumped whenever the handle's weights are (re)written
         self._weights_lock = threading.Lock()
         self._engine_rw = _RWLock()
         self._grid_cache: Dict = {}
@@ -559,6 +560,7 @@ class NerfactoModel(nn.Module):
                     if self._weights_dirty:
                         self._upload(lib)
                         self._weights_dirty = False
+                        self._engine_generation += 1   # (a kept render state of the old weights no longer matches: _render_normals)
                 finally:
                     self._engine_rw.release_write()
         if not self._fallback_warned and self.effective_precision != self.config.precision:
@@ -673,24 +675,32 @@ class NerfactoModel(nn.Module):
         return self.get_outputs(ray_bundle)
 
     def _with_normals(self, b: RayBundle, H: int, W: int, shape, single_chunk: bool = False) -> Dict[str, Tensor]:
-        out = {k: v.view(*shape, v.shape[-1]) for k, v in self._render(b, H, W, single_chunk).items()}
         mode = self.config.compute_normals if self.config.predict_normals else "never"
+        if mode not in ("lazy", "always", "never"):
+            raise ValueError(f"compute_normals must be 'lazy', 'always' or 'never', got {mode!r}")
+        # Behind the proposal sampler the normals kernel marches the SAME final bins as the colour render: the render's workspace (which
+        # holds them) stays alive with the outputs, and the normals launch reads it instead of running the proposal kernel a second time
+        # (SnRenderOpts.reuse_final_bins; 17.5 -> 10 ms at 1920x1080).  The price: that workspace is released when the outputs dict
+        # is, not when this call returns.
+        keep_bins = mode != "never" and self.config.num_proposal_iterations > 0 and H * W > 0
+        raw, state = self._render_ex(b, H, W, single_chunk, keep_state=keep_bins)
+        out = {k: v.view(*shape, v.shape[-1]) for k, v in raw.items()}
         if mode == "never":
             return out
-        if mode not in ("lazy", "always"):
-            raise ValueError(f"compute_normals must be 'lazy', 'always' or 'never', got {mode!r}")
 
         def producer():
             with torch.no_grad():
-                return {k: v.view(*shape, v.shape[-1]) for k, v in self._render_normals(b, H, W).items()}
+                return {k: v.view(*shape, v.shape[-1]) for k, v in self._render_normals(b, H, W, state).items()}
 
         if mode == "always":
             out.update(producer())
             return out
         return LazyOutputs(out, producer)
 
-    def _render_normals(self, b: RayBundle, H: int, W: int) -> Dict[str, Tensor]:
-        """Row a16: "normals" (analytic) and "pred_normals", [H*W,3] each, by the separate normals kernel (csrc/sn_normals.h)."""
+    def _render_normals(self, b: RayBundle, H: int, W: int, state=None) -> Dict[str, Tensor]:
+        """Row a16: "normals" (analytic) and "pred_normals", [H*W,3] each, by the separate normals kernel (csrc/sn_normals.h).
+        ``state`` = what ``_render_ex(..., keep_state=True)`` kept of the colour render of the SAME bundle: its options, its workspace
+        (the final sample bins are still in it) and an event behind its kernels -- the proposal sampler is then not run again."""
         lib = self._ensure_engine()
         dev = self.device
         if H * W == 0:
@@ -703,7 +713,15 @@ class NerfactoModel(nn.Module):
             pred = torch.empty((H * W, 3), dtype=torch.float32, device=dev) if self._has_pred_normals else None
             self._engine_rw.acquire_read()
             try:
-                o, keep = self._opts(H, W, lib)   # (sn_workspace_bytes reads the handle: inside the read lock)
+                if state is not None and state["generation"] == self._engine_generation:
+                    o, keep = state["opts"], state["keep"]
+                    o.reuse_final_bins = 1
+                    o.march_stats = None
+                    cur = torch.cuda.current_stream(dev)
+                    cur.wait_event(state["event"])            # (a viewer thread may read the normals on another stream)
+                    keep[0].record_stream(cur)
+                else:
+                    o, keep = self._opts(H, W, lib)   # (sn_workspace_bytes reads the handle: inside the read lock)
                 st = lib.sn_render_normals(self._handle, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(nears), _lib.ptr(fars), H, W,
                                            C.byref(o), _lib.ptr(normals), _lib.ptr(pred), _lib.current_stream())
                 _lib.check(st, self._handle, "sn_render_normals")
@@ -712,12 +730,17 @@ class NerfactoModel(nn.Module):
         return {"normals": normals, "pred_normals": pred} if pred is not None else {"normals": normals}
 
     def _render(self, b: RayBundle, H: int, W: int, single_chunk: bool = False) -> Dict[str, Tensor]:
+        return self._render_ex(b, H, W, single_chunk)[0]
+
+    def _render_ex(self, b: RayBundle, H: int, W: int, single_chunk: bool = False, keep_state: bool = False):
+        """-> (outputs, state).  state (``keep_state``) = {"opts", "keep" (workspace + grids), "event", "generation"} for a normals launch
+        on the same bundle that re-uses this render's final sample bins (``_render_normals``); None otherwise."""
         lib = self._ensure_engine()
         if H * W == 0:  # an empty bundle renders to empty outputs, as the reference's chunk loop does
             z = lambda c: torch.empty((0, c), dtype=torch.float32, device=self.device)  # noqa: E731
             out = {"rgb": z(3), "accumulation": z(1), "depth": z(1), "expected_depth": z(1)}
             out.update({f"prop_depth_{i}": z(1) for i in range(self.config.num_proposal_iterations)})
-            return out
+            return out, None
         dev = self.device
         f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
         origins, directions, nears, fars = f32(b.origins), f32(b.directions), f32(b.nears), f32(b.fars)
@@ -734,6 +757,11 @@ class NerfactoModel(nn.Module):
                                         C.byref(o), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc), _lib.ptr(exp), pp[0], pp[1],
                                         _lib.current_stream())
                 _lib.check(st, self._handle, "sn_render_rays")
+                state = None
+                if keep_state:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                    state = {"opts": o, "keep": keep, "event": ev, "generation": self._engine_generation}
             finally:
                 self._engine_rw.release_read()
             # (the workspace and grids in `keep` are consumed by work already enqueued on this stream; the caching allocator is
@@ -741,7 +769,7 @@ class NerfactoModel(nn.Module):
         out = {"rgb": rgb, "accumulation": acc, "depth": depth, "expected_depth": exp}
         for i, p in enumerate(props):
             out[f"prop_depth_{i}"] = p
-        return out
+        return out, state
 
 
 class SIGNeRFModel(NerfactoModel):

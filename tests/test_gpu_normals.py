@@ -116,3 +116,50 @@ def test_normals_flat_bundle_with_aabb_nears_fars(gpu):
         e = rmse(out[k][hit.to(gpu)], ref[k][hit])
         print(f"{k} (flat bundle, aabb bounds): rmse {e:.2e}")
         assert e <= RMSE_TOL, k
+
+
+def test_normals_reuse_the_final_bins_of_the_colour_render(gpu, monkeypatch):
+    """Behind the proposal sampler the normals kernel marches the bins the colour render left in its workspace
+    (SnRenderOpts.reuse_final_bins; the workspace lives as long as the outputs dict) instead of running the proposal kernel again:
+    bit-identical to the stand-alone launch -- lazily after other renders, in "always" mode, for a flat bundle (another chunking, so
+    another workspace plan) -- and the stand-alone launch is what runs once the weights have changed in between."""
+    from signerf_amd import _lib
+
+    cfg = small_config(num_proposal_samples_per_ray=(48, 24), num_nerf_samples_per_ray=16)
+    model, sd = make_model(cfg, gpu)
+    H, W = 37, 43
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 40.0, 40.0, W / 2, H / 2, W, H).to(gpu)
+    bundle = cams[3].generate_rays(camera_indices=0)
+    lib = _lib.load()
+    real = lib.sn_render_normals
+    flags = []
+
+    def spy(*a):
+        flags.append(int(a[7]._obj.reuse_final_bins))
+        return real(*a)
+
+    monkeypatch.setattr(lib, "sn_render_normals", spy, raising=False)
+    alone = model._render_normals(bundle, H, W)
+    assert flags == [0] and float(alone["normals"].std()) > 0.05
+    out = model.get_outputs_for_camera_ray_bundle(bundle)
+    for i in (0, 1, 2, 5):   # other frames in between: the allocator would hand a released workspace to them
+        model.get_outputs_for_camera_ray_bundle(cams[i].generate_rays(camera_indices=0))["rgb"].sum().item()
+    assert flags == [0]
+    for k in ("normals", "pred_normals"):
+        assert torch.equal(out[k].view(-1, 3), alone[k]), k
+    assert flags == [0, 1]
+    model.config.compute_normals = "always"
+    out = model.get_outputs_for_camera_ray_bundle(bundle)
+    assert flags == [0, 1, 1] and torch.equal(out["normals"].view(-1, 3), alone["normals"]) and torch.equal(out["pred_normals"].view(-1, 3), alone["pred_normals"])
+    flat = bundle.flatten()
+    alone_flat = model._render_normals(flat, 1, H * W)
+    out = model.get_outputs(flat)
+    assert flags == [0, 1, 1, 0, 1] and torch.equal(out["normals"], alone_flat["normals"]) and torch.equal(out["pred_normals"], alone_flat["pred_normals"])
+    # the weights change between the colour render and the first read of the normals: the kept bins are the old weights' -> stand-alone launch
+    model.config.compute_normals = "lazy"
+    out = model.get_outputs_for_camera_ray_bundle(bundle)
+    sd2 = {k: (v * 1.25 if k == "proposal_networks.1.mlp_base.mlp.layers.1.weight" else v) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd2, strict=False)
+    n = out["normals"]
+    assert flags[-1] == 0
+    assert torch.equal(n.view(-1, 3), model._render_normals(bundle, H, W)["normals"])

@@ -64,4 +64,14 @@ for prec in ("fp16x2", "fp32"):
     model.config.precision = prec
     t = timed(lambda: model._render_normals(flat, H, W))
     line += f"; normals render precision={prec}: {t:.2f} ms ({W * H * S / t / 1e6:.2f} G ray-samples/s)"
+if cfg.num_proposal_iterations > 0:   # r05: the normals launch re-uses the final bins the colour render left in its workspace
+    model.config.precision = "fp16x2"
+
+    def both():
+        _, st = model._render_ex(flat, H, W, keep_state=True)
+        model._render_normals(flat, H, W, st)
+
+    t_both = timed(both)
+    t_sep = timed(lambda: (model._render(flat, H, W), model._render_normals(flat, H, W)))
+    line += f"; colour + normals of one frame (fp16x2): {t_both:.2f} ms with the colour render's bins re-used, {t_sep:.2f} ms with the proposal sampler run twice"
 print(line + f"; a split-precision request resolves to {'fp16x2' if eff == 1 else 'EXACT FP32 (fallback)'} for the normals kernel")
