@@ -258,7 +258,7 @@ def _fit(cfg, dev, steps, points, seed, lr, log):
         opt.step()
         sched.step()
         if it % 25 == 0 or it == steps - 1:
-            parts = [float(x) for x in loss_parts]
+            parts = [float(x.detach()) for x in loss_parts]
             hist.append((it, parts))
             if log:
                 log(f"step {it:4d}  main h-mse {parts[0]:8.3f}  rgb {parts[1] / 50.0:.4f}  props {' '.join('%.3f' % x for x in parts[2:])}  "
