@@ -739,13 +739,13 @@ def get_outputs(params: Dict[str, Tensor], cfg: NerfactoConfig, origins: Tensor,
             density, _, pq, _ = density_field(params, f"proposal_networks.{level}.mlp_base", cfg.proposals[level], pos, cfg.average_init_density,
                                               scene_aabb(cfg))
             weights = get_weights(ends - starts, density)
-            if weight_nudge is not None and level in weight_nudge:
-                weights = weights + weight_nudge[level]
             if return_debug:
                 dbg[f"prop_q_{level}"], dbg[f"prop_density_{level}"], dbg[f"prop_weights_{level}"] = pq, density, weights
                 dbg[f"prop_sbins_{level}"], dbg[f"prop_pos_{level}"] = sbins, pos
             d, _ = render_depth_median(weights, starts, ends)
             prop_depths.append(d)
+            if weight_nudge is not None and level in weight_nudge:   # (the probe: what the NEXT resampling step sees)
+                weights = weights + weight_nudge[level]
     pos = sample_positions(origins, directions, starts, ends)
     density, h, q, selector = density_field(params, "field.mlp_base", cfg.main, pos, cfg.average_init_density, scene_aabb(cfg),
                                             half=cfg.mlp_precision == "fp16")

@@ -22,8 +22,8 @@ around the analytic hit distance) plus volume and near-surface points.  sigma = 
 early-termination logic, the PDF merge and the median search of the kernels see in production.
 
 Full-size shapes (L=16, T=2^19; proposal nets T=2^17): the state dict is ~75 MB and is regenerated where it is needed (well under a minute
-on an MI355X through torch, ~8 minutes on 8 CPU cores), cached under $SIGNERF_TRAINED_CACHE (default /tmp).  GPU fits are not bit-reproducible
-(atomic scatter-adds), so what is committed is a FINGERPRINT with tolerances (tests/golden/trained_scene_fingerprint.json) and the
+on an MI355X through torch -- ~40 s with the deterministic scatter --, ~8 minutes on 8 CPU cores), cached under $SIGNERF_TRAINED_CACHE (default /tmp).  A fit is run-to-run identical on one machine type (deterministic
+scatter, no GEMM atomics: `fit`), not across CPU / GPU or library versions, so what is committed is a FINGERPRINT with tolerances (tests/golden/trained_scene_fingerprint.json) and the
 64x64 oracle render of the CPU fit made in the build container (tests/golden/trained_scene_64.npz): a regenerated scene must render
 the same picture (PSNR, silhouette IoU, depth vs the analytic depth), not the same bits.
 
