@@ -232,13 +232,22 @@ def scenario(seed, gpu, inspect=(), normals=False, full_tables=False, tcnn=False
            f"camera kind {kind}, render box {box is not None}, crop box {obb is not None}")
     problems, msgs = [], []
     sensitive = trained and iters > 0
-    if sensitive:   # the yardstick: the oracle against itself with the last bit of its exponentials taken another way
+    if sensitive:
+        # the yardstick: the oracle against ITSELF as another correct implementation would differ from it -- the last bit of its
+        # exponentials taken another way AND every component of the rays moved by one ulp up or down (the kernels' positions differ from
+        # the oracle's by exactly that: max |q - q_oracle| = 6e-8)
         _TOTALS["pixels"] += H * W
         _TOTALS["scenarios"] += 1
+        gj = torch.Generator().manual_seed(55000 + seed)
+
+        def jiggle(t):
+            up = torch.rand(t.shape, generator=gj) < 0.5
+            return torch.where(up, torch.nextafter(t, torch.full_like(t, float("inf"))), torch.nextafter(t, torch.full_like(t, float("-inf"))))
+
         for mode in ("rounded", "exp2"):
             onf.EXP_MODE = mode
             try:
-                r1 = onf.get_outputs_for_camera_ray_bundle(sd, ocfg, bundle.origins.cpu(), bundle.directions.cpu(), n, f)
+                r1 = onf.get_outputs_for_camera_ray_bundle(sd, ocfg, jiggle(bundle.origins.cpu()), jiggle(bundle.directions.cpu()), n, f)
             finally:
                 onf.EXP_MODE = "torch"
             for k in _SENSITIVE_KEYS:
@@ -401,7 +410,8 @@ def main():
     if _TOTALS["scenarios"]:
         t = _TOTALS
         print(f"outlier pixels (beyond 1e-2) over the {t['scenarios']} scenarios behind a proposal sampler, {t['pixels']} pixels: "
-              f"HIP vs oracle {t['hip']}; the oracle against itself with a correctly rounded exp {t['rounded']}, with exp2(x log2 e) {t['exp2']}")
+              f"HIP vs oracle {t['hip']}; the oracle against itself with its rays moved by +-1 ulp and a correctly rounded exp {t['rounded']}, "
+              f"the same with exp2(x log2 e) {t['exp2']}")
         for k in _SENSITIVE_KEYS:
             if t["hip"][k] > 3 * max(t["rounded"][k], t["exp2"][k]) + 3:
                 bad += 1
