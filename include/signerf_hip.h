@@ -63,10 +63,26 @@ extern "C" {
 #define SN_MAX_LEVELS 16
 #define SN_MAX_PROPOSALS 2
 
+/* ---- ABI evolution (r06) -----------------------------------------------------------------------------------------------------
+ * The option structs below have grown by appended fields in every round.  Two guards keep a binding that was compiled against one
+ * header safe in front of a library built from another:
+ *   - sn_abi_version() returns the SN_ABI_VERSION the LIBRARY was built with; a binding compares it with the macro of its own header
+ *     before anything else (the Python shim does so at load time).  It changes whenever a signature changes or a struct changes other
+ *     than by appending fields.
+ *   - every struct a caller fills in and that may still grow -- SnFieldDesc, SnRenderOpts, SnMaskOpts, and SnDebugLayout, which the library
+ *     fills in -- begins with `uint32_t struct_size` = sizeof(that struct) IN THE CALLER'S HEADER.  The library reads (writes, for
+ *     SnDebugLayout) exactly that many bytes: fields the caller's header does not know take their zero defaults (every appended field is
+ *     defined so that zero means "as before"), pointers among them stay NULL -- the library never reads or writes through memory
+ *     behind the caller's struct.  A struct_size below the first versioned layout (0: never set) or above the library's own sizeof
+ *     (a caller newer than the library) is refused with SN_ERR_INVALID and a text that names both sizes.
+ *   SnHashMlpDesc (embedded), SnCameraDesc and SnDebugDump are frozen at their r06 layout; changing them bumps SN_ABI_VERSION. */
+#define SN_ABI_VERSION 6
+int sn_abi_version(void);
+
 #define SN_OK 0
 #define SN_ERR_INVALID 1     /* bad argument / unsupported architecture */
 #define SN_ERR_HIP 2         /* a HIP runtime call failed */
-#define SN_ERR_STATE 3       /* weights missing / not finalized */
+#define SN_ERR_STATE 3       /* weights missing / not finalized; reuse_final_bins on a workspace that does not hold this frame's bins */
 #define SN_ERR_WORKSPACE 4   /* workspace too small */
 
 typedef struct SnContext* SnHandle;
@@ -91,6 +107,7 @@ typedef struct SnHashMlpDesc {
 
 /* Architecture of the nerfacto field + proposal nets (A0). */
 typedef struct SnFieldDesc {
+    uint32_t struct_size;         /* sizeof(SnFieldDesc) in the caller's header ("ABI evolution" above) */
     SnHashMlpDesc main_field;
     int32_t geo_feat_dim;         /* 15 */
     int32_t hidden_dim_color;     /* 64 */
@@ -127,6 +144,7 @@ typedef struct SnFieldDesc {
 
 /* Per-call render options (NerfactoModelConfig values that shape one eval render). */
 typedef struct SnRenderOpts {
+    uint32_t struct_size;                          /* sizeof(SnRenderOpts) in the caller's header ("ABI evolution" above) */
     int32_t num_proposal_iterations;               /* 0 => initial sampler feeds the main field directly */
     int32_t num_proposal_samples[SN_MAX_PROPOSALS]; /* 256, 96 */
     int32_t num_nerf_samples;                      /* 48 (64 in the synthetic benchmark) */
@@ -170,8 +188,14 @@ typedef struct SnRenderOpts {
      * bins that the PRECEDING sn_render_rays call on this workspace left there -- same rays, frame size, sampler options and proposal
      * counts, nothing written to the workspace in between, the two calls ordered on the device (same stream, or an event) -- so the
      * normals kernel reads them and the proposal kernel is not launched (it is deterministic: the bins are the ones it would write
-     * again, bit for bit; 7.5 of 17.5 ms at 1920x1080 with 256 + 96 + 48 samples).  The caller vouches for all of it; the library cannot
-     * check what a workspace holds.  Ignored when num_proposal_iterations is 0 and by every other entry point. */
+     * again, bit for bit; 7.5 of 17.5 ms at 1920x1080 with 256 + 96 + 48 samples).  r06: the library keeps, per workspace address, a host-side
+     * STAMP of the last call that wrote bins there -- handle, the handle's weights epoch (every sn_upload_weights / sn_finalize_weights
+     * advances it), frame size, sample counts, sampler options, the ray / nears / fars / grid pointers -- set by sn_render_rays, cleared
+     * by every other call that is handed that workspace; sn_render_normals compares it with its own arguments and returns SN_ERR_STATE on
+     * a mismatch (another frame or handle rendered into the workspace since, the weights changed, a different bundle) instead of
+     * compositing normals along somebody else's bins.  What the stamp cannot see remains the caller's word: that nothing ELSE wrote to
+     * that memory, that the rays behind the pointers are unchanged, and that the two calls are ordered on the device.
+     * Ignored when num_proposal_iterations is 0 and by every other entry point. */
     int32_t reuse_final_bins;
 } SnRenderOpts;
 
@@ -338,6 +362,7 @@ int sn_render_rays_debug(SnHandle h, const float* origins, const float* directio
                          float* rgb, float* depth, float* accumulation, float* expected_depth,
                          float* prop_depth_0, float* prop_depth_1, const SnDebugDump* dump, SnStream stream);
 typedef struct SnDebugLayout {
+    uint32_t struct_size;              /* IN: sizeof(SnDebugLayout) in the caller's header -- the library writes no more than that ("ABI evolution") */
     int32_t n_dense;                   /* leading levels that are read from de-hashed copies */
     int32_t n_bc;                      /* of those, the leading levels stored in bilinear-coefficient form: 32 bytes per grid point (x, y, z) =
                                         * {A, B | C, D} x 2 features, A = v(x,y,z), B = v(x+1,y,z) - A, C = v(x,y+1,z) - A,
@@ -361,6 +386,16 @@ int sn_debug_read(SnHandle h, int32_t which, int32_t what, void* dst, size_t byt
  * of the same handle calls this to have it re-read. */
 int sn_debug_reload_env(SnHandle h);
 
+/* (r06) The position maps of the kernels on explicit samples: origins / directions [n,3], starts / ends [n] (device) -> the normalised,
+ * selector-multiplied positions q [n,3] as computed by (any pointer may be NULL)
+ *   q_strict  the literal torch-path arithmetic (Frustums.get_positions, SceneContraction(inf) with its four IEEE divisions, (p + 2) / 4):
+ *             what the stage kernels, the normals kernel and the non-default ("ALT") render instantiations use;
+ *   q_exact   the division-free form of the SAME map (v_rcp_f32 + Newton steps + exact residuals; csrc/sn_device.h sn_sample_q_exact)
+ *             that the main kernel uses behind the uniform sampler -- must equal q_strict bit for bit (tests/test_gpu_stages.py);
+ *   q_fast    the reduced form (FMA positions, one v_rcp_f32; <= 2 ulp) the fused kernels use behind the proposal sampler. */
+int sn_debug_sample_positions(const float* origins, const float* directions, const float* starts, const float* ends, int64_t n,
+                              float* q_strict, float* q_exact, float* q_fast, SnStream stream);
+
 /* ---- measurement aid (bench.py's issue roofs need the clock the chip actually sustains under the render) ------------------
  * Enqueues eight ONE-WAVE workgroups (one per XCD: the dies of one part run at different clocks under load) that idle for `seconds` (<= 1)
  * of the device's constant-rate wall clock and report how many shader cycles passed meanwhile: out[0] = shader cycles (s_memtime) and
@@ -372,6 +407,7 @@ int sn_clock_probe(uint64_t* out, double seconds, SnStream stream);
  * (signerf/datasetgenerator/datasetgenerator.py:758-818).  Stays on the device: no cv2 round trip (:776-778), no host sync on
  * `torch.sum(visible_mask) > 1e-6` (:770). */
 typedef struct SnMaskOpts {
+    uint32_t struct_size;            /* sizeof(SnMaskOpts) in the caller's header ("ABI evolution") */
     int32_t inverse_mask;            /* DatasetGeneratorConfig.inverse_mask */
     int32_t dilate_w, dilate_h;      /* mask_dialation, cv2.MORPH_ELLIPSE size; 0 = no dilation; each <= 256 */
     int32_t has_manual_depth;        /* manual_depth is not None */

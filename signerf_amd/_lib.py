@@ -12,6 +12,8 @@ from typing import Optional
 
 SN_MAX_LEVELS = 16
 SN_MAX_PROPOSALS = 2
+SN_OK, SN_ERR_INVALID, SN_ERR_HIP, SN_ERR_STATE, SN_ERR_WORKSPACE = 0, 1, 2, 3, 4
+SN_ABI_VERSION = 6   # include/signerf_hip.h "ABI evolution": load() refuses a library built with another one
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # SIGNERF_HIP_LIB: load another build of the library (A/B experiments with tools/ab_lib.py); the default is the in-tree build
@@ -31,8 +33,18 @@ class SnHashMlpDesc(C.Structure):
     ]
 
 
-class SnFieldDesc(C.Structure):
+class _Sized(C.Structure):
+    """A versioned struct of the C ABI: its first field is `struct_size` = sizeof(the struct) in THIS binding's layout, which the library uses
+    to read (or write) no more than the binding knows (include/signerf_hip.h "ABI evolution").  Set at construction."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(self)
+
+
+class SnFieldDesc(_Sized):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("main_field", SnHashMlpDesc),
         ("geo_feat_dim", C.c_int32),
         ("hidden_dim_color", C.c_int32),
@@ -51,8 +63,9 @@ class SnFieldDesc(C.Structure):
     ]
 
 
-class SnRenderOpts(C.Structure):
+class SnRenderOpts(_Sized):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("num_proposal_iterations", C.c_int32),
         ("num_proposal_samples", C.c_int32 * SN_MAX_PROPOSALS),
         ("num_nerf_samples", C.c_int32),
@@ -87,8 +100,9 @@ class SnCameraDesc(C.Structure):
     ]
 
 
-class SnMaskOpts(C.Structure):
+class SnMaskOpts(_Sized):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("inverse_mask", C.c_int32),
         ("dilate_w", C.c_int32),
         ("dilate_h", C.c_int32),
@@ -110,8 +124,9 @@ class SnDebugDump(C.Structure):
     ]
 
 
-class SnDebugLayout(C.Structure):
+class SnDebugLayout(_Sized):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("n_dense", C.c_int32),
         ("n_bc", C.c_int32),
         ("dense_res", C.c_uint32 * 12),
@@ -130,6 +145,7 @@ class SnDebugLayout(C.Structure):
 # (tests/test_cabi.py checks the two against each other).
 _FP = C.c_void_p  # device pointer
 SIGNATURES = {
+    "sn_abi_version": (C.c_int, []),
     "sn_create": (C.c_int, [C.POINTER(SnFieldDesc), C.POINTER(C.c_void_p)]),
     "sn_destroy": (C.c_int, [C.c_void_p]),
     "sn_last_error": (C.c_char_p, [C.c_void_p]),
@@ -149,6 +165,7 @@ SIGNATURES = {
     "sn_debug_layout": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(SnDebugLayout)]),
     "sn_debug_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _FP, C.c_size_t, C.c_void_p]),
     "sn_debug_reload_env": (C.c_int, [C.c_void_p]),
+    "sn_debug_sample_positions": (C.c_int, [_FP, _FP, _FP, _FP, C.c_int64, _FP, _FP, _FP, C.c_void_p]),
     "sn_clock_probe": (C.c_int, [_FP, C.c_double, C.c_void_p]),
     "sn_effective_precision": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "sn_render_normals": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.POINTER(SnRenderOpts), _FP, _FP, C.c_void_p]),
@@ -189,9 +206,15 @@ def load() -> C.CDLL:
         except OSError as e:  # pragma: no cover
             raise SignerfHipError(f"cannot load {LIB_PATH}: {e}") from e
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)
+            fn = getattr(lib, name, None)
+            if fn is None:
+                raise SignerfHipError(f"{LIB_PATH} does not export {name}: it was built from another include/signerf_hip.h -- rebuild it "
+                                      "(`python -m signerf_amd.build --force`)")
             fn.restype = res
             fn.argtypes = args
+        got = lib.sn_abi_version()
+        if got != SN_ABI_VERSION:
+            raise SignerfHipError(f"{LIB_PATH} reports SN_ABI_VERSION {got}, this binding was written for {SN_ABI_VERSION}: rebuild the library")
         _lib = lib
         return lib
 

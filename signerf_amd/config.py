@@ -60,6 +60,13 @@ class NerfactoModelConfig(InstantiateConfig):
     rendered -- by a separate kernel -- the first time one of the two keys is read from the returned dict, so
     ``DatasetGenerator.render_camera``, which reads only rgb and depth (datasetgenerator.py:700-701), never pays for them;
     "always": rendered with every call, as nerfstudio does; "never": the keys are absent."""
+    normals_bin_reuse_max_mb: int = 1024
+    """Behind the proposal sampler a LAZY normals launch re-uses the final sample bins of the colour render instead of running the
+    proposal kernel again (1920x1080: 16.7 -> 9.2 ms for the normals).  The price is memory: the render's whole workspace -- ~0.45 GB at
+    1920x1080, ~0.14 GB at 800x800 -- stays alive for as long as the returned outputs dict does (until the normals have been read),
+    multiplied by the number of outputs dicts a viewer or dataset loop holds on to.  Renders whose workspace is larger than this many MB
+    let it go when the call returns and their lazy normals pay the proposal kernel again; 0 = never keep.  ("always" mode frees the
+    workspace at the end of the call whatever this says.)"""
     disable_scene_contraction: bool = False
     average_init_density: float = 1.0
     eval_num_rays_per_chunk: int = 4096

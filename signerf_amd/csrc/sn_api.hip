@@ -13,6 +13,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "sn_device.h"
@@ -77,6 +78,8 @@ struct SnContext {
     bool normals_split_ok = true;  // the normals kernel's own conditioned operands fit fp16 (sn_finalize_weights)
     float grad_scale_normals = 1.0f;  // power of two carried by the split-precision reverse-pass layer of the normals kernel
     bool finalized = false;
+    std::atomic<uint64_t> weights_epoch{0};  // advanced by every sn_upload_weights / sn_finalize_weights (the workspace stamps carry it)
+    uint64_t id = 0;                         // process-unique handle number (a stamp must not match a NEW handle at a recycled address)
     SnPosMap pos_map{};  // SnFieldDesc.disable_scene_contraction + aabb, as the kernels take it (sn_create)
     // ordering of weight uploads against renders in flight (RenderGuard below): the completion event of the LAST render of every
     // stream that rendered with this handle (a stream is in-order, so its last render covers its earlier ones)
@@ -200,6 +203,111 @@ void mark_weights_written(SnHandle h, hipStream_t st) {
 }
 
 thread_local std::string g_error_copy;  // sn_last_error hands out a per-thread copy: another thread may rewrite the handle's text
+
+int fail(SnHandle h, int code, const std::string& msg);
+
+// include/signerf_hip.h "ABI evolution": the caller's struct begins with the sizeof ITS header gives it.  Exactly that many bytes are
+// copied into the library's own (zeroed) struct: fields the caller does not know keep their zero defaults, nothing behind the caller's
+// struct is read.  min_size = the struct's size in the first versioned header (r06).
+template <typename T>
+int adopt_struct(SnHandle h, const T* in, size_t min_size, T& out, const char* what) {
+    memset((void*)&out, 0, sizeof(T));
+    uint32_t sz = 0;
+    memcpy(&sz, (const void*)in, sizeof(sz));
+    if (sz < min_size || sz > sizeof(T))
+        return fail(h, SN_ERR_INVALID, std::string(what) + ".struct_size = " + std::to_string(sz) + ": this library (SN_ABI_VERSION " + std::to_string(SN_ABI_VERSION) +
+                                           ") knows sizes " + std::to_string(min_size) + " .. " + std::to_string(sizeof(T)) +
+                                           (sz == 0 ? " -- struct_size was not set (set it to sizeof of the struct in your header)"
+                                                    : sz > sizeof(T) ? " -- the caller was built against a newer header than the library" : ""));
+    memcpy((void*)&out, (const void*)in, sz);
+    out.struct_size = (uint32_t)sizeof(T);
+    return SN_OK;
+}
+// sizes of the versioned structs in the first versioned header (r06): every field up to and including the last one r05 had
+constexpr size_t kFieldDescMin = offsetof(SnFieldDesc, half_grid) + sizeof(int32_t);
+constexpr size_t kRenderOptsMin = offsetof(SnRenderOpts, reuse_final_bins) + sizeof(int32_t);
+constexpr size_t kMaskOptsMin = offsetof(SnMaskOpts, additional_depth_radius) + sizeof(float);
+constexpr size_t kDebugLayoutMin = offsetof(SnDebugLayout, half_grid_bytes) + sizeof(uint64_t);
+
+// SnRenderOpts.reuse_final_bins: what the final bins in a workspace belong to, kept on the HOST per workspace address (the library
+// cannot read a workspace back without a device sync).  sn_render_rays stamps the workspace it wrote bins into; every other entry point
+// that is handed a workspace clears its stamp; sn_render_normals with reuse_final_bins compares.  Process-wide, so that a render of
+// ANOTHER handle into the same memory invalidates the stamp as well.
+struct WorkspaceStamp {
+    uint64_t handle_id, weights_epoch, serial;
+    int32_t height, width, nprop, n_prop_samples[SN_MAX_PROPOSALS], n_nerf, spacing_mode;
+    float near_plane, far_plane;
+    const void *origins, *directions, *nears, *fars, *sbins, *pdf_u[SN_MAX_PROPOSALS];
+    int device;
+};
+struct StampTable {
+    std::mutex mu;
+    std::unordered_map<const void*, WorkspaceStamp> m;
+    uint64_t serial = 0;
+    static constexpr size_t kMax = 1024;
+};
+StampTable g_stamps;
+std::atomic<uint64_t> g_next_handle_id{1};
+
+WorkspaceStamp make_stamp(SnHandle h, const float* origins, const float* directions, const float* nears, const float* fars, int32_t height,
+                          int32_t width, const SnRenderOpts& o) {
+    WorkspaceStamp s;
+    memset(&s, 0, sizeof(s));
+    s.handle_id = h->id;
+    s.weights_epoch = h->weights_epoch.load(std::memory_order_relaxed);
+    s.height = height;
+    s.width = width;
+    s.nprop = o.num_proposal_iterations;
+    for (int i = 0; i < SN_MAX_PROPOSALS; ++i) {
+        s.n_prop_samples[i] = i < o.num_proposal_iterations ? o.num_proposal_samples[i] : 0;
+        s.pdf_u[i] = i < o.num_proposal_iterations ? o.pdf_u[i] : nullptr;
+    }
+    s.n_nerf = o.num_nerf_samples;
+    s.spacing_mode = o.spacing_mode;
+    s.near_plane = o.near_plane;
+    s.far_plane = o.far_plane;
+    s.origins = origins;
+    s.directions = directions;
+    s.nears = nears;
+    s.fars = fars;
+    s.sbins = o.initial_spacing_bins;
+    s.device = h->device;
+    return s;
+}
+void stamp_workspace(const void* ws, WorkspaceStamp s) {
+    std::lock_guard<std::mutex> g(g_stamps.mu);
+    if (g_stamps.m.size() >= StampTable::kMax && !g_stamps.m.count(ws)) {  // bounded: drop the oldest entry
+        auto oldest = g_stamps.m.begin();
+        for (auto it = g_stamps.m.begin(); it != g_stamps.m.end(); ++it)
+            if (it->second.serial < oldest->second.serial) oldest = it;
+        g_stamps.m.erase(oldest);
+    }
+    s.serial = ++g_stamps.serial;
+    g_stamps.m[ws] = s;
+}
+void clear_stamp(const void* ws) {
+    if (!ws) return;
+    std::lock_guard<std::mutex> g(g_stamps.mu);
+    g_stamps.m.erase(ws);
+}
+// empty string = the workspace holds the bins this call would compute; otherwise what differs
+std::string stamp_mismatch(const void* ws, const WorkspaceStamp& want) {
+    std::lock_guard<std::mutex> g(g_stamps.mu);
+    auto it = g_stamps.m.find(ws);
+    if (it == g_stamps.m.end()) return "no sn_render_rays call of this process left final bins in this workspace (or another call has used it since)";
+    const WorkspaceStamp& s = it->second;
+    if (s.handle_id != want.handle_id || s.device != want.device) return "the bins in this workspace were written by another handle";
+    if (s.weights_epoch != want.weights_epoch) return "the handle's weights changed after the render that wrote these bins";
+    if (s.height != want.height || s.width != want.width) return "the bins belong to a frame of another size";
+    if (s.nprop != want.nprop || s.n_nerf != want.n_nerf || memcmp(s.n_prop_samples, want.n_prop_samples, sizeof(s.n_prop_samples)) != 0)
+        return "the bins were sampled with other sample counts";
+    if (s.spacing_mode != want.spacing_mode || memcmp(&s.near_plane, &want.near_plane, 4) != 0 || memcmp(&s.far_plane, &want.far_plane, 4) != 0)
+        return "the bins were sampled with another initial sampler / collider planes";
+    if (s.origins != want.origins || s.directions != want.directions || s.nears != want.nears || s.fars != want.fars)
+        return "the bins belong to another ray bundle (origins / directions / nears / fars pointers differ)";
+    if (s.sbins != want.sbins || memcmp(s.pdf_u, want.pdf_u, sizeof(s.pdf_u)) != 0) return "the bins were sampled on other sampler grids";
+    return "";
+}
 
 int fail(SnHandle h, int code, const std::string& msg) {
     if (h) {
@@ -832,8 +940,13 @@ bool valid_opts(const SnFieldDesc& d, const SnRenderOpts& o, std::string& why) {
 
 extern "C" {
 
-int sn_create(const SnFieldDesc* desc, SnHandle* out) {
-    if (!desc || !out) return fail(nullptr, SN_ERR_INVALID, "sn_create: null argument");
+int sn_abi_version(void) { return SN_ABI_VERSION; }
+
+int sn_create(const SnFieldDesc* desc_in, SnHandle* out) {
+    if (!desc_in || !out) return fail(nullptr, SN_ERR_INVALID, "sn_create: null argument");
+    SnFieldDesc desc_own;
+    if (int rc = adopt_struct(nullptr, desc_in, kFieldDescMin, desc_own, "sn_create: SnFieldDesc")) return rc;
+    const SnFieldDesc* desc = &desc_own;
     std::string why;
     if (!check_hashmlp(desc->main_field, 16, 64, 16, why)) return fail(nullptr, SN_ERR_INVALID, "main field: " + why);
     if (desc->geo_feat_dim != 15 || desc->hidden_dim_color != 64 || desc->sh_levels != 4)
@@ -868,6 +981,7 @@ int sn_create(const SnFieldDesc* desc, SnHandle* out) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->n_cus = cus;
     }
     load_switches(c);
+    c->id = g_next_handle_id.fetch_add(1);
     *out = c;
     return SN_OK;
 }
@@ -916,6 +1030,7 @@ int sn_upload_weights(SnHandle h, const char* name, const void* data, size_t byt
     if (!h || !name || !data) return fail(h, SN_ERR_INVALID, "sn_upload_weights: null argument");
     hipStream_t st = (hipStream_t)stream;
     const std::string n(name);
+    h->weights_epoch.fetch_add(1);  // (bins a workspace holds were sampled with the previous weights: SnRenderOpts.reuse_final_bins)
     wait_for_renders(h, st);  // renders in flight on other streams still read the buffers this call overwrites (or frees)
     auto upload_table = [&](DevBuf& buf, const SnHashMlpDesc& d) -> int {
         const size_t want = ((size_t)d.num_levels << d.log2_hashmap_size) * 2 * sizeof(float);
@@ -955,6 +1070,7 @@ int sn_upload_weights(SnHandle h, const char* name, const void* data, size_t byt
 int sn_finalize_weights(SnHandle h, SnStream stream) {
     if (!h) return SN_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
+    h->weights_epoch.fetch_add(1);
     load_switches(h);
     wait_for_renders(h, st);
     const SnFieldDesc& d = h->desc;
@@ -1392,8 +1508,23 @@ int sn_intersect_obb(const float* origins, const float* directions, int64_t n_ra
     return SN_OK;
 }
 
-size_t sn_workspace_bytes(SnHandle h, int32_t height, int32_t width, const SnRenderOpts* opts) {
-    if (!h || !opts || height <= 0 || width <= 0 || opts->chunk_rays < 1) return 0;
+int sn_debug_sample_positions(const float* origins, const float* directions, const float* starts, const float* ends, int64_t n,
+                              float* q_strict, float* q_exact, float* q_fast, SnStream stream) {
+    if (!origins || !directions || !starts || !ends || n < 0) return fail(nullptr, SN_ERR_INVALID, "sn_debug_sample_positions: bad argument");
+    if (n == 0) return SN_OK;
+    hipLaunchKernelGGL(sn_debug_sample_positions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, origins,
+                       directions, starts, ends, n, q_strict, q_exact, q_fast);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, SN_ERR_HIP, std::string("sn_debug_sample_positions launch: ") + hipGetErrorString(e));
+    return SN_OK;
+}
+
+size_t sn_workspace_bytes(SnHandle h, int32_t height, int32_t width, const SnRenderOpts* opts_in) {
+    if (!h || !opts_in || height <= 0 || width <= 0) return 0;
+    SnRenderOpts own;
+    if (adopt_struct(h, opts_in, kRenderOptsMin, own, "sn_workspace_bytes: SnRenderOpts")) return 0;  // (the text is in sn_last_error)
+    const SnRenderOpts* opts = &own;
+    if (opts->chunk_rays < 1) return 0;
     return plan_workspace(height, width, *opts, h->n_cus, true).total;  // (the size with the tail split on covers both settings of SN_TAIL_SPLIT)
 }
 
@@ -1510,6 +1641,9 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
                             float* prop_depth_0, float* prop_depth_1, const SnDebugDump* dump, SnStream stream) {
     if (!h) return SN_ERR_INVALID;
     if (!origins || !directions || !opts || height <= 0 || width <= 0) return fail(h, SN_ERR_INVALID, "sn_render_rays: bad argument");
+    SnRenderOpts opts_own;
+    if (int rc = adopt_struct(h, opts, kRenderOptsMin, opts_own, "sn_render_rays: SnRenderOpts")) return rc;
+    opts = &opts_own;
     if ((nears == nullptr) != (fars == nullptr)) return fail(h, SN_ERR_INVALID, "sn_render_rays: nears and fars must both be given or both be NULL");
     if (!h->finalized) return fail(h, SN_ERR_STATE, "sn_render_rays: weights not finalized");
     std::string why;
@@ -1535,6 +1669,17 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
         SN_HIP(h, hipMemsetAsync(d_minmax + wp.n_chunks, 0x00, (size_t)wp.n_chunks * 4, st));
     }
 
+    // every refusal that depends on the options comes BEFORE the first launch (a call must not return SN_ERR_INVALID with the
+    // proposal kernel already enqueued and its counters half updated)
+    if (opts->march_stats) {
+        const bool tcnn_ = d.main_field.grid_mode == 1, alt_ = needs_generic_kernels(h, opts);
+        const bool split_ = opts->precision >= 1 && h->split_ok, half1_ = split_ && opts->precision == 2;
+        if (half1_ || dump || alt_)
+            return fail(h, SN_ERR_INVALID, "SnRenderOpts.march_stats: no counting instantiation for this variant (single fp16 / instrumented / generic sampler)");
+        if (!(split_ && !tcnn_ && h->nd_torch == SN_DENSE_LEVELS_DEFAULT))
+            return fail(h, SN_ERR_INVALID, "SnRenderOpts.march_stats: the counting instantiation of the main kernel exists for the default variant only (torch grid, 11 de-hashed levels, precision 1)");
+    }
+    clear_stamp(ws);  // whatever this workspace held is being overwritten
     float* d_ebins = nullptr;
     if (nprop > 0)
         if (int rc = launch_proposals(h, origins, directions, nears, fars, height, width, opts, wp, g, ws, prop_depth_0, prop_depth_1, st, &d_ebins, dump))
@@ -1695,6 +1840,7 @@ static int render_rays_impl(SnHandle h, const float* origins, const float* direc
                            opts->chunk_rays, wp.n_chunks, expected_depth);
         SN_HIP(h, hipGetLastError());
     }
+    if (nprop > 0) stamp_workspace(ws, make_stamp(h, origins, directions, nears, fars, height, width, *opts));  // SnRenderOpts.reuse_final_bins
     return SN_OK;
 }
 
@@ -1728,7 +1874,15 @@ int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out) {
     if (!h || !out) return fail(h, SN_ERR_INVALID, "sn_debug_layout: null argument");
     if (which < -1 || which >= h->desc.num_proposals) return fail(h, SN_ERR_INVALID, "sn_debug_layout: bad field selector");
     if (!h->finalized) return fail(h, SN_ERR_STATE, "sn_debug_layout: weights not finalized");
+    // the caller's struct may be SHORTER than this library's (include/signerf_hip.h "ABI evolution"): fill in our own, copy out its size
+    SnDebugLayout* const caller_out = out;
+    SnDebugLayout own;
+    if (int rc = adopt_struct(h, caller_out, kDebugLayoutMin, own, "sn_debug_layout: SnDebugLayout")) return rc;
+    uint32_t caller_size = 0;
+    memcpy(&caller_size, (const void*)caller_out, sizeof(caller_size));
+    out = &own;
     memset(out, 0, sizeof(*out));
+    out->struct_size = caller_size;
     const SnDenseCopy& dc = which < 0 ? h->dense_info : h->dense_info_prop[which];
     out->n_dense = which < 0 ? h->nd_torch : h->nd_prop[which];
     for (int l = 0; l < 12; ++l) {
@@ -1748,6 +1902,7 @@ int sn_debug_layout(SnHandle h, int32_t which, SnDebugLayout* out) {
     for (int i = 0; i < SN_MAX_PROPOSALS; ++i)
         total += h->table_prop[i].bytes + h->pairs_prop[i].bytes + h->wpack_prop[i].bytes + h->dense_prop[i].bytes;
     out->handle_bytes = total;
+    memcpy((void*)caller_out, (const void*)&own, caller_size);
     return SN_OK;
 }
 
@@ -1801,6 +1956,9 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
                       int32_t width, const SnRenderOpts* opts, float* normals, float* pred_normals, SnStream stream) {
     if (!h) return SN_ERR_INVALID;
     if (!origins || !directions || !opts || height <= 0 || width <= 0) return fail(h, SN_ERR_INVALID, "sn_render_normals: bad argument");
+    SnRenderOpts opts_own;
+    if (int rc = adopt_struct(h, opts, kRenderOptsMin, opts_own, "sn_render_normals: SnRenderOpts")) return rc;
+    opts = &opts_own;
     if ((nears == nullptr) != (fars == nullptr)) return fail(h, SN_ERR_INVALID, "sn_render_normals: nears and fars must both be given or both be NULL");
     if (!h->finalized) return fail(h, SN_ERR_STATE, "sn_render_normals: weights not finalized");
     if (pred_normals && !h->has_pred_normals)
@@ -1819,11 +1977,20 @@ int sn_render_normals(SnHandle h, const float* origins, const float* directions,
     const int nprop = opts->num_proposal_iterations;
     float* d_ebins = nullptr;
     if (nprop > 0) {
-        if (opts->reuse_final_bins) {   // the bins of the preceding sn_render_rays on this workspace (the caller vouches: signerf_hip.h)
+        const WorkspaceStamp want = make_stamp(h, origins, directions, nears, fars, height, width, *opts);
+        if (opts->reuse_final_bins) {
+            // the bins of the preceding sn_render_rays on this workspace: the host-side stamp of that call must describe THIS call (r06;
+            // what no stamp can see -- foreign writes to the memory, rays changed in place, device ordering -- stays the caller's word)
+            const std::string why_not = stamp_mismatch(ws, want);
+            if (!why_not.empty()) return fail(h, SN_ERR_STATE, "sn_render_normals: reuse_final_bins: " + why_not);
             d_ebins = (float*)(ws + wp.off_ebins);
-        } else if (int rc = launch_proposals(h, origins, directions, nears, fars, height, width, opts, wp, g, ws, nullptr, nullptr, st, &d_ebins)) {
-            return rc;
+        } else {
+            clear_stamp(ws);
+            if (int rc = launch_proposals(h, origins, directions, nears, fars, height, width, opts, wp, g, ws, nullptr, nullptr, st, &d_ebins)) return rc;
+            stamp_workspace(ws, want);  // (the proposal kernel is deterministic: these ARE the bins a colour render of the same call would leave)
         }
+    } else {
+        clear_stamp(ws);
     }
     SnNormalsParams p;
     memset(&p, 0, sizeof(p));
@@ -2061,11 +2228,15 @@ int sn_aabb_mask_condition(const float* origins, const float* directions, const 
                            size_t workspace_bytes, SnStream stream) {
     if (!origins || !directions || !depth || !aabb || !opts || !mask || height <= 0 || width <= 0)
         return fail(nullptr, SN_ERR_INVALID, "sn_aabb_mask_condition: bad argument");
+    SnMaskOpts opts_own;
+    if (int rc = adopt_struct(nullptr, opts, kMaskOptsMin, opts_own, "sn_aabb_mask_condition: SnMaskOpts")) return rc;
+    opts = &opts_own;
     if (opts->dilate_w < 0 || opts->dilate_h < 0 || opts->dilate_w > SN_MASK_MAX_K || opts->dilate_h > SN_MASK_MAX_K ||
         ((opts->dilate_w == 0) != (opts->dilate_h == 0)))
         return fail(nullptr, SN_ERR_INVALID, "sn_aabb_mask_condition: dilation size must be 0 or within [1," + std::to_string(SN_MASK_MAX_K) + "] in both dimensions");
     if (!workspace || workspace_bytes < sn_mask_workspace_bytes(height, width))
         return fail(nullptr, SN_ERR_WORKSPACE, "sn_aabb_mask_condition: workspace too small");
+    clear_stamp(workspace);  // (a caller may hand the mask step the memory a render used: its bins are gone then)
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)height * width;
     SnMaskParams p;

@@ -129,6 +129,50 @@ SN_DEV bool sn_sample_q_fast(const float o[3], const float d[3], float start, fl
     return sel;
 }
 
+// r06 -- the STRICT map at (nearly) the fast form's price: q is sn_sample_q's, bit for bit, without its four IEEE divisions.
+// The main kernel behind the UNIFORM sampler uses it: there a sample's position depends on no computed weight, so with strict position
+// arithmetic every voxel and every blend offset of the fused kernel is the oracle's (tests/test_gpu_fused_indices.py: 0 flips).
+//   * (d t) / 2 == (d / 2) t: a power-of-two scale commutes with the rounding of the product (dh = d * 0.5, formed once per ray);
+//   * m = max(mag, 1): for mag < 1 the reference skips the contraction -- with m = 1 every quotient p / 1 and k = 2 - 1 / 1 = 1 is exact,
+//     so the branch-free form returns p itself (NaN positions: min / max skip them, k p stays NaN in that coordinate; sn_main.h restores
+//     the all-NaN sample from it as before);
+//   * y = RN(1 / m) from v_rcp_f32 (1 ulp) + TWO Newton steps: equal to the IEEE quotient for every fp32 m whose significand is not all
+//     ones, whichever neighbour of it the instruction returns (one step is not enough when v_rcp_f32 errs upwards: 32 of 2^23
+//     significands; tools/recip_exhaustive.py emulates the fmas exactly over all 2^23 significands x {RN - 1 ulp, RN, RN + 1 ulp});
+//     for an all-ones significand m = 2^e (2 - 2^-23) the quotient is 2^-(e+1) (1 + 2^-23) = bits 0x7F000000 - bits(m), substituted by
+//     a select;
+//   * p / m = RN(q0 + (p - q0 m) y), q0 = RN(p y): the correctly rounded quotient from the correctly rounded reciprocal + one exact
+//     residual (Markstein; sn_proposal.h uses the same identity, tests/test_recip_division.py holds it against 480 M emulated pairs);
+//   * (k p' + 2) / 4 == fma(k p', 0.25, 0.5): again a power-of-two scale.
+// 32 VALU instead of the fast form's 16 and the literal form's ~52.  Checked on the hardware itself against sn_sample_q
+// (sn_debug_sample_positions: random, near-halfway and all-ones cases; tests/test_gpu_stages.py).
+SN_DEV bool sn_sample_q_exact(const float o[3], const float dh[3], float start, float end, float q[3]) {
+#pragma clang fp contract(off)
+    const float t = start + end;
+    float p[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = o[c] + dh[c] * t;
+    const float mag = fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2]));
+    const float m = fmaxf(mag, 1.0f);
+    float y = __builtin_amdgcn_rcpf(m);
+    y = __builtin_fmaf(__builtin_fmaf(-m, y, 1.0f), y, y);
+    y = __builtin_fmaf(__builtin_fmaf(-m, y, 1.0f), y, y);
+    const uint32_t mb = __float_as_uint(m);
+    y = (mb & 0x7fffffu) == 0x7fffffu ? __uint_as_float(0x7F000000u - mb) : y;  // (a select, not a branch: a branch here splits the hash phase's scheduling region)
+    const float k = 2.0f - y;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float q0 = p[c] * y;
+        const float pc = __builtin_fmaf(__builtin_fmaf(-q0, m, p[c]), y, q0);
+        q[c] = __builtin_fmaf(k * pc, 0.25f, 0.5f);
+    }
+    const bool sel = sn_in_unit_cube(q);
+    const float msel = sel ? 1.0f : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[c] = q[c] * msel;
+    return sel;
+}
+
 // Same, from a world position (stage-level field_forward).
 SN_DEV bool sn_position_q(const float pin[3], float q[3], const SnPosMap* pm = nullptr) {
 #pragma clang fp contract(off)

@@ -690,6 +690,16 @@ SN_DEV void sn_main_field_f16(const char* __restrict__ ldsb, float* feat, const 
 #ifndef SN_H16_PAIRS
 #define SN_H16_PAIRS 1
 #endif
+// r06: position arithmetic of the production instantiations.  1 = sn_sample_q_exact (the oracle's q bit for bit), 0 = sn_sample_q_fast
+// (FMA positions + v_rcp_f32 contraction, <= 2 ulp).  UNIFORM: behind the initial sampler alone (MODE 0: a position depends on no computed
+// weight, so exact positions make every voxel and blend offset the oracle's); BINS: behind the proposal sampler (MODE 1: the bins
+// themselves already differ from the oracle's in the last bits).  Same-box A/B: profiles/r06_exact_positions_ab.txt.
+#ifndef SN_EXACT_POS_UNIFORM
+#define SN_EXACT_POS_UNIFORM 1
+#endif
+#ifndef SN_EXACT_POS_BINS
+#define SN_EXACT_POS_BINS 0
+#endif
 #ifndef SN_STRIP_W
 #define SN_STRIP_W 8  // r02 same-box A/B over widths 0 / 4 / 8 / 12 / 16: 2.826 / 2.803 / 2.805 / 2.817 / 2.823 ms (camera 0)
 #endif
@@ -911,6 +921,8 @@ void sn_render_main_kernel(SnMainParams p) {
     const float near = p.nears ? p.nears[ray] : p.near_plane;
     const float far = p.fars ? p.fars[ray] : p.far_plane;
     const float s_near = sn_spacing(near, su), s_far = sn_spacing(far, su);
+    constexpr bool EXACTQ = !ALT && (MODE == 0 ? SN_EXACT_POS_UNIFORM != 0 : SN_EXACT_POS_BINS != 0);
+    const float dh[3] = {d[0] * 0.5f, d[1] * 0.5f, d[2] * 0.5f};  // sn_sample_q_exact: (d t) / 2 == (d / 2) t
     SnShOps sh;
     SnShOpsH shh;
     SnShOpsF shf;
@@ -938,7 +950,11 @@ void sn_render_main_kernel(SnMainParams p) {
         asm volatile("" ::: "memory");
         const float t1 = bin(i + 1);
         float q[3];
-        const bool sel = ALT ? sn_sample_q(o, d, t0, t1, q, pm) : sn_sample_q_fast(o, d, t0, t1, q);  // (ALT: the strict form, see sn_sample_q_fast)
+        // ALT: the literal strict form (it also serves the box map); EXACTQ: the same q from sn_sample_q_exact; else the fast form
+        const bool sel = ALT ? sn_sample_q(o, d, t0, t1, q, pm) : (EXACTQ ? sn_sample_q_exact(o, dh, t0, t1, q) : sn_sample_q_fast(o, d, t0, t1, q));
+        // (the exact form's longer dependent chain in one scheduling region with the first level group made hipcc serialise that group --
+        // load, wait, blend, level by level; fenced off, the group schedules like the other three: 16 gathers in flight)
+        if (EXACTQ) __builtin_amdgcn_sched_barrier(0);
         float feat[32];
         {
             // plain table: the x-paired layout (sn_device.h) measured no gain here (r01: 4.11 vs 4.18 ms) -- splitting a level

@@ -397,3 +397,35 @@ __global__ void sn_composite_kernel(SnCompositeStageParams p) {
         atomicMax(&p.minmax[1], sn_float_ordered(last_mid));
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// test instrumentation (r06): the three position maps of sn_device.h on explicit samples, one sample per thread.  The fused kernel
+// behind the uniform sampler uses sn_sample_q_exact, whose q must BE sn_sample_q's (the literal IEEE form): compared bit for bit on the
+// hardware by tests/test_gpu_stages.py (random, near-halfway and all-ones-significand cases).  The wave-uniform branch of the exact form
+// needs whole waves: the grid is padded and inactive lanes compute on a dummy sample.
+// ------------------------------------------------------------------------------------------
+__global__ void sn_debug_sample_positions_kernel(const float* origins, const float* directions, const float* starts, const float* ends, int64_t n,
+                                                 float* q_strict, float* q_exact, float* q_fast) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const int64_t j = live ? i : 0;
+    float o[3], d[3], dh[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = origins[j * 3 + c];
+        d[c] = directions[j * 3 + c];
+        dh[c] = d[c] * 0.5f;
+    }
+    const float t0 = starts[j], t1 = ends[j];
+    float qs[3], qe[3], qf[3];
+    sn_sample_q(o, d, t0, t1, qs);
+    sn_sample_q_exact(o, dh, t0, t1, qe);
+    sn_sample_q_fast(o, d, t0, t1, qf);
+    if (!live) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (q_strict) q_strict[i * 3 + c] = qs[c];
+        if (q_exact) q_exact[i * 3 + c] = qe[c];
+        if (q_fast) q_fast[i * 3 + c] = qf[c];
+    }
+}

@@ -634,7 +634,7 @@ class NerfactoModel(nn.Module):
         bg = BACKGROUNDS[cfg.background_color]
         o.background_mode = 0 if bg is None else 1
         o.spacing_mode = INITIAL_SAMPLERS[cfg.proposal_initial_sampler]
-        stats = getattr(self, "_march_stats", None)   # diagnostics (ops.render_with_march_stats): 6 int64 counters the kernels add to
+        stats = getattr(self, "_march_stats", None)   # diagnostics (ops.render_with_march_stats): 3 uint64 counters the kernels add to
         o.march_stats = stats.data_ptr() if stats is not None else None
         for c in range(3):
             o.background_rgb[c] = 0.0 if bg is None else bg[c]
@@ -683,14 +683,19 @@ class NerfactoModel(nn.Module):
         # (SnRenderOpts.reuse_final_bins; 17.5 -> 10 ms at 1920x1080).  The price: that workspace is released when the outputs dict
         # is, not when this call returns.
         keep_bins = mode != "never" and self.config.num_proposal_iterations > 0 and H * W > 0
-        raw, state = self._render_ex(b, H, W, single_chunk, keep_state=keep_bins)
+        # lazy mode: only below config.normals_bin_reuse_max_mb (the workspace then lives as long as the outputs dict does)
+        cap = None if mode == "always" else int(self.config.normals_bin_reuse_max_mb) << 20
+        raw, state = self._render_ex(b, H, W, single_chunk, keep_state=keep_bins, keep_state_max_bytes=cap)
         out = {k: v.view(*shape, v.shape[-1]) for k, v in raw.items()}
         if mode == "never":
             return out
 
+        held = [state]   # released with the first (only) normals launch, not with the outputs dict
+
         def producer():
             with torch.no_grad():
-                return {k: v.view(*shape, v.shape[-1]) for k, v in self._render_normals(b, H, W, state).items()}
+                st, held[0] = held[0], None
+                return {k: v.view(*shape, v.shape[-1]) for k, v in self._render_normals(b, H, W, st).items()}
 
         if mode == "always":
             out.update(producer())
@@ -707,23 +712,37 @@ class NerfactoModel(nn.Module):
             z = torch.empty((0, 3), dtype=torch.float32, device=dev)
             return {"normals": z, "pred_normals": z.clone()} if self._has_pred_normals else {"normals": z}
         f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
-        origins, directions, nears, fars = f32(b.origins), f32(b.directions), f32(b.nears), f32(b.fars)
+        reuse = state is not None and state["generation"] == self._engine_generation
+        # the very tensors the colour render marched (the library's workspace stamp compares their addresses: a second fp32 / contiguous
+        # copy of a bundle that needed one would be "another bundle")
+        origins, directions, nears, fars = state["rays"] if reuse else (f32(b.origins), f32(b.directions), f32(b.nears), f32(b.fars))
         with torch.cuda.device(dev):
             normals = torch.empty((H * W, 3), dtype=torch.float32, device=dev)
             pred = torch.empty((H * W, 3), dtype=torch.float32, device=dev) if self._has_pred_normals else None
             self._engine_rw.acquire_read()
             try:
-                if state is not None and state["generation"] == self._engine_generation:
+                st = _lib.SN_ERR_STATE
+                if reuse:
                     o, keep = state["opts"], state["keep"]
                     o.reuse_final_bins = 1
                     o.march_stats = None
                     cur = torch.cuda.current_stream(dev)
                     cur.wait_event(state["event"])            # (a viewer thread may read the normals on another stream)
                     keep[0].record_stream(cur)
-                else:
+                    st = lib.sn_render_normals(self._handle, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(nears), _lib.ptr(fars), H, W,
+                                               C.byref(o), _lib.ptr(normals), _lib.ptr(pred), _lib.current_stream())
+                    if st == _lib.SN_ERR_STATE:
+                        # the library found that the workspace no longer holds this frame's bins (weights re-uploaded in between, the
+                        # memory handed to another call): not an error for the caller -- the proposal kernel runs again
+                        msg = lib.sn_last_error(self._handle)
+                        warnings.warn("lazy normals: the kept sample bins could not be re-used (%s); running the proposal sampler again"
+                                      % (msg.decode() if msg else ""), RuntimeWarning)
+                        reuse = False
+                if not reuse:
                     o, keep = self._opts(H, W, lib)   # (sn_workspace_bytes reads the handle: inside the read lock)
-                st = lib.sn_render_normals(self._handle, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(nears), _lib.ptr(fars), H, W,
-                                           C.byref(o), _lib.ptr(normals), _lib.ptr(pred), _lib.current_stream())
+                    o.march_stats = None              # (the colour render of this frame has counted the proposal levels already)
+                    st = lib.sn_render_normals(self._handle, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(nears), _lib.ptr(fars), H, W,
+                                               C.byref(o), _lib.ptr(normals), _lib.ptr(pred), _lib.current_stream())
                 _lib.check(st, self._handle, "sn_render_normals")
             finally:
                 self._engine_rw.release_read()
@@ -732,9 +751,10 @@ class NerfactoModel(nn.Module):
     def _render(self, b: RayBundle, H: int, W: int, single_chunk: bool = False) -> Dict[str, Tensor]:
         return self._render_ex(b, H, W, single_chunk)[0]
 
-    def _render_ex(self, b: RayBundle, H: int, W: int, single_chunk: bool = False, keep_state: bool = False):
-        """-> (outputs, state).  state (``keep_state``) = {"opts", "keep" (workspace + grids), "event", "generation"} for a normals launch
-        on the same bundle that re-uses this render's final sample bins (``_render_normals``); None otherwise."""
+    def _render_ex(self, b: RayBundle, H: int, W: int, single_chunk: bool = False, keep_state: bool = False, keep_state_max_bytes=None):
+        """-> (outputs, state).  state (``keep_state``) = {"opts", "keep" (workspace + grids), "rays", "event", "generation"} for a normals
+        launch on the same bundle that re-uses this render's final sample bins (``_render_normals``); None otherwise -- also when the
+        workspace is larger than ``keep_state_max_bytes`` (config.normals_bin_reuse_max_mb)."""
         lib = self._ensure_engine()
         if H * W == 0:  # an empty bundle renders to empty outputs, as the reference's chunk loop does
             z = lambda c: torch.empty((0, c), dtype=torch.float32, device=self.device)  # noqa: E731
@@ -758,10 +778,10 @@ class NerfactoModel(nn.Module):
                                         _lib.current_stream())
                 _lib.check(st, self._handle, "sn_render_rays")
                 state = None
-                if keep_state:
+                if keep_state and (keep_state_max_bytes is None or keep[0].numel() <= keep_state_max_bytes):
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream(dev))
-                    state = {"opts": o, "keep": keep, "event": ev, "generation": self._engine_generation}
+                    state = {"opts": o, "keep": keep, "rays": (origins, directions, nears, fars), "event": ev, "generation": self._engine_generation}
             finally:
                 self._engine_rw.release_read()
             # (the workspace and grids in `keep` are consumed by work already enqueued on this stream; the caching allocator is

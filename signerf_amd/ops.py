@@ -53,6 +53,21 @@ def field_forward(model, positions: Tensor, directions: Optional[Tensor] = None,
     return (density, rgb, geo) if return_geo else (density, rgb)
 
 
+def sample_positions(origins: Tensor, directions: Tensor, starts: Tensor, ends: Tensor) -> dict:
+    """Test instrumentation (sn_debug_sample_positions): the normalised, selector-multiplied positions q [n,3] of n explicit samples
+    (origins / directions [n,3], starts / ends [n]) through the kernels' three position maps: ``strict`` (the literal torch-path arithmetic),
+    ``exact`` (its division-free form in the main kernel behind the uniform sampler: must equal ``strict`` bit for bit) and ``fast``."""
+    lib = _lib.load()
+    o, d, t0, t1 = _f32(origins), _f32(directions), _f32(starts), _f32(ends)
+    n = o.shape[0]
+    with torch.cuda.device(o.device):
+        out = {k: torch.empty((n, 3), dtype=torch.float32, device=o.device) for k in ("strict", "exact", "fast")}
+        _lib.check(lib.sn_debug_sample_positions(_lib.ptr(o), _lib.ptr(d), _lib.ptr(t0), _lib.ptr(t1), n, _lib.ptr(out["strict"]),
+                                                 _lib.ptr(out["exact"]), _lib.ptr(out["fast"]), _lib.current_stream()),
+                   None, "sn_debug_sample_positions")
+    return out
+
+
 def composite(euclid_bins: Tensor, density: Tensor, rgb_samples: Tensor):
     """RaySamples.get_weights + RGB / median-depth / accumulation / expected-depth renderers (rows a10, a17).
 

@@ -57,6 +57,12 @@ int main(void) {
          offsetof(SnDebugLayout, handle_bytes));
   printf("%zu %zu %zu %zu\n", sizeof(SnCameraDesc), offsetof(SnCameraDesc, height), offsetof(SnCameraDesc, camera_type),
          offsetof(SnCameraDesc, distortion));
+  /* r06: the versioned structs begin with struct_size; their last fields */
+  printf("%zu %zu %zu %zu\n", offsetof(SnFieldDesc, struct_size), offsetof(SnRenderOpts, struct_size), offsetof(SnMaskOpts, struct_size),
+         offsetof(SnDebugLayout, struct_size));
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", offsetof(SnFieldDesc, main_field), offsetof(SnFieldDesc, half_grid), offsetof(SnRenderOpts, march_stats),
+         offsetof(SnRenderOpts, reuse_final_bins), sizeof(SnMaskOpts), offsetof(SnMaskOpts, manual_min), offsetof(SnMaskOpts, additional_depth_radius));
+  printf("%d\n", SN_ABI_VERSION);
   return 0;
 }
 """
@@ -76,8 +82,59 @@ int main(void) {
             _lib.SnFieldDesc.dense_levels.offset, _lib.SnFieldDesc.dense_copy_cap_mb.offset, _lib.SnDebugLayout.table_bytes.offset,
             _lib.SnDebugLayout.handle_bytes.offset,
             C.sizeof(_lib.SnCameraDesc), _lib.SnCameraDesc.height.offset, _lib.SnCameraDesc.camera_type.offset,
-            _lib.SnCameraDesc.distortion.offset]
+            _lib.SnCameraDesc.distortion.offset,
+            0, 0, 0, 0,
+            _lib.SnFieldDesc.main_field.offset, _lib.SnFieldDesc.half_grid.offset, _lib.SnRenderOpts.march_stats.offset,
+            _lib.SnRenderOpts.reuse_final_bins.offset, C.sizeof(_lib.SnMaskOpts), _lib.SnMaskOpts.manual_min.offset,
+            _lib.SnMaskOpts.additional_depth_radius.offset,
+            _lib.SN_ABI_VERSION]
     assert got == want
+    for cls in (_lib.SnFieldDesc, _lib.SnRenderOpts, _lib.SnMaskOpts, _lib.SnDebugLayout):
+        assert cls.struct_size.offset == 0 and cls().struct_size == C.sizeof(cls)   # set at construction
+
+
+def test_abi_version_and_struct_size_handshake(built_lib):
+    """include/signerf_hip.h "ABI evolution": the library states its version; a versioned struct is read up to the size its CALLER declares
+    -- never behind it -- and a size the library does not know (0 = unset, larger = a newer caller) is refused with both sizes in the text.
+    sn_create checks the descriptor before it touches a device, so all of this runs without a GPU."""
+    lib = _lib.load()
+    assert lib.sn_abi_version() == _lib.SN_ABI_VERSION == 6
+    h = C.c_void_p(None)
+
+    def create(d):
+        h.value = None
+        st = lib.sn_create(C.byref(d), C.byref(h))
+        msg = (lib.sn_last_error(None) or b"").decode()
+        if st == 0:
+            lib.sn_destroy(h)
+        return st, msg
+
+    def good():
+        from helpers import small_config
+        m = small_config().setup()
+        return m._field_desc()
+
+    d = good()
+    full = C.sizeof(_lib.SnFieldDesc)
+    assert d.struct_size == full
+    ok_status = create(d)[0]
+    assert ok_status in (0, 2)                 # created (GPU box) or "no HIP device" (here): the descriptor itself passed
+    for bad, word in ((0, "was not set"), (8, "knows sizes"), (full + 4, "newer header")):
+        d = good()
+        d.struct_size = bad
+        st, msg = create(d)
+        assert st == 1 and "struct_size" in msg and word in msg and str(full) in msg, (bad, msg)
+    # a value the library rejects, placed in a field BEHIND the size the caller declares, is never looked at ...
+    d = good()
+    d.half_grid = 0
+    d.dense_levels = 12345                      # (rounded down to a built count: harmless) ...
+    d.disable_scene_contraction = 7             # ... this one is refused when it is inside the declared size
+    st, msg = create(d)
+    assert st == 1 and "disable_scene_contraction" in msg
+    # (there is no older versioned layout than r06's, so a SHORTER legal size does not exist yet: the lower bound is the r06 size itself)
+    d.struct_size = full - 4
+    st, msg = create(d)
+    assert st == 1 and "knows sizes" in msg
 
 
 def test_error_path_without_gpu(built_lib):

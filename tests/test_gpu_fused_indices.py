@@ -12,8 +12,9 @@ uploaded hash tables:
      plain rows, or the bilinear coefficients {v00, v10 - v00, v01 - v00, (v11 - v10) - (v01 - v00)} of the coarsest levels);
   B. GIVEN the position a kernel hashed (also dumped), the rows it fetched are the oracle's rows, bit for bit -- every level, every
      corner, every sample (the "c" corner is floor + 1: it differs from the oracle's ceil only where that corner's weight is exactly 0);
-  C. the positions differ from the oracle's strict-IEEE positions by a few ulp; the voxel-boundary flips that causes are COUNTED and
-     bounded, and each one sits within 1e-3 voxel of a grid plane;
+  C. behind the UNIFORM sampler (r06) the positions ARE the oracle's strict-IEEE positions, bit for bit (sn_sample_q_exact): 0 voxel
+     flips; behind the proposal sampler they follow K2's bins and differ by a few ulp; the voxel-boundary flips that causes are COUNTED
+     and bounded, and each one sits within 0.2 voxel of a grid plane;
   D. median index and PDF searchsorted indices against the oracle's: identical, or counted ties.
 The instrumented render must equal the production render bit for bit.
 """
@@ -107,7 +108,7 @@ def _oracle_rows(q, scalings, log2_t):
     return idx, rows_f1, wx * wy * wz, q[:, None, :] * scalings.view(-1, 1)
 
 
-def _check_rows(name, rec, q_dump, q_oracle, lay, scalings, log2_t, flip_bound):
+def _check_rows(name, rec, q_dump, q_oracle, lay, scalings, log2_t, flip_bound, exact_positions=False):
     P = rec.shape[0]
     rows = _decode(rec, lay, log2_t).cpu()
     qd = q_dump.cpu()
@@ -131,6 +132,11 @@ def _check_rows(name, rec, q_dump, q_oracle, lay, scalings, log2_t, flip_bound):
           f"{n_flip} / {flipped.numel()} ({frac:.2e}), farthest from a grid plane {worst:.2e} voxel")
     assert dq <= 4e-7 * max(1.0, float(q_oracle.abs().max())) + flip_bound[2]
     assert frac <= flip_bound[0] and worst <= flip_bound[1]
+    if exact_positions:
+        # r06: behind the uniform sampler the main kernel forms its positions with sn_sample_q_exact -- the oracle's q BIT FOR BIT, hence
+        # every voxel, every blend offset and every fetched row (but the zero-weight floor + 1 corners) the oracle's
+        n_q = int((qd.contiguous().view(torch.int32) != q_oracle.contiguous().view(torch.int32)).sum())
+        assert n_q == 0 and n_flip == 0, f"{name}: {n_q} position words and {n_flip} voxels differ from the oracle's"
     return n_flip
 
 
@@ -220,7 +226,7 @@ def _run_uniform(cfg, model, sd, gpu, bundle, name):
     lay = ops.debug_layout(model, -1)
     assert int(dump["main_fetch"].min()) >= 0 and not bool(torch.isnan(dump["main_q"]).any())   # every ray-sample recorded
     _check_rows(name, dump["main_fetch"].view(H * W * S, 16, 8), dump["main_q"].view(-1, 3), dbg["q"].reshape(-1, 3), lay, sc,
-                cfg.log2_hashmap_size, flip_bound=(1e-3, 1e-3, 0.0))
+                cfg.log2_hashmap_size, flip_bound=(0.0, 0.0, 0.0), exact_positions=True)
     med = dump["median_index"].cpu().to(torch.int64)
     n_med = int((med != dbg["median_index"].view(-1)).sum())
     print(f"{name}: median-index mismatches {n_med} / {med.numel()}")

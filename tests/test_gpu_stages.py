@@ -234,3 +234,106 @@ def test_composite_nan_and_inf_inputs(gpu):
     assert float(out["weights"][:16, 5:].abs().max()) == 0.0
     assert float((out["rgb"].cpu() - onf.render_rgb(rgb_s, w)).abs().max()) <= 1e-5
     assert float((out["accumulation"].cpu() - onf.render_accumulation(w)[:, 0]).abs().max()) <= 1e-5
+
+
+# ---- r06: the main kernel's division-free position map == the literal strict one, on the hardware -------------------------------
+def _positions_case(gpu, name, o, d, t0, t1, oracle_rows=0):
+    got = ops.sample_positions(o, d, t0, t1)
+    s, e = got["strict"].view(torch.int32), got["exact"].view(torch.int32)
+    nan_s = torch.isnan(got["strict"]).any(dim=-1)
+    nan_e = torch.isnan(got["exact"]).any(dim=-1)
+    assert torch.equal(nan_s, nan_e), f"{name}: NaN samples differ"
+    ok = ~nan_s
+    bad = int((s[ok] != e[ok]).any(dim=-1).sum())
+    fast_diff = int((got["fast"].view(torch.int32)[ok] != s[ok]).any(dim=-1).sum())
+    print(f"{name}: {o.shape[0]} samples, exact != strict in {bad}; (fast != strict in {fast_diff}, max |dq| "
+          f"{float((got['fast'][ok] - got['strict'][ok]).abs().max()):.1e}); {int(nan_s.sum())} NaN samples")
+    assert bad == 0, f"{name}: sn_sample_q_exact differs from sn_sample_q in {bad} samples"
+    if oracle_rows:   # the strict kernel itself against torch's CPU arithmetic (the oracle's own functions)
+        n = min(oracle_rows, o.shape[0])
+        pos = onf.sample_positions(o[:n].cpu(), d[:n].cpu(), t0[:n].cpu().view(n, 1, 1), t1[:n].cpu().view(n, 1, 1))[:, 0]   # one sample per ray
+        q_ref, _ = onf.normalized_positions(pos)
+        keep = ~torch.isnan(q_ref).any(dim=-1)
+        assert torch.equal(got["strict"][:n].cpu()[keep].view(torch.int32), q_ref[keep].view(torch.int32)), f"{name}: strict kernel != torch CPU"
+    return bad
+
+
+def _unit(v):
+    return v / v.norm(dim=-1, keepdim=True)
+
+
+def test_exact_position_map_random(gpu):
+    g = torch.Generator(device="cpu").manual_seed(0)
+    n = 1 << 22
+    o = ((torch.rand(n, 3, generator=g) - 0.5) * 1.4).to(gpu)
+    d = _unit(torch.randn(n, 3, generator=g)).to(gpu)
+    # sample distances of the lindisp sampler between 0 and 1000: s uniform, t = s^-1(s)
+    s = torch.rand(n, generator=g)
+    t0 = torch.where(s < 0.5, 2 * s, 1 / (2 - 2 * s).clamp_min(1e-3)).to(gpu)
+    t1 = t0 * (1 + 0.05 * torch.rand(n, generator=g).to(gpu))
+    _positions_case(gpu, "lindisp samples in [0, 1000]", o, d, t0, t1, oracle_rows=1 << 20)
+    # inside the unit box (the contraction is the identity) and around its faces
+    t0s = torch.rand(n, generator=g).to(gpu) * 1.5
+    _positions_case(gpu, "around the unit box", o, d, t0s, t0s + 1e-3, oracle_rows=1 << 19)
+    # rays along an axis, origins at 0, components that are exact ties of the max
+    axis = torch.zeros(n, 3)
+    axis[torch.arange(n), torch.randint(0, 3, (n,), generator=g)] = 1.0
+    _positions_case(gpu, "axis-parallel rays", torch.zeros(n, 3, device=gpu), axis.to(gpu), t0, t1, oracle_rows=1 << 18)
+
+
+def test_exact_position_map_every_significand_of_the_contraction_norm(gpu):
+    """mag takes EVERY fp32 significand (2^23, at three exponents): o = 0, d = (1, a, b), start = 0, end = 2 mag, so p_x = mag exactly --
+    the reciprocal's two Newton steps and the all-ones substitution are exercised on the hardware's own v_rcp_f32."""
+    man = torch.arange(1 << 23, dtype=torch.int32, device=gpu)
+    for e in (0, 3, 9):
+        mag = (man | ((127 + e) << 23)).view(torch.float32)
+        n = mag.numel()
+        d = torch.stack([torch.ones(n, device=gpu), torch.full((n,), 0.37, device=gpu), torch.full((n,), -0.81, device=gpu)], dim=-1)
+        o = torch.zeros(n, 3, device=gpu)
+        t0 = torch.zeros(n, device=gpu)
+        t1 = mag * 2.0
+        _positions_case(gpu, f"every significand of |p|_inf at 2^{e}", o, d, t0, t1, oracle_rows=(1 << 20) if e == 0 else 0)
+    # the all-ones significands themselves, every exponent the sampler can reach, other coordinates random
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for e in range(0, 11):
+        n = 1 << 16
+        mag = torch.full((n,), float(np.float32(2.0 - 2.0 ** -23) * np.float32(2.0 ** e)), device=gpu)
+        d = torch.cat([torch.ones(n, 1), torch.rand(n, 2, generator=g) * 2 - 1], dim=-1).to(gpu)
+        _positions_case(gpu, f"all-ones significand at 2^{e}", torch.zeros(n, 3, device=gpu), d, torch.zeros(n, device=gpu), mag * 2.0, oracle_rows=n)
+
+
+def test_exact_position_map_quotients_near_one_and_halfway(gpu):
+    """Coordinates that nearly tie with the largest one (quotients just below a power of two: where q0 = RN(p y) can be 1.5 ulp off) and
+    quotients constructed to sit next to a rounding boundary."""
+    g = torch.Generator(device="cpu").manual_seed(2)
+    n = 1 << 22
+    mag = torch.exp(torch.rand(n, generator=g) * np.log(1500.0)).to(torch.float32)          # [1, 1500]
+    j = torch.randint(0, 64, (n,), generator=g)
+    py = (mag.view(torch.int32) - j.to(torch.int32)).view(torch.float32)                     # mag minus 0..63 ulp
+    scale = 2.0 ** -torch.randint(0, 8, (n,), generator=g).to(torch.float32)
+    pz = py * scale * torch.where(torch.rand(n, generator=g) < 0.5, -1.0, 1.0)               # ... and the same just below 2^-k
+    # p = o + (d / 2) t with o = 0, t = 2: p = d exactly
+    d = torch.stack([mag, py, pz], dim=-1).to(gpu)
+    _positions_case(gpu, "near-tie coordinates", torch.zeros(n, 3, device=gpu), d, torch.zeros(n, device=gpu), torch.full((n,), 2.0, device=gpu),
+                    oracle_rows=1 << 20)
+    # quotient targets next to a midpoint: p = RN(m (qt + (1/2 +- tiny) ulp))
+    qt = torch.rand(n, generator=g, dtype=torch.float64) * 0.98 + 0.01
+    qt32 = qt.to(torch.float32).to(torch.float64)
+    ulp = torch.tensor(np.spacing(qt32.numpy().astype(np.float32)).astype(np.float64))
+    p = (mag.to(torch.float64) * (qt32 + ulp * (0.5 + (torch.rand(n, generator=g, dtype=torch.float64) - 0.5) * 2.0 ** -20))).to(torch.float32)
+    d = torch.stack([mag, p, -p], dim=-1).to(gpu)
+    _positions_case(gpu, "quotients next to a rounding boundary", torch.zeros(n, 3, device=gpu), d, torch.zeros(n, device=gpu),
+                    torch.full((n,), 2.0, device=gpu), oracle_rows=1 << 20)
+
+
+def test_exact_position_map_non_finite(gpu):
+    """NaN / inf positions: both forms hand a NaN sample to the field (which coordinates are NaN may differ; the kernels restore the
+    all-NaN sample from any NaN coordinate, sn_main.h)."""
+    o = torch.tensor([[0.0, 0.0, 0.0], [float("nan"), 0.0, 0.0], [0.0, 0.0, 0.0], [0.1, 0.2, 0.3]], device=gpu).repeat(64, 1)
+    d = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.6, 0.8, 0.0], [0.0, 0.0, 1.0]], device=gpu).repeat(64, 1)
+    t0 = torch.tensor([1e10, 1.0, float("inf"), 3e38], device=gpu).repeat(64)
+    got = ops.sample_positions(o, d, t0, t0)
+    nan_s = torch.isnan(got["strict"]).any(dim=-1)
+    assert torch.equal(nan_s, torch.isnan(got["exact"]).any(dim=-1))
+    ok = ~nan_s
+    assert torch.equal(got["strict"][ok], got["exact"][ok])

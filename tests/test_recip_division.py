@@ -55,3 +55,37 @@ def test_all_ones_denominators_hold_too():
     assert ((den.view(np.uint32) & 0x7FFFFF) == 0x7FFFFF).all()
     num = np.random.default_rng(2).uniform(0.01, 1.0, den.size).astype(f32)
     assert int((_recip_quotient(num, den) != (num / den).astype(f32)).sum()) == 0
+
+
+# ---- r06: the reciprocal of the main kernel's exact position map (csrc/sn_device.h sn_sample_q_exact) ----------------------------------
+def test_two_newton_steps_give_the_ieee_reciprocal_for_every_significand():
+    """tools/recip_exhaustive.py, exhaustively over all 2^23 significands and every start within one ulp of RN(1 / m): two Newton steps
+    return RN(1 / m) except (possibly) for the all-ones significand, which the kernel substitutes; ONE step would not be enough."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import recip_exhaustive as rx
+
+    for d in (-1, 0, 1):
+        bad = rx.mismatches(2, d)
+        assert set(int(b) for b in bad) <= {0x7FFFFF}, (d, bad[:8])
+    assert rx.mismatches(1, 1).size > 1            # why the kernel takes two
+    for e in range(-3, 12):                        # the substitution itself
+        m = np.array([np.float32(2.0 - 2.0 ** -23) * np.float32(2.0 ** e)], dtype=f32)
+        assert (np.uint32(0x7F000000) - m.view(np.uint32)).view(f32)[0] == (f64(1.0) / m.astype(f64)).astype(f32)[0]
+
+
+def test_quotients_of_the_contraction_from_the_exact_reciprocal():
+    """p / m for the contraction's operands: m = max |coordinate| in [1, 2000], |p| <= m (quotients in [-1, 1], many of them just below 1 or
+    just below a power of two), by q0 = RN(p y), q = RN(q0 + (p - q0 m) y) with y = RN(1 / m)."""
+    rng = np.random.default_rng(3)
+    n = 2_000_000
+    m = np.exp(rng.uniform(0.0, np.log(2000.0), n)).astype(f32)
+    for k in range(3):
+        p = (m * (rng.uniform(0, 1, n) ** (1 + 2 * k))).astype(f32)
+        assert _mismatches(p, m) == 0 and _mismatches(-p, m) == 0
+    for _ in range(2):                              # within 64 ulp of the norm, and the same scaled by 2^-k
+        j = rng.integers(0, 64, n).astype(np.int32)
+        p = (m.view(np.int32) - j).view(f32) * np.ldexp(1.0, -rng.integers(0, 8, n)).astype(f32)
+        assert _mismatches(p, m) == 0
+    assert _mismatches(m.copy(), m) == 0            # the coordinate that IS the norm: exactly 1
