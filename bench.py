@@ -40,7 +40,34 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 PEAK_CLOCK_GHZ = 2.4            # MI355X_MICROARCH.md: peak engine clock (the chip sustains 1.75-1.85 GHz under these kernels: power)
 BYTES_PER_MAIN_SAMPLE = 1024.0  # 16 levels x 8 corners x 2 features x 4 B
 N_CUS, N_SIMDS = 256, 1024      # MI355X_MICROARCH.md chip-level parameters
-VALU_ISSUE_CYCLES = 4.0         # one VALU / MFMA issue slot per SIMD every 4 cycles (measured 3.86 with several waves, profiles/r02_overlap2_probe.txt)
+VALU_ISSUE_CYCLES = 4.0         # (r01-r05's flat price of a VALU / MFMA issue slot; r06: only the default of an opcode the table below does not list)
+# r06 -- what ONE wave64 instruction costs the vector issue port of a SIMD, per opcode, measured (tools/probes/valu_issue_probe.hip,
+# profiles/r06_valu_issue_probe.txt: 1-8 waves per SIMD of independent instructions of one kind, no memory, no MFMA).  Three classes:
+#   2 cycles  v_fma_f32 / v_fmac / v_mul / v_sub / v_add_f32, v_add_u32, v_xor, v_and, v_or, v_bitop3, v_mov    (2.2-2.6 measured with >= 3 waves: the
+#             guide's "v_fma_f32 (wave64) 2 cyc (SIMD-32)"; ONE wave alone issues one per 4.4-5.4 cycles, which is where r02's 3.86 came from)
+#   4 cycles  v_cvt_pkrtz_f16_f32, v_fma_mix_f32, v_pk_max_f16, v_pk_fma_f32, v_mad_u32_u24, v_mul_u32_u24, v_max_i32, v_cvt_i32_f32,
+#             v_fract_f32, v_lshlrev_b32, v_max3_f32, v_add_f64, v_cvt_f64_f32   (4.1-4.4 measured)
+#   8 cycles  v_rcp_f32, v_exp_f32, v_permlane32_swap  (8.1-8.3);   v_cndmask_b32 with a VCC mask: 19.5 (!)
+# The roof prices every class at its NOMINAL cost (2 / 4 / 8 / 20) -- the hardware's best, not the 3-wave figure -- and an MFMA's issue at 4.
+ISSUE_CYCLES = {
+    2.0: ("v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_sub_f32", "v_subrev_f32", "v_add_f32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_xor_b32", "v_and_b32",
+          "v_or_b32", "v_bitop3_b32", "v_mov_b32", "v_mov_b64", "v_accvgpr_read_b32", "v_accvgpr_write_b32"),
+    8.0: ("v_rcp_f32", "v_exp_f32", "v_log_f32", "v_rsq_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32", "v_permlane32_swap_b32", "v_permlane16_swap_b32"),
+    20.0: ("v_cndmask_b32",),
+}
+ISSUE_CYCLES_OF = {op: c for c, ops in ISSUE_CYCLES.items() for op in ops}
+
+
+def issue_port_cycles(opcodes):
+    """(vector-issue-port cycles per wave-step, {class: instructions}) of an opcode histogram (tools/kernel_counts.py `opcodes`): listed
+    opcodes at their class price, every other VALU opcode and every MFMA at 4 cycles."""
+    total, by = 0.0, {}
+    for op, n in opcodes.items():
+        c = 4.0 if op.startswith(("v_mfma", "v_smfma")) else ISSUE_CYCLES_OF.get(op, VALU_ISSUE_CYCLES)
+        total += c * n
+        k = "mfma issue (4)" if op.startswith(("v_mfma", "v_smfma")) else "%g-cycle" % c
+        by[k] = by.get(k, 0) + n
+    return total, by
 GATHER_MIN_CYCLES = 16.0        # a 64-lane gather costs the CU's L1/TA >= 16 cycles (4 lanes per clock), DESIGN.md "What the L1 charges"
 MFMA_F16_CYCLES = 32.0          # v_mfma_f32_32x32x16_f16 pipe time per SIMD
 MFMA_F32_CYCLES = 64.0          # v_mfma_f32_32x32x2_f32
@@ -57,7 +84,7 @@ ROOFLINE_LEADING_KEYS = (
     "hbm_algorithmic_ratio", "traffic_over_algorithmic", "traffic_frac_of_hbm_peak", "l2_hit_rate",
     "mfma_frac", "sustained_clock_ghz",
     "configs3_ms_per_frame", "configs4_ms_per_view", "trained_800_ms", "T21_ms",
-    "frac_at_sustained_clock", "issue_cycles_per_wave_instruction", "frames_in_flight",
+    "simd_issue_frac", "l1_gather_issue_frac", "frac_at_sustained_clock",
 )
 
 
@@ -278,6 +305,53 @@ def inrun_traffic(precision, kernel_pattern="sn_render_main_kernel", extra_args=
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def device_identity(dev):
+    """What tells two GPUs of a node apart, as short strings: name, PCI bus id, UUID, compute units (torch's device properties)."""
+    pr = torch.cuda.get_device_properties(dev)
+    bus = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+    return {"name": pr.name, "pci": bus, "uuid": str(getattr(pr, "uuid", "")), "cus": pr.multi_processor_count,
+            "arch": getattr(pr, "gcnArchName", "")}
+
+
+def preflight(world, rank, dev, backend, shared_gpu):
+    """N > 1, BEFORE the first render (the first real 8-GPU run should be boring): every rank reports who it is --
+    rank, device index, PCI bus id, UUID -- over the process group itself (the first collective of the run: if the backend cannot even do
+    this, the job fails here with a clear text and not inside the timed region), and the facts are CHECKED: the world size the backend
+    sees, one distinct device per rank (RCCL), one library version everywhere.  Returns flat fields for `config` (rank 0) -- the driver's
+    record keeps scalars."""
+    rccl = None
+    if backend == "nccl":
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001
+            rccl = "unknown (%s)" % type(e).__name__
+    me = dict(device_identity(dev), rank=rank, device_index=dev.index, pid=os.getpid(), rccl=rccl, torch=torch.__version__)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    assert [e["rank"] for e in everyone] == list(range(world)), "all_gather_object returned ranks out of order"
+    assert dist.get_world_size() == world, "the process group does not see WORLD_SIZE ranks"
+    distinct = len({(e["pci"], e["uuid"]) for e in everyone})
+    if backend == "nccl" and not shared_gpu:
+        assert distinct == world, "two ranks report the same GPU (PCI bus id / UUID): %r" % [(e["rank"], e["pci"]) for e in everyone]
+    assert len({e["rccl"] for e in everyone}) == 1 and len({e["torch"] for e in everyone}) == 1, "ranks run different RCCL / torch builds"
+    # one tiny device-side collective as well: the sum of the ranks (catches a fabric that moves objects over the host but not tensors)
+    t = torch.tensor([float(rank)], device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t)
+    assert float(t.item()) == world * (world - 1) / 2, "all_reduce of the rank numbers returned %r" % float(t.item())
+    return {"preflight": "ok", "rccl_version": me["rccl"], "distinct_devices": distinct,
+            "device_name": me["name"], "device_cus": me["cus"],
+            "devices": "; ".join("r%d %s" % (e["rank"], e["pci"]) for e in everyone)[:120]}
+
+
+def rank_spread(value, world, dev, backend):
+    """min / max / mean / arg-max over the ranks of one per-rank number (the one-launch render time: a slow die shows here)."""
+    t = torch.zeros(world, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t)
+    v = t.tolist()
+    return {"min": min(v), "max": max(v), "mean": sum(v) / len(v), "slowest_rank": max(range(world), key=lambda i: v[i]), "per_rank": v}
+
+
 def physical_cores():
     """(physical cores, logical CPUs) of the host."""
     pairs, phys, core = set(), None, None
@@ -323,7 +397,7 @@ def run_with_watchdog(fn, timeout_s, on_timeout):
 
 def cpu_quota():
     """CPUs the container may actually use: the cgroup CPU quota (v2 cpu.max, v1 cfs_quota / cfs_period), None when unlimited.  A GPU box of
-    this pool shows 256 logical CPUs and grants 16 (measured r04: host threads stop scaling there, tools/png_scaling_probe.py)."""
+    this pool shows 256 logical CPUs and grants 16 (measured r04: host threads stop scaling there, docs/history/tools/png_scaling_probe.py)."""
     try:
         with open("/sys/fs/cgroup/cpu.max") as f:
             q, per = f.read().split()[:2]
@@ -338,12 +412,13 @@ def cpu_quota():
         return None
 
 
-def cpu_baseline(main_cfg, main_sd, width, height, samples, runs=3, runs_config4=1):
+def cpu_baseline(main_cfg, main_sd, width, height, samples, runs=5, runs_config4=3):
     """The CPU oracle (kind "port": nerfstudio itself cannot be installed here) timed on the bounded samples BASELINE.md §2 names
     (SURVEY §8(d)): a centred 200x200 crop of the headline frame (config 2), config 1 in full, a centred 240x135 crop of config 4;
-    `time.perf_counter` around the render, one warm-up, MEDIAN of `runs` timed renders (the plan says 5; the default run bounds the
-    CPU leg to ~1.5 min: 3 renders of configs 2 and 1, one 45 s render of config 4 -- `--cpu-runs 5 --cpu-runs-config4 5` gives the
-    plan's figures, profiles/r03_cpu_baseline.json).  Threads = physical cores, set explicitly."""
+    `time.perf_counter` around the render, one warm-up, MEDIAN of the timed renders -- BASELINE.md's 5 for configs 2 and 1 (r06; ~8 s and
+    ~0.1 s each on the GPU box's 16 granted cores), 3 for the config-4 crop (~45 s each: five of them would put the default run past five
+    minutes; `--cpu-runs-config4 5` gives the plan's count).  The CPU leg of a default run: ~3 min.  Threads = the cores the container is
+    granted, set explicitly."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_config, small_config
     from oracle import nerfacto as onf
@@ -385,7 +460,7 @@ def cpu_baseline(main_cfg, main_sd, width, height, samples, runs=3, runs_config4
            "cgroup_cpu_quota": quota,
            "kind": "port", "host_cpu": cpu, "timer": "time.perf_counter around the render, 1 warm-up + median of the timed renders",
            "sample": f"config 2: centred {crop}x{crop} crop of the {width}x{height}x{samples} frame, median of {len(all2)} renders = {dt2:.1f} s, "
-                     "torch CPU fp32 oracle (BASELINE.md plans the median of 5: `--cpu-runs 5 --cpu-runs-config4 5`); SAMPLE_OTHERS",
+                     "torch CPU fp32 oracle (BASELINE.md section 2: 1 warm-up + median of 5); SAMPLE_OTHERS",
            "runs": len(all2), "seconds_each": all2,
            "rays_per_s": crop * crop / dt2,
            "ms_per_frame_extrapolated": dt2 * 1e3 * (width * height) / (crop * crop), "others": []}
@@ -436,8 +511,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the untimed legs of BASELINE.json configs[3] and configs[4] (`others` in the line)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 --pmc passes that fill roofline.traffic")
-    ap.add_argument("--cpu-runs", type=int, default=3, help="timed CPU-oracle renders of configs 2 and 1 (median reported; BASELINE.md §2: 5)")
-    ap.add_argument("--cpu-runs-config4", type=int, default=1, help="timed CPU-oracle renders of the 240x135 config-4 crop (~45 s each)")
+    ap.add_argument("--cpu-runs", type=int, default=5, help="timed CPU-oracle renders of configs 2 and 1 (median reported; BASELINE.md §2: 5)")
+    ap.add_argument("--cpu-runs-config4", type=int, default=3, help="timed CPU-oracle renders of the 240x135 config-4 crop (~45 s each; BASELINE.md §2 plans 5)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default, the driver's command): every rank renders ONE camera per step.  strong: a step is the whole "
                          "8-camera reference sheet of BASELINE.json configs[2] (datasetgenerator.py:517-519), camera i -> rank i mod N, "
@@ -627,6 +702,7 @@ def main():
 
     model._ensure_engine()  # library load, weight upload and de-hashed copies are set-up, not a step (matters only for --warmup 0)
     torch.cuda.synchronize()
+    pre = preflight(world, rank, dev, args.backend, shared_gpu) if world > 1 else {"preflight": "n/a (one rank)", "device_name": device_identity(dev)["name"]}
     step_fn = sheet_step if strong else step
     if args.warmup < args.frames_in_flight:
         # every render stream allocates its output / workspace blocks on first use (hipMalloc): one priming frame per stream is set-up
@@ -677,6 +753,29 @@ def main():
     kernel_ms = sum(per_step) / max(len(per_step), 1)
     gather_ms = gather_err = None
     gather_by_strategy = {}
+    spread = tiles_check = None
+    if world > 1:
+        # (every rank; after the timed region) the ranks' own one-launch times, and the exchange checked for CONTENT: one more gather of
+        # "camera r from rank r", each tile compared bit for bit with this rank's own render of that camera -- the kernels are
+        # deterministic, so a tile that differs was damaged on the way (or a peer's GPU computes differently)
+        def post_checks():
+            sp = rank_spread(statistics.median(per_step), world, dev, args.backend)
+            o_ = model.get_outputs_for_camera_ray_bundle(cam.generate_rays(camera_indices=0, aabb_box=model.render_aabb))
+            mine_tile = torch.cat([o_["rgb"], o_["depth"]], dim=-1)[None]
+            got = sheet.gather_tiles_async(mine_tile, world, dst=None, strategy="all_gather").wait()
+            bad = 0
+            for r in range(world):
+                o_ = model.get_outputs_for_camera_ray_bundle(cams[r % 8].generate_rays(camera_indices=0, aabb_box=model.render_aabb))
+                want = torch.cat([o_["rgb"], o_["depth"]], dim=-1)
+                bad += 0 if torch.equal(got[r].to(want.device), want) else 1
+            t = torch.tensor([float(bad)], device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t)
+            return sp, {"tiles_checked_per_rank": world, "mismatching_tiles_all_ranks": int(t.item())}
+
+        try:
+            spread, tiles_check = run_with_watchdog(post_checks, args.diagnostics_timeout + 120.0, lambda: os._exit(3))
+        except Exception as e:  # noqa: BLE001  (diagnostics must not cost the line)
+            spread, tiles_check = None, {"error": repr(e)[:120]}
 
     def gather_diagnostics(line=None):
         """The exposed cost of the tile gather, per strategy: diagnostic legs AFTER the timed region.  They must never cost the line -- an
@@ -736,7 +835,14 @@ def main():
                        "dist_world_size": dist.get_world_size() if world > 1 else 1,
                        "dist_backend": dist.get_backend() if world > 1 else None,
                        "cuda_device_count": n_dev, "gather": (args.gather if world > 1 else None),
-                       "gather_strategy": (args.gather_strategy if world > 1 else None)},
+                       "gather_strategy": (args.gather_strategy if world > 1 else None),
+                       # r06 preflight / post-run checks (flat: the driver's record keeps scalars)
+                       **pre,
+                       "rank_kernel_ms_min": spread["min"] if spread else None, "rank_kernel_ms_max": spread["max"] if spread else None,
+                       "rank_kernel_ms_mean": spread["mean"] if spread else None, "slowest_rank": spread["slowest_rank"] if spread else None,
+                       "gathered_tiles_bit_identical": (None if not tiles_check else
+                                                        (tiles_check.get("mismatching_tiles_all_ranks") == 0 if "error" not in tiles_check else tiles_check["error"]))},
+            "rank_kernel_ms": spread, "gathered_tiles_check": tiles_check,
             "ms_per_frame": elapsed / args.steps * 1e3 / (len(mine) if strong else 1) if (not strong or mine) else None,
             "ms_per_sheet": (elapsed / args.steps * 1e3) if strong else None,
             "gather_ms": None,   # (world > 1: filled in below, after the line's own measurements)
@@ -802,9 +908,12 @@ def main():
                 t_kernel = k_med * 1e-3
                 mfma_cyc = MFMA_F32_CYCLES if args.precision == "fp32" else MFMA_F16_CYCLES
                 n_gather = cnt.get("gather", cnt["vmem_load"])
+                port_cycles, port_classes = issue_port_cycles(cnt.get("opcodes") or {"v_unknown": cnt["valu"], "v_mfma": cnt["mfma"]})
                 roofs = {
-                    "simd-issue": {"per_wave_step": cnt["valu"] + cnt["mfma"], "cycles_each": VALU_ISSUE_CYCLES, "units": N_SIMDS,
-                                   "what": "VALU + MFMA instructions through the one vector issue port of a SIMD"},
+                    "simd-issue": {"per_wave_step": cnt["valu"] + cnt["mfma"], "cycles_each": port_cycles / (cnt["valu"] + cnt["mfma"]), "units": N_SIMDS,
+                                   "port_cycles_per_wave_step": port_cycles, "instructions_by_class": port_classes,
+                                   "what": "VALU + MFMA instructions through the one vector issue port of a SIMD, each opcode at its measured class price "
+                                           "(2 / 4 / 8 / 20 cycles per wave64 instruction; profiles/r06_valu_issue_probe.txt); cycles_each = the mix's mean"},
                     "l1-gather-issue": {"per_wave_step": n_gather, "cycles_each": GATHER_MIN_CYCLES, "units": N_CUS,
                                         "what": "64-lane buffer_load gathers through the CU's texture-address / L1 path"},
                     "matrix-pipe": {"per_wave_step": cnt["mfma"], "cycles_each": mfma_cyc, "units": N_SIMDS,
@@ -822,20 +931,24 @@ def main():
                 bound = max(roofs, key=lambda k: roofs[k]["frac"])   # (the ranking is the same at either clock)
                 # Empirical issue model (NOT a roof): in the probes an f16 32x32x16 MFMA keeps the SIMD's vector issue port for ~12-17 cycles
                 # (its 24 source + 16 destination registers), not for one 4-cycle slot -- profiles/r02_overlap2_probe.txt, r02_mlp_probe.txt
-                model_cycles = cnt["valu"] * VALU_ISSUE_CYCLES + cnt["mfma"] * (MFMA_PORT_CYCLES if args.precision != "fp32" else MFMA_F32_CYCLES)
+                model_cycles = (port_cycles - 4.0 * cnt["mfma"]) + cnt["mfma"] * (MFMA_PORT_CYCLES if args.precision != "fp32" else MFMA_F32_CYCLES)
                 model_ms = model_cycles * wave_steps / (N_SIMDS * clock * 1e9) * 1e3
                 line["roofline"] = {
-                    "bound": bound, "achieved": roofs[bound]["achieved"], "peak": roofs[bound]["peak"], "unit": "G wave-instructions/s",
+                    "bound": bound, "achieved": roofs[bound]["achieved"], "peak": roofs[bound]["peak"],
+                    "unit": "G wave-gathers/s" if bound == "l1-gather-issue" else "G wave-instructions/s",
                     "frac": roofs[bound]["frac"], "traffic": traffic_now, "traffic_source": traffic_source,
                     "frac_at_sustained_clock": roofs[bound]["frac_at_sustained_clock"], "peak_at_sustained_clock": roofs[bound]["peak_at_sustained_clock"],
-                    "issue_cycles_per_wave_instruction": roofs[bound]["cycles_each"], "peak_clock_ghz": PEAK_CLOCK_GHZ,
+                    "issue_cycles_per_wave_instruction": roofs["simd-issue"]["cycles_each"], "peak_clock_ghz": PEAK_CLOCK_GHZ,
                     "kernel": cnt["kernel"], "kernel_ms": k_med, "sustained_clock_ghz": clock,
                     "instructions_per_wave_step": {k: cnt[k] for k in ("valu", "mfma", "vmem_load", "lds", "packed_f32") if k in cnt} | {"gather": n_gather},
                     "roofs": roofs,
                     "empirical_issue_model": {"ms": model_ms, "frac": model_ms / k_med, "priced_at": "sustained clock",
-                                              "what": "VALU x 4 cycles + MFMA x %g cycles of vector-issue-port time per wave-step at the sustained clock "
+                                              "what": "VALU at their class prices + MFMA x %g cycles of vector-issue-port time per wave-step at the sustained clock "
                                                       "(measured port cost of an MFMA; the f32-input MFMA holds the port for its whole 64 cycles)"
                                                       % (MFMA_PORT_CYCLES if args.precision != "fp32" else MFMA_F32_CYCLES)},
+                    "simd_issue_frac": roofs["simd-issue"]["frac"], "l1_gather_issue_frac": roofs["l1-gather-issue"]["frac"], "matrix_pipe_frac": roofs["matrix-pipe"]["frac"],
+                    "repriced_r06": "r01-r05 priced every VALU at 4 cycles (simd-issue 0.58); the probe shows 2 / 4 / 8-cycle classes: simd-issue is "
+                                    "lower, the L1 gather path (16 cycles per 64-lane gather per CU) is the largest fraction",
                     "note": "bound = the hardware resource with the largest busy fraction.  `frac` prices it at the PART's 2.4 GHz peak clock, "
                             "`frac_at_sustained_clock` at the clock the chip sustains under this kernel (measured in this run; package power limit): the "
                             "difference between the two is power, not scheduling.  The matrix pipe hides plain VALU issued beside it only in part "
@@ -872,12 +985,15 @@ def main():
                 clock = sustained_clock_ghz(6)
                 tiles = ((W + 7) // 8) * ((H + 7) // 8)
                 slots = sum(n * (c["valu"] + c["mfma"]) for n, c in zip(steps_k2, k2)) + S * (k1["valu"] + k1["mfma"])
+                # (K2's loops: no per-opcode histogram from mfma_loops -- priced at K1's mean cycles per instruction, the same opcode families)
+                k1_cycles, _ = issue_port_cycles(k1.get("opcodes") or {"v_unknown": k1["valu"], "v_mfma": k1["mfma"]})
+                mean_cycles = k1_cycles / (k1["valu"] + k1["mfma"])
                 achieved = slots * tiles / (k_med * 1e-3) / 1e9
-                peak = N_SIMDS * PEAK_CLOCK_GHZ / VALU_ISSUE_CYCLES
+                peak = N_SIMDS * PEAK_CLOCK_GHZ / mean_cycles
                 line["roofline"] = {
                     "bound": "simd-issue", "achieved": achieved, "peak": peak, "unit": "G wave-instructions/s", "frac": achieved / peak,
-                    "frac_at_sustained_clock": achieved / (N_SIMDS * clock / VALU_ISSUE_CYCLES),
-                    "issue_cycles_per_wave_instruction": VALU_ISSUE_CYCLES, "peak_clock_ghz": PEAK_CLOCK_GHZ,
+                    "frac_at_sustained_clock": achieved / (N_SIMDS * clock / mean_cycles),
+                    "issue_cycles_per_wave_instruction": mean_cycles, "peak_clock_ghz": PEAK_CLOCK_GHZ,
                     "traffic": None, "traffic_source": "not measured for this workload", "kernel": "sn_proposal_kernel<0,5,4> + sn_render_main_kernel<1,*> (whole render call)", "kernel_ms": k_med,
                     "sustained_clock_ghz": clock,
                     "instructions_per_wave_step": {"K2 net %d (%d steps)" % (i, n): {k: c.get(k, 0) for k in ("valu", "mfma", "gather")}

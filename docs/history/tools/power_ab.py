@@ -22,7 +22,7 @@ import sys
 import threading
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # docs/history/tools/ -> repository root
 sys.path.insert(0, ROOT)
 
 # name -> (extra compile flags | None = product library, environment, precision)

@@ -12,7 +12,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # docs/history/tools/ -> repository root
 sys.path.insert(0, ROOT)
 from signerf_amd import Cameras, scene, sheet  # noqa: E402
 

@@ -73,8 +73,10 @@ extern "C" {
  *     fills in -- begins with `uint32_t struct_size` = sizeof(that struct) IN THE CALLER'S HEADER.  The library reads (writes, for
  *     SnDebugLayout) exactly that many bytes: fields the caller's header does not know take their zero defaults (every appended field is
  *     defined so that zero means "as before"), pointers among them stay NULL -- the library never reads or writes through memory
- *     behind the caller's struct.  A struct_size below the first versioned layout (0: never set) or above the library's own sizeof
- *     (a caller newer than the library) is refused with SN_ERR_INVALID and a text that names both sizes.
+ *     behind the caller's struct.  A struct_size below the smallest layout the library accepts (0: never set) or above the library's own
+ *     sizeof (a caller newer than the library) is refused with SN_ERR_INVALID and a text that names the accepted range.  (Accepted today:
+ *     from the layout without the r04 / r05 appendices -- SnFieldDesc up to `aabb`, SnRenderOpts up to `spacing_mode`, SnDebugLayout up to
+ *     `feature_scale` -- to the full r06 layout.)
  *   SnHashMlpDesc (embedded), SnCameraDesc and SnDebugDump are frozen at their r06 layout; changing them bumps SN_ABI_VERSION. */
 #define SN_ABI_VERSION 6
 int sn_abi_version(void);

@@ -223,11 +223,14 @@ int adopt_struct(SnHandle h, const T* in, size_t min_size, T& out, const char* w
     out.struct_size = (uint32_t)sizeof(T);
     return SN_OK;
 }
-// sizes of the versioned structs in the first versioned header (r06): every field up to and including the last one r05 had
-constexpr size_t kFieldDescMin = offsetof(SnFieldDesc, half_grid) + sizeof(int32_t);
-constexpr size_t kRenderOptsMin = offsetof(SnRenderOpts, reuse_final_bins) + sizeof(int32_t);
+// Smallest struct_size accepted.  r06's header is the first versioned one, so no binding with a shorter struct exists yet; the lower bounds
+// are nevertheless set where the r04 / r05 appendices begin, so that the short-struct path -- the one a future appendix will rely on -- is a
+// path the tests execute today (tests/test_cabi.py, tests/test_gpu_abi.py: a caller that declares the shorter size and has garbage, a wild
+// pointer included, in the memory behind it).
+constexpr size_t kFieldDescMin = offsetof(SnFieldDesc, dense_levels);      // ... up to the r03 fields (disable_scene_contraction, aabb)
+constexpr size_t kRenderOptsMin = offsetof(SnRenderOpts, march_stats);     // ... up to the r03 fields (background, spacing_mode)
 constexpr size_t kMaskOptsMin = offsetof(SnMaskOpts, additional_depth_radius) + sizeof(float);
-constexpr size_t kDebugLayoutMin = offsetof(SnDebugLayout, half_grid_bytes) + sizeof(uint64_t);
+constexpr size_t kDebugLayoutMin = offsetof(SnDebugLayout, table_bytes);   // ... up to feature_scale
 
 // SnRenderOpts.reuse_final_bins: what the final bins in a workspace belong to, kept on the HOST per workspace address (the library
 // cannot read a workspace back without a device sync).  sn_render_rays stamps the workspace it wrote bins into; every other entry point

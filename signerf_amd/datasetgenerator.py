@@ -423,10 +423,21 @@ class DatasetGenerator:
 
         sync = self._sync_group(world)   # created while every rank is here: the serial stage below may take hours
         # From here on EVERY exit path of EVERY rank goes through `_finish`: the idle ranks wait there with a 24 h timeout, so a
-        # rank 0 that raised in init_directory() or in stage 1 -- before the old try block began -- would have parked them.
+        # rank 0 that raised in init_directory() or in stage 1 -- before the old try block began -- would have parked them.  (r06: and a
+        # rank 0 that fails before stage 1 tells the others BEFORE they enter that stage's collectives, see init_error below.)
         try:
+            # rank 0 prepares the output directory BEFORE the expensive stage (a missing dependency or an unwritable path fails now).  With
+            # the pre-compute stage ahead, a failure here must not leave the other ranks alone in that stage's collectives (they would sit in
+            # the budget all-reduce and the gathers until the RCCL / gloo timeout): the error is held, every rank learns of it
+            # through the budget reduce below (-1), nobody enters stage 1, rank 0 re-raises and all meet in `_finish`.
+            init_error = None
             if rank == 0:
-                self.init_directory()        # before the expensive stage: a missing dependency or an unwritable path fails now
+                try:
+                    self.init_directory()
+                except BaseException as e:   # noqa: BLE001  (re-raised below, after the ranks have agreed)
+                    if not (self.precompute and world > 1):
+                        raise
+                    init_error = e
 
             # Stage 1 (every rank): all NeRF renders, one gather per image size (an original dataset may hold several).  Views beyond the
             # memory budget are rendered inside the serial loop instead (rank 0 alone): correct, just not sharded.
@@ -441,7 +452,11 @@ class DatasetGenerator:
                     groups.setdefault((int(c._host[0, 16]), int(c._host[0, 17])), []).append(c)
                 # the number of views per gather must be the SAME on every rank or the per-group collectives desynchronise: the ranks
                 # agree on the smallest budget (total_memory // 4 per device: equal on a homogeneous node, not assumed)
-                budget = self._agreed_budget_bytes(world)
+                budget = self._agreed_budget_bytes(world, failed=init_error is not None)
+                if budget < 0:
+                    if init_error is not None:
+                        raise init_error
+                    raise RuntimeError("generate_dataset: rank 0 could not prepare the dataset directory; nothing was rendered on this rank")
                 for (w, h), cams in groups.items():
                     per_view = 3 * 5 * 4 * w * h   # the [n,H,W,5] fp32 tiles + the gather buffer + the reorder copy at their peak
                     fit = int(min(len(cams), budget // per_view))
@@ -536,9 +551,10 @@ class DatasetGenerator:
         return dist.new_group(ranks=ranks, backend="gloo", timeout=_dt.timedelta(seconds=float(self.serial_stage_timeout_s)),
                               use_local_synchronization=self.group is not None)
 
-    def _agreed_budget_bytes(self, world: int) -> int:
-        """``_precompute_budget_bytes`` reduced to the minimum over the ranks (one tiny collective per dataset)."""
-        budget = self._precompute_budget_bytes()
+    def _agreed_budget_bytes(self, world: int, failed: bool = False) -> int:
+        """``_precompute_budget_bytes`` reduced to the minimum over the ranks (one tiny collective per dataset).  ``failed``: this rank
+        cannot go on (rank 0's ``init_directory`` raised) -- it contributes -1, so that EVERY rank sees a negative budget and skips stage 1."""
+        budget = -1 if failed else self._precompute_budget_bytes()
         if world > 1:
             import torch.distributed as dist
 

@@ -45,7 +45,7 @@ def test_roofline_leads_with_flat_scalars_in_the_order_the_driver_keeps():
     must survive -- one-launch and exact-fp32 times, the HBM line as a RATIO, measured traffic, cache hit rate, the other configurations --
     are the first keys, flat, whatever order the run computed them in."""
     rf = {"note": "x" * 300, "roofs": {"simd-issue": {}}, "bound": "simd-issue", "achieved": 357.8, "peak": 614.4, "unit": "G wave-instructions/s", "frac": 0.58,
-          "traffic": 5.4e9, "kernel_ms": 2.78, "sustained_clock_ghz": 1.75, "frac_at_sustained_clock": 0.79, "issue_cycles_per_wave_instruction": 4.0,
+          "traffic": 5.4e9, "kernel_ms": 2.78, "sustained_clock_ghz": 1.75, "frac_at_sustained_clock": 0.79, "issue_cycles_per_wave_instruction": 3.2, "simd_issue_frac": 0.46, "l1_gather_issue_frac": 0.5,
           "one_launch_ray_samples_per_s": 14.7e9, "frames_in_flight": 2, "l2_hit_rate": 0.62, "other_configs": {"configs3": {}}}
     line = {"dtype": "fp16x2-split multiply ...", "roofline": rf,
             "alt_precision": {"precision": "fp32", "kernel_ms": 7.0, "ray_samples_per_s_per_gpu": 5.85e9},
@@ -76,3 +76,11 @@ def test_roofline_leads_with_flat_scalars_in_the_order_the_driver_keeps():
     # an exact-fp32 run is its own fp32 figure; missing legs give None, not a KeyError
     out32 = bench.flat_roofline({"kernel_ms": 7.0, "one_launch_ray_samples_per_s": 5.85e9}, {"dtype": "f32 (exact fp32 MFMA)"})
     assert out32["exact_fp32_ms"] == 7.0 and out32["exact_fp32_ray_samples_per_s"] == 5.85e9 and out32["configs3_ms_per_frame"] is None
+
+
+def test_issue_port_pricing_by_opcode_class():
+    """r06: the vector issue port's price of a wave64 instruction by opcode class (profiles/r06_valu_issue_probe.txt): 2 cycles for the plain
+    fp32 / integer ALU ops, 8 for transcendentals and the half-wave swap, 20 for a VCC-masked select, 4 for everything else and an MFMA's issue."""
+    cyc, by = bench.issue_port_cycles({"v_fmac_f32": 10, "v_cvt_pkrtz_f16_f32": 5, "v_exp_f32": 2, "v_cndmask_b32": 1, "v_mfma_f32_32x32x16_f16": 3, "v_never_heard_of": 1})
+    assert cyc == 10 * 2 + 5 * 4 + 2 * 8 + 20 + 3 * 4 + 4
+    assert by == {"2-cycle": 10, "4-cycle": 6, "8-cycle": 2, "20-cycle": 1, "mfma issue (4)": 3}

@@ -124,17 +124,20 @@ def test_abi_version_and_struct_size_handshake(built_lib):
         d.struct_size = bad
         st, msg = create(d)
         assert st == 1 and "struct_size" in msg and word in msg and str(full) in msg, (bad, msg)
-    # a value the library rejects, placed in a field BEHIND the size the caller declares, is never looked at ...
+    # A caller compiled against a SHORTER layout (the struct without the r04 / r05 appendices: dense_levels, dense_copy_cap_mb, half_grid):
+    # what sits in the memory behind the size it declares is never looked at.  Shown with a field the library validates: inside the
+    # declared size a bad value is refused, behind it the same bytes are ignored (and take their zero default).
+    short = _lib.SnFieldDesc.dense_levels.offset
     d = good()
-    d.half_grid = 0
-    d.dense_levels = 12345                      # (rounded down to a built count: harmless) ...
-    d.disable_scene_contraction = 7             # ... this one is refused when it is inside the declared size
+    d.disable_scene_contraction = 7             # inside every accepted size: refused
+    assert create(d)[0] == 1 and "disable_scene_contraction" in create(d)[1]
+    d = good()
+    d.struct_size = short
+    d.dense_levels, d.dense_copy_cap_mb, d.half_grid = -7, -7, 1234567     # behind the declared size: garbage, never read
+    assert create(d)[0] == ok_status
+    d.struct_size = short - 4                   # below the smallest accepted layout
     st, msg = create(d)
-    assert st == 1 and "disable_scene_contraction" in msg
-    # (there is no older versioned layout than r06's, so a SHORTER legal size does not exist yet: the lower bound is the r06 size itself)
-    d.struct_size = full - 4
-    st, msg = create(d)
-    assert st == 1 and "knows sizes" in msg
+    assert st == 1 and "knows sizes" in msg and str(short) in msg
 
 
 def test_error_path_without_gpu(built_lib):

@@ -376,9 +376,11 @@ def _worker(rank, world, port, out_dir, mode="synthetic"):
         json.dump({"raised": raised, "seconds": time.perf_counter() - t0}, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
         dist.destroy_process_group()
         return
-    elif mode == "init_raises":   # rank 0 fails BEFORE the serial stage (an unwritable path); nothing is pre-computed, so the
-        # other ranks go straight to the closing barrier and must be met there
-        gen = me._generator(out_dir, "sharded", precompute=False, serial_stage_timeout_s=600.0)
+    elif mode in ("init_raises", "init_raises_precompute"):
+        # rank 0 fails BEFORE the serial stage (an unwritable path).  Nothing pre-computed: the other ranks go straight to the
+        # closing barrier and must be met there.  ADVICE r05, pre-compute ON (the default): the other ranks must not be left alone in the
+        # stage-1 collectives either -- they learn of the failure through the budget reduce and raise a RuntimeError of their own.
+        gen = me._generator(out_dir, "sharded", precompute=(mode == "init_raises_precompute"), serial_stage_timeout_s=600.0)
         if rank == 0:
             def broken_init():
                 raise PermissionError("cannot create the dataset directory")
@@ -389,7 +391,9 @@ def _worker(rank, world, port, out_dir, mode="synthetic"):
             gen.generate_dataset(me._Graph(), ref, synthetic_camera_to_worlds=syn)
         except PermissionError as e:
             raised = str(e)
-        json.dump({"raised": raised, "seconds": time.perf_counter() - t0}, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
+        except RuntimeError as e:
+            raised = "RuntimeError: " + str(e)
+        json.dump({"raised": raised, "seconds": time.perf_counter() - t0, "rendered": me.RENDERED}, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
         dist.destroy_process_group()
         return
     else:
@@ -455,3 +459,16 @@ def test_rank0_failure_before_the_serial_stage_releases_the_idle_ranks(tmp_path,
     r0, r1 = (json.load(open(tmp_path / f"rank{r}.json")) for r in range(2))
     assert r0["raised"] == "cannot create the dataset directory" and r1["raised"] is None
     assert r0["seconds"] < 60.0 and r1["seconds"] < 60.0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank0_failure_before_the_precompute_stage_keeps_every_rank_out_of_its_collectives(tmp_path, standins, world):
+    """the default (pre-compute ON).  `init_directory` raises on rank 0; the other ranks are about to enter the stage-1
+    collectives (the budget all-reduce, then the gathers) and would wait there for rank 0 until the collective timeout.  The failure now
+    travels through the budget reduce: nobody renders, rank 0 re-raises its own error, the others raise a RuntimeError, all within seconds."""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "init_raises_precompute"), nprocs=world, join=True)
+    rs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+    assert rs[0]["raised"] == "cannot create the dataset directory"
+    for r in rs[1:]:
+        assert r["raised"].startswith("RuntimeError: generate_dataset: rank 0 could not prepare")
+    assert all(r["seconds"] < 60.0 and not r["rendered"] for r in rs)

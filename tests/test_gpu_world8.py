@@ -1,4 +1,4 @@
-"""World-8 rehearsal on ONE GPU: BASELINE.json configs[2] (3x3 sheet: 8 cameras on 8 MI355X, RCCL tile all-gather) and
+"""World-2 / -4 / -8 rehearsal on ONE GPU (r06: the four launch shapes of the driver's 1 / 2 / 4 / 8 curve have all executed): BASELINE.json configs[2] (3x3 sheet: 8 cameras on 8 MI355X, RCCL tile all-gather) and
 the 8-GPU leg of configs[4] (DatasetGenerator's 8 + 50 views, /root/reference/signerf/datasetgenerator/datasetgenerator.py:331,517-519) at
 the RANK COUNT they name.  The GPU box has one GPU, so the eight ranks share cuda:0 and the process group is gloo (tiles staged through
 the host; RCCL refuses several ranks per device): ownership (camera i -> rank i mod 8, `per = 1`), the ragged 58 = 7 x 8 + 2 split, every
@@ -78,16 +78,19 @@ def _sheet_worker(rank, world, port, out_dir):
     open(os.path.join(out_dir, f"rank{rank}.done"), "w").write("ok")
 
 
-def test_world8_reference_sheet_every_strategy(gpu, tmp_path):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_world8_reference_sheet_every_strategy(gpu, tmp_path, world):
+    """The 8-camera sheet over 2, 4 and 8 ranks (4, 2, 1 cameras per rank): the launch shapes of the driver's scaling curve."""
     from signerf_amd import sheet
 
-    mp.spawn(_sheet_worker, args=(WORLD, _free_port(), str(tmp_path)), nprocs=WORLD, join=True)
-    got = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(WORLD)]
+    mp.spawn(_sheet_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
     single = got[0]["local"]
     assert single.shape == (8, SIZE, SIZE, 4) and float(single[..., :3].std()) > 0.05
-    for r in range(WORLD):
+    for r in range(world):
         assert os.path.exists(os.path.join(tmp_path, f"rank{r}.done")), f"rank {r} did not exit cleanly"
-        assert got[r]["owned"] == [r] and got[r]["n_renders"] == 2 * len(sheet.GATHER_STRATEGIES)   # per = 1: camera r, once per exchange
+        # camera i -> rank i mod world, each once per exchange
+        assert got[r]["owned"] == list(range(r, 8, world)) and got[r]["n_renders"] == (8 // world) * 2 * len(sheet.GATHER_STRATEGIES)
         assert torch.equal(got[r]["local"], single)
         for strategy in sheet.GATHER_STRATEGIES:
             assert torch.equal(got[r][f"{strategy}/None"], single), f"rank {r}: {strategy} all-gather differs from the single-process sheet"
@@ -141,7 +144,7 @@ def _tree(root):
     return out
 
 
-@pytest.mark.parametrize("strategy", ["all_gather", "p2p", "all_to_all"])
+@pytest.mark.parametrize("strategy", ["all_gather", "p2p", pytest.param("all_to_all", marks=pytest.mark.slow)])
 def test_world8_generate_dataset_58_views(gpu, tmp_path, strategy):
     """8 + 50 cameras over 8 ranks (58 = 7 x 8 + 2: ranks 0 and 1 own eight views, the others seven), tiles gathered to rank 0, which alone
     runs the serial diffusion sequence and writes the files: byte-identical to the single-process dataset, every rank exits."""
@@ -157,18 +160,27 @@ def test_world8_generate_dataset_58_views(gpu, tmp_path, strategy):
 
 
 # ---- bench.py at the driver's N = 8 command line (gloo, ranks share the GPU) ------------------------------------------------------------------
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_world8_dry_run(gpu, scaling):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+@pytest.mark.parametrize("world,scaling", [(8, "weak"), (8, "strong"), (4, "weak"), (2, "weak"), (2, "strong")])
+def test_bench_world8_dry_run(gpu, world, scaling):
+    """bench.py at the driver's N = 2 / 4 / 8 command lines (gloo, the ranks share the GPU): the line, the r06 preflight (every rank
+    identified over the process group before the first render) and the post-run checks (per-rank one-launch times, the gathered tiles bit
+    for bit against local renders)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
            "--backend", "gloo", "--width", "96", "--height", "96", "--no-cpu-baseline", "--no-alt-precision", "--scaling", scaling]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 8 and d["scaling"] == scaling and d["config"]["dist_world_size"] == 8 and d["config"]["ranks_share_a_gpu"] is True
-    assert d["config"]["cameras_per_step"] == 8
-    assert abs(d["value"] - 8 * 96 * 96 * 64 * 3 / d["timed_region_s"]) / d["value"] < 1e-6
+    assert d["n_gpus"] == world and d["scaling"] == scaling and d["config"]["dist_world_size"] == world and d["config"]["ranks_share_a_gpu"] is True
+    cams_per_step = 8 if scaling == "strong" else world
+    assert d["config"]["cameras_per_step"] == cams_per_step
+    assert abs(d["value"] - cams_per_step * 96 * 96 * 64 * 3 / d["timed_region_s"]) / d["value"] < 1e-6
+    c = d["config"]
+    assert c["preflight"] == "ok" and c["distinct_devices"] == 1 and c["devices"].count("r") >= world     # (one shared GPU here; RCCL asserts N distinct)
+    assert c["gathered_tiles_bit_identical"] is True and d["gathered_tiles_check"]["tiles_checked_per_rank"] == world
+    assert 0 < c["rank_kernel_ms_min"] <= c["rank_kernel_ms_mean"] <= c["rank_kernel_ms_max"] and 0 <= c["slowest_rank"] < world
+    assert len(d["rank_kernel_ms"]["per_rank"]) == world and all(v > 0 for v in d["rank_kernel_ms"]["per_rank"])
     assert set(d["gather_ms"]["exposed_by_strategy"]) == {"all_gather", "p2p", "all_to_all"}
     assert all(v is not None and v > 0 for v in d["gather_ms"]["exposed_by_strategy"].values())

@@ -165,10 +165,14 @@ def loop_counts(kernel_substr: str, lib: str = LIB) -> dict:
         best = max(spans, key=lambda sp: sp[1] - sp[0])
     out = {"kernel": names[0], "loop_bytes": best[1] - best[0]}
     vmcnt = []
+    opcodes = {}
     for addr, op, ln in insts:
         if best[0] <= addr <= best[1]:
             c = classify(op)
             out[c] = out.get(c, 0) + 1
+            if c in ("valu", "mfma"):   # per-opcode histogram of what goes through the vector issue port (encoding suffixes dropped)
+                base_op = re.sub(r"_(e32|e64|dpp|sdwa)$", "", op)
+                opcodes[base_op] = opcodes.get(base_op, 0) + 1
             m = re.search(r"vmcnt\((\d+)\)", ln) if op == "s_waitcnt" else None
             if m:
                 vmcnt.append(int(m.group(1)))
@@ -181,11 +185,18 @@ def loop_counts(kernel_substr: str, lib: str = LIB) -> dict:
     # how deep the loop lets its vector loads run ahead: the largest N of an `s_waitcnt vmcnt(N)` = loads still in flight when the first
     # result is consumed, and the mean over all such waits.  r05: one global atomic in a rarely taken branch of K1's loop made hipcc
     # schedule the hash phase load -> wait -> blend level by level (max 4 instead of 20 in flight): identical instruction counts, +10 % time
+    out["opcodes"] = dict(sorted(opcodes.items(), key=lambda kv: -kv[1]))
     out["vmcnt_max"] = max(vmcnt) if vmcnt else 0
     out["vmcnt_mean"] = sum(vmcnt) / len(vmcnt) if vmcnt else 0.0
     return out
 
 
 if __name__ == "__main__":
-    pat = sys.argv[1] if len(sys.argv) > 1 else "sn_render_main_kernelILi0ELi1ELi0ELi11ELb0E"
-    print(loop_counts(pat))
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    pat = args[0] if args else "sn_render_main_kernelILi0ELi1ELi0ELi11ELb0E"
+    res = loop_counts(pat)
+    ops = res.pop("opcodes")
+    print(res)
+    if "--opcodes" in sys.argv:
+        for k, v in ops.items():
+            print(f"{v:5d} {k}")

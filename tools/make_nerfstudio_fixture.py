@@ -25,7 +25,8 @@ THE FIVE-MINUTE RECIPE (any machine with network access; CPU is enough for every
 --all = the torch-fallback fixture + the OpenCV fixture + (when CUDA and tinycudann import) the tiny-cuda-nn fixture; --self-check then runs
 tests/test_oracle_vs_nerfstudio_fixture.py on the spot and prints which of the oracle's unpinned statements the data confirmed or refuted.
 Expected sizes: nerfstudio_nerfacto_torch.npz ~1.3 MB (the 0.9 MB of small-config parameters + 3 renders of 40 x 32 + 11 ray bundles of
-56 x 40), opencv_morphology.npz ~25 KB, nerfstudio_nerfacto_tcnn.npz ~1 MB.  Runtime: under a minute on a laptop CPU.
+56 x 40 + the `facts.*` entries: the real module's state-dict keys / buffers and SHEncoding / HashEncoding evaluated in isolation, which
+decide SURVEY Appendix A's "M / L" recollections A7 and A13 by data), opencv_morphology.npz ~25 KB, nerfstudio_nerfacto_tcnn.npz ~1 MB.  Runtime: under a minute on a laptop CPU.
 
     python tools/make_nerfstudio_fixture.py [--tcnn]     (the torch-fallback fixture [+ tiny-cuda-nn])
     python tools/make_nerfstudio_fixture.py --cv2        (only the OpenCV fixture; nerfstudio is not imported)
@@ -119,6 +120,68 @@ def _dataset_camera_rays(c2w, W, H):
 CV2_KSIZES = [(50, 50), (20, 20), (11, 11), (7, 7), (5, 5), (3, 3), (1, 1), (2, 2), (4, 6), (9, 5), (50, 30), (1, 7), (8, 1)]  # (width, height)
 
 
+def _module_facts(ns_model, load_result):
+    """r06: the two recollections SURVEY Appendix A grades "M / L", decided by DATA the moment this script runs:
+      * A7  -- what the REAL module's state dict holds: every key with its shape and dtype, buffers included (does HashEncoding keep
+               `scalings` / `hash_offset` as buffers?  under which names?), and what `load_state_dict(strict=False)` of this
+               repository's synthetic scene reported missing / unexpected;
+      * A13 -- SHEncoding(levels=4, implementation="torch") evaluated on a fixed direction set, on the raw directions AND on the
+               (d + 1) / 2 that NerfactoField.get_outputs hands it (`get_normalized_directions`): tells whether the torch fallback's basis
+               sees [0, 1]^3 or [-1, 1]^3 inputs independently of any render;
+    plus HashEncoding's own per-level scalings and one forward of it on fixed points (corner order / hash constants in isolation)."""
+    from nerfstudio.field_components.encodings import HashEncoding, SHEncoding
+    from nerfstudio.utils.math import components_from_spherical_harmonics  # noqa: F401  (exists in 1.0.2; the encoding calls it)
+
+    fx = {}
+    sdict = ns_model.state_dict()
+    fx["facts.state_dict_keys"] = np.array(list(sdict.keys()))
+    fx["facts.state_dict_shapes"] = np.array([",".join(str(int(x)) for x in v.shape) for v in sdict.values()])
+    fx["facts.state_dict_dtypes"] = np.array([str(v.dtype) for v in sdict.values()])
+    fx["facts.named_buffers"] = np.array([n for n, _ in ns_model.named_buffers()])
+    fx["facts.named_parameters"] = np.array([n for n, _ in ns_model.named_parameters()])
+    fx["facts.load_missing_keys"] = np.array(list(load_result.missing_keys))
+    fx["facts.load_unexpected_keys"] = np.array(list(load_result.unexpected_keys))
+    for n, b in ns_model.named_buffers():          # small buffers verbatim (scalings, offsets ...)
+        if b.numel() <= 64:
+            fx["facts.buffer." + n] = b.detach().cpu().numpy()
+    # A13: a fixed direction set -- the six axes, the cube diagonals and seeded random unit vectors
+    g = torch.Generator().manual_seed(7)
+    d = torch.randn(64, 3, generator=g)
+    d = torch.cat([torch.eye(3), -torch.eye(3), torch.tensor([[1.0, 1.0, 1.0], [-1.0, 1.0, -1.0]]), d])
+    d = d / d.norm(dim=-1, keepdim=True)
+    sh = SHEncoding(levels=4, implementation="torch")
+    with torch.no_grad():
+        fx["facts.sh.directions"] = d.numpy()
+        fx["facts.sh.on_raw_directions"] = sh(d).numpy()
+        fx["facts.sh.on_normalized_directions"] = sh((d + 1.0) / 2.0).numpy()
+    # what the FIELD itself feeds the encoding: hook the module the model owns
+    seen = {}
+    enc = ns_model.field.direction_encoding
+    hook = enc.register_forward_hook(lambda m, inp, out: seen.update(inp=inp[0].detach().cpu(), out=out.detach().cpu()))
+    try:
+        from nerfstudio.cameras.rays import Frustums, RaySamples
+
+        fr = Frustums(origins=torch.zeros(len(d), 1, 3), directions=d[:, None, :], starts=torch.full((len(d), 1, 1), 0.1),
+                      ends=torch.full((len(d), 1, 1), 0.2), pixel_area=torch.ones(len(d), 1, 1))
+        rs = RaySamples(frustums=fr, camera_indices=torch.zeros(len(d), 1, 1, dtype=torch.long))
+        ns_model.eval()
+        with torch.no_grad():
+            ns_model.field(rs)
+        fx["facts.sh.field_input"] = seen["inp"].numpy()           # [-1, 1] or [0, 1]?  decides SnFieldDesc.sh_remap for the torch path
+        fx["facts.sh.field_output"] = seen["out"].numpy()
+    finally:
+        hook.remove()
+    # A7 in isolation
+    he = HashEncoding(num_levels=16, min_res=16, max_res=2048, log2_hashmap_size=14, features_per_level=2, implementation="torch")
+    q = torch.rand(256, 3, generator=g)
+    with torch.no_grad():
+        fx["facts.hash.scalings"] = he.scalings.detach().cpu().numpy() if hasattr(he, "scalings") else np.zeros(0)
+        fx["facts.hash.table"] = he.hash_table.detach().cpu().numpy()
+        fx["facts.hash.q"] = q.numpy()
+        fx["facts.hash.features"] = he(q).numpy()
+    return fx
+
+
 def emit_cv2_fixture(out_dir):
     """Inputs + outputs of the two OpenCV calls of datasetgenerator.py:776-777.  No OpenCV source is stored."""
     import cv2
@@ -197,6 +260,7 @@ def main():
     for k, v in sd.items():
         fx["param." + k] = v.numpy()
     fx.update(_dataset_camera_rays(c2w[1], 56, 40))
+    fx.update(_module_facts(ns_model, res))
     np.savez_compressed(os.path.join(out_dir, "nerfstudio_nerfacto_torch.npz"), **fx)
     print("wrote nerfstudio_nerfacto_torch.npz:", sorted(k for k in fx if not k.startswith("param."))[:12], "...")
 

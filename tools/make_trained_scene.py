@@ -22,7 +22,7 @@ around the analytic hit distance) plus volume and near-surface points.  sigma = 
 early-termination logic, the PDF merge and the median search of the kernels see in production.
 
 Full-size shapes (L=16, T=2^19; proposal nets T=2^17): the state dict is ~75 MB and is regenerated where it is needed (well under a minute
-on an MI355X through torch -- ~40 s with the deterministic scatter --, ~8 minutes on 8 CPU cores), cached under $SIGNERF_TRAINED_CACHE (default /tmp).  A fit is run-to-run identical on one machine type (deterministic
+on an MI355X through torch -- ~40 s with the deterministic scatter --, ~8 minutes on 8 CPU cores), cached under $SIGNERF_TRAINED_CACHE (default ~/.cache/signerf_amd, mode 0700; loaded with weights_only).  A fit is run-to-run identical on one machine type (deterministic
 scatter, no GEMM atomics: `fit`), not across CPU / GPU or library versions, so what is committed is a FINGERPRINT with tolerances (tests/golden/trained_scene_fingerprint.json) and the
 64x64 oracle render of the CPU fit made in the build container (tests/golden/trained_scene_64.npz): a regenerated scene must render
 the same picture (PSNR, silhouette IoU, depth vs the analytic depth), not the same bits.
@@ -267,19 +267,32 @@ def _fit(cfg, dev, steps, points, seed, lr, log):
     return out, {"steps": steps, "points": points, "seed": seed, "device": str(dev), "seconds": time.time() - t0, "final_losses": hist[-1][1]}
 
 
-def scene_key(cfg, steps: int, points: int, seed: int) -> str:
-    sig = json.dumps({"v": SCENE_VERSION, "L": cfg.num_levels, "T": cfg.log2_hashmap_size, "max": cfg.max_res, "hid": cfg.hidden_dim,
+def scene_key(cfg, steps: int, points: int, seed: int, device: str = "") -> str:
+    """Cache key of a fit.  The fitting DEVICE TYPE and the torch version are part of it (a CPU fit and a GPU fit of the same
+    scene differ in the last bits, and a scene fitted on one must not be served to a run that reports the other)."""
+    sig = json.dumps({"v": SCENE_VERSION, "device": str(device).split(":")[0], "torch": torch.__version__, "L": cfg.num_levels, "T": cfg.log2_hashmap_size, "max": cfg.max_res, "hid": cfg.hidden_dim,
                       "props": [(a["num_levels"], a["log2_hashmap_size"], a["max_res"], a["hidden_dim"]) for a in cfg.proposal_net_args_list[:cfg.num_proposal_iterations]],
                       "aid": cfg.average_init_density, "steps": steps, "points": points, "seed": seed, "normals": cfg.predict_normals}, sort_keys=True)
     return hashlib.sha1(sig.encode()).hexdigest()[:12]
 
 
+def cache_dir() -> str:
+    """$SIGNERF_TRAINED_CACHE, else a per-user directory (mode 0700) -- not a predictable path in a world-writable /tmp."""
+    d = os.environ.get("SIGNERF_TRAINED_CACHE")
+    if not d:
+        base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+        d = os.path.join(base, "signerf_amd")
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    return d
+
+
 def trained_state_dict(cfg, device: str = None, steps: int = STEPS, points: int = POINTS, seed: int = 0, cache: bool = True, log=None):
     """The fitted state dict (CPU fp32, nerfstudio's torch-path names) + meta; cached on disk per (shapes, steps, points, seed)."""
     device = device or ("cuda" if torch.cuda.is_available() else "cpu")
-    path = os.path.join(os.environ.get("SIGNERF_TRAINED_CACHE", "/tmp"), f"signerf_trained_{scene_key(cfg, steps, points, seed)}.pt")
-    if cache and os.path.exists(path):
-        blob = torch.load(path, map_location="cpu")
+    path = os.path.join(cache_dir(), f"signerf_trained_{scene_key(cfg, steps, points, seed, device)}.pt")
+    if cache and os.path.exists(path) and os.stat(path).st_uid == os.getuid():
+        # tensors and plain containers only (weights_only): a cache file is data, never code
+        blob = torch.load(path, map_location="cpu", weights_only=True)
         return blob["state_dict"], blob["meta"]
     sd, meta = fit(cfg, device, steps, points, seed, log=log)
     if cache:
