@@ -140,6 +140,24 @@ def test_abi_version_and_struct_size_handshake(built_lib):
     assert st == 1 and "knows sizes" in msg and str(short) in msg
 
 
+def test_plain_c_client_of_the_abi(built_lib, tmp_path):
+    """tests/c/cabi_client.c: a C99 program that includes the header, dlopens the library and walks the ABI handshake (version, unset /
+    too-new struct_size, unsupported architecture, a valid descriptor) -- the boundary holds no C++ or torch type, and is usable from
+    the language a foreign binding would be written in."""
+    import torch
+
+    exe = tmp_path / "cabi_client"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "cabi_client.c"), "-o", str(exe), "-ldl"], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([str(exe), built_lib], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = dict(ln.split(" ", 1) for ln in r.stdout.splitlines() if " " in ln)
+    assert out["result"] == "ok" and out["abi_version"] == "%d header %d" % (_lib.SN_ABI_VERSION, _lib.SN_ABI_VERSION)
+    sizes = out["sizeof"].split()
+    assert int(sizes[1]) == C.sizeof(_lib.SnFieldDesc) and int(sizes[3]) == C.sizeof(_lib.SnRenderOpts)
+
+
 def test_error_path_without_gpu(built_lib):
     """sn_create validates the architecture before touching the device, and reports through sn_last_error."""
     lib = _lib.load()
