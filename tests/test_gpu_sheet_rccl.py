@@ -42,3 +42,24 @@ def test_overlapped_tile_gather_over_rccl(gpu):
         assert torch.equal(sheet.gather_tiles(frames[0], 1), frames[0])
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_preflight_and_rank_spread_over_rccl(gpu):
+    """bench.py's N > 1 preflight (r06) on the one backend it is written for: a single-rank RCCL group runs its all_gather_object, the RCCL
+    version query, the device identity and the device-side all-reduce -- the calls the first real 8-GPU run makes before its first render."""
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
+    try:
+        pre = bench.preflight(1, 0, gpu, "nccl", False)
+        assert pre["preflight"] == "ok" and pre["distinct_devices"] == 1 and pre["devices"].startswith("r0 ")
+        assert pre["rccl_version"] and pre["rccl_version"][0].isdigit(), pre      # RCCL reports a version through torch.cuda.nccl
+        assert pre["device_cus"] == 256
+        ident = bench.device_identity(gpu)
+        assert ident["pci"].count(":") == 2 and ident["cus"] == 256
+        sp = bench.rank_spread(2.75, 1, gpu, "nccl")
+        assert sp == {"min": 2.75, "max": 2.75, "mean": 2.75, "slowest_rank": 0, "per_rank": [2.75]}
+    finally:
+        dist.destroy_process_group()

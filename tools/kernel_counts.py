@@ -105,14 +105,19 @@ def mfma_loops(kernel_substr: str, lib: str = LIB) -> list:
     out = []
     for lo, hi in sorted(picked):
         c = {"kernel": name, "loop_bytes": hi - lo}
+        opcodes = {}
         for addr, op, ln in insts:
             if lo <= addr <= hi:
                 k = classify(op)
                 c[k] = c.get(k, 0) + 1
+                if k in ("valu", "mfma"):
+                    base_op = re.sub(r"_(e32|e64|dpp|sdwa)$", "", op)
+                    opcodes[base_op] = opcodes.get(base_op, 0) + 1
                 if op.startswith(("buffer_load_dwordx2", "buffer_load_dwordx4")):
                     c["gather"] = c.get("gather", 0) + 1
                 if op.startswith("v_pk_") and op.endswith("_f32"):
                     c["packed_f32"] = c.get("packed_f32", 0) + 1
+        c["opcodes"] = dict(sorted(opcodes.items(), key=lambda kv: -kv[1]))
         out.append(c)
     return out
 
