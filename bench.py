@@ -328,17 +328,21 @@ def preflight(world, rank, dev, backend, shared_gpu):
     me = dict(device_identity(dev), rank=rank, device_index=dev.index, pid=os.getpid(), rccl=rccl, torch=torch.__version__)
     everyone = [None] * world
     dist.all_gather_object(everyone, me)
+    # HARD failures: what cannot be true of a working process group (a wrong answer here would make every later number meaningless)
     assert [e["rank"] for e in everyone] == list(range(world)), "all_gather_object returned ranks out of order"
     assert dist.get_world_size() == world, "the process group does not see WORLD_SIZE ranks"
-    distinct = len({(e["pci"], e["uuid"]) for e in everyone})
-    if backend == "nccl" and not shared_gpu:
-        assert distinct == world, "two ranks report the same GPU (PCI bus id / UUID): %r" % [(e["rank"], e["pci"]) for e in everyone]
-    assert len({e["rccl"] for e in everyone}) == 1 and len({e["torch"] for e in everyone}) == 1, "ranks run different RCCL / torch builds"
     # one tiny device-side collective as well: the sum of the ranks (catches a fabric that moves objects over the host but not tensors)
     t = torch.tensor([float(rank)], device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(t)
     assert float(t.item()) == world * (world - 1) / 2, "all_reduce of the rank numbers returned %r" % float(t.item())
-    return {"preflight": "ok", "rccl_version": me["rccl"], "distinct_devices": distinct,
+    # SOFT findings (reported in the line, never fatal: a property this torch build does not expose must not cost the measurement)
+    distinct = len({(e["pci"], e["uuid"], e["device_index"]) for e in everyone})
+    notes = []
+    if backend == "nccl" and not shared_gpu and distinct != world:
+        notes.append("ranks share a device identity: %s" % [(e["rank"], e["pci"], e["device_index"]) for e in everyone])
+    if len({e["rccl"] for e in everyone}) != 1 or len({e["torch"] for e in everyone}) != 1:
+        notes.append("ranks run different RCCL / torch builds")
+    return {"preflight": "ok" if not notes else ("warning: " + "; ".join(notes))[:120], "rccl_version": me["rccl"], "distinct_devices": distinct,
             "device_name": me["name"], "device_cus": me["cus"],
             "devices": "; ".join("r%d %s" % (e["rank"], e["pci"]) for e in everyone)[:120]}
 
@@ -758,24 +762,48 @@ def main():
         # (every rank; after the timed region) the ranks' own one-launch times, and the exchange checked for CONTENT: one more gather of
         # "camera r from rank r", each tile compared bit for bit with this rank's own render of that camera -- the kernels are
         # deterministic, so a tile that differs was damaged on the way (or a peer's GPU computes differently)
+        my_kernel_ms = statistics.median(per_step)   # (taken now: rank 0 re-uses the name `per_step` further down)
+
         def post_checks():
-            sp = rank_spread(statistics.median(per_step), world, dev, args.backend)
-            o_ = model.get_outputs_for_camera_ray_bundle(cam.generate_rays(camera_indices=0, aabb_box=model.render_aabb))
-            mine_tile = torch.cat([o_["rgb"], o_["depth"]], dim=-1)[None]
+            """Three collectives, executed by every rank WHATEVER happens to its local work in between (a rank that raised between two of
+            them would leave the others waiting in the next one): local failures travel as sentinel values instead."""
+            local_err = None
+            sp = rank_spread(my_kernel_ms, world, dev, args.backend)
+            try:
+                o_ = model.get_outputs_for_camera_ray_bundle(cam.generate_rays(camera_indices=0, aabb_box=model.render_aabb))
+                mine_tile = torch.cat([o_["rgb"], o_["depth"]], dim=-1)[None]
+            except Exception as e:  # noqa: BLE001
+                local_err, mine_tile = repr(e)[:120], torch.zeros((1, H, W, 4), dtype=torch.float32, device=dev)
             got = sheet.gather_tiles_async(mine_tile, world, dst=None, strategy="all_gather").wait()
             bad = 0
-            for r in range(world):
-                o_ = model.get_outputs_for_camera_ray_bundle(cams[r % 8].generate_rays(camera_indices=0, aabb_box=model.render_aabb))
-                want = torch.cat([o_["rgb"], o_["depth"]], dim=-1)
-                bad += 0 if torch.equal(got[r].to(want.device), want) else 1
+            try:
+                for r in range(world):
+                    o_ = model.get_outputs_for_camera_ray_bundle(cams[r % 8].generate_rays(camera_indices=0, aabb_box=model.render_aabb))
+                    want = torch.cat([o_["rgb"], o_["depth"]], dim=-1)
+                    bad += 0 if torch.equal(got[r].to(want.device), want) else 1
+            except Exception as e:  # noqa: BLE001
+                local_err, bad = local_err or repr(e)[:120], world
             t = torch.tensor([float(bad)], device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t)
-            return sp, {"tiles_checked_per_rank": world, "mismatching_tiles_all_ranks": int(t.item())}
+            out = {"tiles_checked_per_rank": world, "mismatching_tiles_all_ranks": int(t.item())}
+            if local_err:
+                out["local_error_rank_%d" % rank] = local_err
+            return sp, out
 
-        try:
-            spread, tiles_check = run_with_watchdog(post_checks, args.diagnostics_timeout + 120.0, lambda: os._exit(3))
-        except Exception as e:  # noqa: BLE001  (diagnostics must not cost the line)
-            spread, tiles_check = None, {"error": repr(e)[:120]}
+        def run_post_checks(line=None):
+            """Under a watchdog, like the gather diagnostics: a check that hangs must not cost the line.  Rank 0 calls this AFTER its line
+            is built (the other ranks wait for it inside the first collective): if the limit passes, it prints the line as it stands and
+            every rank leaves with status 0 -- the measurement itself is complete."""
+            def bail():
+                if line is not None:
+                    line["config"]["gathered_tiles_bit_identical"] = "post-run checks did not finish within their time limit"
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+
+            try:
+                return run_with_watchdog(post_checks, args.diagnostics_timeout if rank == 0 else args.diagnostics_timeout + 240.0, bail)
+            except Exception as e:  # noqa: BLE001  (diagnostics must not cost the line)
+                return None, {"error": repr(e)[:120]}
 
     def gather_diagnostics(line=None):
         """The exposed cost of the tile gather, per strategy: diagnostic legs AFTER the timed region.  They must never cost the line -- an
@@ -801,6 +829,7 @@ def main():
         return by, err[0]
 
     if world > 1 and rank != 0:
+        run_post_checks()
         gather_diagnostics()
     if rank == 0:
         n_steps = len(per_step)
@@ -838,11 +867,10 @@ def main():
                        "gather_strategy": (args.gather_strategy if world > 1 else None),
                        # r06 preflight / post-run checks (flat: the driver's record keeps scalars)
                        **pre,
-                       "rank_kernel_ms_min": spread["min"] if spread else None, "rank_kernel_ms_max": spread["max"] if spread else None,
-                       "rank_kernel_ms_mean": spread["mean"] if spread else None, "slowest_rank": spread["slowest_rank"] if spread else None,
-                       "gathered_tiles_bit_identical": (None if not tiles_check else
-                                                        (tiles_check.get("mismatching_tiles_all_ranks") == 0 if "error" not in tiles_check else tiles_check["error"]))},
-            "rank_kernel_ms": spread, "gathered_tiles_check": tiles_check,
+                       # (filled in by the post-run checks below, once the line's own measurements are in it)
+                       "rank_kernel_ms_min": None, "rank_kernel_ms_max": None, "rank_kernel_ms_mean": None, "slowest_rank": None,
+                       "gathered_tiles_bit_identical": None},
+            "rank_kernel_ms": None, "gathered_tiles_check": None,
             "ms_per_frame": elapsed / args.steps * 1e3 / (len(mine) if strong else 1) if (not strong or mine) else None,
             "ms_per_sheet": (elapsed / args.steps * 1e3) if strong else None,
             "gather_ms": None,   # (world > 1: filled in below, after the line's own measurements)
@@ -961,8 +989,8 @@ def main():
             # fixed by the kernel (per wave-step of 64 samples: 120 v_mfma_f32_32x32x16_f16 in split precision, 320
             # v_mfma_f32_32x32x2_f32 in exact fp32; rocprofv3 SQ_INSTS_MFMA agrees, profiles/) -- issued flops / kernel time
             # against the dense peak of that MFMA type (MI355X_MICROARCH.md: 2.5 PFLOP/s f16, 157.3 TFLOP/s f32-input).
-            per_step, flop, peak = (120, 2 * 32 * 32 * 16, 2500.0) if args.precision == "fp16x2" else (320, 2 * 32 * 32 * 2, 157.3)
-            issued = (W * H * S / 64) * per_step * flop
+            mfma_per_step, flop, peak = (120, 2 * 32 * 32 * 16, 2500.0) if args.precision == "fp16x2" else (320, 2 * 32 * 32 * 2, 157.3)
+            issued = (W * H * S / 64) * mfma_per_step * flop
             line["roofline_mfma"] = {"bound": "mfma", "achieved": issued / (k_med * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                                      "frac": issued / (k_med * 1e-3) / 1e12 / peak,
                                      "frac_at_sustained_clock": (issued / (k_med * 1e-3) / 1e12 / (peak * clock / PEAK_CLOCK_GHZ)) if clock == clock else None,
@@ -1060,6 +1088,14 @@ def main():
             rf["other_configs"] = oc
         line["roofline"] = flat_roofline(rf, line)   # the leading keys: flat scalars, in the order the driver's record keeps
         if world > 1:
+            spread, tiles_check = run_post_checks(line)
+            if spread:
+                line["config"].update({"rank_kernel_ms_min": spread["min"], "rank_kernel_ms_max": spread["max"], "rank_kernel_ms_mean": spread["mean"],
+                                       "slowest_rank": spread["slowest_rank"]})
+            if tiles_check:
+                line["config"]["gathered_tiles_bit_identical"] = (tiles_check.get("mismatching_tiles_all_ranks") == 0 if "error" not in tiles_check
+                                                                  else tiles_check["error"])
+            line["rank_kernel_ms"], line["gathered_tiles_check"] = spread, tiles_check
             gather_by_strategy, gather_err = gather_diagnostics(line)
             gather_ms = gather_by_strategy.get(args.gather_strategy)
             line["gather_ms"] = {"exposed": None, "error": gather_err, "exposed_by_strategy": gather_by_strategy} if gather_ms is None else {
