@@ -262,6 +262,63 @@ def test_config2_fused_indices_full_size_crop(bench_model, gpu, cam, y0, x0):
     _run_uniform(cfg, model, sd, gpu, _bundle_crop(cams[cam], y0, x0, 40, 40), f"config 2 (40x40 crop of camera {cam}'s 800x800 frame)")
 
 
+def test_uniform_sampler_positions_are_exact_beyond_the_benchmark_cameras(gpu):
+    """r06: the bit-exact position map off the benchmark's beaten path -- (i) per-ray nears / fars from a render box (the kernel then
+    computes its bins PER LANE instead of once per workgroup; rays that miss carry nerfstudio's sentinel and are compared where finite),
+    (ii) random cameras inside and far outside the unit box, looking anywhere, so that samples sit deep in the contracted region,
+    (iii) a far plane of 10 (other bins)."""
+    from signerf_amd import SceneBox
+    from test_gpu_random_parity import _random_c2w
+
+    cfg = small_config(num_proposal_iterations=0, num_nerf_samples_per_ray=24)
+    model, sd = make_model(cfg, gpu)
+    model.eval()
+    sc = onf.hash_scalings(cfg.num_levels, cfg.base_res, cfg.max_res)
+    lay = ops.debug_layout(model, -1)
+    g = torch.Generator().manual_seed(11)
+    cases = []
+    box = SceneBox(aabb=torch.tensor([[-0.2, -0.15, -0.1], [0.15, 0.2, 0.12]]))
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 40.0, 40.0, 20.0, 16.0, 40, 32).to(gpu)
+    cases.append(("render box, camera 2", cams[2].generate_rays(camera_indices=0, aabb_box=box), None))
+    for i in range(4):
+        c2w = _random_c2w(g).clone()                       # a random orientation, the position within +-1.5
+        c2w[:, 3] *= (0.05, 4.0, 1.0, 1.0)[i]            # ... deep inside the unit box / far outside it / as drawn
+        rc = Cameras(c2w[None, :3], 30.0, 30.0, 16.0, 12.0, 32, 24).to(gpu)
+        cases.append((f"random camera {i}", rc[0].generate_rays(camera_indices=0), 10.0 if i == 3 else None))
+    total = 0
+    for name, bundle, far in cases:
+        H, W = bundle.origins.shape[:2]
+        old_far = model.config.far_plane
+        if far is not None:
+            model.config.far_plane = far
+        try:
+            out, dump = ops.render_rays_debug(model, bundle, want=("main_fetch", "main_q", "median_index"))
+        finally:
+            model.config.far_plane = old_far
+        ocfg = oracle_config(cfg)
+        if far is not None:
+            ocfg = type(ocfg)(**{**ocfg.__dict__, "far_plane": far})
+        n = None if bundle.nears is None else bundle.nears.cpu().reshape(-1, 1)
+        f = None if bundle.fars is None else bundle.fars.cpu().reshape(-1, 1)
+        with torch.no_grad():
+            ref = onf.get_outputs(sd, ocfg, bundle.origins.cpu().reshape(-1, 3), bundle.directions.cpu().reshape(-1, 3), n, f, return_debug=True)
+        q_ref = ref["_debug"]["q"].reshape(-1, 3)
+        q_hip = dump["main_q"].view(-1, 3).cpu()
+        ok = torch.isfinite(q_ref).all(dim=-1) & torch.isfinite(q_hip).all(dim=-1)
+        assert torch.equal(torch.isfinite(q_ref).all(dim=-1), torch.isfinite(q_hip).all(dim=-1)), name
+        diff = int((q_hip[ok].view(torch.int32) != q_ref[ok].view(torch.int32)).any(dim=-1).sum())
+        S = cfg.num_nerf_samples_per_ray
+        rows = _decode(dump["main_fetch"].view(H * W * S, 16, 8), lay, cfg.log2_hashmap_size).cpu()
+        _, rows_o, _, _ = _oracle_rows(q_ref[ok], sc, cfg.log2_hashmap_size)
+        flips = int((rows[ok] != rows_o).any(dim=-1).sum())
+        beyond = float((ref["_debug"]["q"].reshape(-1, 3)[ok] - 0.5).abs().max())
+        print(f"{name}: {int(ok.sum())} finite samples of {ok.numel()}, positions differing from the oracle's {diff}, voxel flips {flips}, "
+              f"max |q - 0.5| {beyond:.3f} (0.25 = the unit box's face, 0.5 = infinity)")
+        assert diff == 0 and flips == 0, name
+        total += int(ok.sum())
+    assert total > 50_000
+
+
 def _run_proposal(cfg, model, sd, bundle, name):
     """Two proposal nets (256 + 96) + 48 main samples: K2's fetches and searchsorted indices, K1's fetches in bins mode."""
     H, W = bundle.origins.shape[:2]
