@@ -53,10 +53,12 @@ def memoised_oracle():
     real = onf.get_outputs_for_camera_ray_bundle
 
     def cached(params, cfg, origins, directions, nears=None, fars=None, chunk=None):
-        pk = _PARAM_DIGESTS.get(id(params))
+        pk = _PARAM_DIGESTS.pop(id(params), None)
         if pk is None or pk[0] is not params:
             pk = (params, "|".join(k + ":" + _digest(v) for k, v in sorted(params.items())))
-            _PARAM_DIGESTS[id(params)] = pk
+        _PARAM_DIGESTS[id(params)] = pk            # (re-inserted last: the dict is an LRU)
+        while len(_PARAM_DIGESTS) > 8:             # an entry HOLDS its state dict (so that its id cannot be re-used while the entry lives); keep few
+            _PARAM_DIGESTS.pop(next(iter(_PARAM_DIGESTS)))
         key = (pk[1], repr(cfg), _digest(origins), _digest(directions), _digest(nears), _digest(fars), chunk, onf.EXP_MODE if hasattr(onf, "EXP_MODE") else None)
         hit = _ORACLE_CACHE.get(key)
         if hit is None:
