@@ -122,14 +122,14 @@ def test_trained_scene_matches_its_fingerprint(trained):
 
 
 def test_trained_config4_shaped_96x96(trained, gpu):
-    """Proposal nets 256 + 96 + 48 main samples (BASELINE configs[3]'s sampler) on the trained field, 96x96, both precisions."""
+    """Proposal nets 256 + 96 + 48 main samples (BASELINE configs[3]'s sampler) on the trained field, 72x72 (r06: was 96x96), both precisions."""
     cfg, sd, model, _ = trained
-    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 96.0, 96.0, 48.0, 48.0, 96, 96).to(gpu)
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 72.0, 72.0, 36.0, 36.0, 72, 72).to(gpu)
     for precision in ("fp16x2", "fp32"):
         model.config.precision = precision
         out, ref = _pair(cfg, model, sd, cams[1].generate_rays(camera_indices=0))
         assert model.effective_precision == precision   # tables of trained magnitude stay on the split-precision path
-        _check(f"trained, config-4-shaped 96x96, {precision}", out, ref)
+        _check(f"trained, config-4-shaped 72x72, {precision}", out, ref)
     model.config.precision = "fp16x2"
 
 
@@ -167,11 +167,15 @@ def test_trained_config4_full_size_crop_with_indices(trained, gpu, cam, y0, x0):
     W, H = 1920, 1080
     cams = Cameras(scene.benchmark_cameras(8)[:, :3], 1.2 * H, 1.2 * H, W / 2, H / 2, W, H).to(gpu)
     bundle = _crop(cams[cam], y0, x0, 48, 48)
-    out, ref = _pair(cfg, model, sd, bundle)
+    out = model.get_outputs_for_camera_ray_bundle(bundle)
     name = f"trained, 48x48 crop of camera {cam}'s 1920x1080 frame"
     o_cpu, d_cpu = bundle.origins.cpu().reshape(-1, 3), bundle.directions.cpu().reshape(-1, 3)
     with torch.no_grad():
-        dref = onf.get_outputs(sd, oracle_config(cfg), o_cpu, d_cpu, return_debug=True)["_debug"]
+        # ONE oracle pass gives the frame and its debug record (2304 rays are a single chunk of the camera-bundle loop, so get_outputs IS the frame)
+        assert o_cpu.shape[0] <= oracle_config(cfg).eval_num_rays_per_chunk
+        full = onf.get_outputs(sd, oracle_config(cfg), o_cpu, d_cpu, return_debug=True)
+        dref = full.pop("_debug")
+        ref = {k: v.view(48, 48, -1) for k, v in full.items()}
         ulp = onf.get_outputs(sd, oracle_config(cfg), torch.nextafter(o_cpu, o_cpu + 1.0), d_cpu, return_debug=True)   # the yardstick
         dulp = ulp.pop("_debug")
     # (camera 5's crop holds the horizon band: accumulation 0.79 on average, cumsum(w) crosses 0.5 on shallow slopes -- 5 ties of 2304 measured;
