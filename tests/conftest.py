@@ -10,8 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "slow: a second / third parametrisation of a parity case another test already covers; runs only with "
-                                       "SIGNERF_RUN_SLOW=1 (r06: keeps `pytest -m gpu` -- the round's correctness record -- well inside its time limit)")
+    config.addinivalue_line("markers", "slow: a further parametrisation of a case another test already covers; runs only with SIGNERF_RUN_SLOW=1 "
+                                       "(r06; once the oracle's threads were bounded -- oracle_threads below -- only one test still carries it)")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -72,6 +72,35 @@ def memoised_oracle():
     onf.get_outputs_for_camera_ray_bundle = real
     _ORACLE_CACHE.clear()
     _PARAM_DIGESTS.clear()
+
+
+def _granted_cpus():
+    """CPUs the container may actually use (cgroup quota; bench.py::cpu_quota), None when unlimited."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+            q, per = float(f.read()), float(g.read())
+            return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+@pytest.fixture(scope="session", autouse=True)
+def oracle_threads():
+    """The CPU oracle is most of the GPU suite's wall time.  A GPU box of the pool shows 256 logical CPUs and GRANTS 16 (cgroup quota): torch's
+    default of one thread per core then runs 128 threads on 16 CPUs' worth of time, throttled -- 1.6x slower than 16 threads (measured r04,
+    bench.py's cpu_baseline).  The suite therefore runs torch with as many threads as the container is granted."""
+    import torch
+
+    q = _granted_cpus()
+    if q is not None and q >= 1 and torch.get_num_threads() > int(q + 0.5):
+        torch.set_num_threads(max(1, int(q + 0.5)))
+    yield
 
 
 @pytest.fixture(scope="session")

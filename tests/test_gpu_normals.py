@@ -59,7 +59,7 @@ def test_normals_with_proposal_sampler_and_ragged_image(gpu):
     _check(out, ref, exact_bins=False)
 
 
-@pytest.mark.parametrize("precision", ["fp16x2", pytest.param("fp32", marks=pytest.mark.slow)])
+@pytest.mark.parametrize("precision", ["fp16x2", "fp32"])
 def test_normals_full_tables(gpu, precision):
     """The benchmark field (L=16, T=2^19) at 64x64x64, both MFMA arithmetic modes of the normals kernel."""
     cfg = scene.benchmark_config(64)

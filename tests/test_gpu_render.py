@@ -187,7 +187,7 @@ def test_full_size_properties_1920x1080_nerfacto(gpu, cam, y0, x0):
         assert r["abs_rmse"] <= EXPECTED_DEPTH_TOL
 
 
-@pytest.mark.parametrize("density_bias", [pytest.param(4.0, marks=pytest.mark.slow), 0.0, pytest.param(-1.0, marks=pytest.mark.slow)])
+@pytest.mark.parametrize("density_bias", [4.0, 0.0, -1.0])
 def test_config4_depth_error_is_scale_free(gpu, density_bias):
     """nerfacto's eval depths live on [0, far_plane = 1000] and the sampler is uniform in s = 1 - 1/(2d): one ulp of s is
     2 d^2 * 6e-8 of depth, i.e. 1e-7 at d = 1 and 5e-3 at d = 200 -- an ABSOLUTE 1e-3 gate measures the scene's scale, not the
@@ -213,7 +213,7 @@ def test_config4_depth_error_is_scale_free(gpu, density_bias):
     assert rmse(out["rgb"], ref["rgb"]) <= RMSE_TOL and rmse(out["accumulation"], ref["accumulation"]) <= RMSE_TOL
 
 
-@pytest.mark.parametrize("workload,density_bias", [("sheet64", -2.0), ("sheet64", -3.0), ("nerfacto", -2.0), pytest.param("nerfacto", -3.0, marks=pytest.mark.slow)])
+@pytest.mark.parametrize("workload,density_bias", [("sheet64", -2.0), ("sheet64", -3.0), ("nerfacto", -2.0), ("nerfacto", -3.0)])
 def test_thin_media_keep_accumulation_in_the_informative_range(gpu, workload, density_bias):
     """SURVEY 8(d) asks for `0.05 < accumulation.mean() < 0.95` lest the accumulation gate be vacuous; the benchmark scene (density bias +4,
     far plane 1000) is opaque by the far plane -- accumulation 1.000 in every pixel of both BASELINE frames (profiles/r04_full_frame_parity.txt).

@@ -154,7 +154,7 @@ def test_trained_config2_full_size_crop(trained_main_only, gpu, cam, y0, x0):
     _check(f"trained, 48x48 crop of camera {cam}'s 800x800x64 frame", out, ref)
 
 
-@pytest.mark.parametrize("cam,y0,x0", [(0, 504, 1128), pytest.param(5, 552, 1008, marks=pytest.mark.slow)])
+@pytest.mark.parametrize("cam,y0,x0", [(0, 504, 1128), (5, 552, 1008)])
 def test_trained_config4_full_size_crop_with_indices(trained, gpu, cam, y0, x0):
     """48x48 crops (sphere + ground + sky) of the 1920x1080 nerfacto frame of the trained scene: the render gates, and -- through the
     instrumented kernels (sn_render_rays_debug) -- the searchsorted indices of both resampling steps and the median index against the

@@ -144,7 +144,7 @@ def _tree(root):
     return out
 
 
-@pytest.mark.parametrize("strategy", ["all_gather", pytest.param("p2p", marks=pytest.mark.slow), pytest.param("all_to_all", marks=pytest.mark.slow)])
+@pytest.mark.parametrize("strategy", ["all_gather", "p2p", pytest.param("all_to_all", marks=pytest.mark.slow)])
 def test_world8_generate_dataset_58_views(gpu, tmp_path, strategy):
     """8 + 50 cameras over 8 ranks (58 = 7 x 8 + 2: ranks 0 and 1 own eight views, the others seven), tiles gathered to rank 0, which alone
     runs the serial diffusion sequence and writes the files: byte-identical to the single-process dataset, every rank exits."""
