@@ -15,6 +15,17 @@ from signerf_amd.config import NerfactoModelConfig  # noqa: E402
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def use_granted_cpus():
+    """torch threads = the CPUs the container is GRANTED (cgroup quota), not the host's core count: a GPU box of the pool shows 256 logical
+    CPUs and grants 16, and 128 throttled threads run the oracle 2.4x slower than 16 (r06: the GPU suite 404 -> 166 s).  Returns the count."""
+    import conftest  # tests/conftest.py (the same rule, applied to every test session)
+
+    q = conftest._granted_cpus()
+    if q is not None and q >= 1 and torch.get_num_threads() > int(q + 0.5):
+        torch.set_num_threads(max(1, int(q + 0.5)))
+    return torch.get_num_threads()
+
+
 def oracle_config(cfg: NerfactoModelConfig, scene_aabb=None) -> onf.NerfactoConfig:
     grid = "torch" if cfg.implementation == "torch" else "tcnn"
     props = tuple(

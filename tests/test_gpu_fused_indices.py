@@ -249,9 +249,9 @@ def bench_model(gpu):
 
 
 def test_config2_fused_indices_96x96(bench_model, gpu):
-    cfg, model, sd = bench_model       # (r06: 72x72, was 96x96)
-    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 72.0, 72.0, 36.0, 36.0, 72, 72).to(gpu)
-    _run_uniform(cfg, model, sd, gpu, cams[1].generate_rays(camera_indices=0), "config 2 (72x72x64, full tables)")
+    cfg, model, sd = bench_model
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 96.0, 96.0, 48.0, 48.0, 96, 96).to(gpu)
+    _run_uniform(cfg, model, sd, gpu, cams[1].generate_rays(camera_indices=0), "config 2 (96x96x64, full tables)")
 
 
 @pytest.mark.parametrize("cam,y0,x0", [(0, 380, 380), (5, 96, 640)])
@@ -378,11 +378,11 @@ def _run_proposal(cfg, model, sd, bundle, name):
 
 
 def test_config4_fused_indices_proposal_path(full_model, gpu):
-    """BASELINE.json configs[3] at 40x72 (r06: was 72x128 -- 29 s of CPU oracle; the full-size crops below keep the frame's own footprint)."""
+    """BASELINE.json configs[3] at 72x128."""
     cfg, model, sd = full_model
-    H, W = 40, 72
-    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 84.0, 84.0, W / 2, H / 2, W, H).to(gpu)
-    _run_proposal(cfg, model, sd, cams[3].generate_rays(camera_indices=0), "config 4 (40x72)")
+    H, W = 72, 128
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 150.0, 150.0, W / 2, H / 2, W, H).to(gpu)
+    _run_proposal(cfg, model, sd, cams[3].generate_rays(camera_indices=0), "config 4 (72x128)")
 
 
 @pytest.mark.parametrize("cam,y0,x0", [(0, 516, 936), (6, 200, 1500)])

@@ -87,11 +87,11 @@ def test_ragged_image_and_aabb_nears_fars(gpu):
 
 @pytest.mark.parametrize("precision", ["fp32", "fp16x2"])
 def test_config4_reduced_proposal_path(gpu, precision):
-    """BASELINE.json configs[3] at 48x88 (r06: was 72x128; the suite's wall time is the CPU oracle's): two proposal nets (256 + 96) + 48 main samples, full-size tables."""
+    """BASELINE.json configs[3] at 72x128: two proposal nets (256 + 96) + 48 main samples, full-size tables."""
     cfg = scene.proposal_config()
     cfg.precision = precision
     model, sd = make_model(cfg, gpu)
-    out, ref = _render_pair(cfg, model, sd, gpu, 48, 88, cam=3, focal=104.0)
+    out, ref = _render_pair(cfg, model, sd, gpu, 72, 128, cam=3, focal=150.0)
     _check(out, ref)
     for i in (0, 1):
         print(fmt_report(f"prop_depth_{i}", depth_error_report(out[f"prop_depth_{i}"], ref[f"prop_depth_{i}"])))
@@ -197,7 +197,7 @@ def test_config4_depth_error_is_scale_free(gpu, density_bias):
     are counted separately, as SURVEY 8(d) prescribes for ties.  profiles/r03_depth_error.txt holds the per-decade table."""
     cfg = scene.proposal_config()
     model, sd = make_model(cfg, gpu, density_bias=density_bias)
-    out, ref = _render_pair(cfg, model, sd, gpu, 48, 88, cam=3, focal=104.0)
+    out, ref = _render_pair(cfg, model, sd, gpu, 72, 128, cam=3, focal=150.0)
     n = ref["depth"].numel()
     for k, rel_gate in (("depth", 1e-5), ("expected_depth", 2e-5), ("prop_depth_0", 1e-5), ("prop_depth_1", 1e-5)):
         g, w = out[k].double().cpu().reshape(-1), ref[k].double().reshape(-1)
@@ -223,7 +223,7 @@ def test_thin_media_keep_accumulation_in_the_informative_range(gpu, workload, de
     relative gate on d measures the scene's scale, test_config4_depth_error_is_scale_free)."""
     cfg = scene.benchmark_config(64) if workload == "sheet64" else scene.proposal_config()
     model, sd = make_model(cfg, gpu, density_bias=density_bias)
-    out, ref = _render_pair(cfg, model, sd, gpu, 48, 88, cam=5, focal=104.0)
+    out, ref = _render_pair(cfg, model, sd, gpu, 72, 128, cam=5, focal=150.0)
     acc = float(ref["accumulation"].mean())
     print(f"{workload}, bias {density_bias:+.0f}: mean accumulation {acc:.3f}, rgb rmse {rmse(out['rgb'], ref['rgb']):.2e}, "
           f"accumulation rmse {rmse(out['accumulation'], ref['accumulation']):.2e}")

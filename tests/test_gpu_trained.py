@@ -122,14 +122,14 @@ def test_trained_scene_matches_its_fingerprint(trained):
 
 
 def test_trained_config4_shaped_96x96(trained, gpu):
-    """Proposal nets 256 + 96 + 48 main samples (BASELINE configs[3]'s sampler) on the trained field, 72x72 (r06: was 96x96), both precisions."""
+    """Proposal nets 256 + 96 + 48 main samples (BASELINE configs[3]'s sampler) on the trained field, 96x96, both precisions."""
     cfg, sd, model, _ = trained
-    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 72.0, 72.0, 36.0, 36.0, 72, 72).to(gpu)
+    cams = Cameras(scene.benchmark_cameras(8)[:, :3], 96.0, 96.0, 48.0, 48.0, 96, 96).to(gpu)
     for precision in ("fp16x2", "fp32"):
         model.config.precision = precision
         out, ref = _pair(cfg, model, sd, cams[1].generate_rays(camera_indices=0))
         assert model.effective_precision == precision   # tables of trained magnitude stay on the split-precision path
-        _check(f"trained, config-4-shaped 72x72, {precision}", out, ref)
+        _check(f"trained, config-4-shaped 96x96, {precision}", out, ref)
     model.config.precision = "fp16x2"
 
 

@@ -27,7 +27,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from helpers import make_model, oracle_config  # noqa: E402
+from helpers import make_model, oracle_config, use_granted_cpus  # noqa: E402
+
+use_granted_cpus()   # the oracle side: as many torch threads as the container is granted (tests/helpers.py)
 from oracle import nerfacto as onf  # noqa: E402  (test infrastructure: this tool is a checker, not a product path)
 from signerf_amd import Cameras, scene  # noqa: E402
 

@@ -19,7 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from helpers import oracle_config, small_config  # noqa: E402
+from helpers import oracle_config, small_config, use_granted_cpus  # noqa: E402
+
+use_granted_cpus()   # the oracle side: as many torch threads as the container is granted (tests/helpers.py)
 from oracle import nerfacto as onf  # noqa: E402
 from signerf_amd import Cameras, SceneBox, scene  # noqa: E402
 from test_gpu_random_parity import _look_at, _random_c2w  # noqa: E402
