@@ -158,6 +158,21 @@ def test_plain_c_client_of_the_abi(built_lib, tmp_path):
     assert int(sizes[1]) == C.sizeof(_lib.SnFieldDesc) and int(sizes[3]) == C.sizeof(_lib.SnRenderOpts)
 
 
+def test_every_entry_point_survives_null_arguments(built_lib):
+    """No entry point dereferences a NULL handle or pointer: SN_ERR_INVALID (size queries: 0, sn_effective_precision: -1, sn_destroy(NULL): ok),
+    the text in sn_last_error.  Run in a child process -- the failure mode would be a segfault."""
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "scripts", "null_arguments.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    got = dict(ln.split() for ln in r.stdout.splitlines() if len(ln.split()) == 2)
+    declared = set(_declared_functions()) - {"sn_create", "sn_abi_version"}
+    assert declared <= set(got) | {"sn_create"} and got["sn_create_null"] == "1", sorted(declared - set(got))
+    special = {"sn_destroy": "0", "sn_last_error": "True", "sn_workspace_bytes": "0", "sn_mask_workspace_bytes": "0", "sn_effective_precision": "-1"}
+    for name, st in got.items():
+        assert st == special.get(name, "1"), (name, st)
+
+
 def test_error_path_without_gpu(built_lib):
     """sn_create validates the architecture before touching the device, and reports through sn_last_error."""
     lib = _lib.load()
